@@ -1,0 +1,267 @@
+/*
+ * strelka_hip.h -- C ABI of the MI355X-native wavefront path tracer that sits behind
+ * Strelka's oka::Render interface.
+ *
+ * This header is the drop-in boundary.  Every entry point names the reference interface it
+ * replaces (paths relative to the arhix52/Strelka tree).  The ABI is plain C: opaque handle,
+ * POD structs, host pointers + counts, int status (0 = ok).  No STL, no glm, no torch types.
+ *
+ * Ownership: the library owns all device memory.  The caller owns every host pointer it passes;
+ * pointers only need to live for the duration of the call.  Device pointers passed in
+ * (skh_render_subframe's d_image, skh_copy_accum's d_dst) are caller-owned HBM buffers.
+ *
+ * Threading: one context per GPU, externally synchronised (same contract as oka::Render, whose
+ * render() is synchronous and not re-entrant: src/render/optix/OptixRender.cpp:874-1057).
+ *
+ * Errors: functions return skh_status; skh_last_error() gives the message.  The library never
+ * aborts (the reference logs + assert(0): OptixRender.cpp:61-103).
+ */
+#ifndef STRELKA_HIP_H
+#define STRELKA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKH_ABI_VERSION 1
+
+/* mirrors oka::Result (include/render/common.h:30-35) */
+typedef enum skh_status
+{
+    SKH_OK = 0,
+    SKH_FAIL = 1,
+    SKH_OUT_OF_MEMORY = 2,
+    SKH_INVALID_ARGUMENT = 3
+} skh_status;
+
+typedef struct skh_context skh_context;
+
+/* oka::Scene::Vertex (include/scene/scene.h:80-89) == Vertex (OptixRenderParams.h:19-28): 32 B AoS.
+ * normal/tangent: 10-10-10 packed (scene.cpp:111-117), uv: 16-16 packed over [-10,10] (RenderPass.cpp:53-67). */
+typedef struct skh_vertex
+{
+    float pos[3];
+    uint32_t tangent;
+    uint32_t normal;
+    uint32_t uv;
+    float pad0;
+    float pad1;
+} skh_vertex;
+
+/* oka::Mesh (include/scene/scene.h:21-27).  Indices are mesh-local; vertex_offset is added at fetch time
+ * (OptixRender_radiance_closest_hit.cpp:365-376). */
+typedef struct skh_mesh
+{
+    uint32_t index_offset; /* mIndex    */
+    uint32_t index_count;  /* mCount    */
+    uint32_t vertex_offset; /* mVbOffset */
+    uint32_t vertex_count; /* mVertexCount */
+} skh_mesh;
+
+/* oka::Curve (include/scene/scene.h:29-42); always cubic B-spline on the render side
+ * (OptixRender.cpp:218-245: degree 3, segments = n-3 per strand). */
+typedef struct skh_curve
+{
+    uint32_t vertex_counts_start;
+    uint32_t vertex_counts_count;
+    uint32_t points_start;
+    uint32_t points_count;
+    uint32_t widths_start;
+    uint32_t widths_count;
+} skh_curve;
+
+/* oka::Instance::Type (include/scene/scene.h:47-52) */
+enum
+{
+    SKH_INSTANCE_MESH = 0,
+    SKH_INSTANCE_LIGHT = 1,
+    SKH_INSTANCE_CURVE = 2
+};
+
+/* oka::Instance (include/scene/scene.h:44-60) with the transform already in the 3x4 row-major
+ * object-to-world form the reference hands to OptiX (OptixRender.cpp:438). 64 B. */
+typedef struct skh_instance
+{
+    float transform[12]; /* row-major 3x4, object -> world */
+    uint32_t type; /* SKH_INSTANCE_* */
+    uint32_t geom_id; /* mMeshId / mCurveId */
+    uint32_t material_id; /* 0xffffffff -> material 0 (OptixRender.cpp:768) */
+    uint32_t light_id; /* only for SKH_INSTANCE_LIGHT */
+} skh_instance;
+
+/* oka::Scene::Light == UniformLight (include/render/Lights.h:5-14): 112 B.
+ * type: 0 rect, 1 disc (no sampler/pdf in the reference), 2 sphere, 3 distant. */
+typedef struct skh_light
+{
+    float points[4][4];
+    float color[4];
+    float normal[4];
+    int32_t type;
+    float half_angle;
+    float pad0;
+    float pad1;
+} skh_light;
+
+/* Fixed-layout "MDL-equivalent" material argument block (replaces the MDL SDK generated argument
+ * block + PTX: OptixRender.cpp:1270-1433, materialmanager.cpp:524-609).  64 B. */
+enum
+{
+    SKH_MAT_DIFFUSE = 0, /* default.mdl::default_material(diffuse_color)  (OptixRender.cpp:1090-1097) */
+    SKH_MAT_PBR = 1, /* OmniPBR: diffuse_color_constant, reflection_roughness_constant, metallic_constant */
+    SKH_MAT_GLASS = 2, /* OmniGlass: glass_color, glass_ior (thin_walled = false) */
+    SKH_MAT_HAIR = 3 /* hair sub-expression (mdlPtxCodeGen.cpp:143-155) */
+};
+
+typedef struct skh_material
+{
+    uint32_t type; /* SKH_MAT_* */
+    float base_color[3];
+    float roughness;
+    float metallic;
+    float specular; /* specular_level, OmniPBR default 0.5 */
+    float ior;
+    float reserved[8];
+} skh_material;
+
+/* Per-launch constants == the subset of Params (OptixRenderParams.h:38-68) that render() fills
+ * every call (OptixRender.cpp:936-1004). Matrices are ROW-major (OptixRender.cpp:953-954). */
+typedef struct skh_frame_params
+{
+    float view_to_world[16];
+    float clip_to_view[16];
+    uint32_t subframe_index; /* Params::subframe_index      */
+    uint32_t samples_this_launch; /* Params::samples_per_launch  */
+    uint32_t spp_total; /* Params::maxSampleCount      */
+    uint32_t max_depth; /* Params::max_depth           */
+    uint32_t rect_light_sampling_method; /* 0 uniform, 1 spherical rectangle */
+    float exposure[3];
+    uint32_t enable_accumulation;
+    uint32_t debug; /* 0 none, 1 normals, 2 diffuse AOV, 3 specular AOV */
+    float shadow_ray_tmin;
+    float material_ray_tmin;
+} skh_frame_params;
+
+/* One ray for skh_trace (the optixTrace call sites: OptixRender.cu:120-129, closest_hit.cu:185-197). */
+typedef struct skh_ray
+{
+    float origin[3];
+    float tmin;
+    float dir[3];
+    float tmax;
+} skh_ray;
+
+/* What optixGetRayTmax / optixGetInstanceIndex / optixGetPrimitiveIndex /
+ * optixGetTriangleBarycentrics / optixGetCurveParameter return.  20 B. */
+typedef struct skh_hit
+{
+    float t; /* < 0 : miss */
+    uint32_t instance_id; /* 0xffffffff : miss */
+    uint32_t prim_id;
+    float u; /* triangle barycentric u, or curve parameter */
+    float v;
+} skh_hit;
+
+enum
+{
+    SKH_TRACE_CLOSEST = 0, /* visibility mask 255 (OptixRender.cu:124) */
+    SKH_TRACE_SHADOW = 1 /* RAY_MASK_SHADOW, terminate on first hit; hit.t = 1 if occluded, -1 if not */
+};
+
+enum
+{
+    SKH_BUILD_LBVH = 0,
+    SKH_BUILD_SAH = 1 /* LBVH followed by SAH-driven collapse/refit */
+};
+
+typedef struct skh_stats
+{
+    uint64_t rays_radiance; /* closest-hit rays actually traced since the last reset */
+    uint64_t rays_shadow; /* any-hit rays actually traced since the last reset */
+    uint64_t nodes_visited; /* counter build only (skh_set_option "count_traversal") */
+    uint64_t prims_tested; /* triangles */
+    uint64_t segs_tested; /* curve segments */
+    uint64_t instances_entered;
+    double ms_trace_closest; /* hipEvent time summed over launches since the last reset */
+    double ms_trace_shadow;
+    double ms_shade;
+    double ms_raygen;
+    double ms_accumulate;
+    double ms_build; /* last skh_build_accel */
+    uint32_t launches_trace_closest;
+    uint32_t launches_trace_shadow;
+    uint32_t launches_shade;
+    uint32_t launches_other;
+} skh_stats;
+
+/* ---- lifetime: RenderFactory::createRender + Render::init (render.cpp:10-35, OptixRender.cpp:1059-1105) ---- */
+skh_status skh_create(int device_ordinal, skh_context** out_ctx);
+void skh_destroy(skh_context* ctx);
+const char* skh_last_error(const skh_context* ctx);
+uint32_t skh_abi_version(void);
+
+/* ---- scene upload: createVertexBuffer/IndexBuffer/PointsBuffer/WidthsBuffer/LightBuffer
+ *      (OptixRender.cpp:1117-1189), reading oka::Scene getters (scene.h:229-327) ---- */
+skh_status skh_set_geometry(skh_context* ctx, const skh_vertex* verts, uint32_t n_verts, const uint32_t* indices,
+                            uint32_t n_indices, const skh_mesh* meshes, uint32_t n_meshes);
+skh_status skh_set_curves(skh_context* ctx, const float* points_xyz, uint32_t n_points, const float* radii,
+                          uint32_t n_radii, const uint32_t* vertex_counts, uint32_t n_vertex_counts,
+                          const skh_curve* curves, uint32_t n_curves);
+skh_status skh_set_instances(skh_context* ctx, const skh_instance* instances, uint32_t n_instances);
+skh_status skh_set_lights(skh_context* ctx, const skh_light* lights, uint32_t n_lights);
+skh_status skh_set_materials(skh_context* ctx, const skh_material* materials, uint32_t n_materials);
+
+/* ---- createAccelerationStructure (OptixRender.cpp:388-496): per-mesh / per-curve BLAS + one TLAS ---- */
+skh_status skh_build_accel(skh_context* ctx, uint32_t flags);
+
+/* ---- updatePathtracerParams (OptixRender.cpp:827-872): (re)allocates accum/AOV buffers, resets history ---- */
+skh_status skh_resize(skh_context* ctx, uint32_t width, uint32_t height);
+
+/* Multi-GPU pixel-tile ownership (new; the reference is single-GPU).  tile_xy holds n_tiles (x0,y0)
+ * pairs of tile_size x tile_size tiles this context renders; NULL / 0 = the whole image. */
+skh_status skh_set_tiles(skh_context* ctx, uint32_t tile_size, const uint32_t* tile_xy, uint32_t n_tiles);
+
+/* ---- OptiXRender::render's optixLaunch (OptixRender.cpp:1006-1021): one sub-frame batch.
+ *      d_image may be NULL (only accum is updated).  Synchronous, like the reference. ---- */
+skh_status skh_render_subframe(skh_context* ctx, const skh_frame_params* params, void* d_image);
+
+/* Convenience for benchmarks: n consecutive sub-frames of params->samples_this_launch samples each,
+ * starting at params->subframe_index, with a single device synchronisation at the end. */
+skh_status skh_render_subframes(skh_context* ctx, const skh_frame_params* params, uint32_t n_subframes,
+                                void* d_image);
+
+/* ---- the tonemap() + gammaCorrection post pass (postprocessing/Tonemappers.cu:111-135), in place on a
+ *      device float4 image.  type: 0 none, 1 Reinhard, 2 ACES fitted, 3 ACES film; gamma <= 0 = off ---- */
+skh_status skh_tonemap(skh_context* ctx, void* d_image, uint32_t width, uint32_t height, uint32_t type,
+                       const float exposure[3], float gamma);
+
+/* ---- read-back: Buffer::map (OptixBuffer.cpp:37-43) ---- */
+skh_status skh_read_accum(skh_context* ctx, float* host_rgba); /* W*H float4, row-major, row 0 = launch y 0 */
+skh_status skh_read_aov(skh_context* ctx, uint32_t which /*0 diffuse, 1 specular*/, float* host_rgba);
+skh_status skh_copy_accum(skh_context* ctx, void* d_dst_rgba); /* device-to-device, W*H float4 */
+/* compact tile accumulators of this context: n_tiles * tile_size^2 float4, tile-major (for the RCCL gather) */
+skh_status skh_copy_accum_tiles(skh_context* ctx, void* d_dst);
+/* scatter gathered compact tiles into a W*H float4 image (root side of the gather) */
+skh_status skh_scatter_tiles(skh_context* ctx, const void* d_src_tiles, const uint32_t* tile_xy, uint32_t n_tiles,
+                             uint32_t tile_size, void* d_dst_rgba, uint32_t width, uint32_t height);
+
+/* ---- ray queries against the built accel (the optixTrace call sites), for tests and micro-benchmarks.
+ *      rays/hits are HOST arrays. ---- */
+skh_status skh_trace(skh_context* ctx, const skh_ray* rays, uint32_t n_rays, uint32_t mode, skh_hit* hits);
+/* same on caller-owned DEVICE arrays, asynchronous on the context stream, repeated `repeat` times */
+skh_status skh_trace_device(skh_context* ctx, const void* d_rays, uint32_t n_rays, uint32_t mode, void* d_hits,
+                            uint32_t repeat);
+
+/* ---- options / stats ---- */
+skh_status skh_set_option(skh_context* ctx, const char* name, int64_t value);
+skh_status skh_get_stats(skh_context* ctx, skh_stats* out);
+skh_status skh_reset_stats(skh_context* ctx);
+skh_status skh_synchronize(skh_context* ctx);
+void* skh_get_stream(skh_context* ctx); /* hipStream_t the kernels are launched on */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRELKA_HIP_H */
