@@ -1,0 +1,200 @@
+"""ctypes binding of the C ABI in include/strelka_hip.h (libstrelka_hip.so, HIP / gfx950).
+
+This is the only way Python reaches the renderer: there is NO CPU fallback.  Loading fails loudly when the library
+has not been built (strelka_amd.build) and skh_create fails loudly when no GPU is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import scene as S
+from .build import LIB
+
+_lib = None
+
+STATS = np.dtype([("rays_radiance", np.uint64), ("rays_shadow", np.uint64), ("nodes_visited", np.uint64),
+                  ("prims_tested", np.uint64), ("segs_tested", np.uint64), ("instances_entered", np.uint64),
+                  ("ms_trace_closest", np.float64), ("ms_trace_shadow", np.float64), ("ms_shade", np.float64),
+                  ("ms_raygen", np.float64), ("ms_accumulate", np.float64), ("ms_build", np.float64),
+                  ("launches_trace_closest", np.uint32), ("launches_trace_shadow", np.uint32),
+                  ("launches_shade", np.uint32), ("launches_other", np.uint32)])
+
+SYMBOLS = ["skh_create", "skh_destroy", "skh_last_error", "skh_abi_version", "skh_set_geometry", "skh_set_curves",
+           "skh_set_instances", "skh_set_lights", "skh_set_materials", "skh_build_accel", "skh_resize", "skh_set_tiles",
+           "skh_render_subframe", "skh_render_subframes", "skh_tonemap", "skh_read_accum", "skh_read_aov",
+           "skh_copy_accum", "skh_copy_accum_tiles", "skh_scatter_tiles", "skh_trace", "skh_trace_device",
+           "skh_set_option", "skh_get_stats", "skh_reset_stats", "skh_synchronize", "skh_get_stream"]
+
+
+class SkhError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise SkhError(f"{LIB} is missing: build it with `python -m strelka_amd.build` (hipcc, gfx950). "
+                       "There is no CPU fallback.")
+    lib = C.CDLL(LIB)
+    vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int, C.c_float
+    lib.skh_create.argtypes = [i32, C.POINTER(vp)]
+    lib.skh_destroy.argtypes = [vp]
+    lib.skh_destroy.restype = None
+    lib.skh_last_error.argtypes = [vp]
+    lib.skh_last_error.restype = C.c_char_p
+    lib.skh_abi_version.restype = u32
+    lib.skh_set_geometry.argtypes = [vp, vp, u32, vp, u32, vp, u32]
+    lib.skh_set_curves.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, u32]
+    for n in ("skh_set_instances", "skh_set_lights", "skh_set_materials"):
+        getattr(lib, n).argtypes = [vp, vp, u32]
+    lib.skh_build_accel.argtypes = [vp, u32]
+    lib.skh_resize.argtypes = [vp, u32, u32]
+    lib.skh_set_tiles.argtypes = [vp, u32, vp, u32]
+    lib.skh_render_subframe.argtypes = [vp, vp, vp]
+    lib.skh_render_subframes.argtypes = [vp, vp, u32, vp]
+    lib.skh_tonemap.argtypes = [vp, vp, u32, u32, u32, vp, f32]
+    lib.skh_read_accum.argtypes = [vp, vp]
+    lib.skh_read_aov.argtypes = [vp, u32, vp]
+    lib.skh_copy_accum.argtypes = [vp, vp]
+    lib.skh_copy_accum_tiles.argtypes = [vp, vp]
+    lib.skh_scatter_tiles.argtypes = [vp, vp, vp, u32, u32, vp, u32, u32]
+    lib.skh_trace.argtypes = [vp, vp, u32, u32, vp]
+    lib.skh_trace_device.argtypes = [vp, vp, u32, u32, vp, u32]
+    lib.skh_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    lib.skh_get_stats.argtypes = [vp, vp]
+    lib.skh_reset_stats.argtypes = [vp]
+    lib.skh_synchronize.argtypes = [vp]
+    lib.skh_get_stream.argtypes = [vp]
+    lib.skh_get_stream.restype = vp
+    for n in SYMBOLS:
+        if n not in ("skh_destroy", "skh_last_error", "skh_abi_version", "skh_get_stream"):
+            getattr(lib, n).restype = i32
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One renderer context per GPU (skh_context).  Method names follow the C ABI."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        st = self.lib.skh_create(device, C.byref(h))
+        if st != 0 or not h:
+            raise SkhError(f"skh_create(device={device}) failed with status {st}: no usable MI355X/HIP device. "
+                           "This renderer has no CPU fallback.")
+        self.h = h
+        self.width = self.height = 0
+        self.tile_size = 32
+        self.tile_xy = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.skh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st, what):
+        if st != 0:
+            raise SkhError(f"{what} failed ({st}): {self.lib.skh_last_error(self.h).decode()}")
+
+    def set_scene(self, arr, build=True, flags=0):
+        L = self.lib
+        self._ck(L.skh_set_geometry(self.h, _p(arr["vertices"]), len(arr["vertices"]), _p(arr["indices"]),
+                                    len(arr["indices"]), _p(arr["meshes"]), len(arr["meshes"])), "skh_set_geometry")
+        if len(arr.get("curves", [])):
+            self._ck(L.skh_set_curves(self.h, _p(arr["curve_points"]), len(arr["curve_points"]), _p(arr["curve_radii"]),
+                                      len(arr["curve_radii"]), _p(arr["curve_vertex_counts"]),
+                                      len(arr["curve_vertex_counts"]), _p(arr["curves"]), len(arr["curves"])),
+                     "skh_set_curves")
+        self._ck(L.skh_set_instances(self.h, _p(arr["instances"]), len(arr["instances"])), "skh_set_instances")
+        self._ck(L.skh_set_lights(self.h, _p(arr["lights"]), len(arr["lights"])), "skh_set_lights")
+        self._ck(L.skh_set_materials(self.h, _p(arr["materials"]), len(arr["materials"])), "skh_set_materials")
+        if build:
+            self.build_accel(flags)
+
+    def build_accel(self, flags=0):
+        self._ck(self.lib.skh_build_accel(self.h, flags), "skh_build_accel")
+
+    def resize(self, w, h):
+        self.width, self.height = w, h
+        self._ck(self.lib.skh_resize(self.h, w, h), "skh_resize")
+
+    def set_tiles(self, tile_size, tile_xy=None):
+        self.tile_size = tile_size
+        if tile_xy is not None:
+            tile_xy = np.ascontiguousarray(tile_xy, np.uint32).reshape(-1, 2)
+        self.tile_xy = tile_xy
+        self._ck(self.lib.skh_set_tiles(self.h, tile_size, _p(tile_xy), 0 if tile_xy is None else len(tile_xy)),
+                 "skh_set_tiles")
+
+    def render_subframe(self, params, d_image=None):
+        p = np.ascontiguousarray(params, dtype=S.FRAME_PARAMS)
+        self._ck(self.lib.skh_render_subframe(self.h, _p(p), d_image), "skh_render_subframe")
+
+    def render_subframes(self, params, n, d_image=None):
+        p = np.ascontiguousarray(params, dtype=S.FRAME_PARAMS)
+        self._ck(self.lib.skh_render_subframes(self.h, _p(p), n, d_image), "skh_render_subframes")
+
+    def read_accum(self):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        self._ck(self.lib.skh_read_accum(self.h, _p(out)), "skh_read_accum")
+        return out
+
+    def read_aov(self, which):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        self._ck(self.lib.skh_read_aov(self.h, which, _p(out)), "skh_read_aov")
+        return out
+
+    def copy_accum(self, d_dst):
+        self._ck(self.lib.skh_copy_accum(self.h, d_dst), "skh_copy_accum")
+
+    def copy_accum_tiles(self, d_dst):
+        self._ck(self.lib.skh_copy_accum_tiles(self.h, d_dst), "skh_copy_accum_tiles")
+
+    def scatter_tiles(self, d_src, tile_xy, tile_size, d_dst, width, height):
+        t = np.ascontiguousarray(tile_xy, np.uint32).reshape(-1, 2)
+        self._ck(self.lib.skh_scatter_tiles(self.h, d_src, _p(t), len(t), tile_size, d_dst, width, height),
+                 "skh_scatter_tiles")
+
+    def tonemap(self, d_image, width, height, type_, exposure, gamma):
+        e = np.ascontiguousarray(exposure, np.float32)
+        self._ck(self.lib.skh_tonemap(self.h, d_image, width, height, type_, _p(e), gamma), "skh_tonemap")
+
+    def trace(self, rays, mode=0):
+        rays = np.ascontiguousarray(rays, dtype=S.RAY)
+        hits = np.zeros(len(rays), S.HIT)
+        self._ck(self.lib.skh_trace(self.h, _p(rays), len(rays), mode, _p(hits)), "skh_trace")
+        return hits
+
+    def trace_device(self, d_rays, n, mode, d_hits, repeat=1):
+        self._ck(self.lib.skh_trace_device(self.h, d_rays, n, mode, d_hits, repeat), "skh_trace_device")
+
+    def set_option(self, name, value):
+        self._ck(self.lib.skh_set_option(self.h, name.encode(), int(value)), f"skh_set_option({name})")
+
+    def stats(self):
+        s = np.zeros((), STATS)
+        self._ck(self.lib.skh_get_stats(self.h, _p(s)), "skh_get_stats")
+        return {k: (float(s[k]) if s[k].dtype.kind == "f" else int(s[k])) for k in STATS.names}
+
+    def reset_stats(self):
+        self._ck(self.lib.skh_reset_stats(self.h), "skh_reset_stats")
+
+    def synchronize(self):
+        self._ck(self.lib.skh_synchronize(self.h), "skh_synchronize")
+
+    def stream(self):
+        return self.lib.skh_get_stream(self.h)

@@ -1,0 +1,436 @@
+// strelka_hip -- LBVH construction on the GPU (gfx950).
+//
+// Replaces the optixAccelBuild call sites of the reference (src/render/optix/OptixRender.cpp:300,366,487):
+// one build over ALL triangles of all meshes (per-mesh BLAS = the radix-tree node covering exactly that mesh's
+// key range), one over all curve segments, one over the instances (TLAS).
+//
+// Pipeline (all kernels hand-written; no rocPRIM/hipCUB):
+//   k_group_bounds  per-group (mesh) AABB by ordered-uint atomics
+//   k_morton        30-bit Morton code of the primitive centroid inside its group's box; key = group:morton
+//   radix sort      8 bits per pass, stable: k_rs_hist -> k_rs_scan -> k_rs_scatter (wave-ballot multisplit)
+//   k_karras        Karras 2012 radix tree over the sorted keys (ties broken by index)
+//   k_refit         bottom-up AABBs, second-arriver pattern with agent-scope fences
+//   k_emit          collapse subtrees of <= leafMax primitives into leaves, write 64-byte BVH2 nodes that hold BOTH
+//                   children's boxes (one 64 B fetch per visited node), inflate boxes conservatively
+//   k_group_roots   find each group's root reference
+// Node layout (16 dwords): lmin.xyz lmax.xyz rmin.xyz rmax.xyz left right pad pad.
+// Child reference: >= 0 internal node index; < 0 leaf: ~ref = (first << 3) | (count - 1); INT_MIN is reserved.
+#pragma once
+#include "skh_device.h"
+
+namespace skh
+{
+
+struct Node64
+{
+    float lmin[3], lmax[3], rmin[3], rmax[3];
+    int left, right, pad0, pad1;
+};
+static_assert(sizeof(Node64) == 64, "node size");
+
+#define SKH_REF_INVALID 0x7fffffff
+#define SKH_REF_SENTINEL ((int)0x80000000)
+
+SKH_DI int make_leaf_ref(uint32_t first, uint32_t count)
+{
+    return ~(int)((first << 3) | (count - 1u));
+}
+SKH_DI uint32_t ordered_from_float(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+SKH_DI float float_from_ordered(uint32_t u)
+{
+    const uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(b);
+}
+SKH_DI uint32_t expand_bits10(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+// ---- per-primitive boxes -------------------------------------------------------------------------------
+// triangles: box of the three object-space positions; group = mesh id
+__global__ void k_tri_boxes(const uint8_t* __restrict__ verts /*32 B stride*/, const uint32_t* __restrict__ indices,
+                            const uint4* __restrict__ meshes /*index_offset,index_count,vertex_offset,vertex_count*/,
+                            const uint32_t* __restrict__ triMesh, const uint32_t* __restrict__ triLocal, uint32_t n,
+                            float4* __restrict__ boxLo, float4* __restrict__ boxHi, uint32_t* __restrict__ grp)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint32_t m = triMesh[i], t = triLocal[i];
+    const uint4 me = meshes[m];
+    v3 lo = mk3(INFINITY), hi = mk3(-INFINITY);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+        const uint32_t vi = me.z + indices[me.x + 3 * t + k];
+        const float* p = reinterpret_cast<const float*>(verts + (size_t)vi * 32);
+        lo = mk3(fminf(lo.x, p[0]), fminf(lo.y, p[1]), fminf(lo.z, p[2]));
+        hi = mk3(fmaxf(hi.x, p[0]), fmaxf(hi.y, p[1]), fmaxf(hi.z, p[2]));
+    }
+    boxLo[i] = make_float4(lo.x, lo.y, lo.z, 0.0f);
+    boxHi[i] = make_float4(hi.x, hi.y, hi.z, 0.0f);
+    grp[i] = m;
+}
+// curve segments: box of the 4 B-spline control points (convex hull property) grown by the largest radius
+__global__ void k_seg_boxes(const float* __restrict__ points, const float* __restrict__ radii,
+                            const uint32_t* __restrict__ segStart, const uint32_t* __restrict__ segCurve, uint32_t n,
+                            float4* __restrict__ boxLo, float4* __restrict__ boxHi, uint32_t* __restrict__ grp)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint32_t s = segStart[i];
+    v3 lo = mk3(INFINITY), hi = mk3(-INFINITY);
+    float rmax = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+        const float* p = points + 3 * (size_t)(s + k);
+        lo = mk3(fminf(lo.x, p[0]), fminf(lo.y, p[1]), fminf(lo.z, p[2]));
+        hi = mk3(fmaxf(hi.x, p[0]), fmaxf(hi.y, p[1]), fmaxf(hi.z, p[2]));
+        rmax = fmaxf(rmax, radii[s + k]);
+    }
+    boxLo[i] = make_float4(lo.x - rmax, lo.y - rmax, lo.z - rmax, 0.0f);
+    boxHi[i] = make_float4(hi.x + rmax, hi.y + rmax, hi.z + rmax, 0.0f);
+    grp[i] = segCurve[i];
+}
+
+__global__ void k_init_group_bounds(uint32_t* __restrict__ gb, uint32_t nGroups)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nGroups * 6)
+        gb[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
+}
+__global__ void k_group_bounds(const float4* __restrict__ boxLo, const float4* __restrict__ boxHi,
+                               const uint32_t* __restrict__ grp, uint32_t n, uint32_t* __restrict__ gb)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float4 lo = boxLo[i], hi = boxHi[i];
+    uint32_t* g = gb + 6 * (size_t)grp[i];
+    atomicMin(g + 0, ordered_from_float(lo.x));
+    atomicMin(g + 1, ordered_from_float(lo.y));
+    atomicMin(g + 2, ordered_from_float(lo.z));
+    atomicMax(g + 3, ordered_from_float(hi.x));
+    atomicMax(g + 4, ordered_from_float(hi.y));
+    atomicMax(g + 5, ordered_from_float(hi.z));
+}
+__global__ void k_decode_group_bounds(const uint32_t* __restrict__ gb, float* __restrict__ out, uint32_t nGroups)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nGroups * 6)
+        out[i] = float_from_ordered(gb[i]);
+}
+__global__ void k_morton(const float4* __restrict__ boxLo, const float4* __restrict__ boxHi, const uint32_t* __restrict__ grp,
+                         const float* __restrict__ gbounds, uint32_t n, uint64_t* __restrict__ keys,
+                         uint32_t* __restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float4 lo = boxLo[i], hi = boxHi[i];
+    const uint32_t g = grp[i];
+    const float* b = gbounds + 6 * (size_t)g;
+    const float cx = 0.5f * (lo.x + hi.x), cy = 0.5f * (lo.y + hi.y), cz = 0.5f * (lo.z + hi.z);
+    const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
+    const float nx = ex > 0.0f ? (cx - b[0]) / ex : 0.0f;
+    const float ny = ey > 0.0f ? (cy - b[1]) / ey : 0.0f;
+    const float nz = ez > 0.0f ? (cz - b[2]) / ez : 0.0f;
+    const uint32_t qx = (uint32_t)fminf(fmaxf(nx * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t qy = (uint32_t)fminf(fmaxf(ny * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t qz = (uint32_t)fminf(fmaxf(nz * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t code = (expand_bits10(qx) << 2) | (expand_bits10(qy) << 1) | expand_bits10(qz);
+    keys[i] = ((uint64_t)g << 32) | code;
+    vals[i] = i;
+}
+
+// ---- stable LSD radix sort, 8 bits per pass -----------------------------------------------------------------
+#define SKH_RS_THREADS 256
+#define SKH_RS_ITEMS 16 // elements per thread per block => 4096 elements per block
+
+__global__ void __launch_bounds__(SKH_RS_THREADS) k_rs_hist(const uint64_t* __restrict__ keys, uint32_t n, uint32_t shift,
+                                                           uint32_t* __restrict__ hist /*[256][numBlocks]*/,
+                                                           uint32_t numBlocks)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (SKH_RS_THREADS * SKH_RS_ITEMS);
+    for (int k = 0; k < SKH_RS_ITEMS; ++k)
+    {
+        const uint32_t i = base + k * SKH_RS_THREADS + threadIdx.x;
+        if (i < n)
+            atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * numBlocks + blockIdx.x] = h[threadIdx.x];
+}
+// exclusive scan of `count` uint32 in place, single workgroup of 1024 threads
+__global__ void __launch_bounds__(1024) k_rs_scan(uint32_t* __restrict__ data, uint32_t count)
+{
+    __shared__ uint32_t s[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0)
+        carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < count; base += 1024)
+    {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < count ? data[i] : 0u;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1)
+        {
+            const uint32_t t = threadIdx.x >= off ? s[threadIdx.x - off] : 0u;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const uint32_t incl = s[threadIdx.x];
+        const uint32_t c = carry;
+        if (i < count)
+            data[i] = c + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023)
+            carry = c + incl;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(SKH_RS_THREADS)
+    k_rs_scatter(const uint64_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, uint64_t* __restrict__ keysOut,
+                 uint32_t* __restrict__ valsOut, uint32_t n, uint32_t shift, const uint32_t* __restrict__ hist,
+                 uint32_t numBlocks)
+{
+    __shared__ uint32_t digitBase[256];
+    __shared__ uint32_t waveCount[4][256];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    digitBase[threadIdx.x] = hist[(size_t)threadIdx.x * numBlocks + blockIdx.x];
+    for (int w = 0; w < 4; ++w)
+        waveCount[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (SKH_RS_THREADS * SKH_RS_ITEMS);
+    for (int k = 0; k < SKH_RS_ITEMS; ++k)
+    {
+        const uint32_t i = base + k * SKH_RS_THREADS + threadIdx.x;
+        const bool valid = i < n;
+        const uint64_t key = valid ? keysIn[i] : 0ull;
+        const uint32_t val = valid ? valsIn[i] : 0u;
+        const uint32_t d = (uint32_t)(key >> shift) & 255u;
+        // wave-level multisplit: lanes with the same digit
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+        {
+            const unsigned long long m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const unsigned long long below = peers & ((1ull << lane) - 1ull);
+        const uint32_t rank = __popcll(below);
+        if (valid && below == 0ull)
+            waveCount[wave][d] = __popcll(peers);
+        __syncthreads();
+        if (valid)
+        {
+            uint32_t off = digitBase[d] + rank;
+            for (uint32_t w = 0; w < wave; ++w)
+                off += waveCount[w][d];
+            keysOut[off] = key;
+            valsOut[off] = val;
+        }
+        __syncthreads();
+        {
+            const uint32_t t = threadIdx.x;
+            digitBase[t] += waveCount[0][t] + waveCount[1][t] + waveCount[2][t] + waveCount[3][t];
+            waveCount[0][t] = waveCount[1][t] = waveCount[2][t] = waveCount[3][t] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- Karras 2012 ------------------------------------------------------------------------------------------
+SKH_DI int delta_keys(const uint64_t* __restrict__ keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n)
+        return -1;
+    const uint64_t a = keys[i], b = keys[j];
+    if (a == b)
+        return 64 + __clz((uint32_t)i ^ (uint32_t)j);
+    return __clzll((long long)(a ^ b));
+}
+// node ids: internal i in [0, n-2]; leaf j is id (n-1)+j
+__global__ void k_karras(const uint64_t* __restrict__ keys, int n, int* __restrict__ childL, int* __restrict__ childR,
+                         int* __restrict__ parent, int* __restrict__ rangeF, int* __restrict__ rangeL)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1)
+        return;
+    const int d = (delta_keys(keys, n, i, i + 1) - delta_keys(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta_keys(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta_keys(keys, n, i, i + lmax * d) > dmin)
+        lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta_keys(keys, n, i, i + (l + t) * d) > dmin)
+            l += t;
+    const int j = i + l * d;
+    const int dnode = delta_keys(keys, n, i, j);
+    int s = 0;
+    int t = l;
+    do
+    {
+        t = (t + 1) >> 1;
+        if (delta_keys(keys, n, i, i + (s + t) * d) > dnode)
+            s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const int first = min(i, j), last = max(i, j);
+    const int L = (first == gamma) ? (n - 1) + gamma : gamma;
+    const int R = (last == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
+    childL[i] = L;
+    childR[i] = R;
+    parent[L] = i;
+    parent[R] = i;
+    rangeF[i] = first;
+    rangeL[i] = last;
+    if (i == 0)
+        parent[0] = -1;
+}
+__global__ void k_refit(const uint32_t* __restrict__ sortedVals, const float4* __restrict__ boxLo,
+                        const float4* __restrict__ boxHi, const int* __restrict__ parent, const int* __restrict__ childL,
+                        const int* __restrict__ childR, uint32_t* __restrict__ flags, float4* __restrict__ nodeLo,
+                        float4* __restrict__ nodeHi, int n)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n)
+        return;
+    const uint32_t p = sortedVals[j];
+    float4 lo = boxLo[p], hi = boxHi[p];
+    int id = (n - 1) + j;
+    nodeLo[id] = lo;
+    nodeHi[id] = hi;
+    int cur = parent[id];
+    while (cur >= 0)
+    {
+        __threadfence(); // release our child's box (agent scope) before announcing arrival
+        const uint32_t old = atomicAdd(&flags[cur], 1u);
+        if (old == 0)
+            return; // first arriver leaves; the second one computes the node
+        __threadfence(); // acquire: the sibling's box was released before its atomic
+        const int other = (childL[cur] == id) ? childR[cur] : childL[cur];
+        const float4 olo = nodeLo[other];
+        const float4 ohi = nodeHi[other];
+        lo = make_float4(fminf(lo.x, olo.x), fminf(lo.y, olo.y), fminf(lo.z, olo.z), 0.0f);
+        hi = make_float4(fmaxf(hi.x, ohi.x), fmaxf(hi.y, ohi.y), fmaxf(hi.z, ohi.z), 0.0f);
+        nodeLo[cur] = lo;
+        nodeHi[cur] = hi;
+        id = cur;
+        cur = parent[cur];
+    }
+}
+SKH_DI void inflate_box(float4& lo, float4& hi)
+{
+    const float m = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(lo.y)), fmaxf(fabsf(lo.z), fabsf(hi.x))), fmaxf(fabsf(hi.y), fabsf(hi.z)));
+    const float e = m * 0x1p-20f + 1e-30f;
+    lo = make_float4(lo.x - e, lo.y - e, lo.z - e, 0.0f);
+    hi = make_float4(hi.x + e, hi.y + e, hi.z + e, 0.0f);
+}
+__global__ void k_emit(const int* __restrict__ childL, const int* __restrict__ childR, const int* __restrict__ rangeF,
+                       const int* __restrict__ rangeL, const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi,
+                       int n, int leafMax, Node64* __restrict__ nodes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1)
+        return;
+    Node64 nd;
+    int refs[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+    {
+        const int c = k == 0 ? childL[i] : childR[i];
+        float4 lo = nodeLo[c], hi = nodeHi[c];
+        inflate_box(lo, hi);
+        float* bmin = k == 0 ? nd.lmin : nd.rmin;
+        float* bmax = k == 0 ? nd.lmax : nd.rmax;
+        bmin[0] = lo.x, bmin[1] = lo.y, bmin[2] = lo.z;
+        bmax[0] = hi.x, bmax[1] = hi.y, bmax[2] = hi.z;
+        if (c >= n - 1)
+            refs[k] = make_leaf_ref((uint32_t)(c - (n - 1)), 1u);
+        else
+        {
+            const int cnt = rangeL[c] - rangeF[c] + 1;
+            refs[k] = cnt <= leafMax ? make_leaf_ref((uint32_t)rangeF[c], (uint32_t)cnt) : c;
+        }
+    }
+    nd.left = refs[0];
+    nd.right = refs[1];
+    nd.pad0 = nd.pad1 = 0;
+    nodes[i] = nd;
+}
+__global__ void k_group_roots(const int* __restrict__ rangeF, const int* __restrict__ rangeL,
+                              const uint64_t* __restrict__ sortedKeys, const uint32_t* __restrict__ groupFirst,
+                              const uint32_t* __restrict__ groupCount, int n, int leafMax, int* __restrict__ groupRoot)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1)
+        return;
+    const int f = rangeF[i], l = rangeL[i];
+    const uint32_t g = (uint32_t)(sortedKeys[f] >> 32);
+    if ((uint32_t)f == groupFirst[g] && (uint32_t)(l - f + 1) == groupCount[g] && (l - f + 1) > leafMax)
+        groupRoot[g] = i;
+}
+
+// gather triangles into leaf order: 48 B records {v0.xyz, primId | v1.xyz, 0 | v2.xyz, 0}
+__global__ void k_gather_tris(const uint8_t* __restrict__ verts, const uint32_t* __restrict__ indices,
+                              const uint4* __restrict__ meshes, const uint32_t* __restrict__ triMesh,
+                              const uint32_t* __restrict__ triLocal, const uint32_t* __restrict__ sortedVals, uint32_t n,
+                              float4* __restrict__ out)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n)
+        return;
+    const uint32_t i = sortedVals[j];
+    const uint32_t m = triMesh[i], t = triLocal[i];
+    const uint4 me = meshes[m];
+    float4 r[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+        const uint32_t vi = me.z + indices[me.x + 3 * t + k];
+        const float* p = reinterpret_cast<const float*>(verts + (size_t)vi * 32);
+        r[k] = make_float4(p[0], p[1], p[2], k == 0 ? __uint_as_float(t) : 0.0f);
+    }
+    out[3 * (size_t)j + 0] = r[0];
+    out[3 * (size_t)j + 1] = r[1];
+    out[3 * (size_t)j + 2] = r[2];
+}
+// gather curve segments into leaf order: 64 B records (4 x {xyz, radius}) + the segment's primitive index
+__global__ void k_gather_segs(const float* __restrict__ points, const float* __restrict__ radii,
+                              const uint32_t* __restrict__ segStart, const uint32_t* __restrict__ segLocal,
+                              const uint32_t* __restrict__ sortedVals, uint32_t n, float4* __restrict__ out,
+                              uint32_t* __restrict__ outPrim)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n)
+        return;
+    const uint32_t i = sortedVals[j];
+    const uint32_t s = segStart[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+        const float* p = points + 3 * (size_t)(s + k);
+        out[4 * (size_t)j + k] = make_float4(p[0], p[1], p[2], radii[s + k]);
+    }
+    outPrim[j] = segLocal[i];
+}
+
+} // namespace skh

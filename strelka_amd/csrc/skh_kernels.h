@@ -1,0 +1,1034 @@
+// strelka_hip -- the wavefront kernels (gfx950).
+//
+// One sub-frame of the reference's megakernel (__raygen__rg + hit programs, src/render/optix/OptixRender.cu:80-248,
+// OptixRender_radiance_closest_hit.cu:456-606) is split into per-bounce kernels over SoA queues in HBM:
+//
+//   k_raygen          camera rays for every owned pixel slot           -> ray queue[0]
+//   per bounce b:
+//     k_trace<closest> BVH traversal (TLAS -> instance -> BLAS)         ray queue[b] -> hit records
+//     k_shade          miss / light hit / surface hit: hit reconstruction, BSDF sample, next-event estimation,
+//                      Russian roulette, wave-ballot compaction          -> ray queue[b+1], shadow queue[b]
+//     k_trace<shadow>  any-hit traversal; un-occluded contributions are added to the path's radiance
+//   k_collect / k_finalize   per-pixel sample sums, AOVs, LDR-space accumulation (OptixRender.cu:60-78,169-247)
+//
+// Queue layout: SoA, one float/uint plane per field, so that a wave's 64 lanes read 256 contiguous bytes per
+// field.  Traversal stack: per-lane, 24 entries in LDS laid out [entry][lane] (conflict-free), spilling to a
+// per-thread global overflow area only for pathological depths.
+#pragma once
+#include "skh_bvh.h"
+
+namespace skh
+{
+
+struct DevInstance // 64 B: what traversal needs when it enters an instance
+{
+    float w2o[12];
+    int rootRef;
+    uint32_t mask; // GEOMETRY_MASK_* (OptixRenderParams.h:9-17); 0 = disabled (degenerate transform / empty geometry)
+    uint32_t type; // 0 mesh, 1 light, 2 curve
+    uint32_t pad;
+};
+struct HostInstance // == skh_instance (64 B), as uploaded
+{
+    float o2w[12];
+    uint32_t type, geom, material, light;
+};
+
+struct DevScene
+{
+    const Node64* tlasNodes;
+    const uint32_t* tlasInst; // leaf order -> instance id
+    int tlasRoot;
+    uint32_t numInstances;
+    const DevInstance* inst;
+    const Node64* triNodes;
+    const float4* tris; // 3 x float4 per triangle, leaf order
+    const Node64* segNodes;
+    const float4* segs; // 4 x float4 per segment, leaf order
+    const uint32_t* segPrim; // leaf order -> segment index inside its curve set
+    // shading side
+    const HostInstance* instances;
+    const uint8_t* verts;
+    const uint32_t* indices;
+    const uint4* meshes;
+    const uint32_t* curveSegBase; // per curve set: first entry in segStartAll
+    const uint32_t* segStartAll; // per segment: index of its first control point
+    const float* cpoints;
+    const float* cradii;
+    const Light* lights;
+    uint32_t numLights;
+    const Material* materials;
+    uint32_t numMaterials;
+};
+
+struct RayQ // SoA planes of `stride` elements: ox oy oz dx dy dz tmin tmax pathId  (36 B / ray)
+{
+    float* base;
+    uint32_t stride;
+    __device__ float* plane(int k) const
+    {
+        return base + (size_t)k * stride;
+    }
+    __device__ uint32_t* ids() const
+    {
+        return reinterpret_cast<uint32_t*>(base + (size_t)8 * stride);
+    }
+};
+struct HitQ // SoA: t inst prim u v  (20 B / hit)
+{
+    float* base;
+    uint32_t stride;
+};
+struct PathS // per path slot: throughput rgb, radiance rgb, lastBsdfPdf, flags
+{
+    float* base;
+    uint32_t stride;
+};
+enum
+{
+    PF_INSIDE = 1,
+    PF_SPECULAR = 2,
+    PF_EVENT_SHIFT = 2 // 2 bits: EventType (OptixRenderParams.h:70-77)
+};
+
+struct FrameP // skh_frame_params + launch geometry
+{
+    float viewToWorld[16];
+    float clipToView[16];
+    uint32_t subframeIndex, samplesThisLaunch, sppTotal, maxDepth, rectMethod;
+    float exposure[3];
+    uint32_t enableAccumulation, debug;
+    float shadowTmin, materialTmin;
+    uint32_t width, height, tileSize, tileShift, numTiles, numSlots;
+};
+
+#define SKH_STACK_LDS 24
+#define SKH_STACK_OVF 104
+#define SKH_TRACE_BLOCK 64
+
+struct TraceCounters
+{
+    uint32_t nodes, prims, segs, insts;
+};
+
+SKH_DI bool slab_test(const v3& lo, const v3& hi, const v3& o, const v3& inv, float tmin, float tmax, float& tnear)
+{
+    const float t0x = (lo.x - o.x) * inv.x, t1x = (hi.x - o.x) * inv.x;
+    const float t0y = (lo.y - o.y) * inv.y, t1y = (hi.y - o.y) * inv.y;
+    const float t0z = (lo.z - o.z) * inv.z, t1z = (hi.z - o.z) * inv.z;
+    const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+    const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+    tnear = tn;
+    return tn <= tf * 1.0000002384185791015625f;
+}
+
+struct HitRec
+{
+    float t;
+    uint32_t inst, prim;
+    float u, v;
+    bool found;
+};
+
+// Two-level traversal.  Closest hit: smallest t, ties broken by the smaller (instance, primitive) key, ray interval
+// open at both ends -- the result is independent of the BVH (DESIGN.md "determinism").
+template <bool ANY_HIT, bool COUNT>
+__device__ __forceinline__ void traverse(const DevScene& sc, const v3& ow, const v3& dw, float tmin, float tmax,
+                                         uint32_t mask, int* __restrict__ lds /* &stack[0][lane] */, int ldsStride,
+                                         int* __restrict__ ovf, uint32_t ovfStride, HitRec& best, TraceCounters& tc)
+{
+    best.t = tmax;
+    best.inst = 0xffffffffu;
+    best.prim = 0xffffffffu;
+    best.u = best.v = 0.0f;
+    best.found = false;
+    if (sc.tlasRoot == SKH_REF_INVALID)
+        return;
+    v3 o = ow, d = dw;
+    v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    RayShear sh;
+    const Node64* nodes = sc.tlasNodes;
+    bool inBlas = false;
+    uint32_t curInst = 0, curType = 0;
+    int sp = 0;
+    int cur = sc.tlasRoot;
+
+#define SKH_PUSH(v)                                        \
+    {                                                      \
+        if (sp < SKH_STACK_LDS)                            \
+            lds[sp * ldsStride] = (v);                     \
+        else if (sp < SKH_STACK_LDS + SKH_STACK_OVF)       \
+            ovf[(size_t)(sp - SKH_STACK_LDS) * ovfStride] = (v); \
+        ++sp;                                              \
+    }
+#define SKH_POP(dst)                                       \
+    {                                                      \
+        --sp;                                              \
+        if (sp < SKH_STACK_LDS)                            \
+            dst = lds[sp * ldsStride];                     \
+        else if (sp < SKH_STACK_LDS + SKH_STACK_OVF)       \
+            dst = ovf[(size_t)(sp - SKH_STACK_LDS) * ovfStride]; \
+        else                                               \
+            dst = SKH_REF_INVALID;                         \
+    }
+
+    for (;;)
+    {
+        // ---- descend through internal nodes ----
+        while (cur >= 0 && cur != SKH_REF_INVALID)
+        {
+            const float4* np = reinterpret_cast<const float4*>(nodes + cur);
+            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            if (COUNT)
+                tc.nodes++;
+            float tl, tr;
+            const bool hl = slab_test(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, inv, tmin, best.t, tl);
+            const bool hr = slab_test(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, inv, tmin, best.t, tr);
+            const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+            if (hl && hr)
+            {
+                const bool leftFirst = tl <= tr;
+                SKH_PUSH(leftFirst ? right : left);
+                cur = leftFirst ? left : right;
+            }
+            else if (hl)
+                cur = left;
+            else if (hr)
+                cur = right;
+            else
+                cur = SKH_REF_INVALID;
+        }
+        // ---- leaf ----
+        if (cur < 0 && cur != SKH_REF_SENTINEL)
+        {
+            const uint32_t enc = (uint32_t)~cur;
+            const uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
+            if (!inBlas)
+            {
+                // TLAS leaves hold exactly one instance
+                const uint32_t id = sc.tlasInst[first];
+                const float4* ip = reinterpret_cast<const float4*>(sc.inst + id);
+                const float4 i3 = ip[3];
+                const uint32_t imask = __float_as_uint(i3.y);
+                if (imask & mask)
+                {
+                    const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2];
+                    if (COUNT)
+                        tc.insts++;
+                    const float m[12] = { i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w };
+                    o = xform_point(m, ow);
+                    d = xform_vector(m, dw);
+                    inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    sh = make_shear(d);
+                    curInst = id;
+                    curType = __float_as_uint(i3.z);
+                    nodes = curType == 2 ? sc.segNodes : sc.triNodes;
+                    inBlas = true;
+                    SKH_PUSH(SKH_REF_SENTINEL);
+                    cur = __float_as_int(i3.x);
+                    continue;
+                }
+            }
+            else if (curType == 2)
+            {
+                for (uint32_t k = 0; k < count; ++k)
+                {
+                    const float4* cp = sc.segs + 4 * (size_t)(first + k);
+                    const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+                    if (COUNT)
+                        tc.segs++;
+                    v4 q[4];
+                    q[0] = mk4(c0.x, c0.y, c0.z, c0.w);
+                    q[1] = mk4(c1.x, c1.y, c1.z, c1.w);
+                    q[2] = mk4(c2.x, c2.y, c2.z, c2.w);
+                    q[3] = mk4(c3.x, c3.y, c3.z, c3.w);
+                    float t, u;
+                    if (intersect_curve_segment(o, d, tmin, best.t, q, t, u) && t < tmax)
+                    {
+                        const uint32_t prim = sc.segPrim[first + k];
+                        if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
+                        {
+                            best.t = t;
+                            best.inst = curInst;
+                            best.prim = prim;
+                            best.u = u;
+                            best.v = 0.0f;
+                            best.found = true;
+                            if (ANY_HIT)
+                                return;
+                        }
+                    }
+                }
+            }
+            else
+            {
+                for (uint32_t k = 0; k < count; ++k)
+                {
+                    const float4* tp = sc.tris + 3 * (size_t)(first + k);
+                    const float4 a = tp[0], b = tp[1], c = tp[2];
+                    if (COUNT)
+                        tc.prims++;
+                    float t, u, v;
+                    if (intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), t, u, v) && t < tmax)
+                    {
+                        const uint32_t prim = __float_as_uint(a.w);
+                        if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
+                        {
+                            best.t = t;
+                            best.inst = curInst;
+                            best.prim = prim;
+                            best.u = u;
+                            best.v = v;
+                            best.found = true;
+                            if (ANY_HIT)
+                                return;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- pop ----
+        for (;;)
+        {
+            if (sp == 0)
+                return;
+            SKH_POP(cur);
+            if (cur == SKH_REF_SENTINEL)
+            {
+                o = ow;
+                d = dw;
+                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                nodes = sc.tlasNodes;
+                inBlas = false;
+                continue;
+            }
+            break;
+        }
+    }
+#undef SKH_PUSH
+#undef SKH_POP
+}
+
+struct StatsDev
+{
+    unsigned long long raysRadiance, raysShadow, nodes, prims, segs, insts;
+};
+
+SKH_DI uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        v += __shfl_xor(v, off);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_trace: persistent waves; wave w takes 64-ray chunks w, w + W, ...  Blocks that share an XCD (blockIdx % 8,
+// observed round-robin placement) walk one contiguous eighth of the queue so their BVH working sets overlap in
+// that XCD's L2.  Placement only affects speed, never results.
+// ------------------------------------------------------------------------------------------------------------
+template <bool ANY_HIT, bool COUNT>
+__global__ void __launch_bounds__(SKH_TRACE_BLOCK)
+    k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, HitQ hq, PathS ps, const float* __restrict__ contrib,
+            uint32_t contribStride, int* __restrict__ ovf, StatsDev* __restrict__ stats)
+{
+    __shared__ int s_stack[SKH_STACK_LDS * SKH_TRACE_BLOCK];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n = *countPtr;
+    const uint32_t numChunks = (n + 63u) >> 6;
+    const uint32_t nb = gridDim.x;
+    // XCD-aware chunk order: block b handles chunks of "its" eighth first
+    const uint32_t xcd = blockIdx.x & 7u, within = blockIdx.x >> 3;
+    const uint32_t perXcdBlocks = (nb + 7u) >> 3;
+    const uint32_t chunksPerXcd = (numChunks + 7u) >> 3;
+    TraceCounters tc = { 0, 0, 0, 0 };
+    const uint32_t gtid = blockIdx.x * SKH_TRACE_BLOCK + lane;
+    const uint32_t ovfStride = nb * SKH_TRACE_BLOCK;
+    for (uint32_t c = within; c < chunksPerXcd; c += perXcdBlocks)
+    {
+        const uint32_t chunk = xcd * chunksPerXcd + c;
+        const uint32_t i = (chunk << 6) + lane;
+        if (chunk >= numChunks || i >= n)
+            continue;
+        const v3 o = mk3(rq.plane(0)[i], rq.plane(1)[i], rq.plane(2)[i]);
+        const v3 d = mk3(rq.plane(3)[i], rq.plane(4)[i], rq.plane(5)[i]);
+        const float tmin = rq.plane(6)[i], tmax = rq.plane(7)[i];
+        HitRec h;
+        traverse<ANY_HIT, COUNT>(sc, o, d, tmin, tmax, ANY_HIT ? 3u : 255u, s_stack + lane, SKH_TRACE_BLOCK, ovf + gtid,
+                                 ovfStride, h, tc);
+        if (ANY_HIT)
+        {
+            if (hq.base) // raw query mode (skh_trace): 1 = occluded, -1 = not
+                hq.base[i] = h.found ? 1.0f : -1.0f;
+            else if (!h.found)
+            {
+                const uint32_t pid = rq.ids()[i];
+                float* rad = ps.base + (size_t)3 * ps.stride;
+                rad[pid] += contrib[i];
+                rad[pid + ps.stride] += contrib[i + contribStride];
+                rad[pid + 2 * (size_t)ps.stride] += contrib[i + 2 * (size_t)contribStride];
+            }
+        }
+        else
+        {
+            hq.base[i] = h.found ? h.t : -1.0f;
+            reinterpret_cast<uint32_t*>(hq.base)[i + hq.stride] = h.inst;
+            reinterpret_cast<uint32_t*>(hq.base)[i + 2 * (size_t)hq.stride] = h.prim;
+            hq.base[i + 3 * (size_t)hq.stride] = h.u;
+            hq.base[i + 4 * (size_t)hq.stride] = h.v;
+        }
+    }
+    if (COUNT)
+    {
+        const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.prims), c2 = wave_sum(tc.segs), d2 = wave_sum(tc.insts);
+        if (lane == 0)
+        {
+            atomicAdd(&stats->nodes, (unsigned long long)a);
+            atomicAdd(&stats->prims, (unsigned long long)b);
+            atomicAdd(&stats->segs, (unsigned long long)c2);
+            atomicAdd(&stats->insts, (unsigned long long)d2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// slot <-> pixel: slot = tile * T^2 + morton(xl, yl): a wave's 64 lanes cover an 8x8 pixel block
+// ------------------------------------------------------------------------------------------------------------
+SKH_DI bool slot_to_pixel(const FrameP& fp, const uint32_t* __restrict__ tileXY, uint32_t slot, uint32_t& px, uint32_t& py)
+{
+    const uint32_t tile = slot >> (2 * fp.tileShift);
+    const uint32_t m = slot & ((1u << (2 * fp.tileShift)) - 1u);
+    px = tileXY[2 * tile] + compact1by1(m);
+    py = tileXY[2 * tile + 1] + compact1by1(m >> 1);
+    return px < fp.width && py < fp.height;
+}
+
+SKH_DI uint32_t wave_compact(bool emit, uint32_t* counter)
+{
+    const unsigned long long m = __ballot(emit);
+    if (m == 0ull)
+        return 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader)
+        base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+__global__ void __launch_bounds__(256) k_raygen(FrameP fp, const uint32_t* __restrict__ tileXY, uint32_t sampleOffset, RayQ rq,
+                                               uint32_t* __restrict__ counter, PathS ps)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t px = 0, py = 0;
+    const bool active = slot < fp.numSlots && slot_to_pixel(fp, tileXY, slot, px, py);
+    v3 o = mk3(0.0f), d = mk3(0.0f);
+    if (active)
+    {
+        const Sampler s = init_sampler(px, py, fp.subframeIndex + sampleOffset, fp.sppTotal, 52u); // OptixRender.cu:101
+        generate_camera_ray(px, py, fp.width, fp.height, fp.clipToView, fp.viewToWorld, sampler_random(s, DIM_PIXEL_X),
+                            sampler_random(s, DIM_PIXEL_Y), o, d);
+        // PerRayData init: OptixRender.cu:96-109
+        ps.base[slot] = 1.0f;
+        ps.base[slot + ps.stride] = 1.0f;
+        ps.base[slot + 2 * (size_t)ps.stride] = 1.0f;
+        ps.base[slot + 3 * (size_t)ps.stride] = 0.0f;
+        ps.base[slot + 4 * (size_t)ps.stride] = 0.0f;
+        ps.base[slot + 5 * (size_t)ps.stride] = 0.0f;
+        ps.base[slot + 6 * (size_t)ps.stride] = 0.0f; // lastBsdfPdf
+        reinterpret_cast<uint32_t*>(ps.base)[slot + 7 * (size_t)ps.stride] = 0u; // flags: outside, eUndef
+    }
+    const uint32_t idx = wave_compact(active, counter);
+    if (active)
+    {
+        rq.plane(0)[idx] = o.x;
+        rq.plane(1)[idx] = o.y;
+        rq.plane(2)[idx] = o.z;
+        rq.plane(3)[idx] = d.x;
+        rq.plane(4)[idx] = d.y;
+        rq.plane(5)[idx] = d.z;
+        rq.plane(6)[idx] = fp.materialTmin; // OptixRender.cu:121
+        rq.plane(7)[idx] = 1e16f; // OptixRender.cu:122
+        rq.ids()[idx] = slot;
+    }
+}
+
+struct SurfaceHit
+{
+    v3 position, normal, geom_normal;
+};
+
+// fillTriangleGeomData: closest_hit.cu:365-421 (position / shading normal / geometric normal; UVs and tangents are
+// only consumed by textured MDL materials, which this build does not have yet)
+SKH_DI SurfaceHit fill_triangle(const DevScene& sc, const HostInstance& hi, const float* w2o, uint32_t prim, float bu,
+                                float bv, bool inside)
+{
+    const uint4 me = sc.meshes[hi.geom];
+    const uint32_t i0 = sc.indices[me.x + prim * 3 + 0];
+    const uint32_t i1 = sc.indices[me.x + prim * 3 + 1];
+    const uint32_t i2 = sc.indices[me.x + prim * 3 + 2];
+    const float4* v0 = reinterpret_cast<const float4*>(sc.verts + (size_t)(me.z + i0) * 32);
+    const float4* v1 = reinterpret_cast<const float4*>(sc.verts + (size_t)(me.z + i1) * 32);
+    const float4* v2 = reinterpret_cast<const float4*>(sc.verts + (size_t)(me.z + i2) * 32);
+    const float4 a0 = v0[0], a1 = v0[1], b0 = v1[0], b1 = v1[1], c0 = v2[0], c1 = v2[1];
+    const v3 p0 = mk3(a0), p1 = mk3(b0), p2 = mk3(c0);
+    const v3 n0 = unpack_normal(__float_as_uint(a1.x)), n1 = unpack_normal(__float_as_uint(b1.x)),
+             n2 = unpack_normal(__float_as_uint(c1.x));
+    SurfaceHit s;
+    s.position = xform_point(hi.o2w, interpolate_attrib(p0, p1, p2, bu, bv));
+    const v3 object_normal = interpolate_attrib(n0, n1, n2, bu, bv);
+    const v3 worldNormal = normalize(xform_normal(w2o, object_normal));
+    v3 geomNormal = cross(p1 - p0, p2 - p0);
+    geomNormal = normalize(xform_normal(w2o, geomNormal));
+    const float flip = inside ? -1.0f : 1.0f;
+    s.geom_normal = geomNormal * flip;
+    s.normal = worldNormal * flip;
+    return s;
+}
+// fillCurveGeomData: closest_hit.cu:423-454
+SKH_DI SurfaceHit fill_curve(const DevScene& sc, const HostInstance& hi, const float* w2o, uint32_t prim, float u, float t,
+                             const v3& rayO, const v3& rayD, bool inside)
+{
+    const uint32_t s0 = sc.segStartAll[sc.curveSegBase[hi.geom] + prim];
+    v4 q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+        const float* p = sc.cpoints + 3 * (size_t)(s0 + k);
+        q[k] = mk4(p[0], p[1], p[2], sc.cradii[s0 + k]);
+    }
+    CubicPoly ip;
+    cubic_from_bspline(ip, q);
+    v3 hitPoint = rayO + t * rayD;
+    hitPoint = xform_point(w2o, hitPoint);
+    v3 worldNormal = normalize(xform_normal(w2o, curve_surface_normal(ip, u, hitPoint)));
+    worldNormal = worldNormal * (inside ? -1.0f : 1.0f);
+    SurfaceHit s;
+    s.position = xform_point(hi.o2w, hitPoint);
+    s.normal = worldNormal;
+    s.geom_normal = worldNormal;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_shade: __miss__ms (OptixRender.cu:250-257), __closesthit__light (:315-341), __closesthit__radiance
+// (closest_hit.cu:456-606) and the tail of the raygen bounce loop (OptixRender.cu:131-153) for one bounce.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_shade(DevScene sc, FrameP fp, uint32_t sampleOffset, uint32_t depth, const uint32_t* __restrict__ tileXY, RayQ rq,
+            const uint32_t* __restrict__ countPtr, HitQ hq, PathS ps, RayQ nextQ, uint32_t* __restrict__ nextCount, RayQ shadowQ,
+            float* __restrict__ contrib, uint32_t* __restrict__ shadowCount)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = *countPtr;
+    const bool valid = i < n;
+    bool emitNext = false, emitShadow = false;
+    v3 nextO = mk3(0.0f), nextD = mk3(0.0f), shO = mk3(0.0f), shD = mk3(0.0f), shC = mk3(0.0f);
+    float shTmax = 0.0f;
+    uint32_t pid = 0;
+    if (valid)
+    {
+        pid = rq.ids()[i];
+        const v3 rayO = mk3(rq.plane(0)[i], rq.plane(1)[i], rq.plane(2)[i]);
+        const v3 rayD = mk3(rq.plane(3)[i], rq.plane(4)[i], rq.plane(5)[i]);
+        const float ht = hq.base[i];
+        const uint32_t hinst = reinterpret_cast<const uint32_t*>(hq.base)[i + hq.stride];
+        const uint32_t hprim = reinterpret_cast<const uint32_t*>(hq.base)[i + 2 * (size_t)hq.stride];
+        const float hu = hq.base[i + 3 * (size_t)hq.stride], hv = hq.base[i + 4 * (size_t)hq.stride];
+        float* P = ps.base;
+        const size_t S = ps.stride;
+        v3 throughput = mk3(P[pid], P[pid + S], P[pid + 2 * S]);
+        v3 radiance = mk3(P[pid + 3 * S], P[pid + 4 * S], P[pid + 5 * S]);
+        float lastBsdfPdf = P[pid + 6 * S];
+        uint32_t flags = reinterpret_cast<uint32_t*>(P)[pid + 7 * S];
+        bool inside = (flags & PF_INSIDE) != 0;
+        bool specularBounce = (flags & PF_SPECULAR) != 0;
+        uint32_t firstEvent = (flags >> PF_EVENT_SHIFT) & 3u;
+        uint32_t px, py;
+        slot_to_pixel(fp, tileXY, pid, px, py);
+        Sampler smp = init_sampler(px, py, fp.subframeIndex + sampleOffset, fp.sppTotal, 52u);
+        smp.depth = depth; // prd.sampler.depth++ once per bounce (OptixRender.cu:153)
+        uint32_t prdDepth = depth;
+        v3 origin = rayO, dir = rayD; // prd.origin / prd.dir keep their old value when no hit program sets them
+
+        if (hinst == 0xffffffffu)
+        {
+            // __miss__ms: bg_color = 0 (OptixRender.cpp:739)
+            radiance = radiance + throughput * mk3(0.0f);
+            throughput = mk3(0.0f);
+            prdDepth = fp.maxDepth;
+        }
+        else
+        {
+            const HostInstance hi = sc.instances[hinst];
+            const float* w2o = sc.inst[hinst].w2o;
+            if (hi.type == 1)
+            {
+                // __closesthit__light
+                const Light& l = sc.lights[hi.light];
+                const v3 hitPoint = rayO + ht * rayD;
+                const v3 lightNormal = calc_light_normal(l, hitPoint);
+                if (-dot(rayD, lightNormal) > 0.0f)
+                {
+                    if (depth == 0 || specularBounce)
+                        radiance = radiance + throughput * mk3(l.color) * -dot(rayD, lightNormal);
+                    else
+                    {
+                        const float lightPdf = get_light_pdf(l, hitPoint, rayO) / (float)sc.numLights;
+                        const float misWeight = mis_weight_balance(lastBsdfPdf, lightPdf);
+                        radiance = radiance + throughput * mk3(l.color) * -dot(rayD, lightNormal) * misWeight;
+                    }
+                }
+                throughput = mk3(0.0f);
+            }
+            else
+            {
+                // __closesthit__radiance
+                const SurfaceHit sh = hi.type == 2 ? fill_curve(sc, hi, w2o, hprim, hu, ht, rayO, rayD, inside) :
+                                                     fill_triangle(sc, hi, w2o, hprim, hu, hv, inside);
+                if (fp.debug == 1)
+                    radiance = (sh.normal + mk3(1.0f)) * 0.5f;
+                else
+                {
+                    const uint32_t mid = hi.material == 0xffffffffu ? 0u : hi.material; // OptixRender.cpp:768
+                    const Material mat = sc.materials[mid < sc.numMaterials ? mid : 0u];
+                    const float xi0 = sampler_random(smp, DIM_BSDF0), xi1 = sampler_random(smp, DIM_BSDF1),
+                                xi2 = sampler_random(smp, DIM_BSDF2);
+                    const v3 k1 = -rayD;
+                    BsdfSample bs;
+                    bsdf_sample(mat, sh.normal, sh.geom_normal, k1, xi0, xi1, xi2, inside, bs);
+                    if (bs.event_type == EV_ABSORB)
+                    {
+                        if (depth == 0)
+                            firstEvent = 1; // eAbsorb
+                        throughput = mk3(0.0f);
+                    }
+                    else
+                    {
+                        specularBounce = (bs.event_type & EV_SPECULAR) != 0;
+                        if (depth == 0)
+                        {
+                            if (bs.event_type & EV_DIFFUSE)
+                                firstEvent = 2;
+                            if (bs.event_type & EV_GLOSSY)
+                                firstEvent = 3;
+                        }
+                        bool errorOut = false;
+                        if (bs.event_type & (EV_DIFFUSE | EV_GLOSSY))
+                        {
+                            // estimateDirectLighting + sampleLight: closest_hit.cu:260-324
+                            v3 toLight = mk3(0.0f);
+                            float lightPdf = 0.0f;
+                            v3 lrad = mk3(0.0f);
+                            bool wantShadow = false;
+                            float distToLight = 0.0f;
+                            if (sc.numLights > 0)
+                            {
+                                const float u = sampler_random(smp, DIM_LIGHT_ID);
+                                const uint32_t lightId = (uint32_t)((float)sc.numLights * u);
+                                const float lightSelectionPdf = 1.0f / (float)sc.numLights;
+                                const Light& light = sc.lights[lightId];
+                                const float ux = sampler_random(smp, DIM_LIGHT_X), uy = sampler_random(smp, DIM_LIGHT_Y);
+                                LightSample d;
+                                d.pointOnLight = mk3(0.0f);
+                                d.pdf = 0.0f;
+                                d.normal = mk3(0.0f);
+                                d.area = 0.0f;
+                                d.L = mk3(0.0f);
+                                d.distToLight = 0.0f;
+                                switch (light.type)
+                                {
+                                case 0:
+                                    d = fp.rectMethod == 0 ? sample_rect_light_uniform(light, ux, uy, sh.position) :
+                                                             sample_rect_light(light, ux, uy, sh.position);
+                                    break;
+                                case 2:
+                                    d = sample_sphere_light(light, ux, uy, sh.position);
+                                    break;
+                                case 3:
+                                    d = sample_distant_light(light, ux, uy);
+                                    break;
+                                default:
+                                    break;
+                                }
+                                toLight = d.L;
+                                const v3 Li = mk3(light.color);
+                                if (dot(sh.normal, d.L) > 0.0f && -dot(d.L, d.normal) > 0.0f && all3(Li))
+                                {
+                                    wantShadow = true;
+                                    distToLight = d.distToLight;
+                                    lightPdf = d.pdf;
+                                    lrad = 1.0f * Li * saturatef(dot(sh.normal, d.L)); // visibility applied by k_trace<shadow>
+                                }
+                                lightPdf *= lightSelectionPdf;
+                            }
+                            if (isnan3(lrad) || isnan(lightPdf))
+                            {
+                                radiance = mk3(10000.0f, 0.0f, 0.0f);
+                                throughput = mk3(0.0f);
+                                errorOut = true;
+                            }
+                            else
+                            {
+                                const bool isNextEventValid = ((dot(toLight, sh.normal) > 0.0f) != inside) && lightPdf != 0.0f;
+                                if (isNextEventValid)
+                                {
+                                    BsdfEval ev;
+                                    bsdf_evaluate(mat, sh.normal, sh.geom_normal, k1, toLight, ev);
+                                    if (isnan3(ev.bsdf_diffuse) || isnan3(ev.bsdf_glossy))
+                                    {
+                                        radiance = mk3(10000.0f, 0.0f, 0.0f);
+                                        throughput = mk3(0.0f);
+                                        errorOut = true;
+                                    }
+                                    else if (ev.pdf > 0.0f && wantShadow)
+                                    {
+                                        const v3 radianceOverPdf = lrad / lightPdf;
+                                        const float misWeight = mis_weight_balance(lightPdf, ev.pdf);
+                                        shC = throughput * radianceOverPdf * misWeight * (ev.bsdf_diffuse + ev.bsdf_glossy);
+                                        shO = offset_ray(sh.position, sh.geom_normal);
+                                        shD = toLight;
+                                        shTmax = distToLight;
+                                        emitShadow = true;
+                                    }
+                                }
+                            }
+                        }
+                        if (!errorOut)
+                        {
+                            if (bs.event_type & EV_TRANSMISSION)
+                            {
+                                inside = !inside;
+                                origin = offset_ray(sh.position, -sh.geom_normal);
+                            }
+                            else
+                                origin = offset_ray(sh.position, sh.geom_normal);
+                            lastBsdfPdf = specularBounce ? 1.0f : bs.pdf;
+                            dir = bs.k2;
+                            throughput = throughput * bs.bsdf_over_pdf;
+                        }
+                    }
+                }
+            }
+        }
+        // tail of the bounce loop: OptixRender.cu:131-153
+        bool alive = true;
+        if (prdDepth > 3)
+        {
+            const float p = fmaxf(throughput.x, fmaxf(throughput.y, throughput.z));
+            if (sampler_random(smp, DIM_RR) > p)
+                alive = false;
+            else
+                throughput = throughput * (1.0f / (p + 1e-5f));
+        }
+        if (alive && dot(throughput, throughput) < 1e-5f)
+            alive = false;
+        if (alive)
+        {
+            ++prdDepth;
+            if (fp.debug == 1)
+                alive = false;
+        }
+        if (alive && prdDepth >= fp.maxDepth)
+            alive = false;
+        emitNext = alive;
+        nextO = origin;
+        nextD = dir;
+        // write back path state
+        P[pid] = throughput.x;
+        P[pid + S] = throughput.y;
+        P[pid + 2 * S] = throughput.z;
+        P[pid + 3 * S] = radiance.x;
+        P[pid + 4 * S] = radiance.y;
+        P[pid + 5 * S] = radiance.z;
+        P[pid + 6 * S] = lastBsdfPdf;
+        reinterpret_cast<uint32_t*>(P)[pid + 7 * S] =
+            (inside ? PF_INSIDE : 0u) | (specularBounce ? PF_SPECULAR : 0u) | (firstEvent << PF_EVENT_SHIFT);
+    }
+    // stream compaction of live paths / shadow rays: one atomic per wave
+    const uint32_t ni = wave_compact(emitNext, nextCount);
+    if (emitNext)
+    {
+        nextQ.plane(0)[ni] = nextO.x;
+        nextQ.plane(1)[ni] = nextO.y;
+        nextQ.plane(2)[ni] = nextO.z;
+        nextQ.plane(3)[ni] = nextD.x;
+        nextQ.plane(4)[ni] = nextD.y;
+        nextQ.plane(5)[ni] = nextD.z;
+        nextQ.plane(6)[ni] = fp.materialTmin;
+        nextQ.plane(7)[ni] = 1e16f;
+        nextQ.ids()[ni] = pid;
+    }
+    const uint32_t si = wave_compact(emitShadow, shadowCount);
+    if (emitShadow)
+    {
+        shadowQ.plane(0)[si] = shO.x;
+        shadowQ.plane(1)[si] = shO.y;
+        shadowQ.plane(2)[si] = shO.z;
+        shadowQ.plane(3)[si] = shD.x;
+        shadowQ.plane(4)[si] = shD.y;
+        shadowQ.plane(5)[si] = shD.z;
+        shadowQ.plane(6)[si] = fp.shadowTmin;
+        shadowQ.plane(7)[si] = shTmax;
+        shadowQ.ids()[si] = pid;
+        contrib[si] = shC.x;
+        contrib[si + shadowQ.stride] = shC.y;
+        contrib[si + 2 * (size_t)shadowQ.stride] = shC.z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// per-pixel sample sums (the `result += prd.radiance` loop of OptixRender.cu:154-167) and the AOV / accumulation
+// epilogue (OptixRender.cu:169-247).  sums: result rgb, diffuse rgb, specular rgb, diffuseSamples, specularSamples
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_collect(FrameP fp, const uint32_t* __restrict__ tileXY, uint32_t sampleOffset, PathS ps,
+                                                float* __restrict__ sums)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t px, py;
+    if (slot >= fp.numSlots || !slot_to_pixel(fp, tileXY, slot, px, py))
+        return;
+    const size_t S = ps.stride, N = fp.numSlots;
+    const v3 rad = mk3(ps.base[slot + 3 * S], ps.base[slot + 4 * S], ps.base[slot + 5 * S]);
+    const uint32_t fe = (reinterpret_cast<const uint32_t*>(ps.base)[slot + 7 * S] >> PF_EVENT_SHIFT) & 3u;
+    float v[11];
+    if (sampleOffset == 0)
+    {
+#pragma unroll
+        for (int k = 0; k < 11; ++k)
+            v[k] = 0.0f;
+    }
+    else
+    {
+#pragma unroll
+        for (int k = 0; k < 11; ++k)
+            v[k] = sums[slot + k * N];
+    }
+    v[0] += rad.x, v[1] += rad.y, v[2] += rad.z;
+    if (fe == 2)
+    {
+        v[3] += rad.x, v[4] += rad.y, v[5] += rad.z;
+        v[9] += 1.0f;
+    }
+    if (fe == 3)
+    {
+        v[6] += rad.x, v[7] += rad.y, v[8] += rad.z;
+        v[10] += 1.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 11; ++k)
+        sums[slot + k * N] = v[k];
+}
+
+__global__ void __launch_bounds__(256)
+    k_finalize(FrameP fp, const uint32_t* __restrict__ tileXY, const float* __restrict__ sums, float4* __restrict__ accum,
+               float4* __restrict__ diffuse, float4* __restrict__ specular, uint16_t* __restrict__ diffuseCounter,
+               uint16_t* __restrict__ specularCounter, float4* __restrict__ image)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t px, py;
+    if (slot >= fp.numSlots || !slot_to_pixel(fp, tileXY, slot, px, py))
+        return;
+    const size_t N = fp.numSlots;
+    const v3 exposure = mk3(fp.exposure[0], fp.exposure[1], fp.exposure[2]);
+    v3 result = mk3(sums[slot], sums[slot + N], sums[slot + 2 * N]);
+    v3 dsum = mk3(sums[slot + 3 * N], sums[slot + 4 * N], sums[slot + 5 * N]);
+    v3 ssum = mk3(sums[slot + 6 * N], sums[slot + 7 * N], sums[slot + 8 * N]);
+    const uint32_t diffuseSamples = (uint32_t)sums[slot + 9 * N], specularSamples = (uint32_t)sums[slot + 10 * N];
+    result = result / (float)fp.samplesThisLaunch;
+    float4 diffuseOut = make_float4(0.0f, 0.0f, 0.0f, 1.0f), specularOut = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    if (diffuseSamples > 0)
+    {
+        dsum = dsum / (float)diffuseSamples;
+        const uint32_t prev = fp.subframeIndex > 0 ? diffuseCounter[slot] : 0u;
+        const float4 h = diffuse[slot];
+        const v3 a = accumulate(mk3(h), dsum, exposure, prev);
+        diffuseOut = make_float4(a.x, a.y, a.z, 1.0f);
+        diffuse[slot] = diffuseOut;
+        diffuseCounter[slot] = (uint16_t)(prev + diffuseSamples);
+    }
+    else
+    {
+        if (fp.subframeIndex == 0)
+        {
+            diffuse[slot] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            diffuseCounter[slot] = 0;
+        }
+        diffuseOut = diffuse[slot];
+    }
+    if (specularSamples > 0)
+    {
+        ssum = ssum / (float)specularSamples;
+        const uint32_t prev = fp.subframeIndex > 0 ? specularCounter[slot] : 0u;
+        const float4 h = specular[slot];
+        const v3 a = accumulate(mk3(h), ssum, exposure, prev);
+        specularOut = make_float4(a.x, a.y, a.z, 1.0f);
+        specular[slot] = specularOut;
+        specularCounter[slot] = (uint16_t)(prev + specularSamples);
+    }
+    else
+    {
+        if (fp.subframeIndex == 0)
+        {
+            specular[slot] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            specularCounter[slot] = 0;
+        }
+        if (specularCounter[slot] > 0)
+            specularOut = specular[slot];
+    }
+    float4 out;
+    if (fp.debug == 2)
+        out = diffuseOut;
+    else if (fp.debug == 3)
+        out = specularOut;
+    else if (fp.enableAccumulation && fp.debug == 0)
+    {
+        const float4 h = accum[slot];
+        const v3 a = accumulate(mk3(h), result, exposure, fp.subframeIndex);
+        out = make_float4(a.x, a.y, a.z, 1.0f);
+        accum[slot] = out;
+    }
+    else
+        out = make_float4(result.x, result.y, result.z, 1.0f);
+    if (image)
+        image[(size_t)py * fp.width + px] = out;
+}
+
+// compact tile-major slots -> row-major W x H image (and back-end of the multi-GPU gather)
+__global__ void __launch_bounds__(256) k_detile(const float4* __restrict__ src, const uint32_t* __restrict__ tileXY,
+                                               uint32_t numSlots, uint32_t tileShift, uint32_t width, uint32_t height,
+                                               float4* __restrict__ dst)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= numSlots)
+        return;
+    const uint32_t tile = slot >> (2 * tileShift);
+    const uint32_t m = slot & ((1u << (2 * tileShift)) - 1u);
+    const uint32_t px = tileXY[2 * tile] + compact1by1(m), py = tileXY[2 * tile + 1] + compact1by1(m >> 1);
+    if (px < width && py < height)
+        dst[(size_t)py * width + px] = src[slot];
+}
+
+__global__ void k_add_stats(const uint32_t* __restrict__ counts, uint32_t numBounces, StatsDev* __restrict__ stats)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        unsigned long long r = 0, s = 0;
+        for (uint32_t b = 0; b < numBounces; ++b)
+        {
+            r += counts[2 * b];
+            s += counts[2 * b + 1];
+        }
+        stats->raysRadiance += r;
+        stats->raysShadow += s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Post: postprocessing/Tonemappers.cu:6-135 (Reinhard / ACES fitted / ACES film + gamma), in place
+// ------------------------------------------------------------------------------------------------------------
+SKH_DI v3 tm_reinhard(const v3& c)
+{
+    const float lum = dot(c, mk3(0.299f, 0.587f, 0.114f));
+    return c / (lum + 1);
+}
+SKH_DI v3 tm_aces_film(const v3& x)
+{
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    const v3 r = (x * (a * x + mk3(b))) / (x * (c * x + mk3(d)) + mk3(e));
+    return mk3(saturatef(r.x), saturatef(r.y), saturatef(r.z));
+}
+SKH_DI v3 tm_aces_fitted(v3 color)
+{
+    const float in[9] = { 0.59719f, 0.35458f, 0.04823f, 0.07600f, 0.90834f, 0.01566f, 0.02840f, 0.13383f, 0.83777f };
+    const float out[9] = { 1.60475f, -0.53108f, -0.07367f, -0.10208f, 1.10813f, -0.00605f, -0.00327f, -0.07276f, 1.07602f };
+    v3 c = mk3(in[0] * color.x + in[1] * color.y + in[2] * color.z, in[3] * color.x + in[4] * color.y + in[5] * color.z,
+               in[6] * color.x + in[7] * color.y + in[8] * color.z);
+    const v3 a = c * (c + mk3(0.0245786f)) - mk3(0.000090537f);
+    const v3 b = c * (0.983729f * c + mk3(0.4329510f)) + mk3(0.238081f);
+    c = a / b;
+    const v3 o = mk3(out[0] * c.x + out[1] * c.y + out[2] * c.z, out[3] * c.x + out[4] * c.y + out[5] * c.z,
+                     out[6] * c.x + out[7] * c.y + out[8] * c.z);
+    return mk3(saturatef(o.x), saturatef(o.y), saturatef(o.z));
+}
+__global__ void __launch_bounds__(256) k_tonemap(float4* __restrict__ image, uint32_t n, uint32_t type, float ex, float ey, float ez,
+                                                float gamma)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    float4 px = image[i];
+    v3 c = mk3(px.x, px.y, px.z);
+    if (type >= 1 && type <= 3)
+    {
+        const v3 r = c * mk3(ex, ey, ez);
+        c = type == 1 ? tm_reinhard(r) : (type == 2 ? tm_aces_fitted(r) : tm_aces_film(r));
+        px.w = 1.0f;
+    }
+    if (gamma > 0.0f)
+    {
+        const float g = 1.0f / gamma;
+        c = mk3(powf(c.x, g), powf(c.y, g), powf(c.z, g));
+        px.w = 1.0f;
+    }
+    image[i] = make_float4(c.x, c.y, c.z, px.w);
+}
+
+// instance records: transform the BLAS root box into world space (TLAS primitive box) and fill DevInstance
+__global__ void k_instance_boxes(const HostInstance* __restrict__ instances, const float* __restrict__ w2oAll /*12 per inst*/,
+                                 const uint8_t* __restrict__ validAll, const float* __restrict__ triGroupBounds,
+                                 const int* __restrict__ triGroupRoot, const float* __restrict__ segGroupBounds,
+                                 const int* __restrict__ segGroupRoot, uint32_t nMeshes, uint32_t nCurves, uint32_t n,
+                                 DevInstance* __restrict__ out, float4* __restrict__ boxLo, float4* __restrict__ boxHi,
+                                 uint32_t* __restrict__ grp)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const HostInstance in = instances[i];
+    DevInstance d;
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+        d.w2o[k] = w2oAll[12 * (size_t)i + k];
+    d.type = in.type;
+    d.pad = 0;
+    d.mask = in.type == 0 ? 1u : (in.type == 2 ? 2u : 4u);
+    const bool isCurve = in.type == 2;
+    const bool has = isCurve ? (in.geom < nCurves) : (in.geom < nMeshes);
+    int root = SKH_REF_INVALID;
+    const float* gb = nullptr;
+    if (has)
+    {
+        root = isCurve ? segGroupRoot[in.geom] : triGroupRoot[in.geom];
+        gb = (isCurve ? segGroupBounds : triGroupBounds) + 6 * (size_t)in.geom;
+    }
+    bool valid = validAll[i] != 0 && root != SKH_REF_INVALID;
+    d.rootRef = root;
+    float4 lo = make_float4(0.0f, 0.0f, 0.0f, 0.0f), hi = lo;
+    if (valid)
+    {
+        v3 wlo = mk3(INFINITY), whi = mk3(-INFINITY);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+        {
+            const v3 p = mk3((k & 1) ? gb[3] : gb[0], (k & 2) ? gb[4] : gb[1], (k & 4) ? gb[5] : gb[2]);
+            const v3 w = xform_point(in.o2w, p);
+            wlo = mk3(fminf(wlo.x, w.x), fminf(wlo.y, w.y), fminf(wlo.z, w.z));
+            whi = mk3(fmaxf(whi.x, w.x), fmaxf(whi.y, w.y), fmaxf(whi.z, w.z));
+        }
+        lo = make_float4(wlo.x, wlo.y, wlo.z, 0.0f);
+        hi = make_float4(whi.x, whi.y, whi.z, 0.0f);
+        // the BLAS boxes are inflated by 2^-20 relative; cover that and the transform rounding
+        inflate_box(lo, hi);
+        inflate_box(lo, hi);
+    }
+    else
+        d.mask = 0;
+    out[i] = d;
+    boxLo[i] = lo;
+    boxHi[i] = hi;
+    grp[i] = 0;
+}
+
+} // namespace skh

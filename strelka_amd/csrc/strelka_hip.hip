@@ -1,0 +1,1198 @@
+// strelka_hip -- host side of the C ABI declared in include/strelka_hip.h (gfx950 / ROCm only).
+// One translation unit: device code comes from skh_device.h / skh_bvh.h / skh_kernels.h.
+#include "../../include/strelka_hip.h"
+#include "skh_kernels.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace skh;
+
+static_assert(sizeof(skh_vertex) == 32 && sizeof(skh_instance) == 64 && sizeof(skh_light) == 112, "ABI layout");
+static_assert(sizeof(skh_material) == 64 && sizeof(skh_frame_params) == 176 && sizeof(skh_ray) == 32, "ABI layout");
+static_assert(sizeof(skh_hit) == 20 && sizeof(Light) == 112 && sizeof(Material) == 64 && sizeof(HostInstance) == 64, "layout");
+
+namespace
+{
+struct DevBuf
+{
+    void* p = nullptr;
+    size_t bytes = 0;
+    template <typename T>
+    T* as() const
+    {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+enum KernelClass
+{
+    KC_TRACE_CLOSEST = 0,
+    KC_TRACE_SHADOW,
+    KC_SHADE,
+    KC_RAYGEN,
+    KC_ACCUM,
+    KC_COUNT
+};
+
+struct TimedSpan
+{
+    int cls;
+    hipEvent_t a, b;
+};
+} // namespace
+
+struct skh_context
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int numCUs = 256;
+
+    // scene (host copies needed for the build)
+    std::vector<skh_mesh> meshes;
+    std::vector<skh_curve> curves;
+    std::vector<uint32_t> curveVertexCounts;
+    uint32_t nVerts = 0, nIndices = 0, nPoints = 0, nInstances = 0, nLights = 0, nMaterials = 0;
+    std::vector<skh_instance> instances;
+
+    DevBuf dVerts, dIndices, dMeshes, dPoints, dRadii, dInstances, dLights, dMaterials;
+    DevBuf dCurveSegBase, dSegStartAll;
+    // accel
+    DevBuf dTriNodes, dTris, dSegNodes, dSegs, dSegPrim, dTlasNodes, dTlasInst, dDevInst;
+    int tlasRoot = SKH_REF_INVALID;
+    bool accelBuilt = false;
+    uint32_t nTris = 0, nSegs = 0;
+
+    // frame
+    uint32_t width = 0, height = 0, tileSize = 32, tileShift = 5, numTiles = 0, numSlots = 0;
+    std::vector<uint32_t> tileXY;
+    bool customTiles = false;
+    DevBuf dTileXY, dAccum, dDiffuse, dSpecular, dDiffCnt, dSpecCnt, dSums, dPath, dRayQ[2], dHits, dShadowQ, dContrib, dCounts,
+        dOvf, dStats, dScratchImage;
+    uint32_t traceBlocks = 0;
+    bool countTraversal = false, timing = false;
+    uint32_t wavesPerCU = 16;
+
+    // timing
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> eventPool;
+    size_t eventsUsed = 0;
+    double msClass[KC_COUNT] = { 0, 0, 0, 0, 0 };
+    uint32_t launches[KC_COUNT] = { 0, 0, 0, 0, 0 };
+    double msBuild = 0.0;
+};
+
+#define SKH_TRY(ctx, expr)                                                                                              \
+    do                                                                                                                  \
+    {                                                                                                                   \
+        hipError_t _e = (expr);                                                                                         \
+        if (_e != hipSuccess)                                                                                           \
+        {                                                                                                               \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                                            \
+            return _e == hipErrorOutOfMemory ? SKH_OUT_OF_MEMORY : SKH_FAIL;                                           \
+        }                                                                                                               \
+    } while (0)
+
+static skh_status dev_alloc(skh_context* c, DevBuf& b, size_t bytes)
+{
+    if (b.p && b.bytes >= bytes && b.bytes <= bytes * 2 + 4096)
+        return SKH_OK;
+    if (b.p)
+    {
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    if (bytes == 0)
+        bytes = 16;
+    SKH_TRY(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return SKH_OK;
+}
+static skh_status dev_upload(skh_context* c, DevBuf& b, const void* src, size_t bytes)
+{
+    skh_status s = dev_alloc(c, b, bytes);
+    if (s != SKH_OK)
+        return s;
+    if (bytes)
+        SKH_TRY(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    SKH_TRY(c, hipStreamSynchronize(c->stream));
+    return SKH_OK;
+}
+static void dev_free(DevBuf& b)
+{
+    if (b.p)
+        (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+// Sobol generator matrices for the 5 dimensions the reference tabulates (RandomSampler.h:139-164), produced from the
+// Joe-Kuo recurrences (d=2: s=1 a=0 m={1}; d=3: s=2 a=1 m={1,3}; d=4: s=3 a=1 m={1,3,1}; d=5: s=3 a=2 m={1,1,1}).
+static void init_sobol_table(uint32_t tab[5][32])
+{
+    for (int i = 0; i < 32; ++i)
+        tab[0][i] = 1u << (31 - i);
+    const int S[4] = { 1, 2, 3, 3 };
+    const uint32_t A[4] = { 0, 1, 1, 2 };
+    const uint32_t M[4][3] = { { 1, 0, 0 }, { 1, 3, 0 }, { 1, 3, 1 }, { 1, 1, 1 } };
+    for (int d = 0; d < 4; ++d)
+    {
+        uint32_t* v = tab[d + 1];
+        const int s = S[d];
+        for (int i = 0; i < s; ++i)
+            v[i] = M[d][i] << (31 - i);
+        for (int i = s; i < 32; ++i)
+        {
+            uint32_t x = v[i - s] ^ (v[i - s] >> s);
+            for (int k = 1; k < s; ++k)
+                if ((A[d] >> (s - 1 - k)) & 1u)
+                    x ^= v[i - k];
+            v[i] = x;
+        }
+    }
+}
+
+// world->object of an affine 3x4, fp64 adjugate, one rounding to fp32 (DESIGN.md "instance transforms")
+static bool invert_affine(const float* m, float* out)
+{
+    const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    const double tx = m[3], ty = m[7], tz = m[11];
+    const double A = e * i - f * h, B = c * h - b * i, C = b * f - c * e;
+    const double D = f * g - d * i, E = a * i - c * g, F = c * d - a * f;
+    const double G = d * h - e * g, H = b * g - a * h, I = a * e - b * d;
+    const double det = a * A + b * D + c * G;
+    const double r = 1.0 / det;
+    const double i00 = A * r, i01 = B * r, i02 = C * r, i10 = D * r, i11 = E * r, i12 = F * r, i20 = G * r, i21 = H * r, i22 = I * r;
+    out[0] = (float)i00, out[1] = (float)i01, out[2] = (float)i02, out[3] = (float)(-(i00 * tx + i01 * ty + i02 * tz));
+    out[4] = (float)i10, out[5] = (float)i11, out[6] = (float)i12, out[7] = (float)(-(i10 * tx + i11 * ty + i12 * tz));
+    out[8] = (float)i20, out[9] = (float)i21, out[10] = (float)i22, out[11] = (float)(-(i20 * tx + i21 * ty + i22 * tz));
+    bool finite = true;
+    for (int k = 0; k < 12; ++k)
+        finite = finite && std::isfinite(out[k]);
+    return finite;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// generic LBVH build over n primitives with boxes + group ids already on the device
+// ---------------------------------------------------------------------------------------------------------------
+struct LbvhOut
+{
+    DevBuf nodes, sortedVals, groupRoot, groupBounds;
+    std::vector<int> hostGroupRoot;
+};
+
+static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const std::vector<uint32_t>& groupCount,
+                             const float4* dBoxLo, const float4* dBoxHi, const uint32_t* dGrp, int leafMax, LbvhOut& out)
+{
+    hipStream_t st = c->stream;
+    skh_status s;
+    if ((s = dev_alloc(c, out.groupBounds, sizeof(float) * 6 * (size_t)std::max(1u, nGroups))) != SKH_OK)
+        return s;
+    if ((s = dev_alloc(c, out.groupRoot, sizeof(int) * (size_t)std::max(1u, nGroups))) != SKH_OK)
+        return s;
+    if ((s = dev_alloc(c, out.nodes, sizeof(Node64) * (size_t)std::max(1u, n))) != SKH_OK)
+        return s;
+    if ((s = dev_alloc(c, out.sortedVals, sizeof(uint32_t) * (size_t)std::max(1u, n))) != SKH_OK)
+        return s;
+    std::vector<uint32_t> groupFirst(nGroups);
+    out.hostGroupRoot.assign(nGroups, SKH_REF_INVALID);
+    uint32_t acc = 0;
+    for (uint32_t g = 0; g < nGroups; ++g)
+    {
+        groupFirst[g] = acc;
+        if (groupCount[g] > 0 && groupCount[g] <= (uint32_t)leafMax)
+            out.hostGroupRoot[g] = ~(int)((acc << 3) | (groupCount[g] - 1u));
+        acc += groupCount[g];
+    }
+    if (n == 0 || nGroups == 0)
+    {
+        if (nGroups)
+            SKH_TRY(c, hipMemcpyAsync(out.groupRoot.p, out.hostGroupRoot.data(), sizeof(int) * nGroups, hipMemcpyHostToDevice, st));
+        SKH_TRY(c, hipStreamSynchronize(st));
+        return SKH_OK;
+    }
+    DevBuf gbU, keysA, keysB, valsB, hist, childL, childR, parent, rangeF, rangeL, flags, nodeLo, nodeHi, gFirst, gCount;
+    auto cleanup = [&]() {
+        for (DevBuf* b : { &gbU, &keysA, &keysB, &valsB, &hist, &childL, &childR, &parent, &rangeF, &rangeL, &flags, &nodeLo, &nodeHi,
+                           &gFirst, &gCount })
+            dev_free(*b);
+    };
+#define LB_ALLOC(buf, bytes)                         \
+    if ((s = dev_alloc(c, buf, (bytes))) != SKH_OK)  \
+    {                                                \
+        cleanup();                                   \
+        return s;                                    \
+    }
+    LB_ALLOC(gbU, sizeof(uint32_t) * 6 * (size_t)nGroups);
+    LB_ALLOC(keysA, sizeof(uint64_t) * (size_t)n);
+    LB_ALLOC(keysB, sizeof(uint64_t) * (size_t)n);
+    LB_ALLOC(valsB, sizeof(uint32_t) * (size_t)n);
+    const uint32_t rsBlocks = (n + SKH_RS_THREADS * SKH_RS_ITEMS - 1) / (SKH_RS_THREADS * SKH_RS_ITEMS);
+    LB_ALLOC(hist, sizeof(uint32_t) * 256 * (size_t)rsBlocks);
+    const uint32_t B = 256, G1 = (n + B - 1) / B;
+    k_init_group_bounds<<<(nGroups * 6 + B - 1) / B, B, 0, st>>>(gbU.as<uint32_t>(), nGroups);
+    k_group_bounds<<<G1, B, 0, st>>>(dBoxLo, dBoxHi, dGrp, n, gbU.as<uint32_t>());
+    k_decode_group_bounds<<<(nGroups * 6 + B - 1) / B, B, 0, st>>>(gbU.as<uint32_t>(), out.groupBounds.as<float>(), nGroups);
+    uint32_t* valsA = out.sortedVals.as<uint32_t>();
+    k_morton<<<G1, B, 0, st>>>(dBoxLo, dBoxHi, dGrp, out.groupBounds.as<float>(), n, keysA.as<uint64_t>(), valsA);
+    // radix sort: 32 bits of Morton word + the group bits
+    uint32_t gbits = 0;
+    while ((1ull << gbits) < (unsigned long long)nGroups)
+        ++gbits;
+    std::vector<uint32_t> shifts = { 0, 8, 16, 24 };
+    for (uint32_t b = 0; b < gbits; b += 8)
+        shifts.push_back(32 + b);
+    uint64_t* kin = keysA.as<uint64_t>();
+    uint64_t* kout = keysB.as<uint64_t>();
+    uint32_t* vin = valsA;
+    uint32_t* vout = valsB.as<uint32_t>();
+    for (uint32_t shift : shifts)
+    {
+        k_rs_hist<<<rsBlocks, SKH_RS_THREADS, 0, st>>>(kin, n, shift, hist.as<uint32_t>(), rsBlocks);
+        k_rs_scan<<<1, 1024, 0, st>>>(hist.as<uint32_t>(), 256 * rsBlocks);
+        k_rs_scatter<<<rsBlocks, SKH_RS_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, hist.as<uint32_t>(), rsBlocks);
+        std::swap(kin, kout);
+        std::swap(vin, vout);
+    }
+    if (vin != valsA) // odd number of passes: bring the values home
+        SKH_TRY(c, hipMemcpyAsync(valsA, vin, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    const uint64_t* sortedKeys = kin;
+    if (n >= 2)
+    {
+        LB_ALLOC(childL, sizeof(int) * (size_t)n);
+        LB_ALLOC(childR, sizeof(int) * (size_t)n);
+        LB_ALLOC(parent, sizeof(int) * 2 * (size_t)n);
+        LB_ALLOC(rangeF, sizeof(int) * (size_t)n);
+        LB_ALLOC(rangeL, sizeof(int) * (size_t)n);
+        LB_ALLOC(flags, sizeof(uint32_t) * (size_t)n);
+        LB_ALLOC(nodeLo, sizeof(float4) * 2 * (size_t)n);
+        LB_ALLOC(nodeHi, sizeof(float4) * 2 * (size_t)n);
+        LB_ALLOC(gFirst, sizeof(uint32_t) * (size_t)nGroups);
+        LB_ALLOC(gCount, sizeof(uint32_t) * (size_t)nGroups);
+        SKH_TRY(c, hipMemsetAsync(flags.p, 0, sizeof(uint32_t) * (size_t)n, st));
+        SKH_TRY(c, hipMemcpyAsync(gFirst.p, groupFirst.data(), sizeof(uint32_t) * nGroups, hipMemcpyHostToDevice, st));
+        SKH_TRY(c, hipMemcpyAsync(gCount.p, groupCount.data(), sizeof(uint32_t) * nGroups, hipMemcpyHostToDevice, st));
+        SKH_TRY(c, hipMemcpyAsync(out.groupRoot.p, out.hostGroupRoot.data(), sizeof(int) * nGroups, hipMemcpyHostToDevice, st));
+        k_karras<<<(n - 1 + B - 1) / B, B, 0, st>>>(sortedKeys, (int)n, childL.as<int>(), childR.as<int>(), parent.as<int>(),
+                                                   rangeF.as<int>(), rangeL.as<int>());
+        k_refit<<<G1, B, 0, st>>>(valsA, dBoxLo, dBoxHi, parent.as<int>(), childL.as<int>(), childR.as<int>(), flags.as<uint32_t>(),
+                                  nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n);
+        k_emit<<<(n - 1 + B - 1) / B, B, 0, st>>>(childL.as<int>(), childR.as<int>(), rangeF.as<int>(), rangeL.as<int>(),
+                                                 nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n, leafMax, out.nodes.as<Node64>());
+        k_group_roots<<<(n - 1 + B - 1) / B, B, 0, st>>>(rangeF.as<int>(), rangeL.as<int>(), sortedKeys, gFirst.as<uint32_t>(),
+                                                        gCount.as<uint32_t>(), (int)n, leafMax, out.groupRoot.as<int>());
+        SKH_TRY(c, hipMemcpyAsync(out.hostGroupRoot.data(), out.groupRoot.p, sizeof(int) * nGroups, hipMemcpyDeviceToHost, st));
+    }
+    else
+        SKH_TRY(c, hipMemcpyAsync(out.groupRoot.p, out.hostGroupRoot.data(), sizeof(int) * nGroups, hipMemcpyHostToDevice, st));
+    hipError_t e = hipStreamSynchronize(st);
+    cleanup();
+    if (e != hipSuccess)
+    {
+        c->err = std::string("lbvh_build: ") + hipGetErrorString(e);
+        return SKH_FAIL;
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess)
+    {
+        c->err = std::string("lbvh_build launch: ") + hipGetErrorString(e);
+        return SKH_FAIL;
+    }
+    return SKH_OK;
+#undef LB_ALLOC
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The entry points below take C linkage from their declarations in include/strelka_hip.h.
+
+uint32_t skh_abi_version(void)
+{
+    return SKH_ABI_VERSION;
+}
+
+skh_status skh_create(int device_ordinal, skh_context** out_ctx)
+{
+    if (!out_ctx)
+        return SKH_INVALID_ARGUMENT;
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_ordinal < 0 || device_ordinal >= count)
+        return SKH_FAIL; // no GPU: the product path fails loudly, there is no CPU fallback
+    skh_context* c = new skh_context();
+    c->device = device_ordinal;
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess)
+    {
+        delete c;
+        return SKH_FAIL;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess)
+        c->numCUs = prop.multiProcessorCount;
+    uint32_t tab[5][32];
+    init_sobol_table(tab);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_sobol), tab, sizeof(tab)) != hipSuccess)
+    {
+        delete c;
+        return SKH_FAIL;
+    }
+    if (dev_alloc(c, c->dStats, sizeof(StatsDev)) != SKH_OK || hipMemset(c->dStats.p, 0, sizeof(StatsDev)) != hipSuccess)
+    {
+        delete c;
+        return SKH_FAIL;
+    }
+    *out_ctx = c;
+    return SKH_OK;
+}
+
+void skh_destroy(skh_context* c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : { &c->dVerts, &c->dIndices, &c->dMeshes, &c->dPoints, &c->dRadii, &c->dInstances, &c->dLights, &c->dMaterials,
+                       &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
+                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
+                       &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
+                       &c->dCounts, &c->dOvf, &c->dStats, &c->dScratchImage })
+        dev_free(*b);
+    for (hipEvent_t e : c->eventPool)
+        (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* skh_last_error(const skh_context* c)
+{
+    return c ? c->err.c_str() : "null context";
+}
+
+skh_status skh_set_geometry(skh_context* c, const skh_vertex* verts, uint32_t n_verts, const uint32_t* indices, uint32_t n_indices,
+                            const skh_mesh* meshes, uint32_t n_meshes)
+{
+    if (!c || (n_verts && !verts) || (n_indices && !indices) || (n_meshes && !meshes))
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    for (uint32_t m = 0; m < n_meshes; ++m)
+    {
+        const skh_mesh& me = meshes[m];
+        if ((uint64_t)me.index_offset + me.index_count > n_indices || (uint64_t)me.vertex_offset + me.vertex_count > n_verts ||
+            me.index_count % 3 != 0)
+        {
+            c->err = "skh_set_geometry: mesh " + std::to_string(m) + " is out of range";
+            return SKH_INVALID_ARGUMENT;
+        }
+    }
+    c->meshes.assign(meshes, meshes + n_meshes);
+    c->nVerts = n_verts;
+    c->nIndices = n_indices;
+    c->accelBuilt = false;
+    skh_status s;
+    if ((s = dev_upload(c, c->dVerts, verts, sizeof(skh_vertex) * (size_t)n_verts)) != SKH_OK)
+        return s;
+    if ((s = dev_upload(c, c->dIndices, indices, sizeof(uint32_t) * (size_t)n_indices)) != SKH_OK)
+        return s;
+    return dev_upload(c, c->dMeshes, meshes, sizeof(skh_mesh) * (size_t)n_meshes);
+}
+
+skh_status skh_set_curves(skh_context* c, const float* points_xyz, uint32_t n_points, const float* radii, uint32_t n_radii,
+                          const uint32_t* vertex_counts, uint32_t n_vertex_counts, const skh_curve* curves, uint32_t n_curves)
+{
+    if (!c || (n_points && !points_xyz) || (n_radii && !radii) || (n_vertex_counts && !vertex_counts) || (n_curves && !curves))
+        return SKH_INVALID_ARGUMENT;
+    if (n_radii != n_points)
+    {
+        c->err = "skh_set_curves: one radius per control point is required";
+        return SKH_INVALID_ARGUMENT;
+    }
+    (void)hipSetDevice(c->device);
+    c->curves.assign(curves, curves + n_curves);
+    c->curveVertexCounts.assign(vertex_counts, vertex_counts + n_vertex_counts);
+    c->nPoints = n_points;
+    c->accelBuilt = false;
+    skh_status s;
+    if ((s = dev_upload(c, c->dPoints, points_xyz, sizeof(float) * 3 * (size_t)n_points)) != SKH_OK)
+        return s;
+    return dev_upload(c, c->dRadii, radii, sizeof(float) * (size_t)n_radii);
+}
+
+skh_status skh_set_instances(skh_context* c, const skh_instance* instances, uint32_t n)
+{
+    if (!c || (n && !instances))
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    c->instances.assign(instances, instances + n);
+    c->nInstances = n;
+    c->accelBuilt = false;
+    return dev_upload(c, c->dInstances, instances, sizeof(skh_instance) * (size_t)n);
+}
+
+skh_status skh_set_lights(skh_context* c, const skh_light* lights, uint32_t n)
+{
+    if (!c || (n && !lights))
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    c->nLights = n;
+    return dev_upload(c, c->dLights, lights, sizeof(skh_light) * (size_t)n);
+}
+
+skh_status skh_set_materials(skh_context* c, const skh_material* materials, uint32_t n)
+{
+    if (!c || (n && !materials))
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    c->nMaterials = n;
+    return dev_upload(c, c->dMaterials, materials, sizeof(skh_material) * (size_t)n);
+}
+
+skh_status skh_build_accel(skh_context* c, uint32_t flags)
+{
+    (void)flags;
+    if (!c)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipStream_t st = c->stream;
+    skh_status s;
+    const uint32_t B = 256;
+    // ---- triangles of all meshes ----
+    const uint32_t nMeshes = (uint32_t)c->meshes.size();
+    std::vector<uint32_t> triMesh, triLocal, meshTriCount(nMeshes);
+    for (uint32_t m = 0; m < nMeshes; ++m)
+    {
+        const uint32_t nt = c->meshes[m].index_count / 3;
+        meshTriCount[m] = nt;
+        for (uint32_t t = 0; t < nt; ++t)
+        {
+            triMesh.push_back(m);
+            triLocal.push_back(t);
+        }
+    }
+    const uint32_t nTris = (uint32_t)triMesh.size();
+    c->nTris = nTris;
+    LbvhOut triOut, segOut, tlasOut;
+    DevBuf dTriMesh, dTriLocal, dBoxLo, dBoxHi, dGrp, dSegStart, dSegCurve, dSegLocal, dW2o, dValid;
+    auto cleanup = [&]() {
+        for (DevBuf* b : { &dTriMesh, &dTriLocal, &dBoxLo, &dBoxHi, &dGrp, &dSegStart, &dSegCurve, &dSegLocal, &dW2o, &dValid,
+                           &triOut.sortedVals, &segOut.sortedVals, &triOut.groupRoot, &segOut.groupRoot, &triOut.groupBounds,
+                           &segOut.groupBounds, &tlasOut.groupRoot, &tlasOut.groupBounds })
+            dev_free(*b);
+    };
+#define BA(expr)                    \
+    if ((s = (expr)) != SKH_OK)     \
+    {                               \
+        cleanup();                  \
+        return s;                   \
+    }
+    BA(dev_upload(c, dTriMesh, triMesh.data(), sizeof(uint32_t) * (size_t)nTris));
+    BA(dev_upload(c, dTriLocal, triLocal.data(), sizeof(uint32_t) * (size_t)nTris));
+    BA(dev_alloc(c, dBoxLo, sizeof(float4) * (size_t)std::max(1u, nTris)));
+    BA(dev_alloc(c, dBoxHi, sizeof(float4) * (size_t)std::max(1u, nTris)));
+    BA(dev_alloc(c, dGrp, sizeof(uint32_t) * (size_t)std::max(1u, nTris)));
+    if (nTris)
+        k_tri_boxes<<<(nTris + B - 1) / B, B, 0, st>>>(c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(), c->dMeshes.as<uint4>(),
+                                                      dTriMesh.as<uint32_t>(), dTriLocal.as<uint32_t>(), nTris, dBoxLo.as<float4>(),
+                                                      dBoxHi.as<float4>(), dGrp.as<uint32_t>());
+    BA(lbvh_build(c, nTris, nMeshes, meshTriCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), 4, triOut));
+    BA(dev_alloc(c, c->dTris, sizeof(float4) * 3 * (size_t)std::max(1u, nTris)));
+    if (nTris)
+        k_gather_tris<<<(nTris + B - 1) / B, B, 0, st>>>(c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(), c->dMeshes.as<uint4>(),
+                                                        dTriMesh.as<uint32_t>(), dTriLocal.as<uint32_t>(),
+                                                        triOut.sortedVals.as<uint32_t>(), nTris, c->dTris.as<float4>());
+    dev_free(c->dTriNodes);
+    c->dTriNodes = triOut.nodes;
+    // ---- curve segments of all curve sets (segment enumeration: OptixRender.cpp:226-245) ----
+    const uint32_t nCurves = (uint32_t)c->curves.size();
+    std::vector<uint32_t> segStart, segCurve, segLocal, curveSegCount(nCurves), curveSegBase(nCurves);
+    for (uint32_t ci = 0; ci < nCurves; ++ci)
+    {
+        const skh_curve& cu = c->curves[ci];
+        curveSegBase[ci] = (uint32_t)segStart.size();
+        uint32_t off = 0, local = 0;
+        for (uint32_t k = 0; k < cu.vertex_counts_count; ++k)
+        {
+            const uint32_t ncp = c->curveVertexCounts[cu.vertex_counts_start + k];
+            for (int i = 0; i < (int)ncp - 3; ++i)
+            {
+                segStart.push_back(cu.points_start + off + (uint32_t)i);
+                segCurve.push_back(ci);
+                segLocal.push_back(local++);
+            }
+            off += ncp;
+        }
+        curveSegCount[ci] = local;
+    }
+    const uint32_t nSegs = (uint32_t)segStart.size();
+    c->nSegs = nSegs;
+    for (uint32_t k = 0; k < nSegs; ++k)
+        if ((uint64_t)segStart[k] + 4 > c->nPoints)
+        {
+            c->err = "skh_build_accel: curve segment reads past the control-point buffer";
+            cleanup();
+            return SKH_INVALID_ARGUMENT;
+        }
+    BA(dev_upload(c, c->dSegStartAll, segStart.data(), sizeof(uint32_t) * (size_t)nSegs));
+    BA(dev_upload(c, c->dCurveSegBase, curveSegBase.data(), sizeof(uint32_t) * (size_t)nCurves));
+    BA(dev_upload(c, dSegCurve, segCurve.data(), sizeof(uint32_t) * (size_t)nSegs));
+    BA(dev_upload(c, dSegLocal, segLocal.data(), sizeof(uint32_t) * (size_t)nSegs));
+    BA(dev_alloc(c, dBoxLo, sizeof(float4) * (size_t)std::max(nSegs, std::max(1u, c->nInstances))));
+    BA(dev_alloc(c, dBoxHi, sizeof(float4) * (size_t)std::max(nSegs, std::max(1u, c->nInstances))));
+    BA(dev_alloc(c, dGrp, sizeof(uint32_t) * (size_t)std::max(nSegs, std::max(1u, c->nInstances))));
+    if (nSegs)
+        k_seg_boxes<<<(nSegs + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), c->dSegStartAll.as<uint32_t>(),
+                                                      dSegCurve.as<uint32_t>(), nSegs, dBoxLo.as<float4>(), dBoxHi.as<float4>(),
+                                                      dGrp.as<uint32_t>());
+    BA(lbvh_build(c, nSegs, nCurves, curveSegCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), 2, segOut));
+    BA(dev_alloc(c, c->dSegs, sizeof(float4) * 4 * (size_t)std::max(1u, nSegs)));
+    BA(dev_alloc(c, c->dSegPrim, sizeof(uint32_t) * (size_t)std::max(1u, nSegs)));
+    if (nSegs)
+        k_gather_segs<<<(nSegs + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), c->dSegStartAll.as<uint32_t>(),
+                                                        dSegLocal.as<uint32_t>(), segOut.sortedVals.as<uint32_t>(), nSegs,
+                                                        c->dSegs.as<float4>(), c->dSegPrim.as<uint32_t>());
+    dev_free(c->dSegNodes);
+    c->dSegNodes = segOut.nodes;
+    // ---- instances -> TLAS ----
+    const uint32_t nInst = c->nInstances;
+    std::vector<float> w2o(12 * (size_t)std::max(1u, nInst));
+    std::vector<uint8_t> valid(std::max(1u, nInst));
+    for (uint32_t i = 0; i < nInst; ++i)
+        valid[i] = invert_affine(c->instances[i].transform, &w2o[12 * (size_t)i]) ? 1 : 0;
+    BA(dev_upload(c, dW2o, w2o.data(), sizeof(float) * w2o.size()));
+    BA(dev_upload(c, dValid, valid.data(), valid.size()));
+    BA(dev_alloc(c, c->dDevInst, sizeof(DevInstance) * (size_t)std::max(1u, nInst)));
+    if (nInst)
+        k_instance_boxes<<<(nInst + B - 1) / B, B, 0, st>>>(c->dInstances.as<HostInstance>(), dW2o.as<float>(), dValid.as<uint8_t>(),
+                                                           triOut.groupBounds.as<float>(), triOut.groupRoot.as<int>(),
+                                                           segOut.groupBounds.as<float>(), segOut.groupRoot.as<int>(), nMeshes, nCurves,
+                                                           nInst, c->dDevInst.as<DevInstance>(), dBoxLo.as<float4>(),
+                                                           dBoxHi.as<float4>(), dGrp.as<uint32_t>());
+    std::vector<uint32_t> one = { nInst };
+    BA(lbvh_build(c, nInst, 1, one, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), 1, tlasOut));
+    dev_free(c->dTlasNodes);
+    dev_free(c->dTlasInst);
+    c->dTlasNodes = tlasOut.nodes;
+    c->dTlasInst = tlasOut.sortedVals;
+    tlasOut.sortedVals = DevBuf();
+    c->tlasRoot = nInst ? tlasOut.hostGroupRoot[0] : SKH_REF_INVALID;
+    hipError_t e = hipStreamSynchronize(st);
+    cleanup();
+    if (e != hipSuccess || (e = hipGetLastError()) != hipSuccess)
+    {
+        c->err = std::string("skh_build_accel: ") + hipGetErrorString(e);
+        return SKH_FAIL;
+    }
+    c->accelBuilt = true;
+    c->msBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return SKH_OK;
+#undef BA
+}
+
+static skh_status alloc_frame(skh_context* c)
+{
+    skh_status s;
+    const uint32_t T = c->tileSize;
+    if (!c->customTiles)
+    {
+        c->tileXY.clear();
+        for (uint32_t y = 0; y < c->height; y += T)
+            for (uint32_t x = 0; x < c->width; x += T)
+            {
+                c->tileXY.push_back(x);
+                c->tileXY.push_back(y);
+            }
+    }
+    c->numTiles = (uint32_t)(c->tileXY.size() / 2);
+    c->numSlots = c->numTiles * T * T;
+    const size_t N = std::max(1u, c->numSlots);
+#define AF(expr)                \
+    if ((s = (expr)) != SKH_OK) \
+        return s;
+    AF(dev_upload(c, c->dTileXY, c->tileXY.data(), sizeof(uint32_t) * c->tileXY.size()));
+    AF(dev_alloc(c, c->dAccum, sizeof(float4) * N));
+    AF(dev_alloc(c, c->dDiffuse, sizeof(float4) * N));
+    AF(dev_alloc(c, c->dSpecular, sizeof(float4) * N));
+    AF(dev_alloc(c, c->dDiffCnt, sizeof(uint16_t) * N));
+    AF(dev_alloc(c, c->dSpecCnt, sizeof(uint16_t) * N));
+    AF(dev_alloc(c, c->dSums, sizeof(float) * 11 * N));
+    AF(dev_alloc(c, c->dPath, sizeof(float) * 8 * N));
+    AF(dev_alloc(c, c->dRayQ[0], sizeof(float) * 9 * N));
+    AF(dev_alloc(c, c->dRayQ[1], sizeof(float) * 9 * N));
+    AF(dev_alloc(c, c->dHits, sizeof(float) * 5 * N));
+    AF(dev_alloc(c, c->dShadowQ, sizeof(float) * 9 * N));
+    AF(dev_alloc(c, c->dContrib, sizeof(float) * 3 * N));
+    AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * 2 * 130));
+    c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
+    AF(dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * c->traceBlocks * SKH_TRACE_BLOCK));
+#undef AF
+    SKH_TRY(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(float4) * N, c->stream));
+    SKH_TRY(c, hipMemsetAsync(c->dDiffuse.p, 0, sizeof(float4) * N, c->stream));
+    SKH_TRY(c, hipMemsetAsync(c->dSpecular.p, 0, sizeof(float4) * N, c->stream));
+    SKH_TRY(c, hipMemsetAsync(c->dDiffCnt.p, 0, sizeof(uint16_t) * N, c->stream));
+    SKH_TRY(c, hipMemsetAsync(c->dSpecCnt.p, 0, sizeof(uint16_t) * N, c->stream));
+    SKH_TRY(c, hipStreamSynchronize(c->stream));
+    return SKH_OK;
+}
+
+skh_status skh_resize(skh_context* c, uint32_t width, uint32_t height)
+{
+    if (!c || width == 0 || height == 0)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    c->width = width;
+    c->height = height;
+    return alloc_frame(c);
+}
+
+skh_status skh_set_tiles(skh_context* c, uint32_t tile_size, const uint32_t* tile_xy, uint32_t n_tiles)
+{
+    if (!c || tile_size < 8 || tile_size > 256 || (tile_size & (tile_size - 1)))
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    c->tileSize = tile_size;
+    c->tileShift = 0;
+    while ((1u << c->tileShift) < tile_size)
+        ++c->tileShift;
+    c->customTiles = tile_xy != nullptr;
+    if (tile_xy)
+        c->tileXY.assign(tile_xy, tile_xy + 2 * (size_t)n_tiles);
+    if (c->width && c->height)
+        return alloc_frame(c);
+    return SKH_OK;
+}
+
+// ---- timing helpers ----
+static hipEvent_t next_event(skh_context* c)
+{
+    if (c->eventsUsed == c->eventPool.size())
+    {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        c->eventPool.push_back(e);
+    }
+    return c->eventPool[c->eventsUsed++];
+}
+struct SpanGuard
+{
+    skh_context* c;
+    int cls;
+    hipEvent_t a = nullptr;
+    SpanGuard(skh_context* c_, int cls_) : c(c_), cls(cls_)
+    {
+        c->launches[cls]++;
+        if (c->timing)
+        {
+            a = next_event(c);
+            (void)hipEventRecord(a, c->stream);
+        }
+    }
+    ~SpanGuard()
+    {
+        if (c->timing)
+        {
+            hipEvent_t b = next_event(c);
+            (void)hipEventRecord(b, c->stream);
+            c->spans.push_back(TimedSpan{ cls, a, b });
+        }
+    }
+};
+static void harvest_spans(skh_context* c)
+{
+    for (const TimedSpan& s : c->spans)
+    {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess)
+            c->msClass[s.cls] += ms;
+    }
+    c->spans.clear();
+    c->eventsUsed = 0;
+}
+
+static DevScene make_dev_scene(const skh_context* c)
+{
+    DevScene sc;
+    sc.tlasNodes = c->dTlasNodes.as<Node64>();
+    sc.tlasInst = c->dTlasInst.as<uint32_t>();
+    sc.tlasRoot = c->tlasRoot;
+    sc.numInstances = c->nInstances;
+    sc.inst = c->dDevInst.as<DevInstance>();
+    sc.triNodes = c->dTriNodes.as<Node64>();
+    sc.tris = c->dTris.as<float4>();
+    sc.segNodes = c->dSegNodes.as<Node64>();
+    sc.segs = c->dSegs.as<float4>();
+    sc.segPrim = c->dSegPrim.as<uint32_t>();
+    sc.instances = c->dInstances.as<HostInstance>();
+    sc.verts = c->dVerts.as<uint8_t>();
+    sc.indices = c->dIndices.as<uint32_t>();
+    sc.meshes = c->dMeshes.as<uint4>();
+    sc.curveSegBase = c->dCurveSegBase.as<uint32_t>();
+    sc.segStartAll = c->dSegStartAll.as<uint32_t>();
+    sc.cpoints = c->dPoints.as<float>();
+    sc.cradii = c->dRadii.as<float>();
+    sc.lights = c->dLights.as<Light>();
+    sc.numLights = c->nLights;
+    sc.materials = c->dMaterials.as<Material>();
+    sc.numMaterials = c->nMaterials;
+    return sc;
+}
+
+static skh_status ensure_ready(skh_context* c)
+{
+    if (!c->accelBuilt)
+    {
+        skh_status s = skh_build_accel(c, SKH_BUILD_LBVH);
+        if (s != SKH_OK)
+            return s;
+    }
+    if (c->nMaterials == 0)
+    {
+        // material 0 = default.mdl::default_material (OptixRender.cpp:1090-1097)
+        skh_material m;
+        memset(&m, 0, sizeof(m));
+        m.type = SKH_MAT_DIFFUSE;
+        m.base_color[0] = m.base_color[1] = m.base_color[2] = 0.8f;
+        skh_status s = skh_set_materials(c, &m, 1);
+        if (s != SKH_OK)
+            return s;
+    }
+    return SKH_OK;
+}
+
+template <bool ANY, bool COUNT>
+static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint32_t* countPtr, HitQ hq, PathS ps, const float* contrib,
+                         uint32_t contribStride)
+{
+    k_trace<ANY, COUNT><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, hq, ps, contrib, contribStride,
+                                                                            c->dOvf.as<int>(), c->dStats.as<StatsDev>());
+}
+
+static skh_status render_one(skh_context* c, const skh_frame_params* p, void* d_image)
+{
+    if (p->max_depth > 128 || p->samples_this_launch == 0)
+    {
+        c->err = "skh_render_subframe: max_depth must be <= 128 (MAX_BOUNCES, RandomSampler.h:35) and samples_this_launch >= 1";
+        return SKH_INVALID_ARGUMENT;
+    }
+    hipStream_t st = c->stream;
+    FrameP fp;
+    memcpy(fp.viewToWorld, p->view_to_world, sizeof(fp.viewToWorld));
+    memcpy(fp.clipToView, p->clip_to_view, sizeof(fp.clipToView));
+    fp.subframeIndex = p->subframe_index;
+    fp.samplesThisLaunch = p->samples_this_launch;
+    fp.sppTotal = p->spp_total;
+    fp.maxDepth = p->max_depth;
+    fp.rectMethod = p->rect_light_sampling_method;
+    memcpy(fp.exposure, p->exposure, sizeof(fp.exposure));
+    fp.enableAccumulation = p->enable_accumulation;
+    fp.debug = p->debug;
+    fp.shadowTmin = p->shadow_ray_tmin;
+    fp.materialTmin = p->material_ray_tmin;
+    fp.width = c->width;
+    fp.height = c->height;
+    fp.tileSize = c->tileSize;
+    fp.tileShift = c->tileShift;
+    fp.numTiles = c->numTiles;
+    fp.numSlots = c->numSlots;
+    const DevScene sc = make_dev_scene(c);
+    const uint32_t N = c->numSlots;
+    if (N == 0)
+        return SKH_OK;
+    const uint32_t gridSlots = (N + 255) / 256;
+    const uint32_t* tiles = c->dTileXY.as<uint32_t>();
+    PathS ps{ c->dPath.as<float>(), N };
+    RayQ rq[2] = { RayQ{ c->dRayQ[0].as<float>(), N }, RayQ{ c->dRayQ[1].as<float>(), N } };
+    RayQ shq{ c->dShadowQ.as<float>(), N };
+    HitQ hq{ c->dHits.as<float>(), N };
+    HitQ nohq{ nullptr, 0 };
+    uint32_t* counts = c->dCounts.as<uint32_t>();
+    for (uint32_t s = 0; s < fp.samplesThisLaunch; ++s)
+    {
+        SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * 2 * (fp.maxDepth + 1), st));
+        {
+            SpanGuard g(c, KC_RAYGEN);
+            k_raygen<<<gridSlots, 256, 0, st>>>(fp, tiles, s, rq[0], counts, ps);
+        }
+        for (uint32_t b = 0; b < fp.maxDepth; ++b)
+        {
+            {
+                SpanGuard g(c, KC_TRACE_CLOSEST);
+                if (c->countTraversal)
+                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b, hq, ps, nullptr, 0);
+                else
+                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b, hq, ps, nullptr, 0);
+            }
+            {
+                SpanGuard g(c, KC_SHADE);
+                k_shade<<<gridSlots, 256, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b, hq, ps, rq[(b + 1) & 1],
+                                                   counts + 2 * (b + 1), shq, c->dContrib.as<float>(), counts + 2 * b + 1);
+            }
+            {
+                SpanGuard g(c, KC_TRACE_SHADOW);
+                if (c->countTraversal)
+                    launch_trace<true, true>(c, sc, shq, counts + 2 * b + 1, nohq, ps, c->dContrib.as<float>(), N);
+                else
+                    launch_trace<true, false>(c, sc, shq, counts + 2 * b + 1, nohq, ps, c->dContrib.as<float>(), N);
+            }
+            if (fp.debug == 1)
+                break;
+        }
+        {
+            SpanGuard g(c, KC_ACCUM);
+            k_add_stats<<<1, 64, 0, st>>>(counts, fp.maxDepth, c->dStats.as<StatsDev>());
+            k_collect<<<gridSlots, 256, 0, st>>>(fp, tiles, s, ps, c->dSums.as<float>());
+        }
+    }
+    {
+        SpanGuard g(c, KC_ACCUM);
+        k_finalize<<<gridSlots, 256, 0, st>>>(fp, tiles, c->dSums.as<float>(), c->dAccum.as<float4>(), c->dDiffuse.as<float4>(),
+                                              c->dSpecular.as<float4>(), c->dDiffCnt.as<uint16_t>(), c->dSpecCnt.as<uint16_t>(),
+                                              reinterpret_cast<float4*>(d_image));
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+    {
+        c->err = std::string("render launch: ") + hipGetErrorString(e);
+        return SKH_FAIL;
+    }
+    return SKH_OK;
+}
+
+skh_status skh_render_subframes(skh_context* c, const skh_frame_params* params, uint32_t n_subframes, void* d_image)
+{
+    if (!c || !params)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    if (c->width == 0)
+    {
+        c->err = "skh_render_subframe: call skh_resize first";
+        return SKH_INVALID_ARGUMENT;
+    }
+    skh_status s = ensure_ready(c);
+    if (s != SKH_OK)
+        return s;
+    skh_frame_params p = *params;
+    for (uint32_t k = 0; k < n_subframes; ++k)
+    {
+        if ((s = render_one(c, &p, d_image)) != SKH_OK)
+            return s;
+        p.subframe_index += p.samples_this_launch;
+    }
+    SKH_TRY(c, hipStreamSynchronize(c->stream)); // the reference's render() is synchronous (OptixRender.cpp:1012)
+    if (c->timing)
+        harvest_spans(c);
+    return SKH_OK;
+}
+
+skh_status skh_render_subframe(skh_context* c, const skh_frame_params* params, void* d_image)
+{
+    return skh_render_subframes(c, params, 1, d_image);
+}
+
+skh_status skh_tonemap(skh_context* c, void* d_image, uint32_t width, uint32_t height, uint32_t type, const float exposure[3], float gamma)
+{
+    if (!c || !d_image || !exposure)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    const uint32_t n = width * height; // the reference's kernels test `> n` (Tonemappers.cu:20); this build uses >= n
+    k_tonemap<<<(n + 255) / 256, 256, 0, c->stream>>>(reinterpret_cast<float4*>(d_image), n, type, exposure[0], exposure[1], exposure[2],
+                                                     gamma);
+    SKH_TRY(c, hipStreamSynchronize(c->stream));
+    return SKH_OK;
+}
+
+static skh_status detile_to(skh_context* c, const DevBuf& src, void* d_dst)
+{
+    k_detile<<<(c->numSlots + 255) / 256, 256, 0, c->stream>>>(src.as<float4>(), c->dTileXY.as<uint32_t>(), c->numSlots, c->tileShift,
+                                                              c->width, c->height, reinterpret_cast<float4*>(d_dst));
+    return SKH_OK;
+}
+
+static skh_status read_slots(skh_context* c, const DevBuf& src, float* host)
+{
+    if (!c || !host || !c->width)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    const size_t bytes = sizeof(float4) * (size_t)c->width * c->height;
+    skh_status s = dev_alloc(c, c->dScratchImage, bytes);
+    if (s != SKH_OK)
+        return s;
+    SKH_TRY(c, hipMemsetAsync(c->dScratchImage.p, 0, bytes, c->stream));
+    detile_to(c, src, c->dScratchImage.p);
+    SKH_TRY(c, hipMemcpyAsync(host, c->dScratchImage.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    SKH_TRY(c, hipStreamSynchronize(c->stream));
+    return SKH_OK;
+}
+skh_status skh_read_accum(skh_context* c, float* host_rgba)
+{
+    return read_slots(c, c->dAccum, host_rgba);
+}
+skh_status skh_read_aov(skh_context* c, uint32_t which, float* host_rgba)
+{
+    if (!c)
+        return SKH_INVALID_ARGUMENT;
+    return read_slots(c, which == 0 ? c->dDiffuse : c->dSpecular, host_rgba);
+}
+skh_status skh_copy_accum(skh_context* c, void* d_dst)
+{
+    if (!c || !d_dst)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    detile_to(c, c->dAccum, d_dst);
+    SKH_TRY(c, hipStreamSynchronize(c->stream));
+    return SKH_OK;
+}
+skh_status skh_copy_accum_tiles(skh_context* c, void* d_dst)
+{
+    if (!c || !d_dst)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    SKH_TRY(c, hipMemcpyAsync(d_dst, c->dAccum.p, sizeof(float4) * (size_t)c->numSlots, hipMemcpyDeviceToDevice, c->stream));
+    SKH_TRY(c, hipStreamSynchronize(c->stream));
+    return SKH_OK;
+}
+skh_status skh_scatter_tiles(skh_context* c, const void* d_src_tiles, const uint32_t* tile_xy, uint32_t n_tiles, uint32_t tile_size,
+                             void* d_dst, uint32_t width, uint32_t height)
+{
+    if (!c || !d_src_tiles || !tile_xy || !d_dst || (tile_size & (tile_size - 1)))
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    DevBuf t;
+    skh_status s = dev_upload(c, t, tile_xy, sizeof(uint32_t) * 2 * (size_t)n_tiles);
+    if (s != SKH_OK)
+        return s;
+    uint32_t shift = 0;
+    while ((1u << shift) < tile_size)
+        ++shift;
+    const uint32_t slots = n_tiles * tile_size * tile_size;
+    k_detile<<<(slots + 255) / 256, 256, 0, c->stream>>>(reinterpret_cast<const float4*>(d_src_tiles), t.as<uint32_t>(), slots, shift,
+                                                        width, height, reinterpret_cast<float4*>(d_dst));
+    hipError_t e = hipStreamSynchronize(c->stream);
+    dev_free(t);
+    if (e != hipSuccess)
+    {
+        c->err = std::string("skh_scatter_tiles: ") + hipGetErrorString(e);
+        return SKH_FAIL;
+    }
+    return SKH_OK;
+}
+
+// ---- raw ray queries ----
+__global__ void k_rays_aos_to_soa(const skh_ray* __restrict__ rays, uint32_t n, RayQ rq)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const skh_ray r = rays[i];
+    rq.plane(0)[i] = r.origin[0];
+    rq.plane(1)[i] = r.origin[1];
+    rq.plane(2)[i] = r.origin[2];
+    rq.plane(3)[i] = r.dir[0];
+    rq.plane(4)[i] = r.dir[1];
+    rq.plane(5)[i] = r.dir[2];
+    rq.plane(6)[i] = r.tmin;
+    rq.plane(7)[i] = r.tmax;
+    rq.ids()[i] = i;
+}
+__global__ void k_hits_soa_to_aos(HitQ hq, uint32_t n, uint32_t mode, skh_hit* __restrict__ hits)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    skh_hit h;
+    h.t = hq.base[i];
+    if (mode == SKH_TRACE_SHADOW)
+    {
+        h.instance_id = h.prim_id = 0xffffffffu;
+        h.u = h.v = 0.0f;
+    }
+    else
+    {
+        h.instance_id = reinterpret_cast<const uint32_t*>(hq.base)[i + hq.stride];
+        h.prim_id = reinterpret_cast<const uint32_t*>(hq.base)[i + 2 * (size_t)hq.stride];
+        h.u = hq.base[i + 3 * (size_t)hq.stride];
+        h.v = hq.base[i + 4 * (size_t)hq.stride];
+    }
+    hits[i] = h;
+}
+
+skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays, uint32_t mode, void* d_hits, uint32_t repeat)
+{
+    if (!c || (n_rays && (!d_rays || !d_hits)) || mode > 1)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    skh_status s = ensure_ready(c);
+    if (s != SKH_OK || n_rays == 0)
+        return s;
+    DevBuf q, h, cnt;
+    auto cleanup = [&]() {
+        dev_free(q);
+        dev_free(h);
+        dev_free(cnt);
+    };
+    if ((s = dev_alloc(c, q, sizeof(float) * 9 * (size_t)n_rays)) != SKH_OK || (s = dev_alloc(c, h, sizeof(float) * 5 * (size_t)n_rays)) != SKH_OK ||
+        (s = dev_upload(c, cnt, &n_rays, sizeof(uint32_t))) != SKH_OK)
+    {
+        cleanup();
+        return s;
+    }
+    if (!c->traceBlocks)
+        c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
+    if ((s = dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * c->traceBlocks * SKH_TRACE_BLOCK)) != SKH_OK)
+    {
+        cleanup();
+        return s;
+    }
+    RayQ rq{ q.as<float>(), n_rays };
+    HitQ hq{ h.as<float>(), n_rays };
+    PathS ps{ nullptr, 0 };
+    const DevScene sc = make_dev_scene(c);
+    k_rays_aos_to_soa<<<(n_rays + 255) / 256, 256, 0, c->stream>>>(reinterpret_cast<const skh_ray*>(d_rays), n_rays, rq);
+    for (uint32_t r = 0; r < std::max(1u, repeat); ++r)
+    {
+        SpanGuard g(c, mode == SKH_TRACE_SHADOW ? KC_TRACE_SHADOW : KC_TRACE_CLOSEST);
+        if (mode == SKH_TRACE_SHADOW)
+        {
+            if (c->countTraversal)
+                launch_trace<true, true>(c, sc, rq, cnt.as<uint32_t>(), hq, ps, nullptr, 0);
+            else
+                launch_trace<true, false>(c, sc, rq, cnt.as<uint32_t>(), hq, ps, nullptr, 0);
+        }
+        else
+        {
+            if (c->countTraversal)
+                launch_trace<false, true>(c, sc, rq, cnt.as<uint32_t>(), hq, ps, nullptr, 0);
+            else
+                launch_trace<false, false>(c, sc, rq, cnt.as<uint32_t>(), hq, ps, nullptr, 0);
+        }
+    }
+    k_hits_soa_to_aos<<<(n_rays + 255) / 256, 256, 0, c->stream>>>(hq, n_rays, mode, reinterpret_cast<skh_hit*>(d_hits));
+    hipError_t e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess || (e = hipGetLastError()) != hipSuccess)
+    {
+        c->err = std::string("skh_trace: ") + hipGetErrorString(e);
+        return SKH_FAIL;
+    }
+    if (c->timing)
+        harvest_spans(c);
+    return SKH_OK;
+}
+
+skh_status skh_trace(skh_context* c, const skh_ray* rays, uint32_t n_rays, uint32_t mode, skh_hit* hits)
+{
+    if (!c || (n_rays && (!rays || !hits)))
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    if (n_rays == 0)
+        return SKH_OK;
+    DevBuf dr, dh;
+    skh_status s;
+    if ((s = dev_upload(c, dr, rays, sizeof(skh_ray) * (size_t)n_rays)) != SKH_OK || (s = dev_alloc(c, dh, sizeof(skh_hit) * (size_t)n_rays)) != SKH_OK)
+    {
+        dev_free(dr);
+        dev_free(dh);
+        return s;
+    }
+    s = skh_trace_device(c, dr.p, n_rays, mode, dh.p, 1);
+    if (s == SKH_OK)
+    {
+        hipError_t e = hipMemcpy(hits, dh.p, sizeof(skh_hit) * (size_t)n_rays, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+        {
+            c->err = std::string("skh_trace readback: ") + hipGetErrorString(e);
+            s = SKH_FAIL;
+        }
+    }
+    dev_free(dr);
+    dev_free(dh);
+    return s;
+}
+
+skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
+{
+    if (!c || !name)
+        return SKH_INVALID_ARGUMENT;
+    const std::string n(name);
+    if (n == "count_traversal")
+        c->countTraversal = value != 0;
+    else if (n == "timing")
+        c->timing = value != 0;
+    else if (n == "waves_per_cu")
+    {
+        if (value < 1 || value > 32)
+            return SKH_INVALID_ARGUMENT;
+        c->wavesPerCU = (uint32_t)value;
+        if (c->width)
+            return alloc_frame(c);
+    }
+    else
+    {
+        c->err = "skh_set_option: unknown option " + n;
+        return SKH_INVALID_ARGUMENT;
+    }
+    return SKH_OK;
+}
+
+skh_status skh_get_stats(skh_context* c, skh_stats* out)
+{
+    if (!c || !out)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    StatsDev sd;
+    SKH_TRY(c, hipStreamSynchronize(c->stream));
+    SKH_TRY(c, hipMemcpy(&sd, c->dStats.p, sizeof(sd), hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    out->rays_radiance = sd.raysRadiance;
+    out->rays_shadow = sd.raysShadow;
+    out->nodes_visited = sd.nodes;
+    out->prims_tested = sd.prims;
+    out->segs_tested = sd.segs;
+    out->instances_entered = sd.insts;
+    out->ms_trace_closest = c->msClass[KC_TRACE_CLOSEST];
+    out->ms_trace_shadow = c->msClass[KC_TRACE_SHADOW];
+    out->ms_shade = c->msClass[KC_SHADE];
+    out->ms_raygen = c->msClass[KC_RAYGEN];
+    out->ms_accumulate = c->msClass[KC_ACCUM];
+    out->ms_build = c->msBuild;
+    out->launches_trace_closest = c->launches[KC_TRACE_CLOSEST];
+    out->launches_trace_shadow = c->launches[KC_TRACE_SHADOW];
+    out->launches_shade = c->launches[KC_SHADE];
+    out->launches_other = c->launches[KC_RAYGEN] + c->launches[KC_ACCUM];
+    return SKH_OK;
+}
+
+skh_status skh_reset_stats(skh_context* c)
+{
+    if (!c)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    SKH_TRY(c, hipStreamSynchronize(c->stream));
+    SKH_TRY(c, hipMemset(c->dStats.p, 0, sizeof(StatsDev)));
+    for (int k = 0; k < KC_COUNT; ++k)
+    {
+        c->msClass[k] = 0.0;
+        c->launches[k] = 0;
+    }
+    return SKH_OK;
+}
+
+skh_status skh_synchronize(skh_context* c)
+{
+    if (!c)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    SKH_TRY(c, hipStreamSynchronize(c->stream));
+    return SKH_OK;
+}
+
+void* skh_get_stream(skh_context* c)
+{
+    return c ? (void*)c->stream : nullptr;
+}
+

@@ -1,0 +1,301 @@
+"""Procedural stand-ins for the BASELINE.json scenes (none of the USD assets exist in the reference tree or in the
+container; SURVEY.md section 8d fixes these recipes).  All generators are seeded (numpy RandomState = MT19937) and emit
+the flat ``oka::Scene`` arrays through strelka_amd.scene.Scene, exactly what the renderer would receive from HdStrelka.
+
+    cornell_box()          C2: classic Cornell box, Lambert only, 1 rect light
+    kitchen_standin()      C3/C4: >= 1.0 M unique triangles, >= 2000 instances of >= 150 meshes, mixed materials
+    hair_standin()         C5: 100 k strands x 16 control points (+2 phantom), hair BSDF
+    coffeemaker_standin()  C1: ~50 k-triangle lathe object on a ground plane
+"""
+import math
+
+import numpy as np
+
+from . import scene as S
+
+
+def _grid_mesh(fn, nu, nv, wrap_u=False):
+    """Triangulated parametric surface p = fn(u, v), u,v in [0,1]; returns (positions, triangles)."""
+    u = np.linspace(0.0, 1.0, nu + 1)
+    v = np.linspace(0.0, 1.0, nv + 1)
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    pos = fn(uu.reshape(-1), vv.reshape(-1)).astype(np.float32)
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    i, j = i.reshape(-1), j.reshape(-1)
+    a = i * (nv + 1) + j
+    b = (i + 1) * (nv + 1) + j
+    tris = np.stack([np.stack([a, b, a + 1], 1), np.stack([a + 1, b, b + 1], 1)], 1).reshape(-1, 3)
+    return pos, tris
+
+
+def _sphere_fn(rs, bump):
+    ph = rs.uniform(0, 2 * math.pi, 6)
+    fr = rs.randint(2, 7, 6)
+
+    def fn(u, v):
+        theta = v * math.pi
+        phi = u * 2 * math.pi
+        r = 1.0 + bump * (np.sin(fr[0] * phi + ph[0]) * np.sin(fr[1] * theta + ph[1]) +
+                          0.5 * np.sin(fr[2] * phi + ph[2]) * np.sin(fr[3] * theta + ph[3]))
+        st = np.sin(theta)
+        return np.stack([r * st * np.cos(phi), r * np.cos(theta), r * st * np.sin(phi)], 1)
+
+    return fn
+
+
+def _torus_fn(rs):
+    r1 = rs.uniform(0.2, 0.45)
+
+    def fn(u, v):
+        a, b = u * 2 * math.pi, v * 2 * math.pi
+        return np.stack([(1 + r1 * np.cos(b)) * np.cos(a), r1 * np.sin(b), (1 + r1 * np.cos(b)) * np.sin(a)], 1)
+
+    return fn
+
+
+def _lathe_fn(rs):
+    k = rs.uniform(0.3, 1.0, 4)
+    ph = rs.uniform(0, 2 * math.pi, 4)
+
+    def fn(u, v):
+        a = u * 2 * math.pi
+        prof = 0.55 + 0.25 * np.sin(k[0] * 6 * v + ph[0]) + 0.12 * np.sin(k[1] * 14 * v + ph[1])
+        prof = prof * np.sin(np.clip(v, 0.0, 1.0) * math.pi) ** 0.35  # closed at both ends
+        return np.stack([prof * np.cos(a), 2.0 * v - 1.0, prof * np.sin(a)], 1)
+
+    return fn
+
+
+def _box_mesh(lo, hi, inward=False, skip_bottom=False):
+    lo, hi = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
+    c = np.array([[lo[0], lo[1], lo[2]], [hi[0], lo[1], lo[2]], [hi[0], hi[1], lo[2]], [lo[0], hi[1], lo[2]],
+                  [lo[0], lo[1], hi[2]], [hi[0], lo[1], hi[2]], [hi[0], hi[1], hi[2]], [lo[0], hi[1], hi[2]]], np.float32)
+    q = [(0, 3, 2, 1), (4, 5, 6, 7), (0, 1, 5, 4), (2, 3, 7, 6), (1, 2, 6, 5), (0, 4, 7, 3)]  # outward CCW
+    tris = []
+    for fi, (a, b, cc, d) in enumerate(q):
+        if skip_bottom and fi == 2:
+            continue
+        tris += [(a, b, cc), (a, cc, d)] if not inward else [(a, cc, b), (a, d, cc)]
+    return c, np.array(tris)
+
+
+def _quad(p0, p1, p2, p3):
+    return np.array([p0, p1, p2, p3], np.float32), np.array([(0, 1, 2), (0, 2, 3)])
+
+
+def _add_mesh(sc, pos, tris):
+    vb, ib = S.deindex(pos, tris)
+    return sc.createMesh(vb, ib)
+
+
+# ----------------------------------------------------------------------------------------------------------
+def cornell_box():
+    """C2: 5 walls + short + tall block = 30 triangles in 3 meshes (white, red, green) + 1 rect-light
+    proxy = 4 instances; light 0.26 x 0.21 at the ceiling, colour (17, 12, 4); camera fov 39.3 deg; Lambert only."""
+    sc = S.Scene()
+    white = sc.addMaterial(S.MAT_DIFFUSE, (0.725, 0.71, 0.68))
+    red = sc.addMaterial(S.MAT_DIFFUSE, (0.63, 0.065, 0.05))
+    green = sc.addMaterial(S.MAT_DIFFUSE, (0.14, 0.45, 0.091))
+    # unit box [-1,1]^3 open towards +z; normals face inward
+    P, T = [], []
+
+    def add(pos, tris):
+        off = sum(len(p) for p in P)
+        P.append(pos)
+        T.append(tris + off)
+
+    add(*_quad((-1, -1, 1), (1, -1, 1), (1, -1, -1), (-1, -1, -1)))  # floor, normal +y
+    add(*_quad((-1, 1, -1), (1, 1, -1), (1, 1, 1), (-1, 1, 1)))  # ceiling, normal -y
+    add(*_quad((-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1)))  # back wall, normal +z
+
+    def block(cx, cz, w, h, ang):  # 5 faces (no bottom), outward normals
+        pos, tris = _box_mesh((-w, 0, -w), (w, h, w), skip_bottom=True)
+        r = S.rotate((0, 1, 0), ang)[:3, :3]
+        pos = (pos.astype(np.float64) @ r.T + np.array([cx, -1.0, cz])).astype(np.float32)
+        return pos, tris
+
+    add(*block(0.33, 0.35, 0.3, 0.6, math.radians(-17)))  # short block
+    add(*block(-0.33, -0.3, 0.3, 1.2, math.radians(17)))  # tall block
+    pw, tw = np.concatenate(P), np.concatenate(T)
+    m_white = _add_mesh(sc, pw, tw)  # 6 + 10 + 10 = 26 triangles
+    m_red = _add_mesh(sc, *_quad((-1, -1, 1), (-1, -1, -1), (-1, 1, -1), (-1, 1, 1)))  # left wall, normal +x
+    m_green = _add_mesh(sc, *_quad((1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1)))  # right wall, normal -x
+    I = np.eye(4)
+    sc.createInstance(S.INSTANCE_MESH, m_white, white, I)
+    sc.createInstance(S.INSTANCE_MESH, m_red, red, I)
+    sc.createInstance(S.INSTANCE_MESH, m_green, green, I)
+    # rect light just under the ceiling, emitting downwards: local -Z is the emitting side (Lights.h:54-62),
+    # so rotate local +Z to world +Y
+    xf = S.translate((0.0, 0.995, 0.0)) @ S.rotate((1, 0, 0), math.radians(-90))
+    sc.createLight({"type": 0, "xform": xf, "useXform": True, "width": 0.52, "height": 0.42, "color": (17.0, 12.0, 4.0),
+                    "intensity": 1.0})
+    cam = S.Camera(fov=39.3)
+    cam.lookAt((0.0, 0.0, 3.9), (0.0, 0.0, 0.0))
+    sc.addCamera(cam)
+    return sc
+
+
+def kitchen_standin(seed=1234, n_meshes=150, n_instances=2000, tri_lo=200, tri_hi=50000, target_tris=None):
+    """C3 "kitchen stand-in" (SURVEY 8d): room 10 x 6 x 4 units, >= 1.0 M unique triangles in >= 2000 instances of
+    >= 150 meshes (sizes log-uniform tri_lo..tri_hi, de-indexed like Mesh.cpp:140-178), 4 rect lights + 1 distant
+    (half-angle 5 deg), materials 60 % diffuse / 25 % glossy (roughness U[0.05,0.6]) / 10 % metal / 5 % glass."""
+    rs = np.random.RandomState(seed)
+    sc = S.Scene()
+    # materials: 0 = default white
+    sc.addMaterial(S.MAT_DIFFUSE, (0.8, 0.8, 0.8))
+    n_mat = 64
+    kinds = rs.choice(4, size=n_mat, p=[0.60, 0.25, 0.10, 0.05])
+    mats = []
+    for k in kinds:
+        col = tuple(rs.uniform(0.15, 0.9, 3))
+        if k == 0:
+            mats.append(sc.addMaterial(S.MAT_DIFFUSE, col))
+        elif k == 1:
+            mats.append(sc.addMaterial(S.MAT_PBR, col, roughness=rs.uniform(0.05, 0.6), metallic=0.0, specular=0.5))
+        elif k == 2:
+            mats.append(sc.addMaterial(S.MAT_PBR, col, roughness=rs.uniform(0.1, 0.5), metallic=1.0, specular=0.5))
+        else:
+            mats.append(sc.addMaterial(S.MAT_GLASS, (0.95, 0.97, 0.98), ior=1.5))
+    glass_mats = [m for m, k in zip(mats, kinds) if k == 3]
+    # room shell (inward-facing), 12 triangles
+    RX, RY, RZ = 5.0, 2.0, 3.0  # half extents: room 10 x 4 (height) x 6
+    room = _add_mesh(sc, *_box_mesh((-RX, 0.0, -RZ), (RX, 2 * RY, RZ), inward=True))
+    sc.createInstance(S.INSTANCE_MESH, room, 0, np.eye(4))
+    # meshes
+    sizes = np.exp(rs.uniform(math.log(tri_lo), math.log(tri_hi), n_meshes))
+    if target_tris:
+        sizes *= target_tris / sizes.sum()
+    mesh_ids, closed = [], []
+    for i, nt in enumerate(sizes):
+        kind = i % 3
+        nt = max(int(nt), 16)
+        nu = max(4, int(round(math.sqrt(nt / 2.0 * 1.5))))
+        nv = max(3, int(round(nt / 2.0 / nu)))
+        if kind == 0:
+            pos, tris = _grid_mesh(_sphere_fn(rs, rs.uniform(0.03, 0.2)), nu, nv)
+        elif kind == 1:
+            pos, tris = _grid_mesh(_torus_fn(rs), nu, nv)
+        else:
+            pos, tris = _grid_mesh(_lathe_fn(rs), nu, nv)
+        # orient consistently outward (parametric grids above come out inward for spheres): flip by signed volume
+        p = pos.astype(np.float64)
+        vol = np.einsum("ij,ij->i", p[tris[:, 0]], np.cross(p[tris[:, 1]], p[tris[:, 2]])).sum()
+        if vol < 0:
+            tris = tris[:, ::-1]
+        mesh_ids.append(_add_mesh(sc, pos, tris))
+        closed.append(kind != 1 or True)
+    # instances: on the floor, on shelves along the walls, a few hanging
+    for k in range(n_instances):
+        m = mesh_ids[k % n_meshes] if k < n_meshes else mesh_ids[rs.randint(n_meshes)]
+        s = rs.uniform(0.06, 0.28) * (1.0 if rs.rand() < 0.9 else 2.2)
+        shelf = rs.randint(0, 4)
+        x = rs.uniform(-RX + 0.4, RX - 0.4)
+        z = rs.uniform(-RZ + 0.4, RZ - 0.4)
+        if rs.rand() < 0.55:  # against a wall, on a shelf level
+            if rs.rand() < 0.5:
+                z = (-RZ + 0.35) if rs.rand() < 0.7 else (RZ - 0.35)
+            else:
+                x = (-RX + 0.35) if rs.rand() < 0.5 else (RX - 0.35)
+            y = 0.45 + 0.8 * shelf
+        else:
+            y = 1.3 * s
+        ang = rs.uniform(0, 2 * math.pi)
+        tilt = rs.uniform(-0.25, 0.25)
+        xf = S.translate((x, y, z)) @ S.rotate((0, 1, 0), ang) @ S.rotate((1, 0, 0), tilt) @ S.scale((s, s * rs.uniform(0.7, 1.4), s))
+        mat = mats[rs.randint(n_mat)]
+        sc.createInstance(S.INSTANCE_MESH, m, mat, xf)
+    # lights: 4 ceiling rect lights facing down + 1 distant light through the (imaginary) window
+    for lx, lz in [(-2.5, -1.2), (2.5, -1.2), (-2.5, 1.2), (2.5, 1.2)]:
+        xf = S.translate((lx, 2 * RY - 0.02, lz)) @ S.rotate((1, 0, 0), math.radians(-90))
+        sc.createLight({"type": 0, "xform": xf, "useXform": True, "width": 1.2, "height": 0.8,
+                        "color": (1.0, 0.96, 0.9), "intensity": 30.0})
+    # distant light (half-angle 5 deg): direction of travel = xform * (0,0,-1)
+    xf = S.rotate((0, 1, 0), math.radians(30)) @ S.rotate((1, 0, 0), math.radians(-55))
+    sc.createLight({"type": 3, "xform": xf, "useXform": True, "halfAngle": math.radians(5.0), "color": (1.0, 0.95, 0.85),
+                    "intensity": 2.0, "radius": 0.0})
+    cam = S.Camera(fov=55.0)
+    cam.lookAt((-4.3, 2.6, 2.6), (0.8, 0.9, -0.6))
+    sc.addCamera(cam)
+    return sc
+
+
+def hair_standin(seed=77, n_strands=100000, n_cp=16):
+    """C5 "hair stand-in" (SURVEY 8d): strands rooted on a unit sphere, length U[0.3,0.6], gravity-bent, root radius
+    4e-4 -> tip 1e-4, +2 phantom points per strand (BasisCurves.cpp:189-232); one ~5 k-triangle scalp mesh; 2 rect
+    lights; hair BSDF."""
+    rs = np.random.RandomState(seed)
+    sc = S.Scene()
+    sc.addMaterial(S.MAT_DIFFUSE, (0.6, 0.5, 0.45))
+    hair = sc.addMaterial(S.MAT_HAIR, (0.35, 0.2, 0.1), roughness=0.3, metallic=0.0, specular=1.0)
+    scalp_pos, scalp_tris = _grid_mesh(_sphere_fn(rs, 0.0), 64, 40)
+    p = scalp_pos.astype(np.float64)
+    if np.einsum("ij,ij->i", p[scalp_tris[:, 0]], np.cross(p[scalp_tris[:, 1]], p[scalp_tris[:, 2]])).sum() < 0:
+        scalp_tris = scalp_tris[:, ::-1]
+    scalp = _add_mesh(sc, scalp_pos * 0.995, scalp_tris)
+    sc.createInstance(S.INSTANCE_MESH, scalp, 0, np.eye(4))
+    # roots on the upper 70 % of the sphere
+    z = rs.uniform(-0.4, 1.0, n_strands)
+    ph = rs.uniform(0, 2 * math.pi, n_strands)
+    r = np.sqrt(1 - z * z)
+    root = np.stack([r * np.cos(ph), z, r * np.sin(ph)], 1)
+    length = rs.uniform(0.3, 0.6, n_strands)
+    t = np.linspace(0.0, 1.0, n_cp)[None, :, None]
+    nrm = root[:, None, :]
+    grav = np.array([0.0, -1.0, 0.0])[None, None, :]
+    jitter = rs.normal(0, 0.02, (n_strands, 1, 3))
+    pts = nrm + nrm * (length[:, None, None] * t) * (1 - 0.5 * t) + grav * (length[:, None, None] * t * t * 0.9) + jitter * t
+    rad = (4e-4 + (1e-4 - 4e-4) * t[..., 0]) * np.ones((n_strands, 1))
+    # phantom points: first' = 2*p0 - p1, last' = 2*pn - pn-1 (BasisCurves.cpp:189-232); widths are already radii
+    first = 2 * pts[:, :1] - pts[:, 1:2]
+    last = 2 * pts[:, -1:] - pts[:, -2:-1]
+    pts = np.concatenate([first, pts, last], 1)
+    rad = np.concatenate([rad[:, :1], rad, rad[:, -1:]], 1)
+    counts = np.full(n_strands, n_cp + 2, np.uint32)
+    cid = sc.createCurve(counts, pts.reshape(-1, 3), rad.reshape(-1))
+    sc.createInstance(S.INSTANCE_CURVE, cid, hair, np.eye(4))
+    for pos, rot in [((2.5, 2.5, 2.5), (-45, 45, 0)), ((-3.0, 1.5, 1.0), (-20, -70, 0))]:
+        xf = S.translate(pos) @ S.rotate((0, 1, 0), math.radians(rot[1])) @ S.rotate((1, 0, 0), math.radians(rot[0] + 180))
+        sc.createLight({"type": 0, "xform": xf, "useXform": True, "width": 1.5, "height": 1.5, "color": (1, 1, 1),
+                        "intensity": 25.0})
+    cam = S.Camera(fov=40.0)
+    cam.lookAt((0.0, 0.6, 4.2), (0.0, 0.2, 0.0))
+    sc.addCamera(cam)
+    return sc
+
+
+def coffeemaker_standin(seed=1, target_tris=50000):
+    """C1 "coffeemaker stand-in" (SURVEY 8d): lathe object ~50 k triangles on a 2-triangle ground plane, 1 rect
+    light 0.4 x 0.4 intensity 160 (the commented default at HdStrelka/RenderPass.cpp:375-381)."""
+    rs = np.random.RandomState(seed)
+    sc = S.Scene()
+    sc.addMaterial(S.MAT_DIFFUSE, (0.7, 0.7, 0.7))
+    body = sc.addMaterial(S.MAT_PBR, (0.8, 0.3, 0.2), roughness=0.25, metallic=0.0)
+    nu = int(math.sqrt(target_tris / 2.0 * 1.4))
+    nv = int(target_tris / 2.0 / nu)
+    pos, tris = _grid_mesh(_lathe_fn(rs), nu, nv)
+    p = pos.astype(np.float64)
+    if np.einsum("ij,ij->i", p[tris[:, 0]], np.cross(p[tris[:, 1]], p[tris[:, 2]])).sum() < 0:
+        tris = tris[:, ::-1]
+    m = _add_mesh(sc, pos, tris)
+    g = _add_mesh(sc, *_quad((-4, 0, -4), (-4, 0, 4), (4, 0, 4), (4, 0, -4)))
+    sc.createInstance(S.INSTANCE_MESH, g, 0, np.eye(4))
+    sc.createInstance(S.INSTANCE_MESH, m, body, S.translate((0, 1.0, 0)))
+    xf = S.translate((0.8, 3.0, 0.8)) @ S.rotate((1, 0, 0), math.radians(-90))
+    sc.createLight({"type": 0, "xform": xf, "useXform": True, "width": 0.4, "height": 0.4, "color": (1, 1, 1),
+                    "intensity": 160.0})
+    cam = S.Camera(fov=45.0)
+    cam.lookAt((2.6, 2.2, 3.2), (0.0, 0.9, 0.0))
+    sc.addCamera(cam)
+    return sc
+
+
+def random_rays(n, seed, lo, hi, tmax=1e16):
+    """Uniform random origins in [lo,hi]^3 and uniform directions, as skh_ray records."""
+    rs = np.random.RandomState(seed)
+    rays = np.zeros(n, S.RAY)
+    rays["origin"] = rs.uniform(lo, hi, (n, 3))
+    d = rs.normal(size=(n, 3))
+    rays["dir"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays["tmin"] = 0.0
+    rays["tmax"] = tmax
+    return rays
