@@ -180,10 +180,12 @@ typedef struct skh_stats
 {
     uint64_t rays_radiance; /* closest-hit rays actually traced since the last reset */
     uint64_t rays_shadow; /* any-hit rays actually traced since the last reset */
-    uint64_t nodes_visited; /* counter build only (skh_set_option "count_traversal") */
-    uint64_t prims_tested; /* triangles */
-    uint64_t segs_tested; /* curve segments */
-    uint64_t instances_entered;
+    /* traversal counters, counter build only (skh_set_option "count_traversal"); [0] closest-hit kernel,
+     * [1] shadow (any-hit) kernel */
+    uint64_t nodes_visited[2]; /* 64-byte BVH nodes fetched */
+    uint64_t prims_tested[2]; /* triangles */
+    uint64_t segs_tested[2]; /* curve segments */
+    uint64_t instances_entered[2];
     double ms_trace_closest; /* hipEvent time summed over launches since the last reset */
     double ms_trace_shadow;
     double ms_shade;

@@ -13,8 +13,8 @@ from .build import LIB
 
 _lib = None
 
-STATS = np.dtype([("rays_radiance", np.uint64), ("rays_shadow", np.uint64), ("nodes_visited", np.uint64),
-                  ("prims_tested", np.uint64), ("segs_tested", np.uint64), ("instances_entered", np.uint64),
+STATS = np.dtype([("rays_radiance", np.uint64), ("rays_shadow", np.uint64), ("nodes_visited", np.uint64, 2),
+                  ("prims_tested", np.uint64, 2), ("segs_tested", np.uint64, 2), ("instances_entered", np.uint64, 2),
                   ("ms_trace_closest", np.float64), ("ms_trace_shadow", np.float64), ("ms_shade", np.float64),
                   ("ms_raygen", np.float64), ("ms_accumulate", np.float64), ("ms_build", np.float64),
                   ("launches_trace_closest", np.uint32), ("launches_trace_shadow", np.uint32),
@@ -188,7 +188,14 @@ class Context:
     def stats(self):
         s = np.zeros((), STATS)
         self._ck(self.lib.skh_get_stats(self.h, _p(s)), "skh_get_stats")
-        return {k: (float(s[k]) if s[k].dtype.kind == "f" else int(s[k])) for k in STATS.names}
+        out = {}
+        for k in STATS.names:
+            v = s[k]
+            if v.ndim:
+                out[k] = [int(x) for x in v]
+            else:
+                out[k] = float(v) if v.dtype.kind == "f" else int(v)
+        return out
 
     def reset_stats(self):
         self._ck(self.lib.skh_reset_stats(self.h), "skh_reset_stats")

@@ -311,7 +311,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const v3& ow, const
 
 struct StatsDev
 {
-    unsigned long long raysRadiance, raysShadow, nodes, prims, segs, insts;
+    unsigned long long raysRadiance, raysShadow, nodes[2], prims[2], segs[2], insts[2];
 };
 
 SKH_DI uint32_t wave_sum(uint32_t v)
@@ -383,10 +383,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK)
         const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.prims), c2 = wave_sum(tc.segs), d2 = wave_sum(tc.insts);
         if (lane == 0)
         {
-            atomicAdd(&stats->nodes, (unsigned long long)a);
-            atomicAdd(&stats->prims, (unsigned long long)b);
-            atomicAdd(&stats->segs, (unsigned long long)c2);
-            atomicAdd(&stats->insts, (unsigned long long)d2);
+            atomicAdd(&stats->nodes[ANY_HIT ? 1 : 0], (unsigned long long)a);
+            atomicAdd(&stats->prims[ANY_HIT ? 1 : 0], (unsigned long long)b);
+            atomicAdd(&stats->segs[ANY_HIT ? 1 : 0], (unsigned long long)c2);
+            atomicAdd(&stats->insts[ANY_HIT ? 1 : 0], (unsigned long long)d2);
         }
     }
 }

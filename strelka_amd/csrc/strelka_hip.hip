@@ -1150,10 +1150,13 @@ skh_status skh_get_stats(skh_context* c, skh_stats* out)
     memset(out, 0, sizeof(*out));
     out->rays_radiance = sd.raysRadiance;
     out->rays_shadow = sd.raysShadow;
-    out->nodes_visited = sd.nodes;
-    out->prims_tested = sd.prims;
-    out->segs_tested = sd.segs;
-    out->instances_entered = sd.insts;
+    for (int k = 0; k < 2; ++k)
+    {
+        out->nodes_visited[k] = sd.nodes[k];
+        out->prims_tested[k] = sd.prims[k];
+        out->segs_tested[k] = sd.segs[k];
+        out->instances_entered[k] = sd.insts[k];
+    }
     out->ms_trace_closest = c->msClass[KC_TRACE_CLOSEST];
     out->ms_trace_shadow = c->msClass[KC_TRACE_SHADOW];
     out->ms_shade = c->msClass[KC_SHADE];

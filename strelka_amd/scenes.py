@@ -184,26 +184,45 @@ def kitchen_standin(seed=1234, n_meshes=150, n_instances=2000, tri_lo=200, tri_h
             tris = tris[:, ::-1]
         mesh_ids.append(_add_mesh(sc, pos, tris))
         closed.append(kind != 1 or True)
-    # instances: on the floor, on shelves along the walls, a few hanging
+    # instances: one per cell of a jittered layout -- a floor grid plus four shelf levels (two rows deep) along the
+    # walls -- so that objects touch but rarely interpenetrate (keeps the instance boxes of the TLAS from piling up)
+    cell = 0.2
+    cells = []
+    xs = np.arange(-RX + 0.3, RX - 0.3 + 1e-6, cell)
+    zs = np.arange(-RZ + 0.3, RZ - 0.3 + 1e-6, cell)
+    for x in xs:
+        for z in zs:
+            cells.append((x, 0.0, z))
+    for lvl in (0.9, 1.6, 2.3, 3.0):
+        for row in (0.12, 0.32):
+            for x in xs:
+                cells.append((x, lvl, -RZ + row))
+                cells.append((x, lvl, RZ - row))
+            for z in zs:
+                cells.append((-RX + row, lvl, z))
+                cells.append((RX - row, lvl, z))
+    cells = np.array(cells)
+    order = rs.permutation(len(cells))
+    assert len(cells) >= n_instances, (len(cells), n_instances)
     for k in range(n_instances):
         m = mesh_ids[k % n_meshes] if k < n_meshes else mesh_ids[rs.randint(n_meshes)]
-        s = rs.uniform(0.06, 0.28) * (1.0 if rs.rand() < 0.9 else 2.2)
-        shelf = rs.randint(0, 4)
-        x = rs.uniform(-RX + 0.4, RX - 0.4)
-        z = rs.uniform(-RZ + 0.4, RZ - 0.4)
-        if rs.rand() < 0.55:  # against a wall, on a shelf level
-            if rs.rand() < 0.5:
-                z = (-RZ + 0.35) if rs.rand() < 0.7 else (RZ - 0.35)
-            else:
-                x = (-RX + 0.35) if rs.rand() < 0.5 else (RX - 0.35)
-            y = 0.45 + 0.8 * shelf
-        else:
-            y = 1.3 * s
+        sx = rs.uniform(0.05, 0.1) * (1.0 if rs.rand() < 0.97 else 3.0)
+        sy = sx * rs.uniform(0.8, 1.5)
+        cx, cy, cz = cells[order[k]]
+        x = cx + rs.uniform(-0.03, 0.03)
+        z = cz + rs.uniform(-0.03, 0.03)
+        y = cy + 1.02 * sy  # meshes span about [-1, 1] in y: rest them on the floor / shelf
         ang = rs.uniform(0, 2 * math.pi)
-        tilt = rs.uniform(-0.25, 0.25)
-        xf = S.translate((x, y, z)) @ S.rotate((0, 1, 0), ang) @ S.rotate((1, 0, 0), tilt) @ S.scale((s, s * rs.uniform(0.7, 1.4), s))
+        xf = S.translate((x, y, z)) @ S.rotate((0, 1, 0), ang) @ S.scale((sx, sy, sx))
         mat = mats[rs.randint(n_mat)]
         sc.createInstance(S.INSTANCE_MESH, m, mat, xf)
+    # shelf boards (thin boxes) so that the shelf objects cast and receive contact shadows
+    board_pos, board_tris = _box_mesh((-1, -1, -1), (1, 1, 1))
+    board = _add_mesh(sc, board_pos, board_tris)
+    for lvl in (0.9, 1.6, 2.3, 3.0):
+        for (bx, bz, hx, hz) in [(0.0, -RZ + 0.22, RX - 0.05, 0.22), (0.0, RZ - 0.22, RX - 0.05, 0.22),
+                                 (-RX + 0.22, 0.0, 0.22, RZ - 0.05), (RX - 0.22, 0.0, 0.22, RZ - 0.05)]:
+            sc.createInstance(S.INSTANCE_MESH, board, 0, S.translate((bx, lvl - 0.012, bz)) @ S.scale((hx, 0.01, hz)))
     # lights: 4 ceiling rect lights facing down + 1 distant light through the (imaginary) window
     for lx, lz in [(-2.5, -1.2), (2.5, -1.2), (-2.5, 1.2), (2.5, 1.2)]:
         xf = S.translate((lx, 2 * RY - 0.02, lz)) @ S.rotate((1, 0, 0), math.radians(-90))
@@ -213,8 +232,8 @@ def kitchen_standin(seed=1234, n_meshes=150, n_instances=2000, tri_lo=200, tri_h
     xf = S.rotate((0, 1, 0), math.radians(30)) @ S.rotate((1, 0, 0), math.radians(-55))
     sc.createLight({"type": 3, "xform": xf, "useXform": True, "halfAngle": math.radians(5.0), "color": (1.0, 0.95, 0.85),
                     "intensity": 2.0, "radius": 0.0})
-    cam = S.Camera(fov=55.0)
-    cam.lookAt((-4.3, 2.6, 2.6), (0.8, 0.9, -0.6))
+    cam = S.Camera(fov=60.0)
+    cam.lookAt((-4.2, 2.3, 2.3), (1.2, 0.7, -1.2))
     sc.addCamera(cam)
     return sc
 

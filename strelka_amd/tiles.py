@@ -1,0 +1,64 @@
+"""Multi-GPU pixel-tile sharding (new functionality: the reference is single-process, single-GPU).
+
+Every pixel is independent (sampler state depends only on (x, y, sampleIndex, sppTotal): RandomSampler.h:130-137;
+accumulation is per pixel: OptixRender.cu:60-78), so the frame is cut into square tiles and rank r of W renders
+tiles t = r (mod W) of the row-major tile list for ALL sub-frames.  Sharding by SAMPLES would change the image (the
+accumulator is a non-linear, order-dependent LDR-space lerp), sharding by tiles reproduces the single-GPU image bit
+for bit.  One collective per frame: a gather of the float4 tile accumulators to rank 0 (RCCL over xGMI; every sender
+uses its own link into the root), followed by a de-tiling scatter on the root.
+"""
+import numpy as np
+
+
+def tile_grid(width, height, tile_size):
+    """(x0, y0) of every tile, row-major; partial tiles at the right/top edge are included."""
+    xs = np.arange(0, width, tile_size, dtype=np.uint32)
+    ys = np.arange(0, height, tile_size, dtype=np.uint32)
+    return np.stack([np.tile(xs, len(ys)), np.repeat(ys, len(xs))], 1).astype(np.uint32)
+
+
+def assign_tiles(width, height, tile_size, world_size, rank):
+    """Tiles owned by `rank`: interleaved round-robin so that expensive image regions spread over all GPUs."""
+    return np.ascontiguousarray(tile_grid(width, height, tile_size)[rank::world_size])
+
+
+def max_tiles_per_rank(width, height, tile_size, world_size):
+    n = len(tile_grid(width, height, tile_size))
+    return (n + world_size - 1) // world_size
+
+
+def gather_tiles(local_tiles, world_size, rank, dist=None, dst=0):
+    """One gather of equally sized (padded) tile-accumulator tensors to `dst`.
+    local_tiles: torch tensor [max_tiles, tile*tile, 4] float32 (rows past this rank's tile count are padding).
+    Returns the list of per-rank tensors on dst, None elsewhere."""
+    import torch
+
+    if world_size == 1 or dist is None:
+        return [local_tiles]
+    out = [torch.empty_like(local_tiles) for _ in range(world_size)] if rank == dst else None
+    dist.gather(local_tiles, gather_list=out, dst=dst)
+    return out
+
+
+def detile_numpy(tiles_rgba, tile_xy, tile_size, width, height, out=None):
+    """Host reference of the de-tiling scatter (tests only; on the GPU the root uses skh_scatter_tiles).
+    Slot order inside a tile is Morton(xl, yl) (skh_kernels.h: slot_to_pixel)."""
+    t = np.asarray(tiles_rgba).reshape(len(tile_xy), tile_size * tile_size, 4)
+    if out is None:
+        out = np.zeros((height, width, 4), np.float32)
+    m = np.arange(tile_size * tile_size, dtype=np.uint32)
+
+    def compact(v):
+        v = v & 0x55555555
+        v = (v ^ (v >> 1)) & 0x33333333
+        v = (v ^ (v >> 2)) & 0x0F0F0F0F
+        v = (v ^ (v >> 4)) & 0x00FF00FF
+        v = (v ^ (v >> 8)) & 0x0000FFFF
+        return v
+
+    xl, yl = compact(m), compact(m >> 1)
+    for k, (x0, y0) in enumerate(np.asarray(tile_xy, np.int64)):
+        px, py = x0 + xl, y0 + yl
+        ok = (px < width) & (py < height)
+        out[py[ok], px[ok]] = t[k][ok]
+    return out
