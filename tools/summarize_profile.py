@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof_<tag>/ (written by tools/profile.sh) into the tracked artefacts under profiles/:
+  profiles/<tag>_kernel_stats.csv          rocprofv3 --kernel-trace --stats summary (per-kernel time)
+  profiles/<tag>_pmc_hbm.csv               per-kernel FETCH_SIZE / WRITE_SIZE averages from the two --pmc passes
+  profiles/traffic_k_trace_closest.json    HBM bytes per launch of the dominant kernel, read by bench.py
+Units/corrections follow /opt/skills/guides (MI355X_MICROARCH.md "HBM", cdna_hip_programming.md section 7):
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) reads, so
+hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  The 2x is calibrated for coalesced streams; a BVH walk issues
+16 B/lane loads to scattered 64 B nodes, so treat the absolute as +-2x and use it for ratios between builds.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    n = name.replace("void ", "").replace("skh::", "")
+    return n.split("(")[0]
+
+
+def pmc(dirpath, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(dirpath, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == counter:
+                a = acc[short(row["Kernel_Name"])]
+                a[0] += float(row["Counter_Value"])
+                a[1] += 1
+    return acc
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    ks = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    if ks:
+        shutil.copy(ks[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    logs = os.path.join(src, "bench_trace.log")
+    if os.path.exists(logs):
+        lines = [l for l in open(logs) if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w").write(lines[-1])
+    fetch = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
+    write = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+    rows = []
+    for k in sorted(set(fetch) | set(write)):
+        f = fetch[k][0] / max(1, fetch[k][1]) if k in fetch else 0.0
+        w = write[k][0] / max(1, write[k][1]) if k in write else 0.0
+        rows.append((k, fetch[k][1] if k in fetch else 0, f, w, (2 * f + w) * 1024))
+    with open(os.path.join(dst, f"{tag}_pmc_hbm.csv"), "w") as fo:
+        fo.write("kernel,launches,avg_FETCH_SIZE_KiB,avg_WRITE_SIZE_KiB,hbm_bytes_per_launch=(2*FETCH+WRITE)*1024\n")
+        for r in rows:
+            fo.write("%s,%d,%.3f,%.3f,%.0f\n" % r)
+    for r in rows:
+        if r[0].startswith("k_trace<false, false>"):
+            json.dump({"kernel": r[0], "tag": tag, "avg_FETCH_SIZE_KiB": r[2], "avg_WRITE_SIZE_KiB": r[3],
+                       "hbm_bytes_per_launch": int(r[4]),
+                       "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, gfx950 FETCH_SIZE x2 correction"},
+                      open(os.path.join(dst, "traffic_k_trace_closest.json"), "w"), indent=1)
+            print("traffic", r)
+    print(open(os.path.join(dst, f"{tag}_pmc_hbm.csv")).read())
+
+
+if __name__ == "__main__":
+    main()
