@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--scene", default="kitchen")
+    ap.add_argument("--waves-per-cu", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="name=value passed to skh_set_option")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -102,6 +104,11 @@ def main():
     W, H = args.width, args.height
 
     ctx = capi.Context(local_rank)
+    if args.waves_per_cu:
+        ctx.set_option("waves_per_cu", args.waves_per_cu)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     ctx.set_scene(arr)
     my_tiles = tiles.assign_tiles(W, H, args.tile, world, rank)
     ctx.set_tiles(args.tile, my_tiles if world > 1 else None)

@@ -4,7 +4,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB = os.path.join(HERE, "libstrelka_hip.so")
+LIB = os.environ.get("SKH_LIB") or os.path.join(HERE, "libstrelka_hip.so")  # SKH_LIB: A/B builds of the same HIP source
 SRC = os.path.join(HERE, "csrc", "strelka_hip.hip")
 DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("skh_device.h", "skh_bvh.h", "skh_kernels.h")] + [
     os.path.join(ROOT, "include", "strelka_hip.h")]

@@ -130,185 +130,6 @@ struct HitRec
     bool found;
 };
 
-// Two-level traversal.  Closest hit: smallest t, ties broken by the smaller (instance, primitive) key, ray interval
-// open at both ends -- the result is independent of the BVH (DESIGN.md "determinism").
-template <bool ANY_HIT, bool COUNT>
-__device__ __forceinline__ void traverse(const DevScene& sc, const v3& ow, const v3& dw, float tmin, float tmax,
-                                         uint32_t mask, int* __restrict__ lds /* &stack[0][lane] */, int ldsStride,
-                                         int* __restrict__ ovf, uint32_t ovfStride, HitRec& best, TraceCounters& tc)
-{
-    best.t = tmax;
-    best.inst = 0xffffffffu;
-    best.prim = 0xffffffffu;
-    best.u = best.v = 0.0f;
-    best.found = false;
-    if (sc.tlasRoot == SKH_REF_INVALID)
-        return;
-    v3 o = ow, d = dw;
-    v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    RayShear sh;
-    const Node64* nodes = sc.tlasNodes;
-    bool inBlas = false;
-    uint32_t curInst = 0, curType = 0;
-    int sp = 0;
-    int cur = sc.tlasRoot;
-
-#define SKH_PUSH(v)                                        \
-    {                                                      \
-        if (sp < SKH_STACK_LDS)                            \
-            lds[sp * ldsStride] = (v);                     \
-        else if (sp < SKH_STACK_LDS + SKH_STACK_OVF)       \
-            ovf[(size_t)(sp - SKH_STACK_LDS) * ovfStride] = (v); \
-        ++sp;                                              \
-    }
-#define SKH_POP(dst)                                       \
-    {                                                      \
-        --sp;                                              \
-        if (sp < SKH_STACK_LDS)                            \
-            dst = lds[sp * ldsStride];                     \
-        else if (sp < SKH_STACK_LDS + SKH_STACK_OVF)       \
-            dst = ovf[(size_t)(sp - SKH_STACK_LDS) * ovfStride]; \
-        else                                               \
-            dst = SKH_REF_INVALID;                         \
-    }
-
-    for (;;)
-    {
-        // ---- descend through internal nodes ----
-        while (cur >= 0 && cur != SKH_REF_INVALID)
-        {
-            const float4* np = reinterpret_cast<const float4*>(nodes + cur);
-            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-            if (COUNT)
-                tc.nodes++;
-            float tl, tr;
-            const bool hl = slab_test(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, inv, tmin, best.t, tl);
-            const bool hr = slab_test(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, inv, tmin, best.t, tr);
-            const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
-            if (hl && hr)
-            {
-                const bool leftFirst = tl <= tr;
-                SKH_PUSH(leftFirst ? right : left);
-                cur = leftFirst ? left : right;
-            }
-            else if (hl)
-                cur = left;
-            else if (hr)
-                cur = right;
-            else
-                cur = SKH_REF_INVALID;
-        }
-        // ---- leaf ----
-        if (cur < 0 && cur != SKH_REF_SENTINEL)
-        {
-            const uint32_t enc = (uint32_t)~cur;
-            const uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
-            if (!inBlas)
-            {
-                // TLAS leaves hold exactly one instance
-                const uint32_t id = sc.tlasInst[first];
-                const float4* ip = reinterpret_cast<const float4*>(sc.inst + id);
-                const float4 i3 = ip[3];
-                const uint32_t imask = __float_as_uint(i3.y);
-                if (imask & mask)
-                {
-                    const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2];
-                    if (COUNT)
-                        tc.insts++;
-                    const float m[12] = { i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w };
-                    o = xform_point(m, ow);
-                    d = xform_vector(m, dw);
-                    inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                    sh = make_shear(d);
-                    curInst = id;
-                    curType = __float_as_uint(i3.z);
-                    nodes = curType == 2 ? sc.segNodes : sc.triNodes;
-                    inBlas = true;
-                    SKH_PUSH(SKH_REF_SENTINEL);
-                    cur = __float_as_int(i3.x);
-                    continue;
-                }
-            }
-            else if (curType == 2)
-            {
-                for (uint32_t k = 0; k < count; ++k)
-                {
-                    const float4* cp = sc.segs + 4 * (size_t)(first + k);
-                    const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
-                    if (COUNT)
-                        tc.segs++;
-                    v4 q[4];
-                    q[0] = mk4(c0.x, c0.y, c0.z, c0.w);
-                    q[1] = mk4(c1.x, c1.y, c1.z, c1.w);
-                    q[2] = mk4(c2.x, c2.y, c2.z, c2.w);
-                    q[3] = mk4(c3.x, c3.y, c3.z, c3.w);
-                    float t, u;
-                    if (intersect_curve_segment(o, d, tmin, best.t, q, t, u) && t < tmax)
-                    {
-                        const uint32_t prim = sc.segPrim[first + k];
-                        if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
-                        {
-                            best.t = t;
-                            best.inst = curInst;
-                            best.prim = prim;
-                            best.u = u;
-                            best.v = 0.0f;
-                            best.found = true;
-                            if (ANY_HIT)
-                                return;
-                        }
-                    }
-                }
-            }
-            else
-            {
-                for (uint32_t k = 0; k < count; ++k)
-                {
-                    const float4* tp = sc.tris + 3 * (size_t)(first + k);
-                    const float4 a = tp[0], b = tp[1], c = tp[2];
-                    if (COUNT)
-                        tc.prims++;
-                    float t, u, v;
-                    if (intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), t, u, v) && t < tmax)
-                    {
-                        const uint32_t prim = __float_as_uint(a.w);
-                        if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
-                        {
-                            best.t = t;
-                            best.inst = curInst;
-                            best.prim = prim;
-                            best.u = u;
-                            best.v = v;
-                            best.found = true;
-                            if (ANY_HIT)
-                                return;
-                        }
-                    }
-                }
-            }
-        }
-        // ---- pop ----
-        for (;;)
-        {
-            if (sp == 0)
-                return;
-            SKH_POP(cur);
-            if (cur == SKH_REF_SENTINEL)
-            {
-                o = ow;
-                d = dw;
-                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                nodes = sc.tlasNodes;
-                inBlas = false;
-                continue;
-            }
-            break;
-        }
-    }
-#undef SKH_PUSH
-#undef SKH_POP
-}
-
 struct StatsDev
 {
     unsigned long long raysRadiance, raysShadow, nodes[2], prims[2], segs[2], insts[2];
@@ -322,62 +143,307 @@ SKH_DI uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+#ifndef SKH_TRACE_MIN_WAVES
+#define SKH_TRACE_MIN_WAVES 1
+#endif
+#ifndef SKH_FETCH_MIN
+#define SKH_FETCH_MIN 20 // refill the wave from the ray queue when at least this many lanes are idle
+#endif
+
 // ------------------------------------------------------------------------------------------------------------
-// k_trace: persistent waves; wave w takes 64-ray chunks w, w + W, ...  Blocks that share an XCD (blockIdx % 8,
-// observed round-robin placement) walk one contiguous eighth of the queue so their BVH working sets overlap in
-// that XCD's L2.  Placement only affects speed, never results.
+// k_trace: persistent waves over the ray queue, two-level BVH traversal (TLAS -> instance -> BLAS).
+//
+// Work distribution: the queue is cut into 8 contiguous ranges, one per XCD label (blockIdx % 8; blocks b and b+8
+// share an XCD under the observed round-robin placement, so neighbouring rays -- similar BVH working set -- land in
+// one XCD's L2).  A wave pulls rays from its range through one returning atomic per refill and steals from the next
+// ranges when its own is empty.  Lanes whose ray has terminated are refilled as soon as SKH_FETCH_MIN lanes are idle
+// ("persistent while-while with dynamic fetch"), which keeps the 64-wide wave populated when ray lengths diverge.
+// Placement and fetch order only affect speed: every ray's result is independent of scheduling.
+//
+// Closest hit = smallest t, ties broken by the smaller (instance, primitive) key, ray interval open at both ends:
+// the result does not depend on the BVH or on the traversal order (DESIGN.md "determinism").
 // ------------------------------------------------------------------------------------------------------------
-template <bool ANY_HIT, bool COUNT>
-__global__ void __launch_bounds__(SKH_TRACE_BLOCK)
-    k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, HitQ hq, PathS ps, const float* __restrict__ contrib,
-            uint32_t contribStride, int* __restrict__ ovf, StatsDev* __restrict__ stats)
+template <bool ANY_HIT, bool COUNT, bool CURVES>
+__global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WAVES)
+    k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
+            uint32_t fetchMin,
+            HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
+            StatsDev* __restrict__ stats)
 {
     __shared__ int s_stack[SKH_STACK_LDS * SKH_TRACE_BLOCK];
     const uint32_t lane = threadIdx.x;
     const uint32_t n = *countPtr;
-    const uint32_t numChunks = (n + 63u) >> 6;
-    const uint32_t nb = gridDim.x;
-    // XCD-aware chunk order: block b handles chunks of "its" eighth first
-    const uint32_t xcd = blockIdx.x & 7u, within = blockIdx.x >> 3;
-    const uint32_t perXcdBlocks = (nb + 7u) >> 3;
-    const uint32_t chunksPerXcd = (numChunks + 7u) >> 3;
+    if (n == 0)
+        return;
+    const uint32_t perGroup = (((n + 7u) >> 3) + 63u) & ~63u;
+    const uint32_t group = blockIdx.x & 7u;
+    uint32_t tries = 0;
+    bool exhausted = false;
+    int* lds = s_stack + lane;
+    int* ovf = ovfBase + (blockIdx.x * SKH_TRACE_BLOCK + lane);
+    const uint32_t ovfStride = gridDim.x * SKH_TRACE_BLOCK;
+    const uint32_t rayMask = CURVES ? (ANY_HIT ? 3u : 255u) : (ANY_HIT ? 1u : 253u);
     TraceCounters tc = { 0, 0, 0, 0 };
-    const uint32_t gtid = blockIdx.x * SKH_TRACE_BLOCK + lane;
-    const uint32_t ovfStride = nb * SKH_TRACE_BLOCK;
-    for (uint32_t c = within; c < chunksPerXcd; c += perXcdBlocks)
+
+    // per-lane traversal state
+    bool hasRay = false;
+    uint32_t ridx = 0;
+    v3 ow = mk3(0.0f), dw = mk3(0.0f), o = mk3(0.0f), d = mk3(0.0f), inv = mk3(0.0f);
+    float tmin = 0.0f, tmax = 0.0f;
+    RayShear sh;
+    sh.kx = sh.ky = sh.kz = 0;
+    sh.Sx = sh.Sy = sh.Sz = 0.0f;
+    const Node64* nodes = sc.tlasNodes;
+    bool inBlas = false;
+    uint32_t curInst = 0, curType = 0;
+    int sp = 0, cur = SKH_REF_INVALID;
+    HitRec best;
+    best.t = 0.0f, best.inst = best.prim = 0xffffffffu, best.u = best.v = 0.0f, best.found = false;
+
+#define SKH_PUSH(v)                                                  \
+    {                                                                \
+        if (sp < SKH_STACK_LDS)                                      \
+            lds[sp * SKH_TRACE_BLOCK] = (v);                         \
+        else if (sp < SKH_STACK_LDS + SKH_STACK_OVF)                 \
+            ovf[(size_t)(sp - SKH_STACK_LDS) * ovfStride] = (v);     \
+        ++sp;                                                        \
+    }
+#define SKH_POP(dst)                                                 \
+    {                                                                \
+        --sp;                                                        \
+        if (sp < SKH_STACK_LDS)                                      \
+            dst = lds[sp * SKH_TRACE_BLOCK];                         \
+        else if (sp < SKH_STACK_LDS + SKH_STACK_OVF)                 \
+            dst = ovf[(size_t)(sp - SKH_STACK_LDS) * ovfStride];     \
+        else                                                         \
+            dst = SKH_REF_INVALID;                                   \
+    }
+
+    for (;;)
     {
-        const uint32_t chunk = xcd * chunksPerXcd + c;
-        const uint32_t i = (chunk << 6) + lane;
-        if (chunk >= numChunks || i >= n)
-            continue;
-        const v3 o = mk3(rq.plane(0)[i], rq.plane(1)[i], rq.plane(2)[i]);
-        const v3 d = mk3(rq.plane(3)[i], rq.plane(4)[i], rq.plane(5)[i]);
-        const float tmin = rq.plane(6)[i], tmax = rq.plane(7)[i];
-        HitRec h;
-        traverse<ANY_HIT, COUNT>(sc, o, d, tmin, tmax, ANY_HIT ? 3u : 255u, s_stack + lane, SKH_TRACE_BLOCK, ovf + gtid,
-                                 ovfStride, h, tc);
-        if (ANY_HIT)
+        // ---------------- refill idle lanes from the queue ----------------
+        const unsigned long long needMask = __ballot(!hasRay);
+        const uint32_t want = (uint32_t)__popcll(needMask);
+        if (!exhausted && (want >= fetchMin || want == 64u))
         {
-            if (hq.base) // raw query mode (skh_trace): 1 = occluded, -1 = not
-                hq.base[i] = h.found ? 1.0f : -1.0f;
-            else if (!h.found)
+            uint32_t base = 0, count = 0;
+            const int leader = __ffsll((long long)needMask) - 1;
+            while (tries < 8u)
             {
-                const uint32_t pid = rq.ids()[i];
-                float* rad = ps.base + (size_t)3 * ps.stride;
-                rad[pid] += contrib[i];
-                rad[pid + ps.stride] += contrib[i + contribStride];
-                rad[pid + 2 * (size_t)ps.stride] += contrib[i + 2 * (size_t)contribStride];
+                const uint32_t g = (group + tries) & 7u;
+                uint32_t b = 0;
+                if ((int)lane == leader)
+                    b = atomicAdd(&fetch[g], want);
+                b = __shfl(b, leader);
+                const uint32_t lo = g * perGroup;
+                const uint32_t hi = min(n, lo + perGroup);
+                if (lo < hi && b < hi - lo)
+                {
+                    base = lo + b;
+                    count = min(want, hi - base);
+                    if (count < want)
+                        ++tries; // this range is now empty
+                    break;
+                }
+                ++tries;
+            }
+            if (tries >= 8u && count == 0)
+                exhausted = true;
+            const uint32_t rank = (uint32_t)__popcll(needMask & ((1ull << lane) - 1ull));
+            if (!hasRay && rank < count)
+            {
+                ridx = base + rank;
+                ow = mk3(rq.plane(0)[ridx], rq.plane(1)[ridx], rq.plane(2)[ridx]);
+                dw = mk3(rq.plane(3)[ridx], rq.plane(4)[ridx], rq.plane(5)[ridx]);
+                tmin = rq.plane(6)[ridx];
+                tmax = rq.plane(7)[ridx];
+                o = ow;
+                d = dw;
+                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                nodes = sc.tlasNodes;
+                inBlas = false;
+                sp = 0;
+                cur = sc.tlasRoot;
+                best.t = tmax;
+                best.inst = best.prim = 0xffffffffu;
+                best.u = best.v = 0.0f;
+                best.found = false;
+                hasRay = true;
             }
         }
-        else
+        if (!__any(hasRay))
         {
-            hq.base[i] = h.found ? h.t : -1.0f;
-            reinterpret_cast<uint32_t*>(hq.base)[i + hq.stride] = h.inst;
-            reinterpret_cast<uint32_t*>(hq.base)[i + 2 * (size_t)hq.stride] = h.prim;
-            hq.base[i + 3 * (size_t)hq.stride] = h.u;
-            hq.base[i + 4 * (size_t)hq.stride] = h.v;
+            if (exhausted)
+                break;
+            continue;
+        }
+        bool terminated = false;
+        if (hasRay)
+        {
+            // ---- descend through internal nodes ----
+            while (cur >= 0 && cur != SKH_REF_INVALID)
+            {
+                const float4* np = reinterpret_cast<const float4*>(nodes + cur);
+                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                if (COUNT)
+                    tc.nodes++;
+                float tl, tr;
+                const bool hl = slab_test(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, inv, tmin, best.t, tl);
+                const bool hr = slab_test(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, inv, tmin, best.t, tr);
+                const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+                if (hl && hr)
+                {
+                    const bool leftFirst = tl <= tr;
+                    SKH_PUSH(leftFirst ? right : left);
+                    cur = leftFirst ? left : right;
+                }
+                else if (hl)
+                    cur = left;
+                else if (hr)
+                    cur = right;
+                else
+                    cur = SKH_REF_INVALID;
+            }
+            // ---- leaf ----
+            bool entered = false;
+            if (cur < 0 && cur != SKH_REF_SENTINEL)
+            {
+                const uint32_t enc = (uint32_t)~cur;
+                const uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
+                if (!inBlas)
+                {
+                    // TLAS leaves hold exactly one instance
+                    const uint32_t id = sc.tlasInst[first];
+                    const float4* ip = reinterpret_cast<const float4*>(sc.inst + id);
+                    const float4 i3 = ip[3];
+                    if (__float_as_uint(i3.y) & rayMask)
+                    {
+                        const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2];
+                        if (COUNT)
+                            tc.insts++;
+                        const float m[12] = { i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w };
+                        o = xform_point(m, ow);
+                        d = xform_vector(m, dw);
+                        inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        sh = make_shear(d);
+                        curInst = id;
+                        curType = __float_as_uint(i3.z);
+                        nodes = (CURVES && curType == 2) ? sc.segNodes : sc.triNodes;
+                        inBlas = true;
+                        SKH_PUSH(SKH_REF_SENTINEL);
+                        cur = __float_as_int(i3.x);
+                        entered = true;
+                    }
+                }
+                else if (CURVES && curType == 2)
+                {
+                    for (uint32_t k = 0; k < count; ++k)
+                    {
+                        const float4* cp = sc.segs + 4 * (size_t)(first + k);
+                        const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+                        if (COUNT)
+                            tc.segs++;
+                        v4 q[4];
+                        q[0] = mk4(c0.x, c0.y, c0.z, c0.w);
+                        q[1] = mk4(c1.x, c1.y, c1.z, c1.w);
+                        q[2] = mk4(c2.x, c2.y, c2.z, c2.w);
+                        q[3] = mk4(c3.x, c3.y, c3.z, c3.w);
+                        float t, u;
+                        if (intersect_curve_segment(o, d, tmin, best.t, q, t, u) && t < tmax)
+                        {
+                            const uint32_t prim = sc.segPrim[first + k];
+                            if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
+                            {
+                                best.t = t;
+                                best.inst = curInst;
+                                best.prim = prim;
+                                best.u = u;
+                                best.v = 0.0f;
+                                best.found = true;
+                            }
+                        }
+                    }
+                }
+                else
+                {
+                    for (uint32_t k = 0; k < count; ++k)
+                    {
+                        const float4* tp = sc.tris + 3 * (size_t)(first + k);
+                        const float4 a = tp[0], b = tp[1], c = tp[2];
+                        if (COUNT)
+                            tc.prims++;
+                        float t, u, v;
+                        if (intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), t, u, v) && t < tmax)
+                        {
+                            const uint32_t prim = __float_as_uint(a.w);
+                            if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
+                            {
+                                best.t = t;
+                                best.inst = curInst;
+                                best.prim = prim;
+                                best.u = u;
+                                best.v = v;
+                                best.found = true;
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- pop ----
+            if (ANY_HIT && best.found)
+                terminated = true;
+            else if (!entered)
+            {
+                for (;;)
+                {
+                    if (sp == 0)
+                    {
+                        terminated = true;
+                        break;
+                    }
+                    SKH_POP(cur);
+                    if (cur == SKH_REF_SENTINEL)
+                    {
+                        o = ow;
+                        d = dw;
+                        inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        nodes = sc.tlasNodes;
+                        inBlas = false;
+                        continue;
+                    }
+                    break;
+                }
+            }
+        }
+        if (terminated)
+        {
+            hasRay = false;
+            const uint32_t i = ridx;
+            if (ANY_HIT)
+            {
+                if (hq.base) // raw query mode (skh_trace): 1 = occluded, -1 = not
+                    hq.base[i] = best.found ? 1.0f : -1.0f;
+                else if (!best.found)
+                {
+                    const uint32_t pid = rq.ids()[i];
+                    float* rad = ps.base + (size_t)3 * ps.stride;
+                    rad[pid] += contrib[i];
+                    rad[pid + ps.stride] += contrib[i + contribStride];
+                    rad[pid + 2 * (size_t)ps.stride] += contrib[i + 2 * (size_t)contribStride];
+                }
+            }
+            else
+            {
+                hq.base[i] = best.found ? best.t : -1.0f;
+                reinterpret_cast<uint32_t*>(hq.base)[i + hq.stride] = best.inst;
+                reinterpret_cast<uint32_t*>(hq.base)[i + 2 * (size_t)hq.stride] = best.prim;
+                hq.base[i + 3 * (size_t)hq.stride] = best.u;
+                hq.base[i + 4 * (size_t)hq.stride] = best.v;
+            }
         }
     }
+#undef SKH_PUSH
+#undef SKH_POP
     if (COUNT)
     {
         const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.prims), c2 = wave_sum(tc.segs), d2 = wave_sum(tc.insts);
@@ -403,23 +469,38 @@ SKH_DI bool slot_to_pixel(const FrameP& fp, const uint32_t* __restrict__ tileXY,
     return px < fp.width && py < fp.height;
 }
 
-SKH_DI uint32_t wave_compact(bool emit, uint32_t* counter)
+// Stream compaction: wave ballot + prefix popcount inside the wave, one LDS slot per wave, ONE global atomic per
+// workgroup (a single queue-tail word sustains only ~88 returning atomics per microsecond on MI355X, so per-wave
+// atomics would serialise a 2 M-path launch for ~0.4 ms).  All threads of the block must call it.
+#define SKH_COMPACT_MAX_WAVES 8
+SKH_DI uint32_t block_compact(bool emit, uint32_t* counter, uint32_t* s_wave /*[SKH_COMPACT_MAX_WAVES + 1]*/)
 {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const unsigned long long m = __ballot(emit);
-    if (m == 0ull)
-        return 0;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader)
-        base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = __shfl(base, leader);
-    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0)
+        s_wave[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < nw; ++w)
+        {
+            const uint32_t cnt = s_wave[w];
+            s_wave[w] = tot;
+            tot += cnt;
+        }
+        s_wave[SKH_COMPACT_MAX_WAVES] = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    const uint32_t r = s_wave[SKH_COMPACT_MAX_WAVES] + s_wave[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads(); // s_wave is reused by the next call
+    return r;
 }
 
-__global__ void __launch_bounds__(256) k_raygen(FrameP fp, const uint32_t* __restrict__ tileXY, uint32_t sampleOffset, RayQ rq,
+__global__ void __launch_bounds__(512) k_raygen(FrameP fp, const uint32_t* __restrict__ tileXY, uint32_t sampleOffset, RayQ rq,
                                                uint32_t* __restrict__ counter, PathS ps)
 {
+    __shared__ uint32_t s_wave[SKH_COMPACT_MAX_WAVES + 1];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t px = 0, py = 0;
     const bool active = slot < fp.numSlots && slot_to_pixel(fp, tileXY, slot, px, py);
@@ -439,7 +520,7 @@ __global__ void __launch_bounds__(256) k_raygen(FrameP fp, const uint32_t* __res
         ps.base[slot + 6 * (size_t)ps.stride] = 0.0f; // lastBsdfPdf
         reinterpret_cast<uint32_t*>(ps.base)[slot + 7 * (size_t)ps.stride] = 0u; // flags: outside, eUndef
     }
-    const uint32_t idx = wave_compact(active, counter);
+    const uint32_t idx = block_compact(active, counter, s_wave);
     if (active)
     {
         rq.plane(0)[idx] = o.x;
@@ -515,13 +596,16 @@ SKH_DI SurfaceHit fill_curve(const DevScene& sc, const HostInstance& hi, const f
 // k_shade: __miss__ms (OptixRender.cu:250-257), __closesthit__light (:315-341), __closesthit__radiance
 // (closest_hit.cu:456-606) and the tail of the raygen bounce loop (OptixRender.cu:131-153) for one bounce.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
     k_shade(DevScene sc, FrameP fp, uint32_t sampleOffset, uint32_t depth, const uint32_t* __restrict__ tileXY, RayQ rq,
             const uint32_t* __restrict__ countPtr, HitQ hq, PathS ps, RayQ nextQ, uint32_t* __restrict__ nextCount, RayQ shadowQ,
             float* __restrict__ contrib, uint32_t* __restrict__ shadowCount)
 {
+    __shared__ uint32_t s_wave[SKH_COMPACT_MAX_WAVES + 1];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = *countPtr;
+    if (blockIdx.x * blockDim.x >= n)
+        return; // whole block past the end of the queue
     const bool valid = i < n;
     bool emitNext = false, emitShadow = false;
     v3 nextO = mk3(0.0f), nextD = mk3(0.0f), shO = mk3(0.0f), shD = mk3(0.0f), shC = mk3(0.0f);
@@ -747,7 +831,7 @@ __global__ void __launch_bounds__(256)
             (inside ? PF_INSIDE : 0u) | (specularBounce ? PF_SPECULAR : 0u) | (firstEvent << PF_EVENT_SHIFT);
     }
     // stream compaction of live paths / shadow rays: one atomic per wave
-    const uint32_t ni = wave_compact(emitNext, nextCount);
+    const uint32_t ni = block_compact(emitNext, nextCount, s_wave);
     if (emitNext)
     {
         nextQ.plane(0)[ni] = nextO.x;
@@ -760,7 +844,7 @@ __global__ void __launch_bounds__(256)
         nextQ.plane(7)[ni] = 1e16f;
         nextQ.ids()[ni] = pid;
     }
-    const uint32_t si = wave_compact(emitShadow, shadowCount);
+    const uint32_t si = block_compact(emitShadow, shadowCount, s_wave);
     if (emitShadow)
     {
         shadowQ.plane(0)[si] = shO.x;

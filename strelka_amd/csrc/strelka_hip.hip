@@ -77,7 +77,8 @@ struct skh_context
         dOvf, dStats, dScratchImage;
     uint32_t traceBlocks = 0;
     bool countTraversal = false, timing = false;
-    uint32_t wavesPerCU = 16;
+    uint32_t wavesPerCU = 20;
+    uint32_t fetchMinClosest = 32, fetchMinShadow = 32;
 
     // timing
     std::vector<TimedSpan> spans;
@@ -627,7 +628,7 @@ static skh_status alloc_frame(skh_context* c)
     AF(dev_alloc(c, c->dHits, sizeof(float) * 5 * N));
     AF(dev_alloc(c, c->dShadowQ, sizeof(float) * 9 * N));
     AF(dev_alloc(c, c->dContrib, sizeof(float) * 3 * N));
-    AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * 2 * 130));
+    AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * (512 + 16 * 130)));
     c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
     AF(dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * c->traceBlocks * SKH_TRACE_BLOCK));
 #undef AF
@@ -765,11 +766,16 @@ static skh_status ensure_ready(skh_context* c)
 }
 
 template <bool ANY, bool COUNT>
-static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint32_t* countPtr, HitQ hq, PathS ps, const float* contrib,
-                         uint32_t contribStride)
+static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint32_t* countPtr, uint32_t* fetch, HitQ hq, PathS ps,
+                         const float* contrib, uint32_t contribStride)
 {
-    k_trace<ANY, COUNT><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, hq, ps, contrib, contribStride,
-                                                                            c->dOvf.as<int>(), c->dStats.as<StatsDev>());
+    // scenes without curve instances run the build of the kernel that has no curve intersector in it (fewer VGPRs)
+    if (c->nSegs)
+        k_trace<ANY, COUNT, true><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, fetch, ANY ? c->fetchMinShadow : c->fetchMinClosest, hq, ps, contrib, contribStride,
+                                                                                      c->dOvf.as<int>(), c->dStats.as<StatsDev>());
+    else
+        k_trace<ANY, COUNT, false><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, fetch, ANY ? c->fetchMinShadow : c->fetchMinClosest, hq, ps, contrib, contribStride,
+                                                                                       c->dOvf.as<int>(), c->dStats.as<StatsDev>());
 }
 
 static skh_status render_one(skh_context* c, const skh_frame_params* p, void* d_image)
@@ -810,34 +816,36 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, void* d_
     RayQ shq{ c->dShadowQ.as<float>(), N };
     HitQ hq{ c->dHits.as<float>(), N };
     HitQ nohq{ nullptr, 0 };
+    // dCounts: [0, 260) queue lengths (2 per bounce), [512, 512 + 16 * 129) ray-fetch cursors (8 per trace launch)
     uint32_t* counts = c->dCounts.as<uint32_t>();
+    uint32_t* fetch = counts + 512;
     for (uint32_t s = 0; s < fp.samplesThisLaunch; ++s)
     {
-        SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * 2 * (fp.maxDepth + 1), st));
+        SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (512 + 16 * (fp.maxDepth + 1)), st));
         {
             SpanGuard g(c, KC_RAYGEN);
-            k_raygen<<<gridSlots, 256, 0, st>>>(fp, tiles, s, rq[0], counts, ps);
+            k_raygen<<<(N + 511) / 512, 512, 0, st>>>(fp, tiles, s, rq[0], counts, ps);
         }
         for (uint32_t b = 0; b < fp.maxDepth; ++b)
         {
             {
                 SpanGuard g(c, KC_TRACE_CLOSEST);
                 if (c->countTraversal)
-                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b, hq, ps, nullptr, 0);
+                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b, fetch + 16 * b, hq, ps, nullptr, 0);
                 else
-                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b, hq, ps, nullptr, 0);
+                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b, fetch + 16 * b, hq, ps, nullptr, 0);
             }
             {
                 SpanGuard g(c, KC_SHADE);
-                k_shade<<<gridSlots, 256, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b, hq, ps, rq[(b + 1) & 1],
+                k_shade<<<(N + 511) / 512, 512, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b, hq, ps, rq[(b + 1) & 1],
                                                    counts + 2 * (b + 1), shq, c->dContrib.as<float>(), counts + 2 * b + 1);
             }
             {
                 SpanGuard g(c, KC_TRACE_SHADOW);
                 if (c->countTraversal)
-                    launch_trace<true, true>(c, sc, shq, counts + 2 * b + 1, nohq, ps, c->dContrib.as<float>(), N);
+                    launch_trace<true, true>(c, sc, shq, counts + 2 * b + 1, fetch + 16 * b + 8, nohq, ps, c->dContrib.as<float>(), N);
                 else
-                    launch_trace<true, false>(c, sc, shq, counts + 2 * b + 1, nohq, ps, c->dContrib.as<float>(), N);
+                    launch_trace<true, false>(c, sc, shq, counts + 2 * b + 1, fetch + 16 * b + 8, nohq, ps, c->dContrib.as<float>(), N);
             }
             if (fp.debug == 1)
                 break;
@@ -1036,7 +1044,7 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
         dev_free(cnt);
     };
     if ((s = dev_alloc(c, q, sizeof(float) * 9 * (size_t)n_rays)) != SKH_OK || (s = dev_alloc(c, h, sizeof(float) * 5 * (size_t)n_rays)) != SKH_OK ||
-        (s = dev_upload(c, cnt, &n_rays, sizeof(uint32_t))) != SKH_OK)
+        (s = dev_alloc(c, cnt, sizeof(uint32_t) * 16)) != SKH_OK)
     {
         cleanup();
         return s;
@@ -1051,24 +1059,28 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
     RayQ rq{ q.as<float>(), n_rays };
     HitQ hq{ h.as<float>(), n_rays };
     PathS ps{ nullptr, 0 };
+    uint32_t* dcount = cnt.as<uint32_t>();
+    uint32_t* dfetch = dcount + 8;
+    SKH_TRY(c, hipMemcpyAsync(dcount, &n_rays, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     const DevScene sc = make_dev_scene(c);
     k_rays_aos_to_soa<<<(n_rays + 255) / 256, 256, 0, c->stream>>>(reinterpret_cast<const skh_ray*>(d_rays), n_rays, rq);
     for (uint32_t r = 0; r < std::max(1u, repeat); ++r)
     {
+        (void)hipMemsetAsync(dfetch, 0, sizeof(uint32_t) * 8, c->stream);
         SpanGuard g(c, mode == SKH_TRACE_SHADOW ? KC_TRACE_SHADOW : KC_TRACE_CLOSEST);
         if (mode == SKH_TRACE_SHADOW)
         {
             if (c->countTraversal)
-                launch_trace<true, true>(c, sc, rq, cnt.as<uint32_t>(), hq, ps, nullptr, 0);
+                launch_trace<true, true>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
             else
-                launch_trace<true, false>(c, sc, rq, cnt.as<uint32_t>(), hq, ps, nullptr, 0);
+                launch_trace<true, false>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
         }
         else
         {
             if (c->countTraversal)
-                launch_trace<false, true>(c, sc, rq, cnt.as<uint32_t>(), hq, ps, nullptr, 0);
+                launch_trace<false, true>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
             else
-                launch_trace<false, false>(c, sc, rq, cnt.as<uint32_t>(), hq, ps, nullptr, 0);
+                launch_trace<false, false>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
         }
     }
     k_hits_soa_to_aos<<<(n_rays + 255) / 256, 256, 0, c->stream>>>(hq, n_rays, mode, reinterpret_cast<skh_hit*>(d_hits));
@@ -1123,6 +1135,12 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         c->countTraversal = value != 0;
     else if (n == "timing")
         c->timing = value != 0;
+    else if (n == "fetch_min_closest" || n == "fetch_min_shadow")
+    {
+        if (value < 1 || value > 64)
+            return SKH_INVALID_ARGUMENT;
+        (n == "fetch_min_closest" ? c->fetchMinClosest : c->fetchMinShadow) = (uint32_t)value;
+    }
     else if (n == "waves_per_cu")
     {
         if (value < 1 || value > 32)
