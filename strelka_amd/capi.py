@@ -38,6 +38,13 @@ def load():
     if not os.path.exists(LIB):
         raise SkhError(f"{LIB} is missing: build it with `python -m strelka_amd.build` (hipcc, gfx950). "
                        "There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64; when torch is used in the same process
+    # (device tensors for d_image, torch.distributed/RCCL) it must be the copy that gets loaded first, otherwise
+    # torch later reports "No HIP GPUs are available".  torch is plumbing here, not a dependency of the kernels.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB)
     vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int, C.c_float
     lib.skh_create.argtypes = [i32, C.POINTER(vp)]

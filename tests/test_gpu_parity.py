@@ -212,3 +212,81 @@ def test_tiles_reproduce_full_frame_bit_for_bit(gpu):
             out[y:y + 16, x:x + 16] = part[y:y + 16, x:x + 16]
     gpu.set_tiles(32, None)
     assert np.array_equal(out, full)
+
+
+def small_hair():
+    return scenes.hair_standin(seed=5, n_strands=1500, n_cp=8)
+
+
+def test_curve_hits_bit_exact(gpu):
+    """Round cubic B-spline segments (the reference's OPTIX_PRIMITIVE_TYPE_ROUND_CUBIC_BSPLINE GAS,
+    OptixRender.cpp:218-316): GPU phantom intersector == oracle, bit for bit, through the curve BLAS."""
+    from tests import orklib
+
+    sc = small_hair()
+    arr = sc.arrays()
+    o = orklib.new_context()
+    o.set_scene(arr)
+    gpu.set_scene(arr)
+    rays = camera_rays(sc, 64, 64, 30000, 11)
+    want = o.trace(rays, 0)
+    got = gpu.trace(rays, 0)
+    curve_inst = int(np.nonzero(arr["instances"]["type"] == S.INSTANCE_CURVE)[0][0])
+    assert (want["instance_id"] == curve_inst).mean() > 0.02  # a few % of the rays hit hair
+    assert_hits_equal(got, want)
+    sub = rays[:1500]
+    assert_hits_equal(o.trace(sub, 0, brute=True), want[:1500])
+    rays["tmax"] = 4.0
+    assert np.array_equal(gpu.trace(rays, 1)["t"], o.trace(rays, 1)["t"])
+
+
+def test_render_hair_matches_oracle(gpu):
+    sc = small_hair()
+    o, want, got = _render_both(gpu, sc, 96, 64, 4, 3)
+    _image_close(got, want, frac_tol=1e-2)
+    assert gpu.stats()["rays_radiance"] == o.stats()["rays_radiance"]
+
+
+def test_debug_views_and_aovs(gpu):
+    """debug 1 = normals after one bounce (closest_hit.cu:504-508), 2 / 3 = diffuse / specular AOVs (OptixRender.cu:225-234)."""
+    from tests import orklib
+
+    sc = small_kitchen()
+    arr = sc.arrays()
+    o = orklib.new_context()
+    o.set_scene(arr)
+    o.resize(64, 48)
+    gpu.set_scene(arr)
+    gpu.resize(64, 48)
+    import torch
+
+    img = torch.zeros((48, 64, 4), dtype=torch.float32, device="cuda")
+    for dbg in (1, 2, 3):
+        for i in range(2):
+            p = S.frame_params(sc.getCamera(), 64, 48, subframe_index=i, spp_total=2, max_depth=4, debug=dbg)
+            o.render_subframe(p)
+            gpu.render_subframe(p, img.data_ptr())
+        want = o.read_image()
+        got = img.cpu().numpy()
+        _image_close(got, want, frac_tol=2e-2)
+    for which in (0, 1):
+        _image_close(gpu.read_aov(which), o.read_aov(which), frac_tol=2e-2)
+
+
+def test_tonemap_kernels_match_oracle(gpu, ork):
+    """postprocessing/Tonemappers.cu: Reinhard / ACES fitted / ACES film + gamma, in place on a device float4 image."""
+    import ctypes as C
+
+    import torch
+
+    rs = np.random.RandomState(3)
+    host = (rs.rand(37, 53, 4) * np.array([40, 10, 300, 1])).astype(np.float32)
+    e = S.default_exposure() * np.float32(200.0)
+    for typ in (0, 1, 2, 3):
+        for gamma in (0.0, 2.4):
+            want = host.copy()
+            ork.ork_tonemap_image(want.ctypes.data_as(C.c_void_p), 37 * 53, typ, e.ctypes.data_as(C.c_void_p), gamma)
+            d = torch.from_numpy(host.copy()).cuda()
+            gpu.tonemap(d.data_ptr(), 53, 37, typ, e, gamma)
+            got = d.cpu().numpy()
+            assert np.allclose(got, want, rtol=2e-5, atol=1e-6), (typ, gamma)
