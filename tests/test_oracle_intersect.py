@@ -1,0 +1,258 @@
+"""Known-answer tests for the parts of the path the reference delegates to closed OptiX / MDL SDK:
+the oracle's intersectors, BVH and BSDF set are pinned analytically here (parity with the reference is unpinned for
+them -- there is no reference arithmetic to compare with)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from strelka_amd import scene as S
+from strelka_amd import scenes
+from tests import orklib
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def f32(*v):
+    return np.array(v, np.float32)
+
+
+def test_triangle_known_answers(ork):
+    tri = f32(0, 0, 0, 1, 0, 0, 0, 1, 0)
+    out = np.zeros(3, np.float32)
+    # straight down onto (0.25, 0.5): t = 2, barycentrics (u, v) = weights of p1, p2 (optixGetTriangleBarycentrics)
+    assert ork.ork_intersect_triangle(p(f32(0.25, 0.5, 2)), p(f32(0, 0, -1)), 0.0, 1e16, p(tri), p(out)) == 1
+    assert np.allclose(out, (2.0, 0.25, 0.5), atol=1e-7)
+    # no back-face culling (OPTIX_RAY_FLAG_NONE): same hit from below
+    assert ork.ork_intersect_triangle(p(f32(0.25, 0.5, -3)), p(f32(0, 0, 1)), 0.0, 1e16, p(tri), p(out)) == 1
+    assert np.allclose(out, (3.0, 0.25, 0.5), atol=1e-7)
+    # outside, parallel, behind the origin, beyond tmax, before tmin
+    assert ork.ork_intersect_triangle(p(f32(0.8, 0.8, 2)), p(f32(0, 0, -1)), 0.0, 1e16, p(tri), p(out)) == 0
+    assert ork.ork_intersect_triangle(p(f32(0.2, 0.2, 2)), p(f32(1, 0, 0)), 0.0, 1e16, p(tri), p(out)) == 0
+    assert ork.ork_intersect_triangle(p(f32(0.2, 0.2, 2)), p(f32(0, 0, 1)), 0.0, 1e16, p(tri), p(out)) == 0
+    assert ork.ork_intersect_triangle(p(f32(0.2, 0.2, 2)), p(f32(0, 0, -1)), 0.0, 1.5, p(tri), p(out)) == 0
+    assert ork.ork_intersect_triangle(p(f32(0.2, 0.2, 2)), p(f32(0, 0, -1)), 2.5, 1e16, p(tri), p(out)) == 0
+    # non-normalised direction: t is in units of the direction (instance transforms scale rays, not t)
+    assert ork.ork_intersect_triangle(p(f32(0.25, 0.5, 2)), p(f32(0, 0, -4)), 0.0, 1e16, p(tri), p(out)) == 1
+    assert np.allclose(out[0], 0.5, atol=1e-7)
+
+
+def test_watertight_shared_edge(ork):
+    """Rays aimed exactly at the shared edge of two triangles hit at least one of them (no cracks)."""
+    a = f32(0, 0, 0, 1, 0, 0, 0, 1, 0)
+    b = f32(1, 0, 0, 1, 1, 0, 0, 1, 0)
+    out = np.zeros(3, np.float32)
+    rs = np.random.RandomState(1)
+    for _ in range(2000):
+        s = np.float32(rs.rand())
+        target = np.array([1 - s, s, 0], np.float32)  # a point on the shared edge x + y = 1
+        o = (target + rs.normal(size=3) + np.array([0, 0, 3])).astype(np.float32)
+        d = (target - o).astype(np.float32)
+        ha = ork.ork_intersect_triangle(p(o), p(d), 0.0, 1e16, p(a), p(out))
+        hb = ork.ork_intersect_triangle(p(o), p(d), 0.0, 1e16, p(b), p(out))
+        assert ha or hb
+
+
+def straight_curve(r0, r1):
+    # cubic B-spline with collinear, equally spaced control points: the segment spans x in [1, 2]
+    return f32(0, 0, 0, r0 + (r0 - r1) * 0.0, 1, 0, 0, r0, 2, 0, 0, r1, 3, 0, 0, r1)
+
+
+def test_curve_known_answers(ork):
+    q = f32(0, 0, 0, 0.1, 1, 0, 0, 0.1, 2, 0, 0, 0.1, 3, 0, 0, 0.1)  # constant radius 0.1 cylinder, axis = x
+    out = np.zeros(2, np.float32)
+    # perpendicular ray through the axis: hits the surface at distance 1 - 0.1, parameter u = x - 1
+    assert ork.ork_intersect_curve(p(f32(1.5, 1, 0)), p(f32(0, -1, 0)), 0.0, 1e16, p(q), p(out)) == 1
+    assert abs(out[0] - 0.9) < 2e-5 and abs(out[1] - 0.5) < 1e-3
+    # offset ray: grazing distance sqrt(r^2 - d^2)
+    assert ork.ork_intersect_curve(p(f32(1.25, 1, 0.06)), p(f32(0, -1, 0)), 0.0, 1e16, p(q), p(out)) == 1
+    assert abs(out[0] - (1 - math.sqrt(0.1 ** 2 - 0.06 ** 2))) < 5e-5 and abs(out[1] - 0.25) < 2e-3
+    # misses: beside the tube, beyond the segment's ends (end caps off), behind, tmax too short
+    assert ork.ork_intersect_curve(p(f32(1.5, 1, 0.11)), p(f32(0, -1, 0)), 0.0, 1e16, p(q), p(out)) == 0
+    assert ork.ork_intersect_curve(p(f32(2.3, 1, 0)), p(f32(0, -1, 0)), 0.0, 1e16, p(q), p(out)) == 0
+    assert ork.ork_intersect_curve(p(f32(0.8, 1, 0)), p(f32(0, -1, 0)), 0.0, 1e16, p(q), p(out)) == 0
+    assert ork.ork_intersect_curve(p(f32(1.5, 1, 0)), p(f32(0, 1, 0)), 0.0, 1e16, p(q), p(out)) == 0
+    assert ork.ork_intersect_curve(p(f32(1.5, 1, 0)), p(f32(0, -1, 0)), 0.0, 0.8, p(q), p(out)) == 0
+    # direction scaling: t halves when the direction doubles
+    assert ork.ork_intersect_curve(p(f32(1.5, 1, 0)), p(f32(0, -2, 0)), 0.0, 1e16, p(q), p(out)) == 1
+    assert abs(out[0] - 0.45) < 2e-5
+    # varying radius (cone-like): radius at u is the B-spline of the control radii
+    qv = f32(0, 0, 0, 0.2, 1, 0, 0, 0.2, 2, 0, 0, 0.1, 3, 0, 0, 0.1)
+    ev = np.zeros(21, np.float32)
+    assert ork.ork_intersect_curve(p(f32(1.5, 1, 0)), p(f32(0, -1, 0)), 0.0, 1e16, p(qv), p(out)) == 1
+    ork.ork_curve_eval(p(qv), float(out[1]), p(f32(1.5, 0.15, 0)), p(ev))
+    hit = np.array([1.5, 1 - out[0], 0])
+    assert abs(np.linalg.norm(hit - ev[:3]) - ev[3]) < 2e-4  # the hit point lies on the swept surface
+
+
+def test_curve_hits_lie_on_the_surface_for_random_rays(ork):
+    rs = np.random.RandomState(2)
+    q = f32(0, 0, 0, 0.05, 1, 0.3, 0, 0.06, 2, -0.2, 0.4, 0.04, 3, 0, 0, 0.03)
+    out = np.zeros(2, np.float32)
+    ev = np.zeros(21, np.float32)
+    hits = 0
+    for _ in range(3000):
+        u = rs.uniform(0.05, 0.95)
+        ork.ork_curve_eval(p(q), float(u), p(f32(0, 0, 0)), p(ev))
+        target = ev[:3] + rs.normal(size=3) * 0.02
+        o = (target + rs.normal(size=3) * 2).astype(np.float32)
+        d = (target - o)
+        d = (d / np.linalg.norm(d)).astype(np.float32)
+        if ork.ork_intersect_curve(p(o), p(d), 0.0, 1e16, p(q), p(out)):
+            hits += 1
+            ork.ork_curve_eval(p(q), float(out[1]), p(f32(0, 0, 0)), p(ev))
+            hp = o + out[0] * d
+            assert abs(np.linalg.norm(hp - ev[:3]) - ev[3]) < 3e-4
+    assert hits > 1500
+
+
+@pytest.mark.parametrize("maker", ["cornell", "kitchen", "hair"])
+def test_bvh_never_changes_a_result(maker):
+    """closest hit and occlusion through the oracle's SAH BVH == brute force over every primitive, bit for bit
+    (ties broken by the smaller (instance, primitive) key, conservative boxes)."""
+    sc = {"cornell": scenes.cornell_box,
+          "kitchen": lambda: scenes.kitchen_standin(seed=3, n_meshes=6, n_instances=61, tri_lo=40, tri_hi=300),
+          "hair": lambda: scenes.hair_standin(seed=4, n_strands=300, n_cp=6)}[maker]()
+    o = orklib.new_context()
+    o.set_scene(sc.arrays())
+    lo, hi = (-0.99, 0.99) if maker == "cornell" else ((-4.5, 4.5) if maker == "kitchen" else (-1.6, 1.6))
+    rays = scenes.random_rays(4000, 5, lo, hi)
+    a, b = o.trace(rays, 0, brute=True), o.trace(rays, 0, brute=False)
+    for f in ("instance_id", "prim_id"):
+        assert np.array_equal(a[f], b[f])
+    for f in ("t", "u", "v"):
+        assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32))
+    rays["tmax"] = 1.0
+    assert np.array_equal(o.trace(rays, 1, brute=True)["t"], o.trace(rays, 1, brute=False)["t"])
+    assert (a["instance_id"] != 0xFFFFFFFF).mean() > 0.2
+
+
+def test_instance_transform_and_masks():
+    """A translated + scaled instance is hit where expected; light proxies are visible to radiance rays (mask 255)
+    and invisible to shadow rays (RAY_MASK_SHADOW): OptixRenderParams.h:9-17."""
+    sc = S.Scene()
+    sc.addMaterial()
+    vb, ib = S.deindex([(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)], [(0, 1, 2), (0, 2, 3)])
+    m = sc.createMesh(vb, ib)
+    sc.createInstance(S.INSTANCE_MESH, m, 0, S.translate((0, 0, -5)) @ S.scale((2, 2, 1)))
+    sc.createLight({"type": 0, "xform": S.translate((0, 0, -2)), "useXform": True, "width": 1, "height": 1, "color": (1, 1, 1), "intensity": 1})
+    o = orklib.new_context()
+    o.set_scene(sc.arrays())
+    r = np.zeros(3, S.RAY)
+    r["origin"] = [(0, 0, 0), (1.5, 1.5, 0), (2.5, 0, 0)]
+    r["dir"] = (0, 0, -1)
+    r["tmax"] = 1e16
+    h = o.trace(r, 0)
+    assert h["instance_id"][0] == 1 and abs(h["t"][0] - 2) < 1e-6  # the light proxy is in front
+    assert h["instance_id"][1] == 0 and abs(h["t"][1] - 5) < 1e-6  # scaled quad reaches +-2
+    assert h["instance_id"][2] == 0xFFFFFFFF
+    s = o.trace(r, 1)
+    assert s["t"][0] > 0  # occluded by the quad; the light itself does not occlude
+    r["tmax"] = 3.0
+    assert o.trace(r, 1)["t"][0] < 0
+
+
+def _sample(ork, mat, n3, k1, xi, inside=0):
+    out = np.zeros(8, np.float32)
+    ork.ork_bsdf_sample(p(mat), p(n3), p(n3), p(k1), p(xi), inside, p(out))
+    return out
+
+
+def _mat(typ, color=(0.8, 0.6, 0.4), rough=0.3, metallic=0.0, spec=0.5, ior=1.5):
+    m = np.zeros((), S.MATERIAL)
+    m["type"], m["base_color"], m["roughness"], m["metallic"], m["specular"], m["ior"] = typ, color, rough, metallic, spec, ior
+    return m
+
+
+@pytest.mark.parametrize("typ,metallic", [(0, 0.0), (1, 0.0), (1, 1.0), (3, 0.0)])
+def test_bsdf_energy_and_pdf_consistency(ork, typ, metallic):
+    """White-furnace style checks: E[bsdf_over_pdf] <= 1 per channel, sample.pdf == evaluate.pdf for the sampled
+    direction, evaluate == pdf * bsdf_over_pdf, and the pdf integrates to <= 1 over the hemisphere."""
+    rs = np.random.RandomState(7)
+    mat = _mat(typ, color=(1, 1, 1), metallic=metallic, rough=0.35, spec=1.0)
+    n = f32(0, 0, 1)
+    k1 = f32(0.4, 0.1, 0.9)
+    k1 /= np.linalg.norm(k1)
+    acc = np.zeros(3)
+    N = 4000
+    for _ in range(N):
+        xi = rs.rand(4).astype(np.float32)
+        s = _sample(ork, mat, n, k1, xi)
+        if s[7] == 0:
+            continue
+        acc += s[3:6]
+        ev = np.zeros(7, np.float32)
+        k2 = np.ascontiguousarray(s[:3])
+        ork.ork_bsdf_evaluate(p(mat), p(n), p(n), p(k1), p(k2), p(ev))
+        assert abs(ev[6] - s[6]) <= 2e-4 * max(1.0, s[6])
+        assert np.allclose(ev[:3] + ev[3:6], s[6] * s[3:6], rtol=2e-3, atol=1e-5)
+        assert abs(np.linalg.norm(k2) - 1) < 1e-5 and k2[2] > 0
+    assert (acc / N <= 1.02).all() and (acc / N > 0.3).all()
+    # pdf integrates to <= 1 (uniform hemisphere Monte Carlo)
+    tot = 0.0
+    M = 20000
+    z = rs.rand(M)
+    ph = rs.rand(M) * 2 * math.pi
+    r = np.sqrt(1 - z * z)
+    dirs = np.stack([r * np.cos(ph), r * np.sin(ph), z], 1).astype(np.float32)
+    ev = np.zeros(7, np.float32)
+    for d in dirs[:4000]:
+        ork.ork_bsdf_evaluate(p(mat), p(n), p(n), p(k1), p(np.ascontiguousarray(d)), p(ev))
+        tot += ev[6]
+    integral = tot / 4000 * 2 * math.pi
+    assert 0.85 < integral < 1.08
+
+
+def test_glass_protocol(ork):
+    """Specular events report pdf 0 (MDL convention the renderer relies on: closest_hit.cu:603); transmission flips
+    sides; inside/outside selects ior1/ior2 (closest_hit.cu:496-498); total internal reflection."""
+    mat = _mat(2, color=(0.9, 0.95, 1.0), ior=1.5)
+    n = f32(0, 0, 1)
+    k1 = f32(0.0, 0.6, 0.8)
+    refl = _sample(ork, mat, n, k1, f32(0.1, 0.2, 0.0, 0))  # xi.z = 0 < F -> reflection
+    assert int(refl[7]) == (4 | 8) and refl[6] == 0 and np.allclose(refl[:3], (0, -0.6, 0.8), atol=1e-6)
+    tr = _sample(ork, mat, n, k1, f32(0.1, 0.2, 0.99, 0))
+    assert int(tr[7]) == (4 | 16) and tr[6] == 0 and tr[2] < 0
+    assert abs(math.hypot(tr[0], tr[1]) - 0.6 / 1.5) < 1e-6  # Snell
+    assert np.allclose(tr[3:6], (0.9, 0.95, 1.0))
+    # from inside, beyond the critical angle: always reflect
+    k1g = f32(0.0, 0.9, math.sqrt(1 - 0.81))
+    tir = _sample(ork, mat, n, k1g, f32(0.1, 0.2, 0.99, 0), inside=1)
+    assert int(tir[7]) == (4 | 8)
+    ev = np.zeros(7, np.float32)
+    ork.ork_bsdf_evaluate(p(mat), p(n), p(n), p(k1), p(f32(0, -0.6, 0.8)), p(ev))
+    assert not ev.any()
+
+
+def test_lambert_matches_the_metal_backend_semantics(ork):
+    """pathtrace.metal:164-201: bsdf*cos = albedo*(n.k2)/pi, pdf = (n.k2)/pi, bsdf_over_pdf = albedo."""
+    mat = _mat(0, color=(0.2, 0.5, 0.7))
+    n = f32(0, 1, 0)
+    k1 = f32(0.3, 0.8, 0.1)
+    k1 /= np.linalg.norm(k1)
+    k2 = f32(-0.5, 0.6, 0.2)
+    k2 /= np.linalg.norm(k2)
+    ev = np.zeros(7, np.float32)
+    ork.ork_bsdf_evaluate(p(mat), p(n), p(n), p(k1), p(k2), p(ev))
+    assert np.allclose(ev[:3], np.array([0.2, 0.5, 0.7]) * k2[1] / math.pi, rtol=1e-6)
+    assert abs(ev[6] - k2[1] / math.pi) < 1e-7 and not ev[3:6].any()
+    s = _sample(ork, mat, n, k1, f32(0.3, 0.6, 0, 0))
+    assert np.allclose(s[3:6], (0.2, 0.5, 0.7)) and int(s[7]) == (1 | 8)
+    # two-sided like MDL's libbsdf: viewed from the back, the sampled direction is on the viewer's side
+    sb = _sample(ork, mat, n, -k1, f32(0.3, 0.6, 0, 0))
+    assert sb[1] < 0
+
+
+def test_offset_ray_branches(ork):
+    """offset_ray (closest_hit.cu:218-233): integer-ULP offset away from the origin, fp offset near it."""
+    out = np.zeros(3, np.float32)
+    n = f32(0, 0, 1)
+    ork.ork_offset_ray(p(f32(5, -7, 3)), p(n), p(out))
+    assert out[0] == 5 and out[1] == -7 and out[2] > 3 and out[2] - 3 < 1e-4
+    ork.ork_offset_ray(p(f32(5, -7, -3)), p(n), p(out))
+    assert out[2] > -3  # negative coordinate: the integer is SUBTRACTED to move along +n
+    ork.ork_offset_ray(p(f32(0.01, 0.0, 0.02)), p(n), p(out))
+    assert abs(out[2] - (0.02 + 1.0 / 65536.0)) < 1e-9  # |p| < 1/32: float offset
