@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_parity.py -m gpu -q 2>&1 | tail -30
+python -m pytest tests -m gpu -q 2>&1 | tail -8

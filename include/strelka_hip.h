@@ -239,6 +239,11 @@ skh_status skh_render_subframes(skh_context* ctx, const skh_frame_params* params
 skh_status skh_tonemap(skh_context* ctx, void* d_image, uint32_t width, uint32_t height, uint32_t type,
                        const float exposure[3], float gamma);
 
+/* ---- device image buffers: OptixBuffer's cudaMalloc / cudaFree / cudaMemcpy (OptixBuffer.cpp:16-43, 45-63) ---- */
+skh_status skh_buffer_alloc(skh_context* ctx, size_t bytes, void** out_device_ptr);
+skh_status skh_buffer_free(skh_context* ctx, void* device_ptr);
+skh_status skh_buffer_download(skh_context* ctx, const void* device_ptr, void* host, size_t bytes);
+
 /* ---- read-back: Buffer::map (OptixBuffer.cpp:37-43) ---- */
 skh_status skh_read_accum(skh_context* ctx, float* host_rgba); /* W*H float4, row-major, row 0 = launch y 0 */
 skh_status skh_read_aov(skh_context* ctx, uint32_t which /*0 diffuse, 1 specular*/, float* host_rgba);

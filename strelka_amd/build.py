@@ -32,5 +32,30 @@ def build(force=False, verbose=False):
     return LIB
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(HOST_DIR, "liboka_hip.so")
+HOST_TEST = os.path.join(HOST_DIR, "host_test")
+
+
+def build_host(force=False, verbose=False):
+    """g++ build of the C++ host mirror (oka::HipRender above the C ABI) and its driver program."""
+    build(force=False, verbose=verbose)
+    srcs = [os.path.join(HOST_DIR, f) for f in ("oka_render.cpp", "oka_render.h", "host_test.cpp")] + [LIB]
+    if not force and os.path.exists(HOST_TEST) and all(os.path.getmtime(s) <= os.path.getmtime(HOST_TEST) for s in srcs):
+        return HOST_TEST
+    libdir = os.path.dirname(LIB)
+    common = ["g++", "-std=c++17", "-O2", "-fPIC", "-Wall"]
+    cmds = [common + ["-shared", "-o", HOST_LIB, os.path.join(HOST_DIR, "oka_render.cpp"), "-L" + libdir, "-lstrelka_hip",
+                      "-Wl,-rpath,$ORIGIN/.."],
+            common + ["-o", HOST_TEST, os.path.join(HOST_DIR, "host_test.cpp"), "-L" + HOST_DIR, "-loka_hip", "-L" + libdir,
+                      "-lstrelka_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."]]
+    for c in cmds:
+        if verbose:
+            print(" ".join(c))
+        subprocess.check_call(c)
+    return HOST_TEST
+
+
 if __name__ == "__main__":
     build(force=True, verbose=True)
+    build_host(force=True, verbose=True)

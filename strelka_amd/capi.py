@@ -23,7 +23,7 @@ STATS = np.dtype([("rays_radiance", np.uint64), ("rays_shadow", np.uint64), ("no
 SYMBOLS = ["skh_create", "skh_destroy", "skh_last_error", "skh_abi_version", "skh_set_geometry", "skh_set_curves",
            "skh_set_instances", "skh_set_lights", "skh_set_materials", "skh_build_accel", "skh_resize", "skh_set_tiles",
            "skh_render_subframe", "skh_render_subframes", "skh_tonemap", "skh_read_accum", "skh_read_aov",
-           "skh_copy_accum", "skh_copy_accum_tiles", "skh_scatter_tiles", "skh_trace", "skh_trace_device",
+           "skh_buffer_alloc", "skh_buffer_free", "skh_buffer_download", "skh_copy_accum", "skh_copy_accum_tiles", "skh_scatter_tiles", "skh_trace", "skh_trace_device",
            "skh_set_option", "skh_get_stats", "skh_reset_stats", "skh_synchronize", "skh_get_stream"]
 
 
@@ -63,6 +63,9 @@ def load():
     lib.skh_render_subframe.argtypes = [vp, vp, vp]
     lib.skh_render_subframes.argtypes = [vp, vp, u32, vp]
     lib.skh_tonemap.argtypes = [vp, vp, u32, u32, u32, vp, f32]
+    lib.skh_buffer_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.skh_buffer_free.argtypes = [vp, vp]
+    lib.skh_buffer_download.argtypes = [vp, vp, vp, C.c_size_t]
     lib.skh_read_accum.argtypes = [vp, vp]
     lib.skh_read_aov.argtypes = [vp, u32, vp]
     lib.skh_copy_accum.argtypes = [vp, vp]

@@ -914,6 +914,35 @@ skh_status skh_tonemap(skh_context* c, void* d_image, uint32_t width, uint32_t h
     return SKH_OK;
 }
 
+skh_status skh_buffer_alloc(skh_context* c, size_t bytes, void** out)
+{
+    if (!c || !out)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    *out = nullptr;
+    SKH_TRY(c, hipMalloc(out, bytes ? bytes : 16));
+    SKH_TRY(c, hipMemset(*out, 0, bytes ? bytes : 16));
+    return SKH_OK;
+}
+skh_status skh_buffer_free(skh_context* c, void* p)
+{
+    if (!c)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    if (p)
+        SKH_TRY(c, hipFree(p));
+    return SKH_OK;
+}
+skh_status skh_buffer_download(skh_context* c, const void* d, void* host, size_t bytes)
+{
+    if (!c || !d || !host)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    SKH_TRY(c, hipStreamSynchronize(c->stream));
+    SKH_TRY(c, hipMemcpy(host, d, bytes, hipMemcpyDeviceToHost));
+    return SKH_OK;
+}
+
 static skh_status detile_to(skh_context* c, const DevBuf& src, void* d_dst)
 {
     k_detile<<<(c->numSlots + 255) / 256, 256, 0, c->stream>>>(src.as<float4>(), c->dTileXY.as<uint32_t>(), c->numSlots, c->tileShift,

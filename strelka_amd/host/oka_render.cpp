@@ -1,0 +1,755 @@
+// Host-side mirror of the reference's render interface above the C ABI -- see oka_render.h.
+// Plain C++17 (g++): no HIP headers, no glm; every device operation goes through include/strelka_hip.h.
+#include "oka_render.h"
+
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+
+namespace oka
+{
+
+// ------------------------------------------------------------------------------------------------------
+// math
+// ------------------------------------------------------------------------------------------------------
+float4x4::float4x4()
+{
+    memset(m, 0, sizeof(m));
+}
+float4x4::float4x4(float diag)
+{
+    memset(m, 0, sizeof(m));
+    m[0][0] = m[1][1] = m[2][2] = m[3][3] = diag;
+}
+float4x4 float4x4::translate(const float3& t)
+{
+    float4x4 r(1.0f);
+    r.m[3][0] = t.x;
+    r.m[3][1] = t.y;
+    r.m[3][2] = t.z;
+    return r;
+}
+float4x4 float4x4::scale(const float3& s)
+{
+    float4x4 r(1.0f);
+    r.m[0][0] = s.x;
+    r.m[1][1] = s.y;
+    r.m[2][2] = s.z;
+    return r;
+}
+float4x4 float4x4::fromQuat(const quat& q)
+{
+    float4x4 r(1.0f);
+    const float x = q.x, y = q.y, z = q.z, w = q.w;
+    r.m[0][0] = 1 - 2 * (y * y + z * z);
+    r.m[0][1] = 2 * (x * y + w * z);
+    r.m[0][2] = 2 * (x * z - w * y);
+    r.m[1][0] = 2 * (x * y - w * z);
+    r.m[1][1] = 1 - 2 * (x * x + z * z);
+    r.m[1][2] = 2 * (y * z + w * x);
+    r.m[2][0] = 2 * (x * z + w * y);
+    r.m[2][1] = 2 * (y * z - w * x);
+    r.m[2][2] = 1 - 2 * (x * x + y * y);
+    return r;
+}
+float4x4 float4x4::operator*(const float4x4& b) const
+{
+    float4x4 r;
+    for (int c = 0; c < 4; ++c)
+        for (int rr = 0; rr < 4; ++rr)
+        {
+            float s = 0;
+            for (int k = 0; k < 4; ++k)
+                s += m[k][rr] * b.m[c][k];
+            r.m[c][rr] = s;
+        }
+    return r;
+}
+float4 float4x4::operator*(const float4& v) const
+{
+    float4 r;
+    r.x = m[0][0] * v.x + m[1][0] * v.y + m[2][0] * v.z + m[3][0] * v.w;
+    r.y = m[0][1] * v.x + m[1][1] * v.y + m[2][1] * v.z + m[3][1] * v.w;
+    r.z = m[0][2] * v.x + m[1][2] * v.y + m[2][2] * v.z + m[3][2] * v.w;
+    r.w = m[0][3] * v.x + m[1][3] * v.y + m[2][3] * v.z + m[3][3] * v.w;
+    return r;
+}
+float4x4 float4x4::transposed() const
+{
+    float4x4 r;
+    for (int c = 0; c < 4; ++c)
+        for (int rr = 0; rr < 4; ++rr)
+            r.m[c][rr] = m[rr][c];
+    return r;
+}
+bool float4x4::operator!=(const float4x4& b) const
+{
+    return memcmp(m, b.m, sizeof(m)) != 0;
+}
+float4x4 float4x4::inverse() const
+{
+    // Gauss-Jordan in fp64 on the row-major view
+    double a[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c)
+        {
+            a[r][c] = m[c][r];
+            a[r][4 + c] = r == c ? 1.0 : 0.0;
+        }
+    for (int i = 0; i < 4; ++i)
+    {
+        int piv = i;
+        for (int r = i + 1; r < 4; ++r)
+            if (fabs(a[r][i]) > fabs(a[piv][i]))
+                piv = r;
+        for (int c = 0; c < 8; ++c)
+            std::swap(a[i][c], a[piv][c]);
+        const double d = a[i][i];
+        for (int c = 0; c < 8; ++c)
+            a[i][c] /= d;
+        for (int r = 0; r < 4; ++r)
+            if (r != i)
+            {
+                const double f = a[r][i];
+                for (int c = 0; c < 8; ++c)
+                    a[r][c] -= f * a[i][c];
+            }
+    }
+    float4x4 out;
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c)
+            out.m[c][r] = (float)a[r][4 + c];
+    return out;
+}
+quat quatFromEulerRadians(const float3& e)
+{
+    const float cx = cosf(e.x * 0.5f), cy = cosf(e.y * 0.5f), cz = cosf(e.z * 0.5f);
+    const float sx = sinf(e.x * 0.5f), sy = sinf(e.y * 0.5f), sz = sinf(e.z * 0.5f);
+    quat q;
+    q.w = cx * cy * cz + sx * sy * sz;
+    q.x = sx * cy * cz - cx * sy * sz;
+    q.y = cx * sy * cz + sx * cy * sz;
+    q.z = cx * cy * sz - sx * sy * cz;
+    return q;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// SettingsManager (settings.h:11-118)
+// ------------------------------------------------------------------------------------------------------
+bool SettingsManager::isNameValid(const char* name)
+{
+    if (mMap.find(name) == mMap.end())
+    {
+        std::cerr << "The setting " << name << " does not exist" << std::endl;
+        assert(0);
+        return false;
+    }
+    return true;
+}
+template <>
+void SettingsManager::setAs<std::string>(const char* name, const std::string& value)
+{
+    mMap[name] = value;
+}
+template <>
+void SettingsManager::setAs<bool>(const char* name, const bool& value)
+{
+    mMap[name] = std::to_string(value);
+}
+template <>
+void SettingsManager::setAs<uint32_t>(const char* name, const uint32_t& value)
+{
+    mMap[name] = std::to_string(value);
+}
+template <>
+void SettingsManager::setAs<int32_t>(const char* name, const int32_t& value)
+{
+    mMap[name] = std::to_string(value);
+}
+template <>
+void SettingsManager::setAs<float>(const char* name, const float& value)
+{
+    mMap[name] = std::to_string(value);
+}
+template <>
+bool SettingsManager::getAs<bool>(const char* name)
+{
+    return isNameValid(name) ? atoi(mMap[name].c_str()) != 0 : false;
+}
+template <>
+uint32_t SettingsManager::getAs<uint32_t>(const char* name)
+{
+    return isNameValid(name) ? (uint32_t)atoll(mMap[name].c_str()) : 0u;
+}
+template <>
+int32_t SettingsManager::getAs<int32_t>(const char* name)
+{
+    return isNameValid(name) ? atoi(mMap[name].c_str()) : 0;
+}
+template <>
+float SettingsManager::getAs<float>(const char* name)
+{
+    return isNameValid(name) ? (float)atof(mMap[name].c_str()) : 0.0f;
+}
+template <>
+std::string SettingsManager::getAs<std::string>(const char* name)
+{
+    return isNameValid(name) ? mMap[name] : std::string();
+}
+
+size_t Buffer::getElementSize(BufferFormat format)
+{
+    switch (format)
+    {
+    case BufferFormat::FLOAT4:
+        return 4 * sizeof(float);
+    case BufferFormat::FLOAT3:
+        return 3 * sizeof(float);
+    case BufferFormat::UNSIGNED_BYTE4:
+        return 4 * sizeof(char);
+    }
+    assert(0);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Camera (camera.cpp)
+// ------------------------------------------------------------------------------------------------------
+void Camera::updateViewMatrix()
+{
+    const float4x4 rotM = float4x4::fromQuat(mOrientation);
+    const float4x4 transM = float4x4::translate(float3{ -position.x, -position.y, -position.z });
+    matrices.view = rotM * transM; // CameraType::firstperson (camera.cpp:14-17)
+}
+void Camera::setPerspective(float _fov, float _aspect, float _znear, float _zfar)
+{
+    fov = _fov;
+    znear = _znear;
+    zfar = _zfar;
+    // perspective(fov, aspect, zfar, znear, &inv): near and far swapped for reverse z (camera.cpp:125-131, 61-118)
+    const float n = zfar, f = znear;
+    const float focal_length = 1.0f / std::tan((fov * 0.01745329251994329576923690768489f) / 2.0f);
+    const float x = focal_length / _aspect;
+    const float y = focal_length;
+    const float A = n / (f - n);
+    const float B = f * A;
+    float4x4 proj; // math (row, col) view: [[x,0,0,0],[0,y,0,0],[0,0,A,B],[0,0,-1,0]]
+    proj.m[0][0] = x;
+    proj.m[1][1] = y;
+    proj.m[2][2] = A;
+    proj.m[3][2] = B;
+    proj.m[2][3] = -1.0f;
+    matrices.perspective = proj;
+    float4x4 inv; // [[1/x,0,0,0],[0,1/y,0,0],[0,0,0,-1],[0,0,1/B,A/B]]
+    inv.m[0][0] = 1 / x;
+    inv.m[1][1] = 1 / y;
+    inv.m[3][2] = -1.0f;
+    inv.m[2][3] = 1 / B;
+    inv.m[3][3] = A / B;
+    matrices.invPerspective = inv;
+}
+void Camera::updateAspectRatio(float aspect)
+{
+    setPerspective(fov, aspect, znear, zfar);
+}
+void Camera::setPosition(const float3& p)
+{
+    position = p;
+    updateViewMatrix();
+}
+void Camera::setRotation(const quat& q)
+{
+    mOrientation = q;
+    updateViewMatrix();
+}
+void Camera::lookAt(const float3& eye, const float3& target, const float3& up)
+{
+    auto sub = [](const float3& a, const float3& b) { return float3{ a.x - b.x, a.y - b.y, a.z - b.z }; };
+    auto crs = [](const float3& a, const float3& b) { return float3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; };
+    auto nrm = [](const float3& a) {
+        const float l = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+        return float3{ a.x / l, a.y / l, a.z / l };
+    };
+    const float3 f = nrm(sub(target, eye)), s = nrm(crs(f, up)), u = crs(s, f);
+    // rotation matrix rows (s, u, -f) -> quaternion
+    const float r00 = s.x, r01 = s.y, r02 = s.z, r10 = u.x, r11 = u.y, r12 = u.z, r20 = -f.x, r21 = -f.y, r22 = -f.z;
+    quat q;
+    const float tr = r00 + r11 + r22;
+    if (tr > 0)
+    {
+        const float S = std::sqrt(tr + 1.0f) * 2;
+        q.w = 0.25f * S;
+        q.x = (r21 - r12) / S;
+        q.y = (r02 - r20) / S;
+        q.z = (r10 - r01) / S;
+    }
+    else if (r00 > r11 && r00 > r22)
+    {
+        const float S = std::sqrt(1.0f + r00 - r11 - r22) * 2;
+        q.w = (r21 - r12) / S;
+        q.x = 0.25f * S;
+        q.y = (r01 + r10) / S;
+        q.z = (r02 + r20) / S;
+    }
+    else if (r11 > r22)
+    {
+        const float S = std::sqrt(1.0f + r11 - r00 - r22) * 2;
+        q.w = (r02 - r20) / S;
+        q.x = (r01 + r10) / S;
+        q.y = 0.25f * S;
+        q.z = (r12 + r21) / S;
+    }
+    else
+    {
+        const float S = std::sqrt(1.0f + r22 - r00 - r11) * 2;
+        q.w = (r10 - r01) / S;
+        q.x = (r02 + r20) / S;
+        q.y = (r12 + r21) / S;
+        q.z = 0.25f * S;
+    }
+    mOrientation = q;
+    position = eye;
+    updateViewMatrix();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Scene (scene.cpp)
+// ------------------------------------------------------------------------------------------------------
+uint32_t packNormals(const float3& normal)
+{
+    uint32_t packed = (uint32_t)((normal.x + 1.0f) / 2.0f * 511.99999f);
+    packed += (uint32_t)((normal.y + 1.0f) / 2.0f * 511.99999f) << 10;
+    packed += (uint32_t)((normal.z + 1.0f) / 2.0f * 511.99999f) << 20;
+    return packed;
+}
+uint32_t packUV(float u, float v)
+{
+    uint32_t packed = (uint32_t)((u + 10.0f) / 20.0f * 16383.99999f);
+    packed += (uint32_t)((v + 10.0f) / 20.0f * 16383.99999f) << 16;
+    return packed;
+}
+uint32_t Scene::createMesh(const std::vector<Vertex>& vb, const std::vector<uint32_t>& ib)
+{
+    Mesh mesh;
+    mesh.mIndex = (uint32_t)mIndices.size();
+    mesh.mCount = (uint32_t)ib.size();
+    mesh.mVbOffset = (uint32_t)mVertices.size();
+    mesh.mVertexCount = (uint32_t)vb.size();
+    mIndices.insert(mIndices.end(), ib.begin(), ib.end());
+    mVertices.insert(mVertices.end(), vb.begin(), vb.end());
+    mMeshes.push_back(mesh);
+    return (uint32_t)mMeshes.size() - 1;
+}
+uint32_t Scene::createInstance(Instance::Type type, uint32_t geomId, uint32_t materialId, const float4x4& transform, uint32_t lightId)
+{
+    Instance inst;
+    inst.type = type;
+    inst.mMeshId = geomId;
+    inst.mMaterialId = materialId;
+    inst.transform = transform;
+    inst.mLightId = lightId;
+    mInstances.push_back(inst);
+    return (uint32_t)mInstances.size() - 1;
+}
+uint32_t Scene::addMaterial(const MaterialDescription& material)
+{
+    mMaterialsDescs.push_back(material);
+    return (uint32_t)mMaterialsDescs.size() - 1;
+}
+uint32_t Scene::createCurve(Curve::Type, const std::vector<uint32_t>& vertexCounts, const std::vector<float3>& points,
+                            const std::vector<float>& widths)
+{
+    Curve c;
+    c.mVertexCountsStart = (uint32_t)mCurveVertexCounts.size();
+    c.mVertexCountsCount = (uint32_t)vertexCounts.size();
+    c.mPointsStart = (uint32_t)mCurvePoints.size();
+    c.mPointsCount = (uint32_t)points.size();
+    c.mWidthsStart = (uint32_t)mCurveWidths.size();
+    c.mWidthsCount = (uint32_t)widths.size();
+    mCurveVertexCounts.insert(mCurveVertexCounts.end(), vertexCounts.begin(), vertexCounts.end());
+    mCurvePoints.insert(mCurvePoints.end(), points.begin(), points.end());
+    mCurveWidths.insert(mCurveWidths.end(), widths.begin(), widths.end());
+    mCurves.push_back(c);
+    return (uint32_t)mCurves.size() - 1;
+}
+uint32_t Scene::addCamera(Camera& camera)
+{
+    mCameras.push_back(camera);
+    return (uint32_t)mCameras.size() - 1;
+}
+uint32_t Scene::createRectLightMesh() // scene.cpp:119-145
+{
+    if (mRectLightMeshId != -1)
+        return mRectLightMeshId;
+    std::vector<Vertex> vb(4);
+    const float3 pos[4] = { { 0.5f, 0.5f, 0 }, { -0.5f, 0.5f, 0 }, { -0.5f, -0.5f, 0 }, { 0.5f, -0.5f, 0 } };
+    for (int i = 0; i < 4; ++i)
+    {
+        vb[i] = Vertex{};
+        vb[i].pos = pos[i];
+        vb[i].normal = packNormals(float3{ 0, 0, 1 });
+    }
+    return createMesh(vb, { 0, 1, 2, 2, 3, 0 });
+}
+uint32_t Scene::createSphereLightMesh() // scene.cpp:147-203
+{
+    if (mSphereLightMeshId != -1)
+        return mSphereLightMeshId;
+    std::vector<Vertex> vertices;
+    std::vector<uint32_t> indices;
+    const int segments = 16, rings = 16;
+    for (int i = 0; i <= rings; ++i)
+    {
+        const float theta = (float)i * (float)M_PI / (float)rings;
+        const float sinTheta = sin(theta), cosTheta = cos(theta);
+        for (int j = 0; j <= segments; ++j)
+        {
+            const float phi = (float)j * 2.0f * (float)M_PI / (float)segments;
+            const float sinPhi = sin(phi), cosPhi = cos(phi);
+            const float3 n{ cosPhi * sinTheta, cosTheta, sinPhi * sinTheta };
+            Vertex v{};
+            v.pos = n;
+            v.normal = packNormals(n);
+            vertices.push_back(v);
+        }
+    }
+    for (int i = 0; i < rings; ++i)
+        for (int j = 0; j < segments; ++j)
+        {
+            const uint32_t p0 = i * (segments + 1) + j, p1 = p0 + 1, p2 = (i + 1) * (segments + 1) + j, p3 = p2 + 1;
+            for (uint32_t k : { p0, p1, p2, p2, p1, p3 })
+                indices.push_back(k);
+        }
+    return createMesh(vertices, indices);
+}
+uint32_t Scene::createDiscLightMesh() // scene.cpp:205-250
+{
+    if (mDiskLightMeshId != -1)
+        return mDiskLightMeshId;
+    std::vector<Vertex> vertices(2);
+    std::vector<uint32_t> indices;
+    vertices[0] = Vertex{};
+    vertices[1] = Vertex{};
+    vertices[1].pos = float3{ 1.0f, 0, 0 };
+    vertices[0].normal = vertices[1].normal = packNormals(float3{ 0, 0, 1 });
+    const float step = 2.0f * (float)M_PI / 16;
+    float angle = 0;
+    for (int i = 0; i < 16; ++i)
+    {
+        indices.push_back(0);
+        indices.push_back((uint32_t)vertices.size() - 1);
+        angle += step;
+        Vertex v{};
+        v.pos = float3{ (float)cos(angle), (float)sin(angle), 0.0f };
+        v.normal = packNormals(float3{ 0, 0, 1 });
+        vertices.push_back(v);
+        indices.push_back((uint32_t)vertices.size() - 1);
+    }
+    return createMesh(vertices, indices);
+}
+float4x4 Scene::getTransform(const UniformLightDesc& desc)
+{
+    const float d2r = 0.01745329251994329576923690768489f;
+    const float4x4 t = float4x4::translate(desc.position);
+    const float4x4 r = float4x4::fromQuat(
+        quatFromEulerRadians(float3{ desc.orientation.x * d2r, desc.orientation.y * d2r, desc.orientation.z * d2r }));
+    const float4x4 s = float4x4::scale(float3{ desc.width, desc.height, 1.0f });
+    return t * r * s;
+}
+uint32_t Scene::createLight(const UniformLightDesc& desc)
+{
+    const uint32_t lightId = (uint32_t)mLights.size();
+    mLights.push_back(Light{});
+    mLightDesc.push_back(desc);
+    updateLight(lightId, desc);
+    float4x4 scaleMatrix(0.0f);
+    uint32_t currentLightMeshId = 0;
+    if (desc.type == 0)
+    {
+        mRectLightMeshId = (int)createRectLightMesh();
+        currentLightMeshId = mRectLightMeshId;
+        scaleMatrix = float4x4::scale(float3{ desc.width, desc.height, 1.0f });
+    }
+    else if (desc.type == 1)
+    {
+        mDiskLightMeshId = (int)createDiscLightMesh();
+        currentLightMeshId = mDiskLightMeshId;
+        scaleMatrix = float4x4::scale(float3{ desc.radius, desc.radius, desc.radius });
+    }
+    else if (desc.type == 2)
+    {
+        mSphereLightMeshId = (int)createSphereLightMesh();
+        currentLightMeshId = mSphereLightMeshId;
+        scaleMatrix = float4x4::scale(float3{ desc.radius, desc.radius, desc.radius });
+    }
+    else if (desc.type == 3)
+    {
+        currentLightMeshId = 0; // "empty": mesh 0 scaled by desc.radius (scene.cpp:337-345)
+        scaleMatrix = float4x4::scale(float3{ desc.radius, desc.radius, desc.radius });
+    }
+    const float4x4 transform = desc.useXform ? desc.xform * scaleMatrix : getTransform(desc);
+    createInstance(Instance::Type::eLight, currentLightMeshId, (uint32_t)-1, transform, lightId);
+    return lightId;
+}
+void Scene::updateLight(uint32_t lightId, const UniformLightDesc& desc)
+{
+    Light& L = mLights[lightId];
+    if (desc.type == 0)
+    {
+        const float4x4 scaleMatrix = float4x4::scale(float3{ desc.width, desc.height, 1.0f });
+        const float4x4 lt = desc.useXform ? desc.xform * scaleMatrix : getTransform(desc);
+        L.points[0] = lt * float4{ 0.5f, 0.5f, 0.0f, 1.0f };
+        L.points[1] = lt * float4{ -0.5f, 0.5f, 0.0f, 1.0f };
+        L.points[2] = lt * float4{ -0.5f, -0.5f, 0.0f, 1.0f };
+        L.points[3] = lt * float4{ 0.5f, -0.5f, 0.0f, 1.0f };
+        L.type = 0;
+    }
+    else if (desc.type == 1)
+    {
+        const float4x4 scaleMatrix = float4x4::scale(float3{ desc.radius, desc.radius, desc.radius });
+        const float4x4 lt = desc.useXform ? desc.xform * scaleMatrix : getTransform(desc);
+        L.points[0] = float4{ desc.radius, 0, 0, 0 };
+        L.points[1] = lt * float4{ 0, 0, 0, 1 };
+        L.points[2] = lt * float4{ 1, 0, 0, 0 };
+        L.points[3] = lt * float4{ 0, 1, 0, 0 };
+        L.normal = lt * float4{ 0, 0, 1, 0 };
+        L.type = 1;
+    }
+    else if (desc.type == 2)
+    {
+        const float4x4 lt = desc.useXform ? float4x4(1.0f) * desc.xform : getTransform(desc);
+        L.points[0] = float4{ desc.radius, 0, 0, 0 };
+        L.points[1] = lt * float4{ 0, 0, 0, 1 };
+        L.type = 2;
+    }
+    else if (desc.type == 3)
+    {
+        L.type = 3;
+        L.halfAngle = desc.halfAngle;
+        const float4x4 lt = desc.useXform ? desc.xform * float4x4(1.0f) : getTransform(desc);
+        const float4 n = lt * float4{ 0, 0, -1, 0 };
+        const float l = std::sqrt(n.x * n.x + n.y * n.y + n.z * n.z + n.w * n.w);
+        L.normal = float4{ n.x / l, n.y / l, n.z / l, n.w / l };
+    }
+    L.color = float4{ desc.color.x * desc.intensity, desc.color.y * desc.intensity, desc.color.z * desc.intensity, 1.0f * desc.intensity };
+}
+
+// ------------------------------------------------------------------------------------------------------
+// HipBuffer / HipRender
+// ------------------------------------------------------------------------------------------------------
+HipBuffer::HipBuffer(skh_context* ctx, void* devicePtr, BufferFormat format, uint32_t width, uint32_t height) : mCtx(ctx), mDeviceData(devicePtr)
+{
+    mFormat = format;
+    mWidth = width;
+    mHeight = height;
+}
+HipBuffer::~HipBuffer()
+{
+    if (mDeviceData)
+        skh_buffer_free(mCtx, mDeviceData);
+}
+void HipBuffer::resize(uint32_t width, uint32_t height)
+{
+    if (mDeviceData)
+        skh_buffer_free(mCtx, mDeviceData);
+    mDeviceData = nullptr;
+    mWidth = width;
+    mHeight = height;
+    skh_buffer_alloc(mCtx, (size_t)mWidth * mHeight * getElementSize(), &mDeviceData);
+}
+void* HipBuffer::map()
+{
+    const size_t bytes = (size_t)mWidth * mHeight * getElementSize();
+    mHostData.resize(bytes);
+    skh_buffer_download(mCtx, mDeviceData, mHostData.data(), bytes);
+    return nullptr;
+}
+
+HipRender::~HipRender()
+{
+    if (mCtx)
+        skh_destroy(mCtx);
+}
+bool HipRender::check(skh_status s, const char* what)
+{
+    if (s == SKH_OK)
+        return true;
+    // reference behaviour: log + assert(0), keep going in release builds (OptixRender.cpp:61-103)
+    mError = std::string(what) + ": " + (mCtx ? skh_last_error(mCtx) : "no context");
+    std::cerr << "[HipRender] " << mError << std::endl;
+    assert(0);
+    return false;
+}
+void HipRender::init()
+{
+    int device = 0;
+    if (const char* lr = getenv("LOCAL_RANK"))
+        device = atoi(lr);
+    check(skh_create(device, &mCtx), "skh_create");
+}
+Buffer* HipRender::createBuffer(const BufferDesc& desc)
+{
+    assert(desc.format == BufferFormat::FLOAT4); // OptixRender.cpp:1109
+    void* d = nullptr;
+    if (!check(skh_buffer_alloc(mCtx, (size_t)desc.width * desc.height * Buffer::getElementSize(desc.format), &d), "skh_buffer_alloc"))
+        return nullptr;
+    return new HipBuffer(mCtx, d, desc.format, desc.width, desc.height);
+}
+void HipRender::uploadScene()
+{
+    Scene& sc = *mScene;
+    static_assert(sizeof(Scene::Vertex) == sizeof(skh_vertex) && sizeof(Mesh) == sizeof(skh_mesh) && sizeof(Curve) == sizeof(skh_curve), "layouts");
+    static_assert(sizeof(Scene::Light) == sizeof(skh_light), "light layout");
+    check(skh_set_geometry(mCtx, reinterpret_cast<const skh_vertex*>(sc.getVertices().data()), (uint32_t)sc.getVertices().size(),
+                           sc.getIndices().data(), (uint32_t)sc.getIndices().size(),
+                           reinterpret_cast<const skh_mesh*>(sc.getMeshes().data()), (uint32_t)sc.getMeshes().size()),
+          "skh_set_geometry");
+    if (!sc.getCurves().empty())
+        check(skh_set_curves(mCtx, reinterpret_cast<const float*>(sc.getCurvesPoint().data()), (uint32_t)sc.getCurvesPoint().size(),
+                             sc.getCurvesWidths().data(), (uint32_t)sc.getCurvesWidths().size(), sc.getCurvesVertexCounts().data(),
+                             (uint32_t)sc.getCurvesVertexCounts().size(), reinterpret_cast<const skh_curve*>(sc.getCurves().data()),
+                             (uint32_t)sc.getCurves().size()),
+              "skh_set_curves");
+    std::vector<skh_instance> inst(sc.getInstances().size());
+    for (size_t i = 0; i < inst.size(); ++i)
+    {
+        const Instance& in = sc.getInstances()[i];
+        // glm::float3x4(glm::rowMajor4(transform)) (OptixRender.cpp:438): rows of the affine transform
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c)
+                inst[i].transform[4 * r + c] = in.transform.m[c][r];
+        inst[i].type = (uint32_t)in.type;
+        inst[i].geom_id = in.mMeshId;
+        inst[i].material_id = in.mMaterialId;
+        inst[i].light_id = in.mLightId;
+    }
+    check(skh_set_instances(mCtx, inst.data(), (uint32_t)inst.size()), "skh_set_instances");
+    check(skh_set_lights(mCtx, reinterpret_cast<const skh_light*>(sc.getLights().data()), (uint32_t)sc.getLights().size()), "skh_set_lights");
+    std::vector<skh_material> mats;
+    for (const auto& m : sc.getMaterials())
+        mats.push_back(m.args);
+    if (mats.empty())
+    {
+        skh_material m; // default.mdl::default_material registered by init() in the reference (OptixRender.cpp:1090-1097)
+        memset(&m, 0, sizeof(m));
+        m.base_color[0] = m.base_color[1] = m.base_color[2] = 0.8f;
+        mats.push_back(m);
+    }
+    check(skh_set_materials(mCtx, mats.data(), (uint32_t)mats.size()), "skh_set_materials");
+    check(skh_build_accel(mCtx, SKH_BUILD_LBVH), "skh_build_accel");
+}
+
+void HipRender::render(Buffer* output)
+{
+    SharedContext& sh = getSharedContext();
+    if (sh.mFrameNumber == 0)
+        uploadScene(); // scene is uploaded once; later edits are ignored, like the reference (OptixRender.cpp:876-888)
+
+    const uint32_t width = output->width();
+    const uint32_t height = output->height();
+    // updatePathtracerParams (OptixRender.cpp:827-872)
+    if (mWidth != width || mHeight != height)
+    {
+        sh.mSubframeIndex = 0;
+        sh.mSettingsManager->setAs<bool>("render/pt/isResized", true);
+        check(skh_resize(mCtx, width, height), "skh_resize");
+        mWidth = width;
+        mHeight = height;
+    }
+    Camera& camera = mScene->getCamera(0);
+    camera.updateAspectRatio(width / (float)height);
+    camera.updateViewMatrix();
+    if (camera.matrices.perspective != mPrevPerspective || camera.matrices.view != mPrevView)
+        sh.mSubframeIndex = 0; // need reset (OptixRender.cpp:903-908)
+
+    SettingsManager& settings = *sh.mSettingsManager;
+    bool settingsChanged = false;
+    const uint32_t rectLightSamplingMethod = settings.getAs<uint32_t>("render/pt/rectLightSamplingMethod");
+    settingsChanged = (mRectLightSamplingMethodPrev != rectLightSamplingMethod);
+    mRectLightSamplingMethodPrev = rectLightSamplingMethod;
+    bool enableAccumulation = settings.getAs<bool>("render/pt/enableAcc");
+    settingsChanged |= (mEnableAccumulationPrev != enableAccumulation);
+    mEnableAccumulationPrev = enableAccumulation;
+    const uint32_t sspTotal = settings.getAs<uint32_t>("render/pt/sppTotal");
+    settingsChanged |= (mSppTotalPrev > sspTotal); // reset only if the new spp is below what was already accumulated
+    mSppTotalPrev = sspTotal;
+    const float gamma = settings.getAs<float>("render/post/gamma");
+    const uint32_t tonemapperType = settings.getAs<uint32_t>("render/pt/tonemapperType");
+    if (settingsChanged)
+        sh.mSubframeIndex = 0;
+
+    skh_frame_params p;
+    memset(&p, 0, sizeof(p));
+    p.max_depth = settings.getAs<uint32_t>("render/pt/depth");
+    p.rect_light_sampling_method = rectLightSamplingMethod;
+    p.debug = settings.getAs<uint32_t>("render/pt/debug");
+    p.shadow_ray_tmin = settings.getAs<float>("render/pt/dev/shadowRayTmin");
+    p.material_ray_tmin = settings.getAs<float>("render/pt/dev/materialRayTmin");
+    // glm::transpose(glm::inverse(view)) / glm::transpose(invPerspective) memcpy'd column-major == row-major matrices
+    const float4x4 v2w = camera.matrices.view.inverse();
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c)
+        {
+            p.view_to_world[4 * r + c] = v2w.m[c][r];
+            p.clip_to_view[4 * r + c] = camera.matrices.invPerspective.m[c][r];
+        }
+    p.subframe_index = (uint32_t)sh.mSubframeIndex;
+    // photometric exposure (OptixRender.cpp:961-987)
+    const float filmIso = settings.getAs<float>("render/post/tonemapper/filmIso");
+    const float cm2_factor = settings.getAs<float>("render/post/tonemapper/cm2_factor");
+    const float fStop = settings.getAs<float>("render/post/tonemapper/fStop");
+    const float shutterSpeed = settings.getAs<float>("render/post/tonemapper/shutterSpeed");
+    float e[3] = { 1.0f, 1.0f, 1.0f };
+    const float lum = e[0] * 0.299f + e[1] * 0.587f + e[2] * 0.114f;
+    const float k = filmIso > 0.0f ? cm2_factor * filmIso / (shutterSpeed * fStop * fStop) / 100.0f : cm2_factor;
+    const float invLum = 1.0f / lum;
+    for (int i = 0; i < 3; ++i)
+        p.exposure[i] = e[i] * k * invLum;
+
+    const uint32_t totalSpp = sspTotal;
+    const uint32_t samplesPerLaunch = settings.getAs<uint32_t>("render/pt/spp");
+    const int32_t leftSpp = (int32_t)totalSpp - (int32_t)sh.mSubframeIndex;
+    uint32_t samplesThisLaunch = enableAccumulation ? (uint32_t)std::min((int32_t)samplesPerLaunch, leftSpp) : samplesPerLaunch;
+    if (p.debug == 1)
+    {
+        samplesThisLaunch = 1;
+        enableAccumulation = false;
+    }
+    p.samples_this_launch = samplesThisLaunch;
+    p.enable_accumulation = enableAccumulation;
+    p.spp_total = totalSpp;
+
+    void* dImage = static_cast<HipBuffer*>(output)->getNativePtr();
+    if (samplesThisLaunch != 0)
+    {
+        check(skh_render_subframe(mCtx, &p, dImage), "skh_render_subframe");
+        if (enableAccumulation)
+            sh.mSubframeIndex += samplesThisLaunch;
+        else
+            sh.mSubframeIndex = 0;
+    }
+    else if (p.debug == 0)
+        check(skh_copy_accum(mCtx, dImage), "skh_copy_accum"); // all spp done: accum -> image (OptixRender.cpp:1022-1043)
+    if (p.debug != 1)
+        check(skh_tonemap(mCtx, dImage, width, height, tonemapperType, p.exposure, gamma), "skh_tonemap");
+    output->unmap();
+    sh.mFrameNumber++;
+    mPrevView = camera.matrices.view;
+    mPrevPerspective = camera.matrices.perspective;
+}
+
+Render* RenderFactory::createRender(RenderType type)
+{
+    if (type == RenderType::eCompute)
+        return new HipRender();
+    return nullptr; // eOptiX / eMetal live in the reference tree
+}
+Render* RenderFactory::createRender()
+{
+    return new HipRender();
+}
+
+} // namespace oka
