@@ -189,7 +189,7 @@ def main():
                        "parallelism": f"pixel tiles round-robin over {world} GPU(s), 1 RCCL gather/frame" if world > 1
                        else "single GPU", "rays_per_frame": int(rays_total / K), "bvh_build_ms": round(build_ms, 2)},
             "kernel_ms_per_frame": {k: round(st[k] / K, 3) for k in ("ms_trace_closest", "ms_trace_shadow", "ms_shade",
-                                                                     "ms_raygen", "ms_accumulate")},
+                                                                     "ms_raygen", "ms_accumulate", "ms_sort")},
             "roofline": {"kernel": "k_trace<closest>", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),

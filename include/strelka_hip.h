@@ -192,6 +192,7 @@ typedef struct skh_stats
     double ms_raygen;
     double ms_accumulate;
     double ms_build; /* last skh_build_accel */
+    double ms_sort; /* ray re-ordering (key build + radix sort) */
     uint32_t launches_trace_closest;
     uint32_t launches_trace_shadow;
     uint32_t launches_shade;

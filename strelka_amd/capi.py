@@ -16,7 +16,7 @@ _lib = None
 STATS = np.dtype([("rays_radiance", np.uint64), ("rays_shadow", np.uint64), ("nodes_visited", np.uint64, 2),
                   ("prims_tested", np.uint64, 2), ("segs_tested", np.uint64, 2), ("instances_entered", np.uint64, 2),
                   ("ms_trace_closest", np.float64), ("ms_trace_shadow", np.float64), ("ms_shade", np.float64),
-                  ("ms_raygen", np.float64), ("ms_accumulate", np.float64), ("ms_build", np.float64),
+                  ("ms_raygen", np.float64), ("ms_accumulate", np.float64), ("ms_build", np.float64), ("ms_sort", np.float64),
                   ("launches_trace_closest", np.uint32), ("launches_trace_shadow", np.uint32),
                   ("launches_shade", np.uint32), ("launches_other", np.uint32)])
 

@@ -157,11 +157,14 @@ __global__ void k_morton(const float4* __restrict__ boxLo, const float4* __restr
 #define SKH_RS_THREADS 256
 #define SKH_RS_ITEMS 16 // elements per thread per block => 4096 elements per block
 
+// n may live on the device (nPtr != nullptr): queue lengths are never read back by the host during a frame
 __global__ void __launch_bounds__(SKH_RS_THREADS) k_rs_hist(const uint64_t* __restrict__ keys, uint32_t n, uint32_t shift,
                                                            uint32_t* __restrict__ hist /*[256][numBlocks]*/,
-                                                           uint32_t numBlocks)
+                                                           uint32_t numBlocks, const uint32_t* __restrict__ nPtr)
 {
     __shared__ uint32_t h[256];
+    if (nPtr)
+        n = *nPtr;
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * (SKH_RS_THREADS * SKH_RS_ITEMS);
@@ -208,9 +211,13 @@ __global__ void __launch_bounds__(1024) k_rs_scan(uint32_t* __restrict__ data, u
 __global__ void __launch_bounds__(SKH_RS_THREADS)
     k_rs_scatter(const uint64_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, uint64_t* __restrict__ keysOut,
                  uint32_t* __restrict__ valsOut, uint32_t n, uint32_t shift, const uint32_t* __restrict__ hist,
-                 uint32_t numBlocks)
+                 uint32_t numBlocks, const uint32_t* __restrict__ nPtr)
 {
     __shared__ uint32_t digitBase[256];
+    if (nPtr)
+        n = *nPtr;
+    if (blockIdx.x * (SKH_RS_THREADS * SKH_RS_ITEMS) >= n)
+        return;
     __shared__ uint32_t waveCount[4][256];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     digitBase[threadIdx.x] = hist[(size_t)threadIdx.x * numBlocks + blockIdx.x];

@@ -166,7 +166,7 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 template <bool ANY_HIT, bool COUNT, bool CURVES>
 __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WAVES)
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
-            uint32_t fetchMin,
+            uint32_t fetchMin, const uint32_t* __restrict__ perm /*optional: sorted order -> queue index*/,
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
             StatsDev* __restrict__ stats)
 {
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
             const uint32_t rank = (uint32_t)__popcll(needMask & ((1ull << lane) - 1ull));
             if (!hasRay && rank < count)
             {
-                ridx = base + rank;
+                ridx = perm ? perm[base + rank] : base + rank;
                 ow = mk3(rq.plane(0)[ridx], rq.plane(1)[ridx], rq.plane(2)[ridx]);
                 dw = mk3(rq.plane(3)[ridx], rq.plane(4)[ridx], rq.plane(5)[ridx]);
                 tmin = rq.plane(6)[ridx];
@@ -455,6 +455,30 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
             atomicAdd(&stats->insts[ANY_HIT ? 1 : 0], (unsigned long long)d2);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Ray re-ordering for coherence: key = direction octant : Morton code of the origin inside the scene box.  Rays that
+// start close together and point the same way walk the same BVH nodes, which raises both the cache hit rate and the
+// fraction of active lanes per wave.  Only the (key, index) pairs are sorted; k_trace gathers rays through the
+// permutation and writes hit records at the ORIGINAL queue index, so nothing downstream changes.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ray_keys(RayQ rq, const uint32_t* __restrict__ countPtr, float lox, float loy, float loz,
+                                                 float sx, float sy, float sz, uint32_t mortonBits /*per axis, <= 10*/,
+                                                 uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *countPtr)
+        return;
+    const float ox = rq.plane(0)[i], oy = rq.plane(1)[i], oz = rq.plane(2)[i];
+    const float dx = rq.plane(3)[i], dy = rq.plane(4)[i], dz = rq.plane(5)[i];
+    const uint32_t qx = (uint32_t)fminf(fmaxf((ox - lox) * sx, 0.0f), 1023.0f);
+    const uint32_t qy = (uint32_t)fminf(fmaxf((oy - loy) * sy, 0.0f), 1023.0f);
+    const uint32_t qz = (uint32_t)fminf(fmaxf((oz - loz) * sz, 0.0f), 1023.0f);
+    const uint32_t code = ((expand_bits10(qx) << 2) | (expand_bits10(qy) << 1) | expand_bits10(qz)) >> (3u * (10u - mortonBits));
+    const uint32_t oct = (dx < 0.0f ? 1u : 0u) | (dy < 0.0f ? 2u : 0u) | (dz < 0.0f ? 4u : 0u);
+    keys[i] = ((uint64_t)oct << (3u * mortonBits)) | code;
+    vals[i] = i;
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -37,6 +37,7 @@ enum KernelClass
     KC_SHADE,
     KC_RAYGEN,
     KC_ACCUM,
+    KC_SORT,
     KC_COUNT
 };
 
@@ -79,13 +80,18 @@ struct skh_context
     bool countTraversal = false, timing = false;
     uint32_t wavesPerCU = 20;
     uint32_t fetchMinClosest = 32, fetchMinShadow = 32;
+    // ray re-ordering (per bounce): 0 = off, else Morton bits per axis of the origin cell (key = octant : morton)
+    uint32_t sortBitsClosest = 0, sortBitsShadow = 0, sortFirstBounce = 1;
+    bool tlasSah = true; // full-sweep SAH TLAS on the host (false: GPU LBVH over the instance boxes)
+    float sceneLo[3] = { 0, 0, 0 }, sceneHi[3] = { 1, 1, 1 };
+    DevBuf dSortKeys[2], dSortVals[2], dSortHist;
 
     // timing
     std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> eventPool;
     size_t eventsUsed = 0;
-    double msClass[KC_COUNT] = { 0, 0, 0, 0, 0 };
-    uint32_t launches[KC_COUNT] = { 0, 0, 0, 0, 0 };
+    double msClass[KC_COUNT] = { 0, 0, 0, 0, 0, 0 };
+    uint32_t launches[KC_COUNT] = { 0, 0, 0, 0, 0, 0 };
     double msBuild = 0.0;
 };
 
@@ -256,9 +262,9 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
     uint32_t* vout = valsB.as<uint32_t>();
     for (uint32_t shift : shifts)
     {
-        k_rs_hist<<<rsBlocks, SKH_RS_THREADS, 0, st>>>(kin, n, shift, hist.as<uint32_t>(), rsBlocks);
+        k_rs_hist<<<rsBlocks, SKH_RS_THREADS, 0, st>>>(kin, n, shift, hist.as<uint32_t>(), rsBlocks, nullptr);
         k_rs_scan<<<1, 1024, 0, st>>>(hist.as<uint32_t>(), 256 * rsBlocks);
-        k_rs_scatter<<<rsBlocks, SKH_RS_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, hist.as<uint32_t>(), rsBlocks);
+        k_rs_scatter<<<rsBlocks, SKH_RS_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, hist.as<uint32_t>(), rsBlocks, nullptr);
         std::swap(kin, kout);
         std::swap(vin, vout);
     }
@@ -311,6 +317,134 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------------
+// TLAS by full-sweep SAH on the host.  The top level holds a few thousand instance boxes (the reference's IAS,
+// OptixRender.cpp:443-495) and every ray walks it, so its quality matters far more than its build time; an exact
+// sweep over three axes costs O(n log^2 n) on a few thousand boxes -- well under a millisecond per thousand.
+// Invalid (masked-out) instances are left out.  Output: 64-byte nodes + leaf order, same encoding as the GPU LBVH.
+// ---------------------------------------------------------------------------------------------------------------
+struct HostBox
+{
+    float lo[3], hi[3];
+};
+static inline float hb_half_area(const float* lo, const float* hi)
+{
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    return ex * ey + ey * ez + ez * ex;
+}
+static int tlas_sah_build(const std::vector<HostBox>& boxes, const std::vector<uint32_t>& ids, std::vector<Node64>& nodes,
+                          std::vector<uint32_t>& order)
+{
+    const uint32_t n = (uint32_t)ids.size();
+    nodes.clear();
+    order.clear();
+    if (n == 0)
+        return SKH_REF_INVALID;
+    order.assign(ids.begin(), ids.end());
+    if (n == 1)
+        return ~(int)((0u << 3) | 0u);
+    struct Task
+    {
+        uint32_t first, count;
+        int parent;
+        int side;
+    };
+    std::vector<Task> stack;
+    stack.push_back(Task{ 0, n, -1, 0 });
+    std::vector<float> rightArea;
+    auto boundsOf = [&](uint32_t first, uint32_t count, float* lo, float* hi) {
+        for (int k = 0; k < 3; ++k)
+        {
+            lo[k] = INFINITY;
+            hi[k] = -INFINITY;
+        }
+        for (uint32_t i = first; i < first + count; ++i)
+        {
+            const HostBox& b = boxes[order[i]];
+            for (int k = 0; k < 3; ++k)
+            {
+                lo[k] = std::min(lo[k], b.lo[k]);
+                hi[k] = std::max(hi[k], b.hi[k]);
+            }
+        }
+    };
+    int rootRef = 0;
+    while (!stack.empty())
+    {
+        const Task t = stack.back();
+        stack.pop_back();
+        int ref;
+        if (t.count == 1)
+            ref = ~(int)((t.first << 3) | 0u);
+        else
+        {
+            // best split over 3 axes by exact sweep
+            float bestCost = INFINITY;
+            int bestAxis = 0;
+            uint32_t bestSplit = t.count / 2;
+            for (int axis = 0; axis < 3; ++axis)
+            {
+                std::sort(order.begin() + t.first, order.begin() + t.first + t.count, [&](uint32_t a, uint32_t b) {
+                    const float ca = boxes[a].lo[axis] + boxes[a].hi[axis], cb = boxes[b].lo[axis] + boxes[b].hi[axis];
+                    return ca < cb || (ca == cb && a < b);
+                });
+                rightArea.assign(t.count + 1, 0.0f);
+                float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+                for (uint32_t i = t.count; i-- > 1;)
+                {
+                    const HostBox& b = boxes[order[t.first + i]];
+                    for (int k = 0; k < 3; ++k)
+                    {
+                        lo[k] = std::min(lo[k], b.lo[k]);
+                        hi[k] = std::max(hi[k], b.hi[k]);
+                    }
+                    rightArea[i] = hb_half_area(lo, hi);
+                }
+                for (int k = 0; k < 3; ++k)
+                {
+                    lo[k] = INFINITY;
+                    hi[k] = -INFINITY;
+                }
+                for (uint32_t i = 1; i < t.count; ++i)
+                {
+                    const HostBox& b = boxes[order[t.first + i - 1]];
+                    for (int k = 0; k < 3; ++k)
+                    {
+                        lo[k] = std::min(lo[k], b.lo[k]);
+                        hi[k] = std::max(hi[k], b.hi[k]);
+                    }
+                    const float cost = hb_half_area(lo, hi) * (float)i + rightArea[i] * (float)(t.count - i);
+                    if (cost < bestCost)
+                    {
+                        bestCost = cost;
+                        bestAxis = axis;
+                        bestSplit = i;
+                    }
+                }
+            }
+            std::sort(order.begin() + t.first, order.begin() + t.first + t.count, [&](uint32_t a, uint32_t b) {
+                const float ca = boxes[a].lo[bestAxis] + boxes[a].hi[bestAxis], cb = boxes[b].lo[bestAxis] + boxes[b].hi[bestAxis];
+                return ca < cb || (ca == cb && a < b);
+            });
+            ref = (int)nodes.size();
+            Node64 nd;
+            memset(&nd, 0, sizeof(nd));
+            boundsOf(t.first, bestSplit, nd.lmin, nd.lmax);
+            boundsOf(t.first + bestSplit, t.count - bestSplit, nd.rmin, nd.rmax);
+            nodes.push_back(nd);
+            stack.push_back(Task{ t.first + bestSplit, t.count - bestSplit, ref, 1 });
+            stack.push_back(Task{ t.first, bestSplit, ref, 0 });
+        }
+        if (t.parent < 0)
+            rootRef = ref;
+        else if (t.side == 0)
+            nodes[t.parent].left = ref;
+        else
+            nodes[t.parent].right = ref;
+    }
+    return rootRef;
+}
+
 // The entry points below take C linkage from their declarations in include/strelka_hip.h.
 
 uint32_t skh_abi_version(void)
@@ -362,7 +496,8 @@ void skh_destroy(skh_context* c)
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
                        &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
-                       &c->dCounts, &c->dOvf, &c->dStats, &c->dScratchImage })
+                       &c->dCounts, &c->dOvf, &c->dStats, &c->dScratchImage, &c->dSortKeys[0], &c->dSortKeys[1], &c->dSortVals[0],
+                       &c->dSortVals[1], &c->dSortHist })
         dev_free(*b);
     for (hipEvent_t e : c->eventPool)
         (void)hipEventDestroy(e);
@@ -574,14 +709,70 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
                                                            segOut.groupBounds.as<float>(), segOut.groupRoot.as<int>(), nMeshes, nCurves,
                                                            nInst, c->dDevInst.as<DevInstance>(), dBoxLo.as<float4>(),
                                                            dBoxHi.as<float4>(), dGrp.as<uint32_t>());
-    std::vector<uint32_t> one = { nInst };
-    BA(lbvh_build(c, nInst, 1, one, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), 1, tlasOut));
-    dev_free(c->dTlasNodes);
-    dev_free(c->dTlasInst);
-    c->dTlasNodes = tlasOut.nodes;
-    c->dTlasInst = tlasOut.sortedVals;
-    tlasOut.sortedVals = DevBuf();
-    c->tlasRoot = nInst ? tlasOut.hostGroupRoot[0] : SKH_REF_INVALID;
+    if (c->tlasSah && nInst > 0)
+    {
+        // instance boxes were produced on the device (k_instance_boxes); the sweep runs on the host
+        std::vector<float4> hlo(nInst), hhi(nInst);
+        std::vector<DevInstance> hinst(nInst);
+        if (hipStreamSynchronize(st) != hipSuccess ||
+            hipMemcpy(hlo.data(), dBoxLo.p, sizeof(float4) * nInst, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(hhi.data(), dBoxHi.p, sizeof(float4) * nInst, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(hinst.data(), c->dDevInst.p, sizeof(DevInstance) * nInst, hipMemcpyDeviceToHost) != hipSuccess)
+        {
+            c->err = "skh_build_accel: instance box read-back failed";
+            cleanup();
+            return SKH_FAIL;
+        }
+        std::vector<HostBox> hb(nInst);
+        std::vector<uint32_t> ids;
+        float slo[3] = { INFINITY, INFINITY, INFINITY }, shi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (uint32_t i = 0; i < nInst; ++i)
+        {
+            hb[i] = HostBox{ { hlo[i].x, hlo[i].y, hlo[i].z }, { hhi[i].x, hhi[i].y, hhi[i].z } };
+            if (hinst[i].mask != 0)
+            {
+                ids.push_back(i);
+                for (int k = 0; k < 3; ++k)
+                {
+                    slo[k] = std::min(slo[k], hb[i].lo[k]);
+                    shi[k] = std::max(shi[k], hb[i].hi[k]);
+                }
+            }
+        }
+        std::vector<Node64> hnodes;
+        std::vector<uint32_t> horder;
+        c->tlasRoot = tlas_sah_build(hb, ids, hnodes, horder);
+        dev_free(c->dTlasNodes);
+        dev_free(c->dTlasInst);
+        BA(dev_upload(c, c->dTlasNodes, hnodes.data(), sizeof(Node64) * hnodes.size()));
+        BA(dev_upload(c, c->dTlasInst, horder.data(), sizeof(uint32_t) * horder.size()));
+        for (int k = 0; k < 3; ++k)
+        {
+            c->sceneLo[k] = ids.empty() ? 0.0f : slo[k];
+            c->sceneHi[k] = ids.empty() ? 1.0f : shi[k];
+        }
+    }
+    else
+    {
+        std::vector<uint32_t> one = { nInst };
+        BA(lbvh_build(c, nInst, 1, one, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), 1, tlasOut));
+        dev_free(c->dTlasNodes);
+        dev_free(c->dTlasInst);
+        c->dTlasNodes = tlasOut.nodes;
+        c->dTlasInst = tlasOut.sortedVals;
+        tlasOut.sortedVals = DevBuf();
+        c->tlasRoot = nInst ? tlasOut.hostGroupRoot[0] : SKH_REF_INVALID;
+        if (nInst)
+        {
+            float gb[6];
+            if (hipMemcpy(gb, tlasOut.groupBounds.p, sizeof(gb), hipMemcpyDeviceToHost) == hipSuccess)
+                for (int k = 0; k < 3; ++k)
+                {
+                    c->sceneLo[k] = gb[k];
+                    c->sceneHi[k] = gb[3 + k];
+                }
+        }
+    }
     hipError_t e = hipStreamSynchronize(st);
     cleanup();
     if (e != hipSuccess || (e = hipGetLastError()) != hipSuccess)
@@ -629,6 +820,12 @@ static skh_status alloc_frame(skh_context* c)
     AF(dev_alloc(c, c->dShadowQ, sizeof(float) * 9 * N));
     AF(dev_alloc(c, c->dContrib, sizeof(float) * 3 * N));
     AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * (512 + 16 * 130)));
+    for (int k = 0; k < 2; ++k)
+    {
+        AF(dev_alloc(c, c->dSortKeys[k], sizeof(uint64_t) * N));
+        AF(dev_alloc(c, c->dSortVals[k], sizeof(uint32_t) * N));
+    }
+    AF(dev_alloc(c, c->dSortHist, sizeof(uint32_t) * 256 * ((N + SKH_RS_THREADS * SKH_RS_ITEMS - 1) / (SKH_RS_THREADS * SKH_RS_ITEMS))));
     c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
     AF(dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * c->traceBlocks * SKH_TRACE_BLOCK));
 #undef AF
@@ -765,16 +962,49 @@ static skh_status ensure_ready(skh_context* c)
     return SKH_OK;
 }
 
+// sorts (key, index) pairs of the rays in rq (length on the device) and returns the permutation, or nullptr when off
+static const uint32_t* sort_rays(skh_context* c, RayQ rq, const uint32_t* countPtr, uint32_t mortonBits)
+{
+    if (mortonBits == 0 || rq.stride == 0)
+        return nullptr;
+    mortonBits = std::min(mortonBits, 10u);
+    hipStream_t st = c->stream;
+    const uint32_t N = rq.stride;
+    float sc[3];
+    for (int k = 0; k < 3; ++k)
+    {
+        const float e = c->sceneHi[k] - c->sceneLo[k];
+        sc[k] = e > 0.0f ? 1024.0f / e : 0.0f;
+    }
+    uint64_t* kin = c->dSortKeys[0].as<uint64_t>();
+    uint64_t* kout = c->dSortKeys[1].as<uint64_t>();
+    uint32_t* vin = c->dSortVals[0].as<uint32_t>();
+    uint32_t* vout = c->dSortVals[1].as<uint32_t>();
+    k_ray_keys<<<(N + 255) / 256, 256, 0, st>>>(rq, countPtr, c->sceneLo[0], c->sceneLo[1], c->sceneLo[2], sc[0], sc[1], sc[2], mortonBits, kin,
+                                                vin);
+    const uint32_t bits = 3 * mortonBits + 3;
+    const uint32_t rsBlocks = (N + SKH_RS_THREADS * SKH_RS_ITEMS - 1) / (SKH_RS_THREADS * SKH_RS_ITEMS);
+    for (uint32_t shift = 0; shift < bits; shift += 8)
+    {
+        k_rs_hist<<<rsBlocks, SKH_RS_THREADS, 0, st>>>(kin, N, shift, c->dSortHist.as<uint32_t>(), rsBlocks, countPtr);
+        k_rs_scan<<<1, 1024, 0, st>>>(c->dSortHist.as<uint32_t>(), 256 * rsBlocks);
+        k_rs_scatter<<<rsBlocks, SKH_RS_THREADS, 0, st>>>(kin, vin, kout, vout, N, shift, c->dSortHist.as<uint32_t>(), rsBlocks, countPtr);
+        std::swap(kin, kout);
+        std::swap(vin, vout);
+    }
+    return vin;
+}
+
 template <bool ANY, bool COUNT>
-static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint32_t* countPtr, uint32_t* fetch, HitQ hq, PathS ps,
-                         const float* contrib, uint32_t contribStride)
+static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint32_t* countPtr, uint32_t* fetch, const uint32_t* perm,
+                         HitQ hq, PathS ps, const float* contrib, uint32_t contribStride)
 {
     // scenes without curve instances run the build of the kernel that has no curve intersector in it (fewer VGPRs)
     if (c->nSegs)
-        k_trace<ANY, COUNT, true><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, fetch, ANY ? c->fetchMinShadow : c->fetchMinClosest, hq, ps, contrib, contribStride,
+        k_trace<ANY, COUNT, true><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, fetch, ANY ? c->fetchMinShadow : c->fetchMinClosest, perm, hq, ps, contrib, contribStride,
                                                                                       c->dOvf.as<int>(), c->dStats.as<StatsDev>());
     else
-        k_trace<ANY, COUNT, false><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, fetch, ANY ? c->fetchMinShadow : c->fetchMinClosest, hq, ps, contrib, contribStride,
+        k_trace<ANY, COUNT, false><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, fetch, ANY ? c->fetchMinShadow : c->fetchMinClosest, perm, hq, ps, contrib, contribStride,
                                                                                        c->dOvf.as<int>(), c->dStats.as<StatsDev>());
 }
 
@@ -828,24 +1058,36 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, void* d_
         }
         for (uint32_t b = 0; b < fp.maxDepth; ++b)
         {
+            const uint32_t* permC = nullptr;
+            if (b >= c->sortFirstBounce && c->sortBitsClosest)
+            {
+                SpanGuard g(c, KC_SORT);
+                permC = sort_rays(c, rq[b & 1], counts + 2 * b, c->sortBitsClosest);
+            }
             {
                 SpanGuard g(c, KC_TRACE_CLOSEST);
                 if (c->countTraversal)
-                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b, fetch + 16 * b, hq, ps, nullptr, 0);
+                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b, fetch + 16 * b, permC, hq, ps, nullptr, 0);
                 else
-                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b, fetch + 16 * b, hq, ps, nullptr, 0);
+                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b, fetch + 16 * b, permC, hq, ps, nullptr, 0);
             }
             {
                 SpanGuard g(c, KC_SHADE);
                 k_shade<<<(N + 511) / 512, 512, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b, hq, ps, rq[(b + 1) & 1],
                                                    counts + 2 * (b + 1), shq, c->dContrib.as<float>(), counts + 2 * b + 1);
             }
+            const uint32_t* permS = nullptr;
+            if (c->sortBitsShadow)
+            {
+                SpanGuard g(c, KC_SORT);
+                permS = sort_rays(c, shq, counts + 2 * b + 1, c->sortBitsShadow);
+            }
             {
                 SpanGuard g(c, KC_TRACE_SHADOW);
                 if (c->countTraversal)
-                    launch_trace<true, true>(c, sc, shq, counts + 2 * b + 1, fetch + 16 * b + 8, nohq, ps, c->dContrib.as<float>(), N);
+                    launch_trace<true, true>(c, sc, shq, counts + 2 * b + 1, fetch + 16 * b + 8, permS, nohq, ps, c->dContrib.as<float>(), N);
                 else
-                    launch_trace<true, false>(c, sc, shq, counts + 2 * b + 1, fetch + 16 * b + 8, nohq, ps, c->dContrib.as<float>(), N);
+                    launch_trace<true, false>(c, sc, shq, counts + 2 * b + 1, fetch + 16 * b + 8, permS, nohq, ps, c->dContrib.as<float>(), N);
             }
             if (fp.debug == 1)
                 break;
@@ -1100,16 +1342,16 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
         if (mode == SKH_TRACE_SHADOW)
         {
             if (c->countTraversal)
-                launch_trace<true, true>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
+                launch_trace<true, true>(c, sc, rq, dcount, dfetch, nullptr, hq, ps, nullptr, 0);
             else
-                launch_trace<true, false>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
+                launch_trace<true, false>(c, sc, rq, dcount, dfetch, nullptr, hq, ps, nullptr, 0);
         }
         else
         {
             if (c->countTraversal)
-                launch_trace<false, true>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
+                launch_trace<false, true>(c, sc, rq, dcount, dfetch, nullptr, hq, ps, nullptr, 0);
             else
-                launch_trace<false, false>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
+                launch_trace<false, false>(c, sc, rq, dcount, dfetch, nullptr, hq, ps, nullptr, 0);
         }
     }
     k_hits_soa_to_aos<<<(n_rays + 255) / 256, 256, 0, c->stream>>>(hq, n_rays, mode, reinterpret_cast<skh_hit*>(d_hits));
@@ -1170,6 +1412,19 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
             return SKH_INVALID_ARGUMENT;
         (n == "fetch_min_closest" ? c->fetchMinClosest : c->fetchMinShadow) = (uint32_t)value;
     }
+    else if (n == "sort_bits_closest" || n == "sort_bits_shadow")
+    {
+        if (value < 0 || value > 10)
+            return SKH_INVALID_ARGUMENT;
+        (n == "sort_bits_closest" ? c->sortBitsClosest : c->sortBitsShadow) = (uint32_t)value;
+    }
+    else if (n == "tlas_sah")
+    {
+        c->tlasSah = value != 0;
+        c->accelBuilt = false;
+    }
+    else if (n == "sort_first_bounce")
+        c->sortFirstBounce = (uint32_t)std::max<int64_t>(0, value);
     else if (n == "waves_per_cu")
     {
         if (value < 1 || value > 32)
@@ -1209,6 +1464,7 @@ skh_status skh_get_stats(skh_context* c, skh_stats* out)
     out->ms_shade = c->msClass[KC_SHADE];
     out->ms_raygen = c->msClass[KC_RAYGEN];
     out->ms_accumulate = c->msClass[KC_ACCUM];
+    out->ms_sort = c->msClass[KC_SORT];
     out->ms_build = c->msBuild;
     out->launches_trace_closest = c->launches[KC_TRACE_CLOSEST];
     out->launches_trace_shadow = c->launches[KC_TRACE_SHADOW];
