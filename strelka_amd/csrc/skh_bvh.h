@@ -21,6 +21,9 @@
 namespace skh
 {
 
+#define SKH_REF_INVALID 0x7fffffff
+#define SKH_REF_SENTINEL ((int)0x80000000)
+
 struct Node64
 {
     float lmin[3], lmax[3], rmin[3], rmax[3];
@@ -28,8 +31,67 @@ struct Node64
 };
 static_assert(sizeof(Node64) == 64, "node size");
 
-#define SKH_REF_INVALID 0x7fffffff
-#define SKH_REF_SENTINEL ((int)0x80000000)
+// 4-wide node with quantised child boxes, 64 bytes: ONE 64-byte fetch per visited node yields four child boxes,
+// halving the number of dependent memory round trips per ray relative to the binary layout (the traversal kernel is
+// latency bound, not bandwidth bound: DESIGN.md section 4).
+//   o[3]    node-box origin (min corner minus a safety margin)
+//   exps    one biased fp32 exponent byte per axis: cell size = 2^(e-127), chosen so that 255 cells cover the extent
+//   qlo/qhi one byte per child per axis (byte c of word a = child c, axis a): child box = o + q * cell, with qlo rounded
+//           down and qhi rounded up, so the decoded box always contains the exact (inflated) child box
+//   child   >= 0 node index, < 0 leaf ~((first << 3) | (count - 1)), SKH_REF_INVALID for an empty slot (qlo 255 > qhi 0)
+struct Node4
+{
+    float o[3];
+    uint32_t exps;
+    uint32_t qlo[3];
+    uint32_t pad0;
+    uint32_t qhi[3];
+    uint32_t pad1;
+    int child[4];
+};
+static_assert(sizeof(Node4) == 64, "node size");
+
+#define SKH_HD __host__ __device__ inline
+SKH_HD void encode_node4(Node4& nd, const float* nlo, const float* nhi, const float clo[4][3], const float chi[4][3], const int* refs,
+                         int cnt)
+{
+    float m = 0.0f;
+    for (int a = 0; a < 3; ++a)
+        m = fmaxf(m, fmaxf(fabsf(nlo[a]), fabsf(nhi[a])));
+    const float margin = m * 0x1p-20f + 1e-30f;
+    nd.exps = 0;
+    nd.pad0 = nd.pad1 = 0;
+    for (int a = 0; a < 3; ++a)
+    {
+        const float o = nlo[a] - margin;
+        const float ext = (nhi[a] + margin) - o;
+        int e = 0;
+        (void)frexpf(fmaxf(ext, 1e-37f) / 255.0f, &e); // ext / 255 = f * 2^e, f in [0.5, 1)  =>  255 * 2^e > ext
+        int biased = e + 127;
+        biased = biased < 1 ? 1 : (biased > 254 ? 254 : biased);
+        const float inv_cell = ldexpf(1.0f, 127 - biased);
+        nd.o[a] = o;
+        nd.exps |= (uint32_t)biased << (8 * a);
+        uint32_t wl = 0, wh = 0;
+        for (int c = 0; c < 4; ++c)
+        {
+            uint32_t ql = 255u, qh = 0u; // empty slot: never overlaps
+            if (c < cnt)
+            {
+                const float fl = floorf((clo[c][a] - margin - o) * inv_cell);
+                const float fh = ceilf((chi[c][a] + margin - o) * inv_cell);
+                ql = (uint32_t)fminf(fmaxf(fl, 0.0f), 255.0f);
+                qh = (uint32_t)fminf(fmaxf(fh, 0.0f), 255.0f);
+            }
+            wl |= ql << (8 * c);
+            wh |= qh << (8 * c);
+        }
+        nd.qlo[a] = wl;
+        nd.qhi[a] = wh;
+    }
+    for (int c = 0; c < 4; ++c)
+        nd.child[c] = c < cnt ? refs[c] : SKH_REF_INVALID;
+}
 
 SKH_DI int make_leaf_ref(uint32_t first, uint32_t count)
 {
@@ -394,6 +456,82 @@ __global__ void k_group_roots(const int* __restrict__ rangeF, const int* __restr
     const uint32_t g = (uint32_t)(sortedKeys[f] >> 32);
     if ((uint32_t)f == groupFirst[g] && (uint32_t)(l - f + 1) == groupCount[g] && (l - f + 1) > leafMax)
         groupRoot[g] = i;
+}
+
+// Collapse the binary radix tree into 4-wide nodes, one tree level per launch.  A work item is (binary node, output slot);
+// its two children are opened greedily by surface area until four slots are filled; children that are themselves
+// internal get an output slot from a global counter and go to the next level's queue.
+struct CollapseItem
+{
+    int bin;
+    int out;
+};
+__global__ void k_collapse4(const CollapseItem* __restrict__ qin, uint32_t nIn, const int* __restrict__ childL,
+                            const int* __restrict__ childR, const int* __restrict__ rangeF, const int* __restrict__ rangeL,
+                            const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi, int n, int leafMax,
+                            Node4* __restrict__ out, uint32_t* __restrict__ allocCounter, CollapseItem* __restrict__ qout,
+                            uint32_t* __restrict__ nOut)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nIn)
+        return;
+    const CollapseItem it = qin[i];
+    int slot[4];
+    int cnt = 2;
+    slot[0] = childL[it.bin];
+    slot[1] = childR[it.bin];
+    auto openable = [&](int c) { return c < n - 1 && (rangeL[c] - rangeF[c] + 1) > leafMax; };
+    auto area = [&](int c) {
+        const float4 lo = nodeLo[c], hi = nodeHi[c];
+        const float ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z;
+        return ex * ey + ey * ez + ez * ex;
+    };
+    while (cnt < 4)
+    {
+        int best = -1;
+        float bestA = -1.0f;
+        for (int k = 0; k < cnt; ++k)
+            if (openable(slot[k]))
+            {
+                const float a = area(slot[k]);
+                if (a > bestA)
+                {
+                    bestA = a;
+                    best = k;
+                }
+            }
+        if (best < 0)
+            break;
+        const int c = slot[best];
+        slot[best] = childL[c];
+        slot[cnt++] = childR[c];
+    }
+    float clo[4][3], chi[4][3];
+    int refs[4];
+    for (int k = 0; k < cnt; ++k)
+    {
+        const int c = slot[k];
+        const float4 lo = nodeLo[c], hi = nodeHi[c];
+        clo[k][0] = lo.x, clo[k][1] = lo.y, clo[k][2] = lo.z;
+        chi[k][0] = hi.x, chi[k][1] = hi.y, chi[k][2] = hi.z;
+        if (c >= n - 1)
+            refs[k] = make_leaf_ref((uint32_t)(c - (n - 1)), 1u);
+        else if (!openable(c))
+            refs[k] = make_leaf_ref((uint32_t)rangeF[c], (uint32_t)(rangeL[c] - rangeF[c] + 1));
+        else
+        {
+            const uint32_t o = atomicAdd(allocCounter, 1u);
+            refs[k] = (int)o;
+            const uint32_t q = atomicAdd(nOut, 1u);
+            qout[q].bin = c;
+            qout[q].out = (int)o;
+        }
+    }
+    const float4 nl = nodeLo[it.bin], nh = nodeHi[it.bin];
+    const float nlo[3] = { nl.x, nl.y, nl.z }, nhi[3] = { nh.x, nh.y, nh.z };
+    Node4 nd;
+    encode_node4(nd, nlo, nhi, clo, chi, refs, cnt);
+    out[it.out] = nd;
 }
 
 // gather triangles into leaf order: 48 B records {v0.xyz, primId | v1.xyz, 0 | v2.xyz, 0}

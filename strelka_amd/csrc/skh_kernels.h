@@ -36,14 +36,14 @@ struct HostInstance // == skh_instance (64 B), as uploaded
 
 struct DevScene
 {
-    const Node64* tlasNodes;
+    const Node4* tlasNodes;
     const uint32_t* tlasInst; // leaf order -> instance id
     int tlasRoot;
     uint32_t numInstances;
     const DevInstance* inst;
-    const Node64* triNodes;
+    const Node4* triNodes;
     const float4* tris; // 3 x float4 per triangle, leaf order
-    const Node64* segNodes;
+    const Node4* segNodes;
     const float4* segs; // 4 x float4 per segment, leaf order
     const uint32_t* segPrim; // leaf order -> segment index inside its curve set
     // shading side
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
     RayShear sh;
     sh.kx = sh.ky = sh.kz = 0;
     sh.Sx = sh.Sy = sh.Sz = 0.0f;
-    const Node64* nodes = sc.tlasNodes;
+    const Node4* nodes = sc.tlasNodes;
     bool inBlas = false;
     uint32_t curInst = 0, curType = 0;
     int sp = 0, cur = SKH_REF_INVALID;
@@ -283,26 +283,64 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
             // ---- descend through internal nodes ----
             while (cur >= 0 && cur != SKH_REF_INVALID)
             {
+                // one 64-byte fetch = four quantised child boxes
                 const float4* np = reinterpret_cast<const float4*>(nodes + cur);
-                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
                 if (COUNT)
                     tc.nodes++;
-                float tl, tr;
-                const bool hl = slab_test(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), o, inv, tmin, best.t, tl);
-                const bool hr = slab_test(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), o, inv, tmin, best.t, tr);
-                const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
-                if (hl && hr)
+                const uint32_t exps = __float_as_uint(w0.w);
+                // per axis: plane t = q * (cell * inv) + (o_node - o_ray) * inv; near/far bytes picked by the sign of inv
+                const float ax = __uint_as_float((exps & 0xffu) << 23) * inv.x, bx = (w0.x - o.x) * inv.x;
+                const float ay = __uint_as_float(((exps >> 8) & 0xffu) << 23) * inv.y, by = (w0.y - o.y) * inv.y;
+                const float az = __uint_as_float(((exps >> 16) & 0xffu) << 23) * inv.z, bz = (w0.z - o.z) * inv.z;
+                const bool px = inv.x >= 0.0f, py = inv.y >= 0.0f, pz = inv.z >= 0.0f;
+                const uint32_t nxw = __float_as_uint(px ? w1.x : w2.x), fxw = __float_as_uint(px ? w2.x : w1.x);
+                const uint32_t nyw = __float_as_uint(py ? w1.y : w2.y), fyw = __float_as_uint(py ? w2.y : w1.y);
+                const uint32_t nzw = __float_as_uint(pz ? w1.z : w2.z), fzw = __float_as_uint(pz ? w2.z : w1.z);
+                float tn[4];
+                int rf[4];
+                rf[0] = __float_as_int(w3.x), rf[1] = __float_as_int(w3.y), rf[2] = __float_as_int(w3.z), rf[3] = __float_as_int(w3.w);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
                 {
-                    const bool leftFirst = tl <= tr;
-                    SKH_PUSH(leftFirst ? right : left);
-                    cur = leftFirst ? left : right;
+                    const float nx = fmaf((float)((nxw >> (8 * k)) & 0xffu), ax, bx), fx = fmaf((float)((fxw >> (8 * k)) & 0xffu), ax, bx);
+                    const float ny = fmaf((float)((nyw >> (8 * k)) & 0xffu), ay, by), fy = fmaf((float)((fyw >> (8 * k)) & 0xffu), ay, by);
+                    const float nz = fmaf((float)((nzw >> (8 * k)) & 0xffu), az, bz), fz = fmaf((float)((fzw >> (8 * k)) & 0xffu), az, bz);
+                    const float tnear = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
+                    const float tfar = fminf(fminf(fx, fy), fminf(fz, best.t));
+                    const bool hit = rf[k] != SKH_REF_INVALID && tnear <= tfar * 1.0000002384185791015625f;
+                    tn[k] = hit ? tnear : INFINITY;
                 }
-                else if (hl)
-                    cur = left;
-                else if (hr)
-                    cur = right;
-                else
-                    cur = SKH_REF_INVALID;
+#ifdef SKH_DEBUG_PRINT
+                if (ridx == 0)
+                    printf("ray o %g %g %g inv %g %g %g ax %g bx %g ay %g by %g az %g bz %g nxw %08x fxw %08x\n", o.x, o.y, o.z, inv.x, inv.y, inv.z, ax, bx, ay, by, az, bz, nxw, fxw);
+                if (ridx == 0)
+                    printf("node %d inBlas %d o %g %g %g exps %08x tn %g %g %g %g rf %d %d %d %d best.t %g tmin %g\n", cur, (int)inBlas, w0.x, w0.y, w0.z, exps, tn[0], tn[1], tn[2], tn[3], rf[0], rf[1], rf[2], rf[3], best.t, tmin);
+#endif
+                // sort the four candidates by entry distance (5-comparator network), nearest first
+#define SKH_CSWAP(a, b)                      \
+    {                                        \
+        const bool sw = tn[b] < tn[a];       \
+        const float ta = sw ? tn[b] : tn[a]; \
+        const float tb = sw ? tn[a] : tn[b]; \
+        const int ra = sw ? rf[b] : rf[a];   \
+        const int rb = sw ? rf[a] : rf[b];   \
+        tn[a] = ta, tn[b] = tb;              \
+        rf[a] = ra, rf[b] = rb;              \
+    }
+                SKH_CSWAP(0, 1)
+                SKH_CSWAP(2, 3)
+                SKH_CSWAP(0, 2)
+                SKH_CSWAP(1, 3)
+                SKH_CSWAP(1, 2)
+#undef SKH_CSWAP
+                if (tn[3] < INFINITY)
+                    SKH_PUSH(rf[3]);
+                if (tn[2] < INFINITY)
+                    SKH_PUSH(rf[2]);
+                if (tn[1] < INFINITY)
+                    SKH_PUSH(rf[1]);
+                cur = tn[0] < INFINITY ? rf[0] : SKH_REF_INVALID;
             }
             // ---- leaf ----
             bool entered = false;

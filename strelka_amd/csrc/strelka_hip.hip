@@ -193,6 +193,7 @@ struct LbvhOut
 {
     DevBuf nodes, sortedVals, groupRoot, groupBounds;
     std::vector<int> hostGroupRoot;
+    uint32_t numNodes = 0;
 };
 
 static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const std::vector<uint32_t>& groupCount,
@@ -204,7 +205,7 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
         return s;
     if ((s = dev_alloc(c, out.groupRoot, sizeof(int) * (size_t)std::max(1u, nGroups))) != SKH_OK)
         return s;
-    if ((s = dev_alloc(c, out.nodes, sizeof(Node64) * (size_t)std::max(1u, n))) != SKH_OK)
+    if ((s = dev_alloc(c, out.nodes, sizeof(Node4) * (size_t)std::max(1u, n))) != SKH_OK)
         return s;
     if ((s = dev_alloc(c, out.sortedVals, sizeof(uint32_t) * (size_t)std::max(1u, n))) != SKH_OK)
         return s;
@@ -291,10 +292,71 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
                                                    rangeF.as<int>(), rangeL.as<int>());
         k_refit<<<G1, B, 0, st>>>(valsA, dBoxLo, dBoxHi, parent.as<int>(), childL.as<int>(), childR.as<int>(), flags.as<uint32_t>(),
                                   nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n);
-        k_emit<<<(n - 1 + B - 1) / B, B, 0, st>>>(childL.as<int>(), childR.as<int>(), rangeF.as<int>(), rangeL.as<int>(),
-                                                 nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n, leafMax, out.nodes.as<Node64>());
         k_group_roots<<<(n - 1 + B - 1) / B, B, 0, st>>>(rangeF.as<int>(), rangeL.as<int>(), sortedKeys, gFirst.as<uint32_t>(),
                                                         gCount.as<uint32_t>(), (int)n, leafMax, out.groupRoot.as<int>());
+        // group roots come back as BINARY node ids; they seed the level-by-level collapse into 4-wide nodes
+        if (hipMemcpyAsync(out.hostGroupRoot.data(), out.groupRoot.p, sizeof(int) * nGroups, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+        {
+            cleanup();
+            c->err = "lbvh_build: root read-back failed";
+            return SKH_FAIL;
+        }
+        std::vector<CollapseItem> seed;
+        for (uint32_t g = 0; g < nGroups; ++g)
+            if (out.hostGroupRoot[g] >= 0 && out.hostGroupRoot[g] != SKH_REF_INVALID)
+            {
+                seed.push_back(CollapseItem{ out.hostGroupRoot[g], (int)seed.size() });
+                out.hostGroupRoot[g] = (int)seed.size() - 1;
+            }
+        DevBuf q[2], ctr;
+        auto cleanup2 = [&]() {
+            dev_free(q[0]);
+            dev_free(q[1]);
+            dev_free(ctr);
+        };
+        if ((s = dev_alloc(c, q[0], sizeof(CollapseItem) * (size_t)n)) != SKH_OK || (s = dev_alloc(c, q[1], sizeof(CollapseItem) * (size_t)n)) != SKH_OK ||
+            (s = dev_alloc(c, ctr, sizeof(uint32_t) * 2)) != SKH_OK)
+        {
+            cleanup2();
+            cleanup();
+            return s;
+        }
+        uint32_t cnt = (uint32_t)seed.size();
+        uint32_t hctr[2] = { cnt, 0 }; // [0] next free output slot, [1] next-level queue length
+        hipError_t he = hipSuccess;
+        if (cnt)
+            he = hipMemcpyAsync(q[0].p, seed.data(), sizeof(CollapseItem) * cnt, hipMemcpyHostToDevice, st);
+        if (he == hipSuccess)
+            he = hipMemcpyAsync(ctr.p, hctr, sizeof(hctr), hipMemcpyHostToDevice, st);
+        if (he == hipSuccess)
+            he = hipMemcpyAsync(out.groupRoot.p, out.hostGroupRoot.data(), sizeof(int) * nGroups, hipMemcpyHostToDevice, st);
+        int cur = 0;
+        while (he == hipSuccess && cnt > 0)
+        {
+            k_collapse4<<<(cnt + B - 1) / B, B, 0, st>>>(q[cur].as<CollapseItem>(), cnt, childL.as<int>(), childR.as<int>(), rangeF.as<int>(),
+                                                        rangeL.as<int>(), nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n, leafMax,
+                                                        out.nodes.as<Node4>(), ctr.as<uint32_t>(), q[cur ^ 1].as<CollapseItem>(),
+                                                        ctr.as<uint32_t>() + 1);
+            he = hipMemcpyAsync(hctr, ctr.p, sizeof(hctr), hipMemcpyDeviceToHost, st);
+            if (he == hipSuccess)
+                he = hipStreamSynchronize(st);
+            cnt = hctr[1];
+            const uint32_t zero = 0;
+            if (he == hipSuccess)
+                he = hipMemcpyAsync(ctr.as<uint32_t>() + 1, &zero, sizeof(uint32_t), hipMemcpyHostToDevice, st);
+            if (he == hipSuccess)
+                he = hipStreamSynchronize(st);
+            cur ^= 1;
+        }
+        cleanup2();
+        if (he != hipSuccess)
+        {
+            cleanup();
+            c->err = std::string("lbvh_build collapse: ") + hipGetErrorString(he);
+            return SKH_FAIL;
+        }
+        out.numNodes = hctr[0];
         SKH_TRY(c, hipMemcpyAsync(out.hostGroupRoot.data(), out.groupRoot.p, sizeof(int) * nGroups, hipMemcpyDeviceToHost, st));
     }
     else
@@ -332,7 +394,27 @@ static inline float hb_half_area(const float* lo, const float* hi)
     const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
     return ex * ey + ey * ez + ez * ex;
 }
-static int tlas_sah_build(const std::vector<HostBox>& boxes, const std::vector<uint32_t>& ids, std::vector<Node64>& nodes,
+struct HostBin // internal node of the host-side binary tree
+{
+    int left, right; // >= 0 HostBin index, < 0 leaf ref
+    float lo[3], hi[3];
+};
+static void hb_box_of_ref(int ref, const std::vector<HostBin>& bin, const std::vector<HostBox>& boxes, const std::vector<uint32_t>& order,
+                          float* lo, float* hi)
+{
+    if (ref >= 0)
+    {
+        memcpy(lo, bin[ref].lo, sizeof(float) * 3);
+        memcpy(hi, bin[ref].hi, sizeof(float) * 3);
+    }
+    else
+    {
+        const HostBox& b = boxes[order[((uint32_t)~ref) >> 3]];
+        memcpy(lo, b.lo, sizeof(float) * 3);
+        memcpy(hi, b.hi, sizeof(float) * 3);
+    }
+}
+static int tlas_sah_build(const std::vector<HostBox>& boxes, const std::vector<uint32_t>& ids, std::vector<Node4>& nodes,
                           std::vector<uint32_t>& order)
 {
     const uint32_t n = (uint32_t)ids.size();
@@ -343,6 +425,7 @@ static int tlas_sah_build(const std::vector<HostBox>& boxes, const std::vector<u
     order.assign(ids.begin(), ids.end());
     if (n == 1)
         return ~(int)((0u << 3) | 0u);
+    std::vector<HostBin> bin;
     struct Task
     {
         uint32_t first, count;
@@ -352,22 +435,6 @@ static int tlas_sah_build(const std::vector<HostBox>& boxes, const std::vector<u
     std::vector<Task> stack;
     stack.push_back(Task{ 0, n, -1, 0 });
     std::vector<float> rightArea;
-    auto boundsOf = [&](uint32_t first, uint32_t count, float* lo, float* hi) {
-        for (int k = 0; k < 3; ++k)
-        {
-            lo[k] = INFINITY;
-            hi[k] = -INFINITY;
-        }
-        for (uint32_t i = first; i < first + count; ++i)
-        {
-            const HostBox& b = boxes[order[i]];
-            for (int k = 0; k < 3; ++k)
-            {
-                lo[k] = std::min(lo[k], b.lo[k]);
-                hi[k] = std::max(hi[k], b.hi[k]);
-            }
-        }
-    };
     int rootRef = 0;
     while (!stack.empty())
     {
@@ -378,16 +445,18 @@ static int tlas_sah_build(const std::vector<HostBox>& boxes, const std::vector<u
             ref = ~(int)((t.first << 3) | 0u);
         else
         {
-            // best split over 3 axes by exact sweep
             float bestCost = INFINITY;
             int bestAxis = 0;
             uint32_t bestSplit = t.count / 2;
-            for (int axis = 0; axis < 3; ++axis)
-            {
+            auto sortAxis = [&](int axis) {
                 std::sort(order.begin() + t.first, order.begin() + t.first + t.count, [&](uint32_t a, uint32_t b) {
                     const float ca = boxes[a].lo[axis] + boxes[a].hi[axis], cb = boxes[b].lo[axis] + boxes[b].hi[axis];
                     return ca < cb || (ca == cb && a < b);
                 });
+            };
+            for (int axis = 0; axis < 3; ++axis)
+            {
+                sortAxis(axis);
                 rightArea.assign(t.count + 1, 0.0f);
                 float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
                 for (uint32_t i = t.count; i-- > 1;)
@@ -422,27 +491,86 @@ static int tlas_sah_build(const std::vector<HostBox>& boxes, const std::vector<u
                     }
                 }
             }
-            std::sort(order.begin() + t.first, order.begin() + t.first + t.count, [&](uint32_t a, uint32_t b) {
-                const float ca = boxes[a].lo[bestAxis] + boxes[a].hi[bestAxis], cb = boxes[b].lo[bestAxis] + boxes[b].hi[bestAxis];
-                return ca < cb || (ca == cb && a < b);
-            });
-            ref = (int)nodes.size();
-            Node64 nd;
-            memset(&nd, 0, sizeof(nd));
-            boundsOf(t.first, bestSplit, nd.lmin, nd.lmax);
-            boundsOf(t.first + bestSplit, t.count - bestSplit, nd.rmin, nd.rmax);
-            nodes.push_back(nd);
+            sortAxis(bestAxis);
+            ref = (int)bin.size();
+            HostBin hbn;
+            hbn.left = hbn.right = SKH_REF_INVALID;
+            for (int k = 0; k < 3; ++k)
+            {
+                hbn.lo[k] = INFINITY;
+                hbn.hi[k] = -INFINITY;
+            }
+            for (uint32_t i = t.first; i < t.first + t.count; ++i)
+                for (int k = 0; k < 3; ++k)
+                {
+                    hbn.lo[k] = std::min(hbn.lo[k], boxes[order[i]].lo[k]);
+                    hbn.hi[k] = std::max(hbn.hi[k], boxes[order[i]].hi[k]);
+                }
+            bin.push_back(hbn);
             stack.push_back(Task{ t.first + bestSplit, t.count - bestSplit, ref, 1 });
             stack.push_back(Task{ t.first, bestSplit, ref, 0 });
         }
         if (t.parent < 0)
             rootRef = ref;
         else if (t.side == 0)
-            nodes[t.parent].left = ref;
+            bin[t.parent].left = ref;
         else
-            nodes[t.parent].right = ref;
+            bin[t.parent].right = ref;
     }
-    return rootRef;
+    // collapse the binary tree into 4-wide nodes (same greedy rule as k_collapse4)
+    struct Item
+    {
+        int bin, out;
+    };
+    std::vector<Item> work;
+    nodes.push_back(Node4{});
+    work.push_back(Item{ rootRef, 0 });
+    for (size_t w = 0; w < work.size(); ++w)
+    {
+        const Item it = work[w];
+        int slot[4];
+        int cnt = 2;
+        slot[0] = bin[it.bin].left;
+        slot[1] = bin[it.bin].right;
+        while (cnt < 4)
+        {
+            int best = -1;
+            float bestA = -1.0f;
+            for (int k = 0; k < cnt; ++k)
+                if (slot[k] >= 0)
+                {
+                    const float a = hb_half_area(bin[slot[k]].lo, bin[slot[k]].hi);
+                    if (a > bestA)
+                    {
+                        bestA = a;
+                        best = k;
+                    }
+                }
+            if (best < 0)
+                break;
+            const int cidx = slot[best];
+            slot[best] = bin[cidx].left;
+            slot[cnt++] = bin[cidx].right;
+        }
+        float clo[4][3], chi[4][3];
+        int refs[4];
+        for (int k = 0; k < cnt; ++k)
+        {
+            hb_box_of_ref(slot[k], bin, boxes, order, clo[k], chi[k]);
+            if (slot[k] >= 0)
+            {
+                refs[k] = (int)nodes.size();
+                nodes.push_back(Node4{});
+                work.push_back(Item{ slot[k], refs[k] });
+            }
+            else
+                refs[k] = slot[k];
+        }
+        Node4 nd;
+        encode_node4(nd, bin[it.bin].lo, bin[it.bin].hi, clo, chi, refs, cnt);
+        nodes[it.out] = nd;
+    }
+    return 0; // the root is node 0
 }
 
 // The entry points below take C linkage from their declarations in include/strelka_hip.h.
@@ -739,12 +867,18 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
                 }
             }
         }
-        std::vector<Node64> hnodes;
+        std::vector<Node4> hnodes;
         std::vector<uint32_t> horder;
         c->tlasRoot = tlas_sah_build(hb, ids, hnodes, horder);
+        if (getenv("SKH_DEBUG"))
+        {
+            fprintf(stderr, "[skh] TLAS: %u instances, %zu valid, %zu nodes, root %d\n", nInst, ids.size(), hnodes.size(), c->tlasRoot);
+            for (uint32_t i = 0; i < std::min(nInst, 8u); ++i)
+                fprintf(stderr, "[skh]  inst %u mask %u root %d box %g %g %g .. %g %g %g\n", i, hinst[i].mask, hinst[i].rootRef, hb[i].lo[0], hb[i].lo[1], hb[i].lo[2], hb[i].hi[0], hb[i].hi[1], hb[i].hi[2]);
+        }
         dev_free(c->dTlasNodes);
         dev_free(c->dTlasInst);
-        BA(dev_upload(c, c->dTlasNodes, hnodes.data(), sizeof(Node64) * hnodes.size()));
+        BA(dev_upload(c, c->dTlasNodes, hnodes.data(), sizeof(Node4) * hnodes.size()));
         BA(dev_upload(c, c->dTlasInst, horder.data(), sizeof(uint32_t) * horder.size()));
         for (int k = 0; k < 3; ++k)
         {
@@ -915,14 +1049,14 @@ static void harvest_spans(skh_context* c)
 static DevScene make_dev_scene(const skh_context* c)
 {
     DevScene sc;
-    sc.tlasNodes = c->dTlasNodes.as<Node64>();
+    sc.tlasNodes = c->dTlasNodes.as<Node4>();
     sc.tlasInst = c->dTlasInst.as<uint32_t>();
     sc.tlasRoot = c->tlasRoot;
     sc.numInstances = c->nInstances;
     sc.inst = c->dDevInst.as<DevInstance>();
-    sc.triNodes = c->dTriNodes.as<Node64>();
+    sc.triNodes = c->dTriNodes.as<Node4>();
     sc.tris = c->dTris.as<float4>();
-    sc.segNodes = c->dSegNodes.as<Node64>();
+    sc.segNodes = c->dSegNodes.as<Node4>();
     sc.segs = c->dSegs.as<float4>();
     sc.segPrim = c->dSegPrim.as<uint32_t>();
     sc.instances = c->dInstances.as<HostInstance>();
