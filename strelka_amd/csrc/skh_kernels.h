@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                 if (!inBlas)
                 {
                     // TLAS leaves hold exactly one instance
-                    const uint32_t id = sc.tlasInst[first];
+                    const uint32_t id = first; // TLAS leaves hold exactly one instance: `first` IS the instance id
                     const float4* ip = reinterpret_cast<const float4*>(sc.inst + id);
                     const float4 i3 = ip[3];
                     if (__float_as_uint(i3.y) & rayMask)

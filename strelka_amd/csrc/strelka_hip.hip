@@ -82,7 +82,6 @@ struct skh_context
     uint32_t fetchMinClosest = 32, fetchMinShadow = 32;
     // ray re-ordering (per bounce): 0 = off, else Morton bits per axis of the origin cell (key = octant : morton)
     uint32_t sortBitsClosest = 0, sortBitsShadow = 0, sortFirstBounce = 1;
-    bool tlasSah = true; // full-sweep SAH TLAS on the host (false: GPU LBVH over the instance boxes)
     float sceneLo[3] = { 0, 0, 0 }, sceneHi[3] = { 1, 1, 1 };
     DevBuf dSortKeys[2], dSortVals[2], dSortHist;
 
@@ -409,7 +408,7 @@ static void hb_box_of_ref(int ref, const std::vector<HostBin>& bin, const std::v
     }
     else
     {
-        const HostBox& b = boxes[order[((uint32_t)~ref) >> 3]];
+        const HostBox& b = boxes[((uint32_t)~ref) >> 3];
         memcpy(lo, b.lo, sizeof(float) * 3);
         memcpy(hi, b.hi, sizeof(float) * 3);
     }
@@ -424,7 +423,7 @@ static int tlas_sah_build(const std::vector<HostBox>& boxes, const std::vector<u
         return SKH_REF_INVALID;
     order.assign(ids.begin(), ids.end());
     if (n == 1)
-        return ~(int)((0u << 3) | 0u);
+        return ~(int)((ids[0] << 3) | 0u);
     std::vector<HostBin> bin;
     struct Task
     {
@@ -442,7 +441,7 @@ static int tlas_sah_build(const std::vector<HostBox>& boxes, const std::vector<u
         stack.pop_back();
         int ref;
         if (t.count == 1)
-            ref = ~(int)((t.first << 3) | 0u);
+            ref = ~(int)((order[t.first] << 3) | 0u); // leaf ref carries the INSTANCE ID (one instance per leaf)
         else
         {
             float bestCost = INFINITY;
@@ -741,12 +740,12 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     }
     const uint32_t nTris = (uint32_t)triMesh.size();
     c->nTris = nTris;
-    LbvhOut triOut, segOut, tlasOut;
+    LbvhOut triOut, segOut;
     DevBuf dTriMesh, dTriLocal, dBoxLo, dBoxHi, dGrp, dSegStart, dSegCurve, dSegLocal, dW2o, dValid;
     auto cleanup = [&]() {
         for (DevBuf* b : { &dTriMesh, &dTriLocal, &dBoxLo, &dBoxHi, &dGrp, &dSegStart, &dSegCurve, &dSegLocal, &dW2o, &dValid,
                            &triOut.sortedVals, &segOut.sortedVals, &triOut.groupRoot, &segOut.groupRoot, &triOut.groupBounds,
-                           &segOut.groupBounds, &tlasOut.groupRoot, &tlasOut.groupBounds })
+                           &segOut.groupBounds })
             dev_free(*b);
     };
 #define BA(expr)                    \
@@ -837,7 +836,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
                                                            segOut.groupBounds.as<float>(), segOut.groupRoot.as<int>(), nMeshes, nCurves,
                                                            nInst, c->dDevInst.as<DevInstance>(), dBoxLo.as<float4>(),
                                                            dBoxHi.as<float4>(), dGrp.as<uint32_t>());
-    if (c->tlasSah && nInst > 0)
+    if (nInst > 0)
     {
         // instance boxes were produced on the device (k_instance_boxes); the sweep runs on the host
         std::vector<float4> hlo(nInst), hhi(nInst);
@@ -888,24 +887,9 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     }
     else
     {
-        std::vector<uint32_t> one = { nInst };
-        BA(lbvh_build(c, nInst, 1, one, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), 1, tlasOut));
         dev_free(c->dTlasNodes);
         dev_free(c->dTlasInst);
-        c->dTlasNodes = tlasOut.nodes;
-        c->dTlasInst = tlasOut.sortedVals;
-        tlasOut.sortedVals = DevBuf();
-        c->tlasRoot = nInst ? tlasOut.hostGroupRoot[0] : SKH_REF_INVALID;
-        if (nInst)
-        {
-            float gb[6];
-            if (hipMemcpy(gb, tlasOut.groupBounds.p, sizeof(gb), hipMemcpyDeviceToHost) == hipSuccess)
-                for (int k = 0; k < 3; ++k)
-                {
-                    c->sceneLo[k] = gb[k];
-                    c->sceneHi[k] = gb[3 + k];
-                }
-        }
+        c->tlasRoot = SKH_REF_INVALID;
     }
     hipError_t e = hipStreamSynchronize(st);
     cleanup();
@@ -1551,11 +1535,6 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 0 || value > 10)
             return SKH_INVALID_ARGUMENT;
         (n == "sort_bits_closest" ? c->sortBitsClosest : c->sortBitsShadow) = (uint32_t)value;
-    }
-    else if (n == "tlas_sah")
-    {
-        c->tlasSah = value != 0;
-        c->accelBuilt = false;
     }
     else if (n == "sort_first_bounce")
         c->sortFirstBounce = (uint32_t)std::max<int64_t>(0, value);
