@@ -172,8 +172,8 @@ enum
 
 enum
 {
-    SKH_BUILD_LBVH = 0,
-    SKH_BUILD_SAH = 1 /* LBVH followed by SAH-driven collapse/refit */
+    SKH_BUILD_LBVH = 0, /* context default (option "build_quality": 1 = PLOC clustering, 0 = Karras radix tree) */
+    SKH_BUILD_SAH = 1 /* force the SAH-class builder: Morton sort + PLOC agglomerative clustering on the GPU */
 };
 
 typedef struct skh_stats

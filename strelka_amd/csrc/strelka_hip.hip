@@ -82,6 +82,7 @@ struct skh_context
     uint32_t fetchMinClosest = 32, fetchMinShadow = 32;
     // ray re-ordering (per bounce): 0 = off, else Morton bits per axis of the origin cell (key = octant : morton)
     uint32_t sortBitsClosest = 0, sortBitsShadow = 0, sortFirstBounce = 1;
+    uint32_t buildQuality = 1; // 0: Karras radix tree (fastest build), 1: PLOC clustering (SAH-class quality)
     float sceneLo[3] = { 0, 0, 0 }, sceneHi[3] = { 1, 1, 1 };
     DevBuf dSortKeys[2], dSortVals[2], dSortHist;
 
@@ -196,7 +197,7 @@ struct LbvhOut
 };
 
 static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const std::vector<uint32_t>& groupCount,
-                             const float4* dBoxLo, const float4* dBoxHi, const uint32_t* dGrp, int leafMax, LbvhOut& out)
+                             const float4* dBoxLo, const float4* dBoxHi, const uint32_t* dGrp, int leafMax, bool ploc, LbvhOut& out)
 {
     hipStream_t st = c->stream;
     skh_status s;
@@ -273,70 +274,131 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
     const uint64_t* sortedKeys = kin;
     if (n >= 2)
     {
+        DevBuf nodeSize, leafOrder, vals2, q[2], ctr, cLo[2], cHi[2], nn, pflags, ppos;
+        auto cleanup2 = [&]() {
+            for (DevBuf* b : { &nodeSize, &leafOrder, &vals2, &q[0], &q[1], &ctr, &cLo[0], &cLo[1], &cHi[0], &cHi[1], &nn, &pflags, &ppos })
+                dev_free(*b);
+        };
+#define LB2(buf, bytes)                              \
+    if ((s = dev_alloc(c, buf, (bytes))) != SKH_OK)  \
+    {                                                \
+        cleanup2();                                  \
+        cleanup();                                   \
+        return s;                                    \
+    }
         LB_ALLOC(childL, sizeof(int) * (size_t)n);
         LB_ALLOC(childR, sizeof(int) * (size_t)n);
-        LB_ALLOC(parent, sizeof(int) * 2 * (size_t)n);
-        LB_ALLOC(rangeF, sizeof(int) * (size_t)n);
-        LB_ALLOC(rangeL, sizeof(int) * (size_t)n);
-        LB_ALLOC(flags, sizeof(uint32_t) * (size_t)n);
         LB_ALLOC(nodeLo, sizeof(float4) * 2 * (size_t)n);
         LB_ALLOC(nodeHi, sizeof(float4) * 2 * (size_t)n);
         LB_ALLOC(gFirst, sizeof(uint32_t) * (size_t)nGroups);
         LB_ALLOC(gCount, sizeof(uint32_t) * (size_t)nGroups);
-        SKH_TRY(c, hipMemsetAsync(flags.p, 0, sizeof(uint32_t) * (size_t)n, st));
+        LB2(nodeSize, sizeof(int) * (size_t)n);
+        LB2(leafOrder, sizeof(uint32_t) * (size_t)n);
+        LB2(vals2, sizeof(uint32_t) * (size_t)n);
+        LB2(q[0], sizeof(CollapseItem) * (size_t)n);
+        LB2(q[1], sizeof(CollapseItem) * (size_t)n);
+        LB2(ctr, sizeof(uint32_t) * 4);
         SKH_TRY(c, hipMemcpyAsync(gFirst.p, groupFirst.data(), sizeof(uint32_t) * nGroups, hipMemcpyHostToDevice, st));
         SKH_TRY(c, hipMemcpyAsync(gCount.p, groupCount.data(), sizeof(uint32_t) * nGroups, hipMemcpyHostToDevice, st));
         SKH_TRY(c, hipMemcpyAsync(out.groupRoot.p, out.hostGroupRoot.data(), sizeof(int) * nGroups, hipMemcpyHostToDevice, st));
-        k_karras<<<(n - 1 + B - 1) / B, B, 0, st>>>(sortedKeys, (int)n, childL.as<int>(), childR.as<int>(), parent.as<int>(),
-                                                   rangeF.as<int>(), rangeL.as<int>());
-        k_refit<<<G1, B, 0, st>>>(valsA, dBoxLo, dBoxHi, parent.as<int>(), childL.as<int>(), childR.as<int>(), flags.as<uint32_t>(),
-                                  nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n);
-        k_group_roots<<<(n - 1 + B - 1) / B, B, 0, st>>>(rangeF.as<int>(), rangeL.as<int>(), sortedKeys, gFirst.as<uint32_t>(),
-                                                        gCount.as<uint32_t>(), (int)n, leafMax, out.groupRoot.as<int>());
+        const std::vector<int> preset = out.hostGroupRoot; // leaf refs of groups with <= leafMax primitives, INVALID otherwise
+        hipError_t he = hipSuccess;
+        if (ploc)
+        {
+            // ---- agglomerative clustering over the Morton order ----
+            for (int k = 0; k < 2; ++k)
+            {
+                LB2(cLo[k], sizeof(float4) * (size_t)n);
+                LB2(cHi[k], sizeof(float4) * (size_t)n);
+            }
+            LB2(nn, sizeof(uint32_t) * (size_t)n);
+            LB2(pflags, sizeof(uint32_t) * (size_t)n);
+            LB2(ppos, sizeof(uint32_t) * (size_t)n);
+            uint32_t nonEmpty = 0;
+            for (uint32_t g = 0; g < nGroups; ++g)
+                nonEmpty += groupCount[g] ? 1u : 0u;
+            uint32_t hc[4] = { 0, 0, 0, 0 }; // [2] PLOC node counter, [3] surviving cluster count
+            he = hipMemcpyAsync(ctr.p, hc, sizeof(hc), hipMemcpyHostToDevice, st);
+            k_ploc_init<<<G1, B, 0, st>>>(valsA, sortedKeys, dBoxLo, dBoxHi, n, cLo[0].as<float4>(), cHi[0].as<float4>(),
+                                          nodeLo.as<float4>(), nodeHi.as<float4>());
+            uint32_t m = n;
+            int cur = 0;
+            for (int iter = 0; he == hipSuccess && m > nonEmpty && iter < 4096; ++iter)
+            {
+                const uint32_t gm = (m + SKH_PLOC_BLOCK - 1) / SKH_PLOC_BLOCK;
+                k_ploc_nn<<<gm, SKH_PLOC_BLOCK, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), m, nn.as<uint32_t>());
+                k_ploc_merge<<<(m + B - 1) / B, B, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), nn.as<uint32_t>(), m, (int)n,
+                                                            childL.as<int>(), childR.as<int>(), nodeSize.as<int>(), nodeLo.as<float4>(),
+                                                            nodeHi.as<float4>(), ctr.as<uint32_t>() + 2, pflags.as<uint32_t>());
+                he = hipMemcpyAsync(ppos.p, pflags.p, sizeof(uint32_t) * (size_t)m, hipMemcpyDeviceToDevice, st);
+                k_rs_scan<<<1, 1024, 0, st>>>(ppos.as<uint32_t>(), m);
+                k_ploc_compact<<<(m + B - 1) / B, B, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), pflags.as<uint32_t>(),
+                                                              ppos.as<uint32_t>(), m, cLo[cur ^ 1].as<float4>(), cHi[cur ^ 1].as<float4>(),
+                                                              ctr.as<uint32_t>() + 3);
+                if (he == hipSuccess)
+                    he = hipMemcpyAsync(hc, ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st);
+                if (he == hipSuccess)
+                    he = hipStreamSynchronize(st);
+                if (hc[3] >= m) // no progress: cannot happen (a mutually-nearest pair always exists), but never spin
+                    break;
+                m = hc[3];
+                cur ^= 1;
+            }
+            if (he == hipSuccess)
+                k_ploc_roots<<<(m + B - 1) / B, B, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), m, out.groupRoot.as<int>());
+        }
+        else
+        {
+            // ---- Karras radix tree ----
+            LB_ALLOC(parent, sizeof(int) * 2 * (size_t)n);
+            LB_ALLOC(rangeF, sizeof(int) * (size_t)n);
+            LB_ALLOC(rangeL, sizeof(int) * (size_t)n);
+            LB_ALLOC(flags, sizeof(uint32_t) * (size_t)n);
+            SKH_TRY(c, hipMemsetAsync(flags.p, 0, sizeof(uint32_t) * (size_t)n, st));
+            k_karras<<<(n - 1 + B - 1) / B, B, 0, st>>>(sortedKeys, (int)n, childL.as<int>(), childR.as<int>(), parent.as<int>(),
+                                                       rangeF.as<int>(), rangeL.as<int>());
+            k_refit<<<G1, B, 0, st>>>(valsA, dBoxLo, dBoxHi, parent.as<int>(), childL.as<int>(), childR.as<int>(), flags.as<uint32_t>(),
+                                      nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n);
+            k_sizes_from_ranges<<<(n - 1 + B - 1) / B, B, 0, st>>>(rangeF.as<int>(), rangeL.as<int>(), (int)n, nodeSize.as<int>());
+            k_group_roots<<<(n - 1 + B - 1) / B, B, 0, st>>>(rangeF.as<int>(), rangeL.as<int>(), sortedKeys, gFirst.as<uint32_t>(),
+                                                            gCount.as<uint32_t>(), (int)n, leafMax, out.groupRoot.as<int>());
+        }
         // group roots come back as BINARY node ids; they seed the level-by-level collapse into 4-wide nodes
-        if (hipMemcpyAsync(out.hostGroupRoot.data(), out.groupRoot.p, sizeof(int) * nGroups, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        if (he != hipSuccess || hipMemcpyAsync(out.hostGroupRoot.data(), out.groupRoot.p, sizeof(int) * nGroups, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess)
         {
+            cleanup2();
             cleanup();
-            c->err = "lbvh_build: root read-back failed";
+            c->err = "lbvh_build: tree build / root read-back failed";
             return SKH_FAIL;
         }
         std::vector<CollapseItem> seed;
         for (uint32_t g = 0; g < nGroups; ++g)
-            if (out.hostGroupRoot[g] >= 0 && out.hostGroupRoot[g] != SKH_REF_INVALID)
+        {
+            if (groupCount[g] <= (uint32_t)leafMax)
+                out.hostGroupRoot[g] = preset[g]; // whole group is one leaf (or empty)
+            else
             {
-                seed.push_back(CollapseItem{ out.hostGroupRoot[g], (int)seed.size() });
+                seed.push_back(CollapseItem{ out.hostGroupRoot[g], (int)seed.size(), (int)groupFirst[g], 0 });
                 out.hostGroupRoot[g] = (int)seed.size() - 1;
             }
-        DevBuf q[2], ctr;
-        auto cleanup2 = [&]() {
-            dev_free(q[0]);
-            dev_free(q[1]);
-            dev_free(ctr);
-        };
-        if ((s = dev_alloc(c, q[0], sizeof(CollapseItem) * (size_t)n)) != SKH_OK || (s = dev_alloc(c, q[1], sizeof(CollapseItem) * (size_t)n)) != SKH_OK ||
-            (s = dev_alloc(c, ctr, sizeof(uint32_t) * 2)) != SKH_OK)
-        {
-            cleanup2();
-            cleanup();
-            return s;
         }
         uint32_t cnt = (uint32_t)seed.size();
         uint32_t hctr[2] = { cnt, 0 }; // [0] next free output slot, [1] next-level queue length
-        hipError_t he = hipSuccess;
         if (cnt)
             he = hipMemcpyAsync(q[0].p, seed.data(), sizeof(CollapseItem) * cnt, hipMemcpyHostToDevice, st);
         if (he == hipSuccess)
             he = hipMemcpyAsync(ctr.p, hctr, sizeof(hctr), hipMemcpyHostToDevice, st);
         if (he == hipSuccess)
             he = hipMemcpyAsync(out.groupRoot.p, out.hostGroupRoot.data(), sizeof(int) * nGroups, hipMemcpyHostToDevice, st);
+        k_iota<<<G1, B, 0, st>>>(leafOrder.as<uint32_t>(), n);
         int cur = 0;
         while (he == hipSuccess && cnt > 0)
         {
-            k_collapse4<<<(cnt + B - 1) / B, B, 0, st>>>(q[cur].as<CollapseItem>(), cnt, childL.as<int>(), childR.as<int>(), rangeF.as<int>(),
-                                                        rangeL.as<int>(), nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n, leafMax,
-                                                        out.nodes.as<Node4>(), ctr.as<uint32_t>(), q[cur ^ 1].as<CollapseItem>(),
-                                                        ctr.as<uint32_t>() + 1);
+            k_collapse4<<<(cnt + B - 1) / B, B, 0, st>>>(q[cur].as<CollapseItem>(), cnt, childL.as<int>(), childR.as<int>(), nodeSize.as<int>(),
+                                                        nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n, leafMax, out.nodes.as<Node4>(),
+                                                        ctr.as<uint32_t>(), q[cur ^ 1].as<CollapseItem>(), ctr.as<uint32_t>() + 1,
+                                                        leafOrder.as<uint32_t>());
             he = hipMemcpyAsync(hctr, ctr.p, sizeof(hctr), hipMemcpyDeviceToHost, st);
             if (he == hipSuccess)
                 he = hipStreamSynchronize(st);
@@ -348,6 +410,14 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
                 he = hipStreamSynchronize(st);
             cur ^= 1;
         }
+        if (he == hipSuccess)
+        {
+            // primitives into final leaf order
+            k_permute_u32<<<G1, B, 0, st>>>(valsA, leafOrder.as<uint32_t>(), n, vals2.as<uint32_t>());
+            he = hipMemcpyAsync(valsA, vals2.p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st);
+            if (he == hipSuccess)
+                he = hipStreamSynchronize(st);
+        }
         cleanup2();
         if (he != hipSuccess)
         {
@@ -356,7 +426,7 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
             return SKH_FAIL;
         }
         out.numNodes = hctr[0];
-        SKH_TRY(c, hipMemcpyAsync(out.hostGroupRoot.data(), out.groupRoot.p, sizeof(int) * nGroups, hipMemcpyDeviceToHost, st));
+#undef LB2
     }
     else
         SKH_TRY(c, hipMemcpyAsync(out.groupRoot.p, out.hostGroupRoot.data(), sizeof(int) * nGroups, hipMemcpyHostToDevice, st));
@@ -717,10 +787,10 @@ skh_status skh_set_materials(skh_context* c, const skh_material* materials, uint
 
 skh_status skh_build_accel(skh_context* c, uint32_t flags)
 {
-    (void)flags;
     if (!c)
         return SKH_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
+    const bool usePloc = (flags & SKH_BUILD_SAH) != 0 || c->buildQuality != 0;
     const auto t0 = std::chrono::steady_clock::now();
     hipStream_t st = c->stream;
     skh_status s;
@@ -763,7 +833,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         k_tri_boxes<<<(nTris + B - 1) / B, B, 0, st>>>(c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(), c->dMeshes.as<uint4>(),
                                                       dTriMesh.as<uint32_t>(), dTriLocal.as<uint32_t>(), nTris, dBoxLo.as<float4>(),
                                                       dBoxHi.as<float4>(), dGrp.as<uint32_t>());
-    BA(lbvh_build(c, nTris, nMeshes, meshTriCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), 4, triOut));
+    BA(lbvh_build(c, nTris, nMeshes, meshTriCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), 4, usePloc, triOut));
     BA(dev_alloc(c, c->dTris, sizeof(float4) * 3 * (size_t)std::max(1u, nTris)));
     if (nTris)
         k_gather_tris<<<(nTris + B - 1) / B, B, 0, st>>>(c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(), c->dMeshes.as<uint4>(),
@@ -812,7 +882,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         k_seg_boxes<<<(nSegs + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), c->dSegStartAll.as<uint32_t>(),
                                                       dSegCurve.as<uint32_t>(), nSegs, dBoxLo.as<float4>(), dBoxHi.as<float4>(),
                                                       dGrp.as<uint32_t>());
-    BA(lbvh_build(c, nSegs, nCurves, curveSegCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), 2, segOut));
+    BA(lbvh_build(c, nSegs, nCurves, curveSegCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), 2, usePloc, segOut));
     BA(dev_alloc(c, c->dSegs, sizeof(float4) * 4 * (size_t)std::max(1u, nSegs)));
     BA(dev_alloc(c, c->dSegPrim, sizeof(uint32_t) * (size_t)std::max(1u, nSegs)));
     if (nSegs)
@@ -1535,6 +1605,11 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 0 || value > 10)
             return SKH_INVALID_ARGUMENT;
         (n == "sort_bits_closest" ? c->sortBitsClosest : c->sortBitsShadow) = (uint32_t)value;
+    }
+    else if (n == "build_quality")
+    {
+        c->buildQuality = value != 0;
+        c->accelBuilt = false;
     }
     else if (n == "sort_first_bounce")
         c->sortFirstBounce = (uint32_t)std::max<int64_t>(0, value);
