@@ -82,6 +82,7 @@ struct skh_context
     uint32_t fetchMinClosest = 32, fetchMinShadow = 32;
     // ray re-ordering (per bounce): 0 = off, else Morton bits per axis of the origin cell (key = octant : morton)
     uint32_t sortBitsClosest = 0, sortBitsShadow = 0, sortFirstBounce = 1;
+    uint32_t leafMaxTris = 2; // measured on MI355X: 2 beats 1, 3, 4, 6, 8 (the kernel is ALU bound, wasted triangle tests cost more than extra nodes)
     uint32_t buildQuality = 1; // 0: Karras radix tree (fastest build), 1: PLOC clustering (SAH-class quality)
     float sceneLo[3] = { 0, 0, 0 }, sceneHi[3] = { 1, 1, 1 };
     DevBuf dSortKeys[2], dSortVals[2], dSortHist;
@@ -833,7 +834,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         k_tri_boxes<<<(nTris + B - 1) / B, B, 0, st>>>(c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(), c->dMeshes.as<uint4>(),
                                                       dTriMesh.as<uint32_t>(), dTriLocal.as<uint32_t>(), nTris, dBoxLo.as<float4>(),
                                                       dBoxHi.as<float4>(), dGrp.as<uint32_t>());
-    BA(lbvh_build(c, nTris, nMeshes, meshTriCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), 4, usePloc, triOut));
+    BA(lbvh_build(c, nTris, nMeshes, meshTriCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), (int)c->leafMaxTris, usePloc, triOut));
     BA(dev_alloc(c, c->dTris, sizeof(float4) * 3 * (size_t)std::max(1u, nTris)));
     if (nTris)
         k_gather_tris<<<(nTris + B - 1) / B, B, 0, st>>>(c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(), c->dMeshes.as<uint4>(),
@@ -1605,6 +1606,13 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 0 || value > 10)
             return SKH_INVALID_ARGUMENT;
         (n == "sort_bits_closest" ? c->sortBitsClosest : c->sortBitsShadow) = (uint32_t)value;
+    }
+    else if (n == "leaf_max_tris")
+    {
+        if (value < 1 || value > 8)
+            return SKH_INVALID_ARGUMENT;
+        c->leafMaxTris = (uint32_t)value;
+        c->accelBuilt = false;
     }
     else if (n == "build_quality")
     {
