@@ -46,6 +46,13 @@ struct DevScene
     const Node4* segNodes;
     const float4* segs; // 4 x float4 per segment, leaf order
     const uint32_t* segPrim; // leaf order -> segment index inside its curve set
+    // flattened world-space hierarchy (default): one tree over every instanced primitive
+    const Node4* wNodes;
+    int wRoot;
+    uint32_t wTriCount; // leaf positions < wTriCount are triangles, the rest curve segments
+    const float4* wTris; // 3 x float4 per instanced triangle: object-space vertices + primId / instId / mask
+    const float4* wSegs; // 4 x float4 per instanced segment
+    const uint2* wSegMeta; // {primId, instId}
     // shading side
     const HostInstance* instances;
     const uint8_t* verts;
@@ -145,6 +152,9 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 
 #ifndef SKH_TRACE_MIN_WAVES
 #define SKH_TRACE_MIN_WAVES 1
+#endif
+#ifndef SKH_SORT_ANYHIT
+#define SKH_SORT_ANYHIT 0
 #endif
 #ifndef SKH_FETCH_MIN
 #define SKH_FETCH_MIN 20 // refill the wave from the ray queue when at least this many lanes are idle
@@ -328,19 +338,35 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
         tn[a] = ta, tn[b] = tb;              \
         rf[a] = ra, rf[b] = rb;              \
     }
-                SKH_CSWAP(0, 1)
-                SKH_CSWAP(2, 3)
-                SKH_CSWAP(0, 2)
-                SKH_CSWAP(1, 3)
-                SKH_CSWAP(1, 2)
+                if (!ANY_HIT || SKH_SORT_ANYHIT)
+                {
+                    SKH_CSWAP(0, 1)
+                    SKH_CSWAP(2, 3)
+                    SKH_CSWAP(0, 2)
+                    SKH_CSWAP(1, 3)
+                    SKH_CSWAP(1, 2)
+                    if (tn[3] < INFINITY)
+                        SKH_PUSH(rf[3]);
+                    if (tn[2] < INFINITY)
+                        SKH_PUSH(rf[2]);
+                    if (tn[1] < INFINITY)
+                        SKH_PUSH(rf[1]);
+                    cur = tn[0] < INFINITY ? rf[0] : SKH_REF_INVALID;
+                }
+                else
+                {
+                    // occlusion query: any order finds an occluder; skip the ordering network
+                    cur = SKH_REF_INVALID;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (tn[k] < INFINITY)
+                        {
+                            if (cur != SKH_REF_INVALID)
+                                SKH_PUSH(cur);
+                            cur = rf[k];
+                        }
+                }
 #undef SKH_CSWAP
-                if (tn[3] < INFINITY)
-                    SKH_PUSH(rf[3]);
-                if (tn[2] < INFINITY)
-                    SKH_PUSH(rf[2]);
-                if (tn[1] < INFINITY)
-                    SKH_PUSH(rf[1]);
-                cur = tn[0] < INFINITY ? rf[0] : SKH_REF_INVALID;
             }
             // ---- leaf ----
             bool entered = false;
@@ -482,6 +508,306 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
     }
 #undef SKH_PUSH
 #undef SKH_POP
+    if (COUNT)
+    {
+        const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.prims), c2 = wave_sum(tc.segs), d2 = wave_sum(tc.insts);
+        if (lane == 0)
+        {
+            atomicAdd(&stats->nodes[ANY_HIT ? 1 : 0], (unsigned long long)a);
+            atomicAdd(&stats->prims[ANY_HIT ? 1 : 0], (unsigned long long)b);
+            atomicAdd(&stats->segs[ANY_HIT ? 1 : 0], (unsigned long long)c2);
+            atomicAdd(&stats->insts[ANY_HIT ? 1 : 0], (unsigned long long)d2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_trace_flat: same contract as k_trace, over the FLATTENED hierarchy (one world-space tree of 4-wide nodes over all
+// instanced primitives).  No TLAS/BLAS switch, no sentinel on the stack: the node loop only ever sees world-space
+// boxes.  A leaf record carries object-space vertices and its instance id; the lane keeps the object-space ray of the
+// last instance it touched and re-derives it (one 48-byte fetch) only when the instance changes, so the
+// intersection arithmetic and hence every hit record stay identical to the two-level formulation.
+// ------------------------------------------------------------------------------------------------------------
+template <bool ANY_HIT, bool COUNT, bool CURVES>
+__global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WAVES)
+    k_trace_flat(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch, uint32_t fetchMin,
+                 const uint32_t* __restrict__ perm, HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride,
+                 int* __restrict__ ovfBase, StatsDev* __restrict__ stats)
+{
+    __shared__ int s_stack[SKH_STACK_LDS * SKH_TRACE_BLOCK];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n = *countPtr;
+    if (n == 0)
+        return;
+    const uint32_t perGroup = (((n + 7u) >> 3) + 63u) & ~63u;
+    const uint32_t group = blockIdx.x & 7u;
+    uint32_t tries = 0;
+    bool exhausted = false;
+    int* lds = s_stack + lane;
+    int* ovf = ovfBase + (blockIdx.x * SKH_TRACE_BLOCK + lane);
+    const uint32_t ovfStride = gridDim.x * SKH_TRACE_BLOCK;
+    const uint32_t rayMask = ANY_HIT ? 3u : 255u;
+    TraceCounters tc = { 0, 0, 0, 0 };
+
+    bool hasRay = false;
+    uint32_t ridx = 0;
+    v3 o = mk3(0.0f), d = mk3(0.0f), inv = mk3(0.0f), oo = mk3(0.0f), od = mk3(0.0f);
+    float tmin = 0.0f, tmax = 0.0f;
+    RayShear sh;
+    sh.kx = sh.ky = sh.kz = 0;
+    sh.Sx = sh.Sy = sh.Sz = 0.0f;
+    uint32_t curInst = 0xffffffffu;
+    int sp = 0, cur = SKH_REF_INVALID;
+    HitRec best;
+    best.t = 0.0f, best.inst = best.prim = 0xffffffffu, best.u = best.v = 0.0f, best.found = false;
+
+#define SKH_PUSH(v)                                                  \
+    {                                                                \
+        if (sp < SKH_STACK_LDS)                                      \
+            lds[sp * SKH_TRACE_BLOCK] = (v);                         \
+        else if (sp < SKH_STACK_LDS + SKH_STACK_OVF)                 \
+            ovf[(size_t)(sp - SKH_STACK_LDS) * ovfStride] = (v);     \
+        ++sp;                                                        \
+    }
+#define SKH_POP(dst)                                                 \
+    {                                                                \
+        --sp;                                                        \
+        if (sp < SKH_STACK_LDS)                                      \
+            dst = lds[sp * SKH_TRACE_BLOCK];                         \
+        else if (sp < SKH_STACK_LDS + SKH_STACK_OVF)                 \
+            dst = ovf[(size_t)(sp - SKH_STACK_LDS) * ovfStride];     \
+        else                                                         \
+            dst = SKH_REF_INVALID;                                   \
+    }
+#define SKH_SWITCH_INSTANCE(id)                                                                                         \
+    if ((id) != curInst)                                                                                                \
+    {                                                                                                                   \
+        const float4* ip = reinterpret_cast<const float4*>(sc.inst + (id));                                             \
+        const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2];                                                                \
+        if (COUNT)                                                                                                      \
+            tc.insts++;                                                                                                 \
+        const float m[12] = { i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w };                 \
+        oo = xform_point(m, o);                                                                                         \
+        od = xform_vector(m, d);                                                                                        \
+        sh = make_shear(od);                                                                                            \
+        curInst = (id);                                                                                                 \
+    }
+
+    for (;;)
+    {
+        // ---------------- refill idle lanes from the queue ----------------
+        const unsigned long long needMask = __ballot(!hasRay);
+        const uint32_t want = (uint32_t)__popcll(needMask);
+        if (!exhausted && (want >= fetchMin || want == 64u))
+        {
+            uint32_t base = 0, count = 0;
+            const int leader = __ffsll((long long)needMask) - 1;
+            while (tries < 8u)
+            {
+                const uint32_t g = (group + tries) & 7u;
+                uint32_t b = 0;
+                if ((int)lane == leader)
+                    b = atomicAdd(&fetch[g], want);
+                b = __shfl(b, leader);
+                const uint32_t lo = g * perGroup;
+                const uint32_t hi = min(n, lo + perGroup);
+                if (lo < hi && b < hi - lo)
+                {
+                    base = lo + b;
+                    count = min(want, hi - base);
+                    if (count < want)
+                        ++tries;
+                    break;
+                }
+                ++tries;
+            }
+            if (tries >= 8u && count == 0)
+                exhausted = true;
+            const uint32_t rank = (uint32_t)__popcll(needMask & ((1ull << lane) - 1ull));
+            if (!hasRay && rank < count)
+            {
+                ridx = perm ? perm[base + rank] : base + rank;
+                o = mk3(rq.plane(0)[ridx], rq.plane(1)[ridx], rq.plane(2)[ridx]);
+                d = mk3(rq.plane(3)[ridx], rq.plane(4)[ridx], rq.plane(5)[ridx]);
+                tmin = rq.plane(6)[ridx];
+                tmax = rq.plane(7)[ridx];
+                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                curInst = 0xffffffffu;
+                sp = 0;
+                cur = sc.wRoot;
+                best.t = tmax;
+                best.inst = best.prim = 0xffffffffu;
+                best.u = best.v = 0.0f;
+                best.found = false;
+                hasRay = true;
+            }
+        }
+        if (!__any(hasRay))
+        {
+            if (exhausted)
+                break;
+            continue;
+        }
+        bool terminated = false;
+        if (hasRay)
+        {
+            // ---- node loop: world-space boxes only ----
+            while (cur >= 0 && cur != SKH_REF_INVALID)
+            {
+                const float4* np = reinterpret_cast<const float4*>(sc.wNodes + cur);
+                const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+                if (COUNT)
+                    tc.nodes++;
+                const uint32_t exps = __float_as_uint(w0.w);
+                const float ax = __uint_as_float((exps & 0xffu) << 23) * inv.x, bx = (w0.x - o.x) * inv.x;
+                const float ay = __uint_as_float(((exps >> 8) & 0xffu) << 23) * inv.y, by = (w0.y - o.y) * inv.y;
+                const float az = __uint_as_float(((exps >> 16) & 0xffu) << 23) * inv.z, bz = (w0.z - o.z) * inv.z;
+                const bool px = inv.x >= 0.0f, py = inv.y >= 0.0f, pz = inv.z >= 0.0f;
+                const uint32_t nxw = __float_as_uint(px ? w1.x : w2.x), fxw = __float_as_uint(px ? w2.x : w1.x);
+                const uint32_t nyw = __float_as_uint(py ? w1.y : w2.y), fyw = __float_as_uint(py ? w2.y : w1.y);
+                const uint32_t nzw = __float_as_uint(pz ? w1.z : w2.z), fzw = __float_as_uint(pz ? w2.z : w1.z);
+                float tn[4];
+                int rf[4];
+                rf[0] = __float_as_int(w3.x), rf[1] = __float_as_int(w3.y), rf[2] = __float_as_int(w3.z), rf[3] = __float_as_int(w3.w);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                {
+                    const float nx = fmaf((float)((nxw >> (8 * k)) & 0xffu), ax, bx), fx = fmaf((float)((fxw >> (8 * k)) & 0xffu), ax, bx);
+                    const float ny = fmaf((float)((nyw >> (8 * k)) & 0xffu), ay, by), fy = fmaf((float)((fyw >> (8 * k)) & 0xffu), ay, by);
+                    const float nz = fmaf((float)((nzw >> (8 * k)) & 0xffu), az, bz), fz = fmaf((float)((fzw >> (8 * k)) & 0xffu), az, bz);
+                    const float tnear = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
+                    const float tfar = fminf(fminf(fx, fy), fminf(fz, best.t));
+                    const bool hit = rf[k] != SKH_REF_INVALID && tnear <= tfar * 1.0000002384185791015625f;
+                    tn[k] = hit ? tnear : INFINITY;
+                }
+#define SKH_CSWAP(a, b)                      \
+    {                                        \
+        const bool sw = tn[b] < tn[a];       \
+        const float ta = sw ? tn[b] : tn[a]; \
+        const float tb = sw ? tn[a] : tn[b]; \
+        const int ra = sw ? rf[b] : rf[a];   \
+        const int rb = sw ? rf[a] : rf[b];   \
+        tn[a] = ta, tn[b] = tb;              \
+        rf[a] = ra, rf[b] = rb;              \
+    }
+                SKH_CSWAP(0, 1)
+                SKH_CSWAP(2, 3)
+                SKH_CSWAP(0, 2)
+                SKH_CSWAP(1, 3)
+                SKH_CSWAP(1, 2)
+#undef SKH_CSWAP
+                if (tn[3] < INFINITY)
+                    SKH_PUSH(rf[3]);
+                if (tn[2] < INFINITY)
+                    SKH_PUSH(rf[2]);
+                if (tn[1] < INFINITY)
+                    SKH_PUSH(rf[1]);
+                cur = tn[0] < INFINITY ? rf[0] : SKH_REF_INVALID;
+            }
+            // ---- leaf ----
+            if (cur < 0)
+            {
+                const uint32_t enc = (uint32_t)~cur;
+                const uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
+                if (CURVES && first >= sc.wTriCount)
+                {
+                    for (uint32_t k = 0; k < count; ++k)
+                    {
+                        const uint32_t sidx = first - sc.wTriCount + k;
+                        const uint2 meta = sc.wSegMeta[sidx];
+                        const float4* cp = sc.wSegs + 4 * (size_t)sidx;
+                        const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+                        if (COUNT)
+                            tc.segs++;
+                        SKH_SWITCH_INSTANCE(meta.y)
+                        v4 q[4];
+                        q[0] = mk4(c0.x, c0.y, c0.z, c0.w);
+                        q[1] = mk4(c1.x, c1.y, c1.z, c1.w);
+                        q[2] = mk4(c2.x, c2.y, c2.z, c2.w);
+                        q[3] = mk4(c3.x, c3.y, c3.z, c3.w);
+                        float t, u;
+                        if (intersect_curve_segment(oo, od, tmin, best.t, q, t, u) && t < tmax)
+                        {
+                            const uint32_t prim = meta.x;
+                            if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
+                            {
+                                best.t = t;
+                                best.inst = curInst;
+                                best.prim = prim;
+                                best.u = u;
+                                best.v = 0.0f;
+                                best.found = true;
+                            }
+                        }
+                    }
+                }
+                else
+                {
+                    for (uint32_t k = 0; k < count; ++k)
+                    {
+                        const float4* tp = sc.wTris + 3 * (size_t)(first + k);
+                        const float4 a = tp[0], b = tp[1], c = tp[2];
+                        if (!(__float_as_uint(c.w) & rayMask))
+                            continue; // light proxies are invisible to shadow rays (RAY_MASK_SHADOW)
+                        if (COUNT)
+                            tc.prims++;
+                        const uint32_t inst = __float_as_uint(b.w);
+                        SKH_SWITCH_INSTANCE(inst)
+                        float t, u, v;
+                        if (intersect_triangle(oo, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), t, u, v) && t < tmax)
+                        {
+                            const uint32_t prim = __float_as_uint(a.w);
+                            if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
+                            {
+                                best.t = t;
+                                best.inst = curInst;
+                                best.prim = prim;
+                                best.u = u;
+                                best.v = v;
+                                best.found = true;
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- pop ----
+            if (ANY_HIT && best.found)
+                terminated = true;
+            else if (sp == 0)
+                terminated = true;
+            else
+                SKH_POP(cur);
+        }
+        if (terminated)
+        {
+            hasRay = false;
+            const uint32_t i = ridx;
+            if (ANY_HIT)
+            {
+                if (hq.base)
+                    hq.base[i] = best.found ? 1.0f : -1.0f;
+                else if (!best.found)
+                {
+                    const uint32_t pid = rq.ids()[i];
+                    float* rad = ps.base + (size_t)3 * ps.stride;
+                    rad[pid] += contrib[i];
+                    rad[pid + ps.stride] += contrib[i + contribStride];
+                    rad[pid + 2 * (size_t)ps.stride] += contrib[i + 2 * (size_t)contribStride];
+                }
+            }
+            else
+            {
+                hq.base[i] = best.found ? best.t : -1.0f;
+                reinterpret_cast<uint32_t*>(hq.base)[i + hq.stride] = best.inst;
+                reinterpret_cast<uint32_t*>(hq.base)[i + 2 * (size_t)hq.stride] = best.prim;
+                hq.base[i + 3 * (size_t)hq.stride] = best.u;
+                hq.base[i + 4 * (size_t)hq.stride] = best.v;
+            }
+        }
+    }
+#undef SKH_PUSH
+#undef SKH_POP
+#undef SKH_SWITCH_INSTANCE
     if (COUNT)
     {
         const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.prims), c2 = wave_sum(tc.segs), d2 = wave_sum(tc.insts);

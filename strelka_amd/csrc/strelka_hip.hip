@@ -82,6 +82,13 @@ struct skh_context
     uint32_t fetchMinClosest = 32, fetchMinShadow = 32;
     // ray re-ordering (per bounce): 0 = off, else Morton bits per axis of the origin cell (key = octant : morton)
     uint32_t sortBitsClosest = 0, sortBitsShadow = 0, sortFirstBounce = 1;
+    // flatten = true: one world-space tree over all instanced primitives instead of TLAS + per-mesh BLAS.  Measured
+    // slower on MI355X for the kitchen scene (928 vs 1104 Mray/s): 1.1 GB of duplicated leaf records fall out of the
+    // 256 MB Infinity Cache, while the shared BLAS data (83 MB) stays resident.  Kept as an option, default off.
+    bool flatten = false;
+    DevBuf dWNodes, dWTris, dWSegs, dWSegMeta;
+    int wRoot = SKH_REF_INVALID;
+    uint32_t wTriCount = 0, wSegCount = 0;
     uint32_t leafMaxTris = 2; // measured on MI355X: 2 beats 1, 3, 4, 6, 8 (the kernel is ALU bound, wasted triangle tests cost more than extra nodes)
     uint32_t buildQuality = 1; // 0: Karras radix tree (fastest build), 1: PLOC clustering (SAH-class quality)
     float sceneLo[3] = { 0, 0, 0 }, sceneHi[3] = { 1, 1, 1 };
@@ -206,7 +213,7 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
         return s;
     if ((s = dev_alloc(c, out.groupRoot, sizeof(int) * (size_t)std::max(1u, nGroups))) != SKH_OK)
         return s;
-    if ((s = dev_alloc(c, out.nodes, sizeof(Node4) * (size_t)std::max(1u, n))) != SKH_OK)
+    if ((s = dev_alloc(c, out.nodes, sizeof(Node4) * ((size_t)std::max(1u, n) + 1))) != SKH_OK)
         return s;
     if ((s = dev_alloc(c, out.sortedVals, sizeof(uint32_t) * (size_t)std::max(1u, n))) != SKH_OK)
         return s;
@@ -275,9 +282,9 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
     const uint64_t* sortedKeys = kin;
     if (n >= 2)
     {
-        DevBuf nodeSize, leafOrder, vals2, q[2], ctr, cLo[2], cHi[2], nn, pflags, ppos;
+        DevBuf nodeSize, leafOrder, vals2, q[2], ctr, cLo[2], cHi[2], nn, pflags, ppos, scanSums;
         auto cleanup2 = [&]() {
-            for (DevBuf* b : { &nodeSize, &leafOrder, &vals2, &q[0], &q[1], &ctr, &cLo[0], &cLo[1], &cHi[0], &cHi[1], &nn, &pflags, &ppos })
+            for (DevBuf* b : { &nodeSize, &leafOrder, &vals2, &q[0], &q[1], &ctr, &cLo[0], &cLo[1], &cHi[0], &cHi[1], &nn, &pflags, &ppos, &scanSums })
                 dev_free(*b);
         };
 #define LB2(buf, bytes)                              \
@@ -315,6 +322,7 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
             LB2(nn, sizeof(uint32_t) * (size_t)n);
             LB2(pflags, sizeof(uint32_t) * (size_t)n);
             LB2(ppos, sizeof(uint32_t) * (size_t)n);
+            LB2(scanSums, sizeof(uint32_t) * (size_t)(n / (SKH_SCAN_BLOCK * SKH_SCAN_ITEMS) + 2));
             uint32_t nonEmpty = 0;
             for (uint32_t g = 0; g < nGroups; ++g)
                 nonEmpty += groupCount[g] ? 1u : 0u;
@@ -332,7 +340,12 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
                                                             childL.as<int>(), childR.as<int>(), nodeSize.as<int>(), nodeLo.as<float4>(),
                                                             nodeHi.as<float4>(), ctr.as<uint32_t>() + 2, pflags.as<uint32_t>());
                 he = hipMemcpyAsync(ppos.p, pflags.p, sizeof(uint32_t) * (size_t)m, hipMemcpyDeviceToDevice, st);
-                k_rs_scan<<<1, 1024, 0, st>>>(ppos.as<uint32_t>(), m);
+                {
+                    const uint32_t sb = (m + SKH_SCAN_BLOCK * SKH_SCAN_ITEMS - 1) / (SKH_SCAN_BLOCK * SKH_SCAN_ITEMS);
+                    k_scan_block<<<sb, SKH_SCAN_BLOCK, 0, st>>>(ppos.as<uint32_t>(), m, scanSums.as<uint32_t>());
+                    k_rs_scan<<<1, 1024, 0, st>>>(scanSums.as<uint32_t>(), sb);
+                    k_scan_add<<<sb, SKH_SCAN_BLOCK, 0, st>>>(ppos.as<uint32_t>(), m, scanSums.as<uint32_t>());
+                }
                 k_ploc_compact<<<(m + B - 1) / B, B, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), pflags.as<uint32_t>(),
                                                               ppos.as<uint32_t>(), m, cLo[cur ^ 1].as<float4>(), cHi[cur ^ 1].as<float4>(),
                                                               ctr.as<uint32_t>() + 3);
@@ -695,7 +708,7 @@ void skh_destroy(skh_context* c)
                        &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
                        &c->dCounts, &c->dOvf, &c->dStats, &c->dScratchImage, &c->dSortKeys[0], &c->dSortKeys[1], &c->dSortVals[0],
-                       &c->dSortVals[1], &c->dSortHist })
+                       &c->dSortVals[1], &c->dSortHist, &c->dWNodes, &c->dWTris, &c->dWSegs, &c->dWSegMeta })
         dev_free(*b);
     for (hipEvent_t e : c->eventPool)
         (void)hipEventDestroy(e);
@@ -786,6 +799,189 @@ skh_status skh_set_materials(skh_context* c, const skh_material* materials, uint
     return dev_upload(c, c->dMaterials, materials, sizeof(skh_material) * (size_t)n);
 }
 
+// Flattened build: enumerate every instanced primitive in world space, build ONE tree (two key groups: triangles,
+// curve segments; a host-made top node joins the two roots), gather object-space leaf records in leaf order.
+static skh_status build_world(skh_context* c, bool usePloc)
+{
+    hipStream_t st = c->stream;
+    skh_status s;
+    const uint32_t B = 256;
+    const uint32_t nMeshes = (uint32_t)c->meshes.size(), nCurves = (uint32_t)c->curves.size(), nInst = c->nInstances;
+    // curve segment tables (segment enumeration: OptixRender.cpp:226-245)
+    std::vector<uint32_t> segStart, curveSegCount(nCurves), curveSegBase(nCurves);
+    for (uint32_t ci = 0; ci < nCurves; ++ci)
+    {
+        const skh_curve& cu = c->curves[ci];
+        curveSegBase[ci] = (uint32_t)segStart.size();
+        uint32_t off = 0, local = 0;
+        for (uint32_t k = 0; k < cu.vertex_counts_count; ++k)
+        {
+            const uint32_t ncp = c->curveVertexCounts[cu.vertex_counts_start + k];
+            for (int i = 0; i < (int)ncp - 3; ++i)
+            {
+                segStart.push_back(cu.points_start + off + (uint32_t)i);
+                ++local;
+            }
+            off += ncp;
+        }
+        curveSegCount[ci] = local;
+    }
+    for (uint32_t k = 0; k < (uint32_t)segStart.size(); ++k)
+        if ((uint64_t)segStart[k] + 4 > c->nPoints)
+        {
+            c->err = "skh_build_accel: curve segment reads past the control-point buffer";
+            return SKH_INVALID_ARGUMENT;
+        }
+    c->nSegs = (uint32_t)segStart.size();
+    if ((s = dev_upload(c, c->dSegStartAll, segStart.data(), sizeof(uint32_t) * segStart.size())) != SKH_OK ||
+        (s = dev_upload(c, c->dCurveSegBase, curveSegBase.data(), sizeof(uint32_t) * curveSegBase.size())) != SKH_OK)
+        return s;
+    // instance records (w2o) + the lists of primitive-carrying instances
+    std::vector<DevInstance> dinst(std::max(1u, nInst));
+    std::vector<uint32_t> wInstT, wFirstT(1, 0u), wInstS, wFirstS(1, 0u);
+    uint64_t Wt64 = 0, Ws64 = 0;
+    for (uint32_t i = 0; i < nInst; ++i)
+    {
+        const skh_instance& in = c->instances[i];
+        DevInstance& d = dinst[i];
+        const bool inv = invert_affine(in.transform, d.w2o);
+        d.rootRef = SKH_REF_INVALID;
+        d.type = in.type;
+        d.pad = 0;
+        d.mask = 0;
+        if (!inv)
+            continue; // singular transform (the reference's distant-light proxy, scene.cpp:337-345): unhittable
+        if (in.type == SKH_INSTANCE_CURVE)
+        {
+            if (in.geom_id < nCurves && curveSegCount[in.geom_id])
+            {
+                d.mask = 2;
+                wInstS.push_back(i);
+                Ws64 += curveSegCount[in.geom_id];
+                wFirstS.push_back((uint32_t)Ws64);
+            }
+        }
+        else if (in.geom_id < nMeshes && c->meshes[in.geom_id].index_count >= 3)
+        {
+            d.mask = in.type == SKH_INSTANCE_MESH ? 1u : 4u;
+            wInstT.push_back(i);
+            Wt64 += c->meshes[in.geom_id].index_count / 3;
+            wFirstT.push_back((uint32_t)Wt64);
+        }
+    }
+    if (Wt64 + Ws64 >= (1ull << 28))
+    {
+        c->err = "skh_build_accel: more than 2^28 instanced primitives; set option flatten=0 for the two-level hierarchy";
+        return SKH_INVALID_ARGUMENT;
+    }
+    const uint32_t Wt = (uint32_t)Wt64, Ws = (uint32_t)Ws64, W = Wt + Ws;
+    c->wTriCount = Wt;
+    c->wSegCount = Ws;
+    c->nTris = Wt;
+    if ((s = dev_upload(c, c->dDevInst, dinst.data(), sizeof(DevInstance) * dinst.size())) != SKH_OK)
+        return s;
+    DevBuf dWInstT, dWFirstT, dWInstS, dWFirstS, dBoxLo, dBoxHi, dGrp;
+    LbvhOut wOut;
+    auto cleanup = [&]() {
+        for (DevBuf* b : { &dWInstT, &dWFirstT, &dWInstS, &dWFirstS, &dBoxLo, &dBoxHi, &dGrp, &wOut.sortedVals, &wOut.groupRoot, &wOut.groupBounds })
+            dev_free(*b);
+    };
+#define BW(expr)                \
+    if ((s = (expr)) != SKH_OK) \
+    {                           \
+        cleanup();              \
+        return s;               \
+    }
+    BW(dev_upload(c, dWInstT, wInstT.data(), sizeof(uint32_t) * wInstT.size()));
+    BW(dev_upload(c, dWFirstT, wFirstT.data(), sizeof(uint32_t) * wFirstT.size()));
+    BW(dev_upload(c, dWInstS, wInstS.data(), sizeof(uint32_t) * wInstS.size()));
+    BW(dev_upload(c, dWFirstS, wFirstS.data(), sizeof(uint32_t) * wFirstS.size()));
+    BW(dev_alloc(c, dBoxLo, sizeof(float4) * (size_t)std::max(1u, W)));
+    BW(dev_alloc(c, dBoxHi, sizeof(float4) * (size_t)std::max(1u, W)));
+    BW(dev_alloc(c, dGrp, sizeof(uint32_t) * (size_t)std::max(1u, W)));
+    if (Wt)
+        k_world_tri_boxes<<<(Wt + B - 1) / B, B, 0, st>>>(c->dInstances.as<uint8_t>(), dWInstT.as<uint32_t>(), dWFirstT.as<uint32_t>(),
+                                                         (uint32_t)wInstT.size(), c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(),
+                                                         c->dMeshes.as<uint4>(), Wt, dBoxLo.as<float4>(), dBoxHi.as<float4>(),
+                                                         dGrp.as<uint32_t>());
+    if (Ws)
+        k_world_seg_boxes<<<(Ws + B - 1) / B, B, 0, st>>>(c->dInstances.as<uint8_t>(), dWInstS.as<uint32_t>(), dWFirstS.as<uint32_t>(),
+                                                         (uint32_t)wInstS.size(), c->dPoints.as<float>(), c->dRadii.as<float>(),
+                                                         c->dCurveSegBase.as<uint32_t>(), c->dSegStartAll.as<uint32_t>(), Ws, Wt,
+                                                         dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>());
+    const std::vector<uint32_t> groupCount = { Wt, Ws };
+    BW(lbvh_build(c, W, 2, groupCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), (int)c->leafMaxTris, usePloc, wOut));
+    BW(dev_alloc(c, c->dWTris, sizeof(float4) * 3 * (size_t)std::max(1u, Wt)));
+    BW(dev_alloc(c, c->dWSegs, sizeof(float4) * 4 * (size_t)std::max(1u, Ws)));
+    BW(dev_alloc(c, c->dWSegMeta, sizeof(uint2) * (size_t)std::max(1u, Ws)));
+    if (Wt)
+        k_gather_world_tris<<<(Wt + B - 1) / B, B, 0, st>>>(c->dInstances.as<uint8_t>(), dWInstT.as<uint32_t>(), dWFirstT.as<uint32_t>(),
+                                                           (uint32_t)wInstT.size(), c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(),
+                                                           c->dMeshes.as<uint4>(), wOut.sortedVals.as<uint32_t>(), Wt,
+                                                           c->dWTris.as<float4>());
+    if (Ws)
+        k_gather_world_segs<<<(Ws + B - 1) / B, B, 0, st>>>(c->dInstances.as<uint8_t>(), dWInstS.as<uint32_t>(), dWFirstS.as<uint32_t>(),
+                                                           (uint32_t)wInstS.size(), c->dPoints.as<float>(), c->dRadii.as<float>(),
+                                                           c->dCurveSegBase.as<uint32_t>(), c->dSegStartAll.as<uint32_t>(),
+                                                           wOut.sortedVals.as<uint32_t>(), Wt, Ws, c->dWSegs.as<float4>(),
+                                                           c->dWSegMeta.as<uint2>());
+    // roots: one per non-empty group; a host-made top node joins them when both exist
+    float gb[12] = { 0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1 };
+    if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(gb, wOut.groupBounds.p, sizeof(gb), hipMemcpyDeviceToHost) != hipSuccess)
+    {
+        cleanup();
+        c->err = "skh_build_accel: group bounds read-back failed";
+        return SKH_FAIL;
+    }
+    const int r0 = Wt ? wOut.hostGroupRoot[0] : SKH_REF_INVALID, r1 = Ws ? wOut.hostGroupRoot[1] : SKH_REF_INVALID;
+    if (Wt && Ws)
+    {
+        Node4 top;
+        float clo[4][3] = {}, chi[4][3] = {}, nlo[3], nhi[3];
+        for (int k = 0; k < 3; ++k)
+        {
+            clo[0][k] = gb[k], chi[0][k] = gb[3 + k], clo[1][k] = gb[6 + k], chi[1][k] = gb[9 + k];
+            nlo[k] = std::min(gb[k], gb[6 + k]);
+            nhi[k] = std::max(gb[3 + k], gb[9 + k]);
+        }
+        const int refs[4] = { r0, r1, SKH_REF_INVALID, SKH_REF_INVALID };
+        encode_node4(top, nlo, nhi, clo, chi, refs, 2);
+        if (hipMemcpy(wOut.nodes.as<Node4>() + wOut.numNodes, &top, sizeof(top), hipMemcpyHostToDevice) != hipSuccess)
+        {
+            cleanup();
+            c->err = "skh_build_accel: top node upload failed";
+            return SKH_FAIL;
+        }
+        c->wRoot = (int)wOut.numNodes;
+        for (int k = 0; k < 3; ++k)
+        {
+            c->sceneLo[k] = nlo[k];
+            c->sceneHi[k] = nhi[k];
+        }
+    }
+    else
+    {
+        c->wRoot = Wt ? r0 : r1;
+        const float* g = Wt ? gb : gb + 6;
+        for (int k = 0; k < 3; ++k)
+        {
+            c->sceneLo[k] = W ? g[k] : 0.0f;
+            c->sceneHi[k] = W ? g[3 + k] : 1.0f;
+        }
+    }
+    dev_free(c->dWNodes);
+    c->dWNodes = wOut.nodes;
+    hipError_t e = hipStreamSynchronize(st);
+    cleanup();
+    if (e != hipSuccess || (e = hipGetLastError()) != hipSuccess)
+    {
+        c->err = std::string("skh_build_accel (flattened): ") + hipGetErrorString(e);
+        return SKH_FAIL;
+    }
+    return SKH_OK;
+#undef BW
+}
+
 skh_status skh_build_accel(skh_context* c, uint32_t flags)
 {
     if (!c)
@@ -793,6 +989,15 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     (void)hipSetDevice(c->device);
     const bool usePloc = (flags & SKH_BUILD_SAH) != 0 || c->buildQuality != 0;
     const auto t0 = std::chrono::steady_clock::now();
+    if (c->flatten)
+    {
+        const skh_status fs = build_world(c, usePloc);
+        if (fs != SKH_OK)
+            return fs;
+        c->accelBuilt = true;
+        c->msBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return SKH_OK;
+    }
     hipStream_t st = c->stream;
     skh_status s;
     const uint32_t B = 256;
@@ -1114,6 +1319,12 @@ static DevScene make_dev_scene(const skh_context* c)
     sc.segNodes = c->dSegNodes.as<Node4>();
     sc.segs = c->dSegs.as<float4>();
     sc.segPrim = c->dSegPrim.as<uint32_t>();
+    sc.wNodes = c->dWNodes.as<Node4>();
+    sc.wRoot = c->wRoot;
+    sc.wTriCount = c->wTriCount;
+    sc.wTris = c->dWTris.as<float4>();
+    sc.wSegs = c->dWSegs.as<float4>();
+    sc.wSegMeta = c->dWSegMeta.as<uint2>();
     sc.instances = c->dInstances.as<HostInstance>();
     sc.verts = c->dVerts.as<uint8_t>();
     sc.indices = c->dIndices.as<uint32_t>();
@@ -1189,12 +1400,24 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
                          HitQ hq, PathS ps, const float* contrib, uint32_t contribStride)
 {
     // scenes without curve instances run the build of the kernel that has no curve intersector in it (fewer VGPRs)
-    if (c->nSegs)
-        k_trace<ANY, COUNT, true><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, fetch, ANY ? c->fetchMinShadow : c->fetchMinClosest, perm, hq, ps, contrib, contribStride,
-                                                                                      c->dOvf.as<int>(), c->dStats.as<StatsDev>());
+    const uint32_t fm = ANY ? c->fetchMinShadow : c->fetchMinClosest;
+    int* ovf = c->dOvf.as<int>();
+    StatsDev* sd = c->dStats.as<StatsDev>();
+    if (c->flatten)
+    {
+        if (c->wSegCount)
+            k_trace_flat<ANY, COUNT, true><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib,
+                                                                                               contribStride, ovf, sd);
+        else
+            k_trace_flat<ANY, COUNT, false><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib,
+                                                                                                contribStride, ovf, sd);
+    }
+    else if (c->nSegs)
+        k_trace<ANY, COUNT, true><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride,
+                                                                                      ovf, sd);
     else
-        k_trace<ANY, COUNT, false><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, fetch, ANY ? c->fetchMinShadow : c->fetchMinClosest, perm, hq, ps, contrib, contribStride,
-                                                                                       c->dOvf.as<int>(), c->dStats.as<StatsDev>());
+        k_trace<ANY, COUNT, false><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride,
+                                                                                       ovf, sd);
 }
 
 static skh_status render_one(skh_context* c, const skh_frame_params* p, void* d_image)
@@ -1606,6 +1829,11 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 0 || value > 10)
             return SKH_INVALID_ARGUMENT;
         (n == "sort_bits_closest" ? c->sortBitsClosest : c->sortBitsShadow) = (uint32_t)value;
+    }
+    else if (n == "flatten")
+    {
+        c->flatten = value != 0;
+        c->accelBuilt = false;
     }
     else if (n == "leaf_max_tris")
     {
