@@ -60,7 +60,7 @@ def main():
         for r in rows:
             fo.write("%s,%d,%.3f,%.3f,%.0f\n" % r)
     for r in rows:
-        if r[0].startswith("k_trace<false, false>"):
+        if r[0].startswith("k_trace<false, false") or r[0].startswith("k_trace_flat<false, false"):
             json.dump({"kernel": r[0], "tag": tag, "avg_FETCH_SIZE_KiB": r[2], "avg_WRITE_SIZE_KiB": r[3],
                        "hbm_bytes_per_launch": int(r[4]),
                        "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, gfx950 FETCH_SIZE x2 correction"},
