@@ -22,6 +22,15 @@ def needs_build():
     return not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS)
 
 
+def build_variant(out_path, defines, verbose=False):
+    """Same source, extra -D flags (tests use it to exercise rarely-taken paths, e.g. a tiny LDS stack)."""
+    cmd = [hipcc()] + FLAGS + ["-D" + d for d in defines] + ["-o", out_path, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out_path
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB

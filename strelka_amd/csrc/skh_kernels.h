@@ -109,7 +109,9 @@ struct FrameP // skh_frame_params + launch geometry
     uint32_t width, height, tileSize, tileShift, numTiles, numSlots;
 };
 
-#define SKH_STACK_LDS 24
+#ifndef SKH_STACK_LDS
+#define SKH_STACK_LDS 24 // per-lane stack entries kept in LDS (tests build a variant with 12 to exercise the overflow path)
+#endif
 #define SKH_STACK_OVF 104
 #define SKH_TRACE_BLOCK 64
 

@@ -322,3 +322,37 @@ def test_results_do_not_depend_on_the_acceleration_structure_or_scheduling(opts)
     base, other = run({}), run(opts)
     for a, b in zip(base, other):
         assert a.tobytes() == b.tobytes()
+
+
+def test_stack_spill_path_is_exact(tmp_path):
+    """A build of the same kernels with a 12-entry LDS stack sends the deeper entries through the per-thread global
+    overflow area all the time; hit records must still be bit-identical to the oracle (the default 24-entry build
+    almost never takes that path)."""
+    import subprocess
+    import sys
+
+    from strelka_amd import build
+
+    lib = build.build_variant(str(tmp_path / "libstrelka_hip_smallstack.so"), ["SKH_STACK_LDS=12"])
+    code = r'''
+import os, sys
+sys.path.insert(0, os.environ["SKH_ROOT"])
+import numpy as np
+from strelka_amd import capi, scenes
+from tests import orklib
+from tests.test_gpu_parity import small_kitchen, small_hair, camera_rays, assert_hits_equal
+ctx = capi.Context(0)
+for sc in (small_kitchen(), small_hair()):
+    arr = sc.arrays()
+    o = orklib.new_context(); o.set_scene(arr); ctx.set_scene(arr)
+    rays = np.concatenate([camera_rays(sc, 64, 64, 20000, 31), scenes.random_rays(20000, 32, -3.5, 3.5)])
+    assert_hits_equal(ctx.trace(rays, 0), o.trace(rays, 0))
+    rays["tmax"] = 3.0
+    assert np.array_equal(ctx.trace(rays, 1)["t"], o.trace(rays, 1)["t"])
+print("SPILL-OK")
+'''
+    import os
+
+    env = dict(os.environ, SKH_LIB=lib, SKH_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "SPILL-OK" in out.stdout, out.stdout + out.stderr
