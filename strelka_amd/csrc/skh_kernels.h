@@ -107,6 +107,7 @@ struct FrameP // skh_frame_params + launch geometry
     uint32_t enableAccumulation, debug;
     float shadowTmin, materialTmin;
     uint32_t width, height, tileSize, tileShift, numTiles, numSlots;
+    uint32_t batch; // sub-frames in flight in this wavefront (>= 1): path p = sub * numSlots + slot
 };
 
 #ifndef SKH_STACK_LDS
@@ -891,24 +892,28 @@ __global__ void __launch_bounds__(512) k_raygen(FrameP fp, const uint32_t* __res
                                                uint32_t* __restrict__ counter, PathS ps)
 {
     __shared__ uint32_t s_wave[SKH_COMPACT_MAX_WAVES + 1];
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    // several sub-frames can be in flight at once (fp.batch): path = sub * numSlots + slot.  Paths of different
+    // sub-frames are independent; only the accumulation (k_finalize_batch) has to respect their order.
+    const uint32_t path = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t sub = path / fp.numSlots;
+    const uint32_t slot = path - sub * fp.numSlots;
     uint32_t px = 0, py = 0;
-    const bool active = slot < fp.numSlots && slot_to_pixel(fp, tileXY, slot, px, py);
+    const bool active = sub < fp.batch && slot_to_pixel(fp, tileXY, slot, px, py);
     v3 o = mk3(0.0f), d = mk3(0.0f);
     if (active)
     {
-        const Sampler s = init_sampler(px, py, fp.subframeIndex + sampleOffset, fp.sppTotal, 52u); // OptixRender.cu:101
+        const Sampler s = init_sampler(px, py, fp.subframeIndex + sampleOffset + sub, fp.sppTotal, 52u); // OptixRender.cu:101
         generate_camera_ray(px, py, fp.width, fp.height, fp.clipToView, fp.viewToWorld, sampler_random(s, DIM_PIXEL_X),
                             sampler_random(s, DIM_PIXEL_Y), o, d);
         // PerRayData init: OptixRender.cu:96-109
-        ps.base[slot] = 1.0f;
-        ps.base[slot + ps.stride] = 1.0f;
-        ps.base[slot + 2 * (size_t)ps.stride] = 1.0f;
-        ps.base[slot + 3 * (size_t)ps.stride] = 0.0f;
-        ps.base[slot + 4 * (size_t)ps.stride] = 0.0f;
-        ps.base[slot + 5 * (size_t)ps.stride] = 0.0f;
-        ps.base[slot + 6 * (size_t)ps.stride] = 0.0f; // lastBsdfPdf
-        reinterpret_cast<uint32_t*>(ps.base)[slot + 7 * (size_t)ps.stride] = 0u; // flags: outside, eUndef
+        ps.base[path] = 1.0f;
+        ps.base[path + ps.stride] = 1.0f;
+        ps.base[path + 2 * (size_t)ps.stride] = 1.0f;
+        ps.base[path + 3 * (size_t)ps.stride] = 0.0f;
+        ps.base[path + 4 * (size_t)ps.stride] = 0.0f;
+        ps.base[path + 5 * (size_t)ps.stride] = 0.0f;
+        ps.base[path + 6 * (size_t)ps.stride] = 0.0f; // lastBsdfPdf
+        reinterpret_cast<uint32_t*>(ps.base)[path + 7 * (size_t)ps.stride] = 0u; // flags: outside, eUndef
     }
     const uint32_t idx = block_compact(active, counter, s_wave);
     if (active)
@@ -921,7 +926,7 @@ __global__ void __launch_bounds__(512) k_raygen(FrameP fp, const uint32_t* __res
         rq.plane(5)[idx] = d.z;
         rq.plane(6)[idx] = fp.materialTmin; // OptixRender.cu:121
         rq.plane(7)[idx] = 1e16f; // OptixRender.cu:122
-        rq.ids()[idx] = slot;
+        rq.ids()[idx] = path;
     }
 }
 
@@ -1020,8 +1025,9 @@ __global__ void __launch_bounds__(512)
         bool specularBounce = (flags & PF_SPECULAR) != 0;
         uint32_t firstEvent = (flags >> PF_EVENT_SHIFT) & 3u;
         uint32_t px, py;
-        slot_to_pixel(fp, tileXY, pid, px, py);
-        Sampler smp = init_sampler(px, py, fp.subframeIndex + sampleOffset, fp.sppTotal, 52u);
+        const uint32_t sub = pid / fp.numSlots;
+        slot_to_pixel(fp, tileXY, pid - sub * fp.numSlots, px, py);
+        Sampler smp = init_sampler(px, py, fp.subframeIndex + sampleOffset + sub, fp.sppTotal, 52u);
         smp.depth = depth; // prd.sampler.depth++ once per bounce (OptixRender.cu:153)
         uint32_t prdDepth = depth;
         v3 origin = rayO, dir = rayD; // prd.origin / prd.dir keep their old value when no hit program sets them
@@ -1295,27 +1301,18 @@ __global__ void __launch_bounds__(256) k_collect(FrameP fp, const uint32_t* __re
         sums[slot + k * N] = v[k];
 }
 
-__global__ void __launch_bounds__(256)
-    k_finalize(FrameP fp, const uint32_t* __restrict__ tileXY, const float* __restrict__ sums, float4* __restrict__ accum,
-               float4* __restrict__ diffuse, float4* __restrict__ specular, uint16_t* __restrict__ diffuseCounter,
-               uint16_t* __restrict__ specularCounter, float4* __restrict__ image)
+// AOV + accumulation epilogue of one launch of `spl` samples at sub-frame index `subframeIndex` (OptixRender.cu:169-247)
+SKH_DI float4 finalize_one(const FrameP& fp, uint32_t subframeIndex, uint32_t spl, v3 result, v3 dsum, v3 ssum, uint32_t diffuseSamples,
+                           uint32_t specularSamples, uint32_t slot, float4* __restrict__ accum, float4* __restrict__ diffuse,
+                           float4* __restrict__ specular, uint16_t* __restrict__ diffuseCounter, uint16_t* __restrict__ specularCounter)
 {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t px, py;
-    if (slot >= fp.numSlots || !slot_to_pixel(fp, tileXY, slot, px, py))
-        return;
-    const size_t N = fp.numSlots;
     const v3 exposure = mk3(fp.exposure[0], fp.exposure[1], fp.exposure[2]);
-    v3 result = mk3(sums[slot], sums[slot + N], sums[slot + 2 * N]);
-    v3 dsum = mk3(sums[slot + 3 * N], sums[slot + 4 * N], sums[slot + 5 * N]);
-    v3 ssum = mk3(sums[slot + 6 * N], sums[slot + 7 * N], sums[slot + 8 * N]);
-    const uint32_t diffuseSamples = (uint32_t)sums[slot + 9 * N], specularSamples = (uint32_t)sums[slot + 10 * N];
-    result = result / (float)fp.samplesThisLaunch;
+    result = result / (float)spl;
     float4 diffuseOut = make_float4(0.0f, 0.0f, 0.0f, 1.0f), specularOut = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
     if (diffuseSamples > 0)
     {
         dsum = dsum / (float)diffuseSamples;
-        const uint32_t prev = fp.subframeIndex > 0 ? diffuseCounter[slot] : 0u;
+        const uint32_t prev = subframeIndex > 0 ? diffuseCounter[slot] : 0u;
         const float4 h = diffuse[slot];
         const v3 a = accumulate(mk3(h), dsum, exposure, prev);
         diffuseOut = make_float4(a.x, a.y, a.z, 1.0f);
@@ -1324,7 +1321,7 @@ __global__ void __launch_bounds__(256)
     }
     else
     {
-        if (fp.subframeIndex == 0)
+        if (subframeIndex == 0)
         {
             diffuse[slot] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
             diffuseCounter[slot] = 0;
@@ -1334,7 +1331,7 @@ __global__ void __launch_bounds__(256)
     if (specularSamples > 0)
     {
         ssum = ssum / (float)specularSamples;
-        const uint32_t prev = fp.subframeIndex > 0 ? specularCounter[slot] : 0u;
+        const uint32_t prev = subframeIndex > 0 ? specularCounter[slot] : 0u;
         const float4 h = specular[slot];
         const v3 a = accumulate(mk3(h), ssum, exposure, prev);
         specularOut = make_float4(a.x, a.y, a.z, 1.0f);
@@ -1343,7 +1340,7 @@ __global__ void __launch_bounds__(256)
     }
     else
     {
-        if (fp.subframeIndex == 0)
+        if (subframeIndex == 0)
         {
             specular[slot] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
             specularCounter[slot] = 0;
@@ -1359,12 +1356,57 @@ __global__ void __launch_bounds__(256)
     else if (fp.enableAccumulation && fp.debug == 0)
     {
         const float4 h = accum[slot];
-        const v3 a = accumulate(mk3(h), result, exposure, fp.subframeIndex);
+        const v3 a = accumulate(mk3(h), result, exposure, subframeIndex);
         out = make_float4(a.x, a.y, a.z, 1.0f);
         accum[slot] = out;
     }
     else
         out = make_float4(result.x, result.y, result.z, 1.0f);
+    return out;
+}
+
+__global__ void __launch_bounds__(256)
+    k_finalize(FrameP fp, const uint32_t* __restrict__ tileXY, const float* __restrict__ sums, float4* __restrict__ accum,
+               float4* __restrict__ diffuse, float4* __restrict__ specular, uint16_t* __restrict__ diffuseCounter,
+               uint16_t* __restrict__ specularCounter, float4* __restrict__ image)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t px, py;
+    if (slot >= fp.numSlots || !slot_to_pixel(fp, tileXY, slot, px, py))
+        return;
+    const size_t N = fp.numSlots;
+    const v3 result = mk3(sums[slot], sums[slot + N], sums[slot + 2 * N]);
+    const v3 dsum = mk3(sums[slot + 3 * N], sums[slot + 4 * N], sums[slot + 5 * N]);
+    const v3 ssum = mk3(sums[slot + 6 * N], sums[slot + 7 * N], sums[slot + 8 * N]);
+    const float4 out = finalize_one(fp, fp.subframeIndex, fp.samplesThisLaunch, result, dsum, ssum, (uint32_t)sums[slot + 9 * N],
+                                    (uint32_t)sums[slot + 10 * N], slot, accum, diffuse, specular, diffuseCounter, specularCounter);
+    if (image)
+        image[(size_t)py * fp.width + px] = out;
+}
+
+// batch of fp.batch sub-frames of ONE sample each, traced together: apply their accumulation steps in sub-frame order
+// (the accumulator is an order-dependent LDR-space lerp: OptixRender.cu:60-78)
+__global__ void __launch_bounds__(256)
+    k_finalize_batch(FrameP fp, const uint32_t* __restrict__ tileXY, PathS ps, float4* __restrict__ accum, float4* __restrict__ diffuse,
+                     float4* __restrict__ specular, uint16_t* __restrict__ diffuseCounter, uint16_t* __restrict__ specularCounter,
+                     float4* __restrict__ image)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t px, py;
+    if (slot >= fp.numSlots || !slot_to_pixel(fp, tileXY, slot, px, py))
+        return;
+    const size_t S = ps.stride;
+    float4 out = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    for (uint32_t sub = 0; sub < fp.batch; ++sub)
+    {
+        const size_t p = (size_t)sub * fp.numSlots + slot;
+        const v3 rad = mk3(ps.base[p + 3 * S], ps.base[p + 4 * S], ps.base[p + 5 * S]);
+        const uint32_t fe = (reinterpret_cast<const uint32_t*>(ps.base)[p + 7 * S] >> PF_EVENT_SHIFT) & 3u;
+        // `result += prd.radiance` starts from 0.0f in the reference (OptixRender.cu:83,154): keep that addition
+        const v3 result = mk3(0.0f) + rad;
+        out = finalize_one(fp, fp.subframeIndex + sub, 1u, result, fe == 2 ? result : mk3(0.0f), fe == 3 ? result : mk3(0.0f), fe == 2 ? 1u : 0u,
+                           fe == 3 ? 1u : 0u, slot, accum, diffuse, specular, diffuseCounter, specularCounter);
+    }
     if (image)
         image[(size_t)py * fp.width + px] = out;
 }

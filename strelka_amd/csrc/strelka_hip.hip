@@ -89,6 +89,7 @@ struct skh_context
     DevBuf dWNodes, dWTris, dWSegs, dWSegMeta;
     int wRoot = SKH_REF_INVALID;
     uint32_t wTriCount = 0, wSegCount = 0;
+    uint32_t subframeBatch = 0, batchCapacity = 1; // option subframe_batch: 0 = auto
     uint32_t leafMaxTris = 2; // measured on MI355X: 2 beats 1, 3, 4, 6, 8 (the kernel is ALU bound, wasted triangle tests cost more than extra nodes)
     uint32_t buildQuality = 1; // 0: Karras radix tree (fastest build), 1: PLOC clustering (SAH-class quality)
     float sceneLo[3] = { 0, 0, 0 }, sceneHi[3] = { 1, 1, 1 };
@@ -1196,17 +1197,20 @@ static skh_status alloc_frame(skh_context* c)
     }
     c->numTiles = (uint32_t)(c->tileXY.size() / 2);
     c->numSlots = c->numTiles * T * T;
-    const size_t N = std::max(1u, c->numSlots);
+    // sub-frame batching: keep >= ~2 M paths per wavefront pass (a 1/8 tile share of a 1080p frame is only 260 k)
+    c->batchCapacity = c->subframeBatch ? c->subframeBatch : std::min(16u, std::max(1u, (1u << 21) / std::max(1u, c->numSlots)));
+    const size_t N1 = std::max(1u, c->numSlots);
+    const size_t N = N1 * c->batchCapacity;
 #define AF(expr)                \
     if ((s = (expr)) != SKH_OK) \
         return s;
     AF(dev_upload(c, c->dTileXY, c->tileXY.data(), sizeof(uint32_t) * c->tileXY.size()));
-    AF(dev_alloc(c, c->dAccum, sizeof(float4) * N));
-    AF(dev_alloc(c, c->dDiffuse, sizeof(float4) * N));
-    AF(dev_alloc(c, c->dSpecular, sizeof(float4) * N));
-    AF(dev_alloc(c, c->dDiffCnt, sizeof(uint16_t) * N));
-    AF(dev_alloc(c, c->dSpecCnt, sizeof(uint16_t) * N));
-    AF(dev_alloc(c, c->dSums, sizeof(float) * 11 * N));
+    AF(dev_alloc(c, c->dAccum, sizeof(float4) * N1));
+    AF(dev_alloc(c, c->dDiffuse, sizeof(float4) * N1));
+    AF(dev_alloc(c, c->dSpecular, sizeof(float4) * N1));
+    AF(dev_alloc(c, c->dDiffCnt, sizeof(uint16_t) * N1));
+    AF(dev_alloc(c, c->dSpecCnt, sizeof(uint16_t) * N1));
+    AF(dev_alloc(c, c->dSums, sizeof(float) * 11 * N1));
     AF(dev_alloc(c, c->dPath, sizeof(float) * 8 * N));
     AF(dev_alloc(c, c->dRayQ[0], sizeof(float) * 9 * N));
     AF(dev_alloc(c, c->dRayQ[1], sizeof(float) * 9 * N));
@@ -1223,11 +1227,11 @@ static skh_status alloc_frame(skh_context* c)
     c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
     AF(dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * c->traceBlocks * SKH_TRACE_BLOCK));
 #undef AF
-    SKH_TRY(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(float4) * N, c->stream));
-    SKH_TRY(c, hipMemsetAsync(c->dDiffuse.p, 0, sizeof(float4) * N, c->stream));
-    SKH_TRY(c, hipMemsetAsync(c->dSpecular.p, 0, sizeof(float4) * N, c->stream));
-    SKH_TRY(c, hipMemsetAsync(c->dDiffCnt.p, 0, sizeof(uint16_t) * N, c->stream));
-    SKH_TRY(c, hipMemsetAsync(c->dSpecCnt.p, 0, sizeof(uint16_t) * N, c->stream));
+    SKH_TRY(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(float4) * N1, c->stream));
+    SKH_TRY(c, hipMemsetAsync(c->dDiffuse.p, 0, sizeof(float4) * N1, c->stream));
+    SKH_TRY(c, hipMemsetAsync(c->dSpecular.p, 0, sizeof(float4) * N1, c->stream));
+    SKH_TRY(c, hipMemsetAsync(c->dDiffCnt.p, 0, sizeof(uint16_t) * N1, c->stream));
+    SKH_TRY(c, hipMemsetAsync(c->dSpecCnt.p, 0, sizeof(uint16_t) * N1, c->stream));
     SKH_TRY(c, hipStreamSynchronize(c->stream));
     return SKH_OK;
 }
@@ -1420,7 +1424,9 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
                                                                                        ovf, sd);
 }
 
-static skh_status render_one(skh_context* c, const skh_frame_params* p, void* d_image)
+// One wavefront pass: either one launch of p->samples_this_launch samples (batch = 1), or `batch` consecutive sub-frames
+// of one sample each traced together (more rays per launch; results identical, see k_finalize_batch).
+static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t batch, void* d_image)
 {
     if (p->max_depth > 128 || p->samples_this_launch == 0)
     {
@@ -1447,11 +1453,13 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, void* d_
     fp.tileShift = c->tileShift;
     fp.numTiles = c->numTiles;
     fp.numSlots = c->numSlots;
+    fp.batch = batch;
     const DevScene sc = make_dev_scene(c);
-    const uint32_t N = c->numSlots;
-    if (N == 0)
+    const uint32_t N = c->numSlots * c->batchCapacity; // plane stride of every queue / path-state buffer
+    const uint32_t NP = c->numSlots * batch; // paths in this pass
+    if (NP == 0)
         return SKH_OK;
-    const uint32_t gridSlots = (N + 255) / 256;
+    const uint32_t gridSlots = (c->numSlots + 255) / 256;
     const uint32_t* tiles = c->dTileXY.as<uint32_t>();
     PathS ps{ c->dPath.as<float>(), N };
     RayQ rq[2] = { RayQ{ c->dRayQ[0].as<float>(), N }, RayQ{ c->dRayQ[1].as<float>(), N } };
@@ -1466,7 +1474,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, void* d_
         SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (512 + 16 * (fp.maxDepth + 1)), st));
         {
             SpanGuard g(c, KC_RAYGEN);
-            k_raygen<<<(N + 511) / 512, 512, 0, st>>>(fp, tiles, s, rq[0], counts, ps);
+            k_raygen<<<(NP + 511) / 512, 512, 0, st>>>(fp, tiles, s, rq[0], counts, ps);
         }
         for (uint32_t b = 0; b < fp.maxDepth; ++b)
         {
@@ -1485,7 +1493,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, void* d_
             }
             {
                 SpanGuard g(c, KC_SHADE);
-                k_shade<<<(N + 511) / 512, 512, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b, hq, ps, rq[(b + 1) & 1],
+                k_shade<<<(NP + 511) / 512, 512, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b, hq, ps, rq[(b + 1) & 1],
                                                    counts + 2 * (b + 1), shq, c->dContrib.as<float>(), counts + 2 * b + 1);
             }
             const uint32_t* permS = nullptr;
@@ -1507,9 +1515,17 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, void* d_
         {
             SpanGuard g(c, KC_ACCUM);
             k_add_stats<<<1, 64, 0, st>>>(counts, fp.maxDepth, c->dStats.as<StatsDev>());
-            k_collect<<<gridSlots, 256, 0, st>>>(fp, tiles, s, ps, c->dSums.as<float>());
+            if (batch == 1)
+                k_collect<<<gridSlots, 256, 0, st>>>(fp, tiles, s, ps, c->dSums.as<float>());
         }
     }
+    if (batch > 1)
+    {
+        SpanGuard g(c, KC_ACCUM);
+        k_finalize_batch<<<gridSlots, 256, 0, st>>>(fp, tiles, ps, c->dAccum.as<float4>(), c->dDiffuse.as<float4>(), c->dSpecular.as<float4>(),
+                                                    c->dDiffCnt.as<uint16_t>(), c->dSpecCnt.as<uint16_t>(), reinterpret_cast<float4*>(d_image));
+    }
+    else
     {
         SpanGuard g(c, KC_ACCUM);
         k_finalize<<<gridSlots, 256, 0, st>>>(fp, tiles, c->dSums.as<float>(), c->dAccum.as<float4>(), c->dDiffuse.as<float4>(),
@@ -1539,11 +1555,15 @@ skh_status skh_render_subframes(skh_context* c, const skh_frame_params* params, 
     if (s != SKH_OK)
         return s;
     skh_frame_params p = *params;
-    for (uint32_t k = 0; k < n_subframes; ++k)
+    // single-sample sub-frames are traced `batchCapacity` at a time when that gives the GPU more rays per launch
+    const uint32_t cap = (p.samples_this_launch == 1 && p.debug != 1) ? c->batchCapacity : 1u;
+    for (uint32_t k = 0; k < n_subframes;)
     {
-        if ((s = render_one(c, &p, d_image)) != SKH_OK)
+        const uint32_t b = std::min(cap, n_subframes - k);
+        if ((s = render_one(c, &p, b, d_image)) != SKH_OK)
             return s;
-        p.subframe_index += p.samples_this_launch;
+        p.subframe_index += p.samples_this_launch * b;
+        k += b;
     }
     SKH_TRY(c, hipStreamSynchronize(c->stream)); // the reference's render() is synchronous (OptixRender.cpp:1012)
     if (c->timing)
@@ -1829,6 +1849,14 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 0 || value > 10)
             return SKH_INVALID_ARGUMENT;
         (n == "sort_bits_closest" ? c->sortBitsClosest : c->sortBitsShadow) = (uint32_t)value;
+    }
+    else if (n == "subframe_batch")
+    {
+        if (value < 0 || value > 64)
+            return SKH_INVALID_ARGUMENT;
+        c->subframeBatch = (uint32_t)value;
+        if (c->width)
+            return alloc_frame(c);
     }
     else if (n == "flatten")
     {

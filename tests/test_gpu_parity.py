@@ -356,3 +356,22 @@ print("SPILL-OK")
     env = dict(os.environ, SKH_LIB=lib, SKH_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "SPILL-OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_subframe_batching_is_exact(gpu):
+    """Tracing several single-sample sub-frames in one wavefront pass (more rays per launch, used when a rank's tile
+    share is small) must give exactly the image of one-at-a-time rendering: accumulation is applied in sub-frame order."""
+    sc = small_kitchen()
+    arr = sc.arrays()
+    gpu.set_scene(arr)
+    imgs = []
+    for batch in (1, 4, 3):
+        gpu.set_option("subframe_batch", batch)
+        gpu.resize(96, 64)
+        gpu.render_subframes(S.frame_params(sc.getCamera(), 96, 64, subframe_index=0, spp_total=7, max_depth=4), 7)
+        imgs.append((gpu.read_accum(), gpu.read_aov(0), gpu.read_aov(1)))
+    gpu.set_option("subframe_batch", 0)
+    gpu.resize(96, 64)
+    for other in imgs[1:]:
+        for a, b in zip(imgs[0], other):
+            assert np.array_equal(a, b)
