@@ -177,7 +177,12 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_k_trace_closest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                # PMC bytes per launch, measured on launches of `rays_per_launch` rays of the same workload; quoted per
+                # launch of THIS run (same figure when the launch sizes agree, which they do for the default config)
+                if tj.get("workload", workload) == workload and tj.get("resolution", f"{W}x{H}") == f"{W}x{H}":
+                    rpl = cst["rays_radiance"] * K / launches
+                    traffic = int(tj["hbm_bytes_per_launch"] * (rpl / tj["rays_per_launch"] if tj.get("rays_per_launch") else 1.0))
             except Exception:
                 traffic = None
         out = {
@@ -193,6 +198,7 @@ def main():
             "roofline": {"kernel": "k_trace<closest>", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                         "rays_per_launch": int(cst["rays_radiance"] * K / launches),
                          "per_ray": {"nodes": round(cst["nodes_visited"][0] / max(1, cst["rays_radiance"]), 2),
                                      "tris": round(cst["prims_tested"][0] / max(1, cst["rays_radiance"]), 2),
                                      "instances": round(cst["instances_entered"][0] / max(1, cst["rays_radiance"]), 2)}},

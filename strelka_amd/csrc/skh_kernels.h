@@ -143,7 +143,20 @@ struct HitRec
 struct StatsDev
 {
     unsigned long long raysRadiance, raysShadow, nodes[2], prims[2], segs[2], insts[2];
+#ifdef SKH_LANE_PROFILE
+    // wave-level event counts of k_trace (profile build only): [0] node-loop iterations, [1] triangle-loop iterations,
+    // [2] instance-entry blocks, [3] outer iterations, [4] refills, [5] lanes refilled, [6] leaf blocks, [7] pop blocks
+    unsigned long long wave[2][8];
+#endif
 };
+
+SKH_DI uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        v = max(v, (uint32_t)__shfl_xor(v, off));
+    return v;
+}
 
 SKH_DI uint32_t wave_sum(uint32_t v)
 {
@@ -158,6 +171,9 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 #endif
 #ifndef SKH_SORT_ANYHIT
 #define SKH_SORT_ANYHIT 0
+#endif
+#ifndef SKH_POP_IN_LOOP
+#define SKH_POP_IN_LOOP 1
 #endif
 #ifndef SKH_FETCH_MIN
 #define SKH_FETCH_MIN 20 // refill the wave from the ray queue when at least this many lanes are idle
@@ -179,11 +195,12 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 template <bool ANY_HIT, bool COUNT, bool CURVES>
 __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WAVES)
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
-            uint32_t fetchMin, const uint32_t* __restrict__ perm /*optional: sorted order -> queue index*/,
+            uint32_t fetchArg /* refill threshold | node-break threshold << 16 */, const uint32_t* __restrict__ perm /*optional: sorted order -> queue index*/,
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
             StatsDev* __restrict__ stats)
 {
     __shared__ int s_stack[SKH_STACK_LDS * SKH_TRACE_BLOCK];
+    const uint32_t fetchMin = fetchArg & 0xffffu, nodeBreak = fetchArg >> 16;
     const uint32_t lane = threadIdx.x;
     const uint32_t n = *countPtr;
     if (n == 0)
@@ -197,6 +214,12 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
     const uint32_t ovfStride = gridDim.x * SKH_TRACE_BLOCK;
     const uint32_t rayMask = CURVES ? (ANY_HIT ? 3u : 255u) : (ANY_HIT ? 1u : 253u);
     TraceCounters tc = { 0, 0, 0, 0 };
+#ifdef SKH_LANE_PROFILE
+    uint32_t wv[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#define SKH_LP(...) __VA_ARGS__
+#else
+#define SKH_LP(...)
+#endif
 
     // per-lane traversal state
     bool hasRay = false;
@@ -237,8 +260,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
         // ---------------- refill idle lanes from the queue ----------------
         const unsigned long long needMask = __ballot(!hasRay);
         const uint32_t want = (uint32_t)__popcll(needMask);
+        SKH_LP(wv[3]++;)
         if (!exhausted && (want >= fetchMin || want == 64u))
         {
+            SKH_LP(wv[4]++; wv[5] += want;)
             uint32_t base = 0, count = 0;
             const int leader = __ffsll((long long)needMask) - 1;
             while (tries < 8u)
@@ -291,11 +316,14 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
             continue;
         }
         bool terminated = false;
+        SKH_LP(uint32_t itN = 0, itT = 0;)
+        const uint32_t breakBelow = ((uint32_t)__popcll(__ballot(hasRay)) * nodeBreak) >> 6;
         if (hasRay)
         {
             // ---- descend through internal nodes ----
             while (cur >= 0 && cur != SKH_REF_INVALID)
             {
+                SKH_LP(itN++;)
                 // one 64-byte fetch = four quantised child boxes
                 const float4* np = reinterpret_cast<const float4*>(nodes + cur);
                 const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
@@ -370,7 +398,27 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                         }
                 }
 #undef SKH_CSWAP
+#if SKH_POP_IN_LOOP
+                // a lane whose node had no hit child takes its next stack entry right here instead of idling until
+                // the whole wave leaves the node loop
+                if (cur == SKH_REF_INVALID && sp > 0)
+                    SKH_POP(cur);
+#endif
+                // few lanes still descending while the rest wait at their leaves: let the leaves go first
+                if ((uint32_t)__popcll(__ballot(cur >= 0 && cur != SKH_REF_INVALID)) < breakBelow)
+                    break;
             }
+#if SKH_POP_IN_LOOP
+            if (cur == SKH_REF_SENTINEL)
+            {
+                o = ow;
+                d = dw;
+                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                nodes = sc.tlasNodes;
+                inBlas = false;
+                cur = SKH_REF_INVALID;
+            }
+#endif
             // ---- leaf ----
             bool entered = false;
             if (cur < 0 && cur != SKH_REF_SENTINEL)
@@ -439,6 +487,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                         const float4 a = tp[0], b = tp[1], c = tp[2];
                         if (COUNT)
                             tc.prims++;
+                        SKH_LP(itT++;)
                         float t, u, v;
                         if (intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), t, u, v) && t < tmax)
                         {
@@ -456,10 +505,11 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                     }
                 }
             }
+            SKH_LP(if (entered) itT |= 0x10000u;)
             // ---- pop ----
             if (ANY_HIT && best.found)
                 terminated = true;
-            else if (!entered)
+            else if (!entered && !(cur >= 0 && cur != SKH_REF_INVALID)) // (a lane taken out of the node loop early keeps its node)
             {
                 for (;;)
                 {
@@ -482,6 +532,11 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                 }
             }
         }
+#ifdef SKH_LANE_PROFILE
+        wv[0] += wave_max(itN);
+        wv[1] += wave_max(itT & 0xffffu);
+        wv[2] += __any((itT >> 16) != 0) ? 1u : 0u;
+#endif
         if (terminated)
         {
             hasRay = false;
@@ -520,8 +575,13 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
             atomicAdd(&stats->prims[ANY_HIT ? 1 : 0], (unsigned long long)b);
             atomicAdd(&stats->segs[ANY_HIT ? 1 : 0], (unsigned long long)c2);
             atomicAdd(&stats->insts[ANY_HIT ? 1 : 0], (unsigned long long)d2);
+#ifdef SKH_LANE_PROFILE
+            for (int k = 0; k < 8; ++k)
+                atomicAdd(&stats->wave[ANY_HIT ? 1 : 0][k], (unsigned long long)wv[k]);
+#endif
         }
     }
+#undef SKH_LP
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -537,6 +597,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                  const uint32_t* __restrict__ perm, HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride,
                  int* __restrict__ ovfBase, StatsDev* __restrict__ stats)
 {
+    fetchMin &= 0xffffu;
     __shared__ int s_stack[SKH_STACK_LDS * SKH_TRACE_BLOCK];
     const uint32_t lane = threadIdx.x;
     const uint32_t n = *countPtr;

@@ -81,6 +81,7 @@ struct skh_context
     // measured on MI355X (kitchen C3, 16 sub-frames per pass): 24 resident waves/CU; refill thresholds 32 (closest) / 44 (any-hit)
     uint32_t wavesPerCU = 24;
     uint32_t fetchMinClosest = 32, fetchMinShadow = 44;
+    uint32_t nodeBreakClosest = 14, nodeBreakShadow = 14; // leave the node loop when fewer than x/64 of the wave's rays are still descending
     // ray re-ordering (per bounce): 0 = off, else Morton bits per axis of the origin cell (key = octant : morton)
     uint32_t sortBitsClosest = 0, sortBitsShadow = 0, sortFirstBounce = 1;
     // flatten = true: one world-space tree over all instanced primitives instead of TLAS + per-mesh BLAS.  Measured
@@ -1407,7 +1408,7 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
                          HitQ hq, PathS ps, const float* contrib, uint32_t contribStride)
 {
     // scenes without curve instances run the build of the kernel that has no curve intersector in it (fewer VGPRs)
-    const uint32_t fm = ANY ? c->fetchMinShadow : c->fetchMinClosest;
+    const uint32_t fm = (ANY ? c->fetchMinShadow : c->fetchMinClosest) | ((ANY ? c->nodeBreakShadow : c->nodeBreakClosest) << 16);
     int* ovf = c->dOvf.as<int>();
     StatsDev* sd = c->dStats.as<StatsDev>();
     if (c->flatten)
@@ -1847,6 +1848,12 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
             return SKH_INVALID_ARGUMENT;
         (n == "fetch_min_closest" ? c->fetchMinClosest : c->fetchMinShadow) = (uint32_t)value;
     }
+    else if (n == "node_break_closest" || n == "node_break_shadow")
+    {
+        if (value < 0 || value > 64)
+            return SKH_INVALID_ARGUMENT;
+        (n == "node_break_closest" ? c->nodeBreakClosest : c->nodeBreakShadow) = (uint32_t)value;
+    }
     else if (n == "sort_bits_closest" || n == "sort_bits_shadow")
     {
         if (value < 0 || value > 10)
@@ -1914,6 +1921,12 @@ skh_status skh_get_stats(skh_context* c, skh_stats* out)
         out->segs_tested[k] = sd.segs[k];
         out->instances_entered[k] = sd.insts[k];
     }
+#ifdef SKH_LANE_PROFILE
+    for (int k = 0; k < 2; ++k)
+        fprintf(stderr, "[lane-profile] %s: rays %llu nodes %llu tris %llu insts %llu | wave: nodeIt %llu triIt %llu instBlk %llu outer %llu refills %llu refilled %llu\n",
+                k ? "shadow" : "closest", k ? sd.raysShadow : sd.raysRadiance, sd.nodes[k], sd.prims[k], sd.insts[k], sd.wave[k][0], sd.wave[k][1],
+                sd.wave[k][2], sd.wave[k][3], sd.wave[k][4], sd.wave[k][5]);
+#endif
     out->ms_trace_closest = c->msClass[KC_TRACE_CLOSEST];
     out->ms_trace_shadow = c->msClass[KC_TRACE_SHADOW];
     out->ms_shade = c->msClass[KC_SHADE];

@@ -59,10 +59,18 @@ def main():
         fo.write("kernel,launches,avg_FETCH_SIZE_KiB,avg_WRITE_SIZE_KiB,hbm_bytes_per_launch=(2*FETCH+WRITE)*1024\n")
         for r in rows:
             fo.write("%s,%d,%.3f,%.3f,%.0f\n" % r)
+    meta = {}
+    plog = os.path.join(src, "bench_pmc_fetch.log")
+    if os.path.exists(plog):
+        lines = [l for l in open(plog) if l.startswith("{")]
+        if lines:
+            b = json.loads(lines[-1])
+            meta = {"workload": b["config"]["workload"], "resolution": b["config"]["resolution"],
+                    "rays_per_launch": b["roofline"].get("rays_per_launch")}
     for r in rows:
         if r[0].startswith("k_trace<false, false") or r[0].startswith("k_trace_flat<false, false"):
             json.dump({"kernel": r[0], "tag": tag, "avg_FETCH_SIZE_KiB": r[2], "avg_WRITE_SIZE_KiB": r[3],
-                       "hbm_bytes_per_launch": int(r[4]),
+                       "hbm_bytes_per_launch": int(r[4]), **meta,
                        "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, gfx950 FETCH_SIZE x2 correction"},
                       open(os.path.join(dst, "traffic_k_trace_closest.json"), "w"), indent=1)
             print("traffic", r)
