@@ -645,44 +645,47 @@ SKH_DI v3 accumulate(const v3& prev, const v3& value, const v3& exposure, uint32
 // =================================================================================================
 struct RayShear
 {
-    int kx, ky, kz;
+    int perm; // dominant axis kz in bits 0..1; bit 2: kx and ky swapped (d[kz] < 0)
     float Sx, Sy, Sz;
 };
+// (v[kx], v[ky], v[kz]) with kx = kz + 1, ky = kz + 2 (mod 3), swapped when d[kz] < 0.  Written as selects on locals so
+// that it compiles to v_cndmask (a chain of compares on a `const v3&` became a branchy switch: ~25 instructions and
+// four branches per component, nine components per triangle).
+SKH_DI v3 shear_permute(const v3& vv, int perm)
+{
+    const float x = vv.x, y = vv.y, z = vv.z;
+    const int kz = perm & 3;
+    const bool z0 = kz == 0, z1 = kz == 1, fl = perm >= 4;
+    const float a = z0 ? y : (z1 ? z : x);
+    const float b = z0 ? z : (z1 ? x : y);
+    const float c = z0 ? x : (z1 ? y : z);
+    return mk3(fl ? b : a, fl ? a : b, c);
+}
 SKH_DI RayShear make_shear(const v3& d)
 {
     RayShear s;
     const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    s.kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
-    s.kx = s.kz + 1;
-    if (s.kx == 3)
-        s.kx = 0;
-    s.ky = s.kx + 1;
-    if (s.ky == 3)
-        s.ky = 0;
-    if (comp(d, s.kz) < 0.0f)
-    {
-        const int t = s.kx;
-        s.kx = s.ky;
-        s.ky = t;
-    }
-    const float dz = comp(d, s.kz);
-    s.Sx = comp(d, s.kx) / dz;
-    s.Sy = comp(d, s.ky) / dz;
-    s.Sz = 1.0f / dz;
+    const int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+    const float dkz = kz == 0 ? d.x : (kz == 1 ? d.y : d.z);
+    s.perm = kz | (dkz < 0.0f ? 4 : 0);
+    const v3 dp = shear_permute(d, s.perm);
+    s.Sx = dp.x / dp.z;
+    s.Sy = dp.y / dp.z;
+    s.Sz = 1.0f / dp.z;
     return s;
 }
 // watertight edge-function test (Woop, Benthin, Wald 2013); accepts tmin < t <= tmax
 SKH_DI bool intersect_triangle(const v3& o, const RayShear& s, float tmin, float tmax, const v3& p0, const v3& p1,
                                const v3& p2, float& t_out, float& u_out, float& v_out)
 {
-    const v3 A = p0 - o, B = p1 - o, C = p2 - o;
-    const float Akz = comp(A, s.kz), Bkz = comp(B, s.kz), Ckz = comp(C, s.kz);
-    const float Ax = comp(A, s.kx) - s.Sx * Akz;
-    const float Ay = comp(A, s.ky) - s.Sy * Akz;
-    const float Bx = comp(B, s.kx) - s.Sx * Bkz;
-    const float By = comp(B, s.ky) - s.Sy * Bkz;
-    const float Cx = comp(C, s.kx) - s.Sx * Ckz;
-    const float Cy = comp(C, s.ky) - s.Sy * Ckz;
+    const v3 A = shear_permute(p0 - o, s.perm), B = shear_permute(p1 - o, s.perm), C = shear_permute(p2 - o, s.perm);
+    const float Akz = A.z, Bkz = B.z, Ckz = C.z;
+    const float Ax = A.x - s.Sx * Akz;
+    const float Ay = A.y - s.Sy * Akz;
+    const float Bx = B.x - s.Sx * Bkz;
+    const float By = B.y - s.Sy * Bkz;
+    const float Cx = C.x - s.Sx * Ckz;
+    const float Cy = C.y - s.Sy * Ckz;
     const float U = Cx * By - Cy * Bx;
     const float V = Ax * Cy - Ay * Cx;
     const float W = Bx * Ay - By * Ax;

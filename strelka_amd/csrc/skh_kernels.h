@@ -147,6 +147,7 @@ struct StatsDev
     // wave-level event counts of k_trace (profile build only): [0] node-loop iterations, [1] triangle-loop iterations,
     // [2] instance-entry blocks, [3] outer iterations, [4] refills, [5] lanes refilled, [6] leaf blocks, [7] pop blocks
     unsigned long long wave[2][8];
+    unsigned long long cyc[2][8]; // summed over waves: [0] refill [1] node loop [2] leaf [3] pop [4] result write [5] whole kernel
 #endif
 };
 
@@ -216,18 +217,20 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
     TraceCounters tc = { 0, 0, 0, 0 };
 #ifdef SKH_LANE_PROFILE
     uint32_t wv[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long cy[6] = { 0, 0, 0, 0, 0, 0 };
+    const unsigned long long cyStart = __builtin_readcyclecounter();
 #define SKH_LP(...) __VA_ARGS__
 #else
 #define SKH_LP(...)
 #endif
 
     // per-lane traversal state
-    bool hasRay = false;
+    bool hasRay = false, pending = false;
     uint32_t ridx = 0;
     v3 ow = mk3(0.0f), dw = mk3(0.0f), o = mk3(0.0f), d = mk3(0.0f), inv = mk3(0.0f);
     float tmin = 0.0f, tmax = 0.0f;
     RayShear sh;
-    sh.kx = sh.ky = sh.kz = 0;
+    sh.perm = 0;
     sh.Sx = sh.Sy = sh.Sz = 0.0f;
     const Node4* nodes = sc.tlasNodes;
     bool inBlas = false;
@@ -260,7 +263,37 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
         // ---------------- refill idle lanes from the queue ----------------
         const unsigned long long needMask = __ballot(!hasRay);
         const uint32_t want = (uint32_t)__popcll(needMask);
-        SKH_LP(wv[3]++;)
+        SKH_LP(wv[3]++; unsigned long long cyA = __builtin_readcyclecounter();)
+        if (want >= fetchMin || want == 64u)
+        {
+            // results of the lanes that finished since the last refill: written together, once per refill
+            if (pending)
+            {
+                pending = false;
+                const uint32_t i = ridx;
+                if (ANY_HIT)
+                {
+                    if (hq.base) // raw query mode (skh_trace): 1 = occluded, -1 = not
+                        hq.base[i] = best.found ? 1.0f : -1.0f;
+                    else if (!best.found)
+                    {
+                        const uint32_t pid = rq.ids()[i];
+                        float* rad = ps.base + (size_t)3 * ps.stride;
+                        rad[pid] += contrib[i];
+                        rad[pid + ps.stride] += contrib[i + contribStride];
+                        rad[pid + 2 * (size_t)ps.stride] += contrib[i + 2 * (size_t)contribStride];
+                    }
+                }
+                else
+                {
+                    hq.base[i] = best.found ? best.t : -1.0f;
+                    reinterpret_cast<uint32_t*>(hq.base)[i + hq.stride] = best.inst;
+                    reinterpret_cast<uint32_t*>(hq.base)[i + 2 * (size_t)hq.stride] = best.prim;
+                    hq.base[i + 3 * (size_t)hq.stride] = best.u;
+                    hq.base[i + 4 * (size_t)hq.stride] = best.v;
+                }
+            }
+        }
         if (!exhausted && (want >= fetchMin || want == 64u))
         {
             SKH_LP(wv[4]++; wv[5] += want;)
@@ -316,7 +349,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
             continue;
         }
         bool terminated = false;
-        SKH_LP(uint32_t itN = 0, itT = 0;)
+        SKH_LP(uint32_t itN = 0, itT = 0; { const unsigned long long t = __builtin_readcyclecounter(); cy[0] += t - cyA; cyA = t; })
         const uint32_t breakBelow = ((uint32_t)__popcll(__ballot(hasRay)) * nodeBreak) >> 6;
         if (hasRay)
         {
@@ -420,6 +453,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
             }
 #endif
             // ---- leaf ----
+            SKH_LP({ const unsigned long long t = __builtin_readcyclecounter(); cy[1] += t - cyA; cyA = t; })
             bool entered = false;
             if (cur < 0 && cur != SKH_REF_SENTINEL)
             {
@@ -505,7 +539,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                     }
                 }
             }
-            SKH_LP(if (entered) itT |= 0x10000u;)
+            SKH_LP(if (entered) itT |= 0x10000u; { const unsigned long long t = __builtin_readcyclecounter(); cy[2] += t - cyA; cyA = t; })
             // ---- pop ----
             if (ANY_HIT && best.found)
                 terminated = true;
@@ -533,6 +567,12 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
             }
         }
 #ifdef SKH_LANE_PROFILE
+        if (hasRay)
+        {
+            const unsigned long long t = __builtin_readcyclecounter();
+            cy[3] += t - cyA;
+        }
+        cyA = __builtin_readcyclecounter();
         wv[0] += wave_max(itN);
         wv[1] += wave_max(itT & 0xffffu);
         wv[2] += __any((itT >> 16) != 0) ? 1u : 0u;
@@ -540,35 +580,25 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
         if (terminated)
         {
             hasRay = false;
-            const uint32_t i = ridx;
-            if (ANY_HIT)
-            {
-                if (hq.base) // raw query mode (skh_trace): 1 = occluded, -1 = not
-                    hq.base[i] = best.found ? 1.0f : -1.0f;
-                else if (!best.found)
-                {
-                    const uint32_t pid = rq.ids()[i];
-                    float* rad = ps.base + (size_t)3 * ps.stride;
-                    rad[pid] += contrib[i];
-                    rad[pid + ps.stride] += contrib[i + contribStride];
-                    rad[pid + 2 * (size_t)ps.stride] += contrib[i + 2 * (size_t)contribStride];
-                }
-            }
-            else
-            {
-                hq.base[i] = best.found ? best.t : -1.0f;
-                reinterpret_cast<uint32_t*>(hq.base)[i + hq.stride] = best.inst;
-                reinterpret_cast<uint32_t*>(hq.base)[i + 2 * (size_t)hq.stride] = best.prim;
-                hq.base[i + 3 * (size_t)hq.stride] = best.u;
-                hq.base[i + 4 * (size_t)hq.stride] = best.v;
-            }
+            pending = true; // the result stays in registers until the next refill: one write block per refill, not per termination
         }
+        SKH_LP(cy[4] += __builtin_readcyclecounter() - cyA;)
     }
 #undef SKH_PUSH
 #undef SKH_POP
     if (COUNT)
     {
         const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.prims), c2 = wave_sum(tc.segs), d2 = wave_sum(tc.insts);
+#ifdef SKH_LANE_PROFILE
+        cy[5] = __builtin_readcyclecounter() - cyStart;
+        for (int k = 0; k < 6; ++k)
+        {
+            // cycle sums are wave-uniform increments taken by the lanes that were active: the busiest lane has (nearly) all of them
+            uint32_t hi = wave_max((uint32_t)(cy[k] >> 8));
+            if (lane == 0)
+                atomicAdd(&stats->cyc[ANY_HIT ? 1 : 0][k], (unsigned long long)hi << 8);
+        }
+#endif
         if (lane == 0)
         {
             atomicAdd(&stats->nodes[ANY_HIT ? 1 : 0], (unsigned long long)a);
@@ -618,7 +648,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
     v3 o = mk3(0.0f), d = mk3(0.0f), inv = mk3(0.0f), oo = mk3(0.0f), od = mk3(0.0f);
     float tmin = 0.0f, tmax = 0.0f;
     RayShear sh;
-    sh.kx = sh.ky = sh.kz = 0;
+    sh.perm = 0;
     sh.Sx = sh.Sy = sh.Sz = 0.0f;
     uint32_t curInst = 0xffffffffu;
     int sp = 0, cur = SKH_REF_INVALID;

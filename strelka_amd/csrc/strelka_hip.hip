@@ -1926,6 +1926,9 @@ skh_status skh_get_stats(skh_context* c, skh_stats* out)
         fprintf(stderr, "[lane-profile] %s: rays %llu nodes %llu tris %llu insts %llu | wave: nodeIt %llu triIt %llu instBlk %llu outer %llu refills %llu refilled %llu\n",
                 k ? "shadow" : "closest", k ? sd.raysShadow : sd.raysRadiance, sd.nodes[k], sd.prims[k], sd.insts[k], sd.wave[k][0], sd.wave[k][1],
                 sd.wave[k][2], sd.wave[k][3], sd.wave[k][4], sd.wave[k][5]);
+    for (int k = 0; k < 2; ++k)
+        fprintf(stderr, "[lane-cycles] %s: refill %.3g node %.3g leaf %.3g pop %.3g write %.3g total %.3g\n", k ? "shadow" : "closest", (double)sd.cyc[k][0],
+                (double)sd.cyc[k][1], (double)sd.cyc[k][2], (double)sd.cyc[k][3], (double)sd.cyc[k][4], (double)sd.cyc[k][5]);
 #endif
     out->ms_trace_closest = c->msClass[KC_TRACE_CLOSEST];
     out->ms_trace_shadow = c->msClass[KC_TRACE_SHADOW];
