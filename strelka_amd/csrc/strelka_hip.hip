@@ -80,8 +80,8 @@ struct skh_context
     bool countTraversal = false, timing = false;
     // measured on MI355X (kitchen C3, 16 sub-frames per pass): 24 resident waves/CU; refill thresholds 32 (closest) / 44 (any-hit)
     uint32_t wavesPerCU = 24;
-    uint32_t fetchMinClosest = 32, fetchMinShadow = 44;
-    uint32_t nodeBreakClosest = 14, nodeBreakShadow = 14; // leave the node loop when fewer than x/64 of the wave's rays are still descending
+    uint32_t fetchMinClosest = 40, fetchMinShadow = 52;
+    uint32_t nodeBreakClosest = 20, nodeBreakShadow = 20; // leave the node loop when fewer than x/64 of the wave's rays are still descending
     // ray re-ordering (per bounce): 0 = off, else Morton bits per axis of the origin cell (key = octant : morton)
     uint32_t sortBitsClosest = 0, sortBitsShadow = 0, sortFirstBounce = 1;
     // flatten = true: one world-space tree over all instanced primitives instead of TLAS + per-mesh BLAS.  Measured
