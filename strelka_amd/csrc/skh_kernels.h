@@ -1082,7 +1082,10 @@ SKH_DI SurfaceHit fill_curve(const DevScene& sc, const HostInstance& hi, const f
 // k_shade: __miss__ms (OptixRender.cu:250-257), __closesthit__light (:315-341), __closesthit__radiance
 // (closest_hit.cu:456-606) and the tail of the raygen bounce loop (OptixRender.cu:131-153) for one bounce.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512)
+#ifndef SKH_SHADE_BLOCK
+#define SKH_SHADE_BLOCK 256 // 132 VGPRs = 3 waves/SIMD: 256-thread blocks (1 wave per SIMD) fill all three, 512-thread blocks only two
+#endif
+__global__ void __launch_bounds__(SKH_SHADE_BLOCK)
     k_shade(DevScene sc, FrameP fp, uint32_t sampleOffset, uint32_t depth, const uint32_t* __restrict__ tileXY, RayQ rq,
             const uint32_t* __restrict__ countPtr, HitQ hq, PathS ps, RayQ nextQ, uint32_t* __restrict__ nextCount, RayQ shadowQ,
             float* __restrict__ contrib, uint32_t* __restrict__ shadowCount)

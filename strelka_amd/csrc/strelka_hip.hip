@@ -1497,7 +1497,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
             }
             {
                 SpanGuard g(c, KC_SHADE);
-                k_shade<<<(NP + 511) / 512, 512, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b, hq, ps, rq[(b + 1) & 1],
+                k_shade<<<(NP + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b, hq, ps, rq[(b + 1) & 1],
                                                    counts + 2 * (b + 1), shq, c->dContrib.as<float>(), counts + 2 * b + 1);
             }
             const uint32_t* permS = nullptr;
