@@ -195,6 +195,10 @@ enum
 // Sobol generator matrices (RandomSampler.h:139-164): filled by the host at context creation from the
 // Joe-Kuo recurrences (skh_capi.h: init_sobol_table) and checked against the reference table by the tests.
 __constant__ uint32_t c_sobol[5][32];
+// the same matrices folded per index byte: g_sobol_lut[(dim * 4 + byte) * 256 + v] = XOR of the columns selected by v.
+// k_shade stages it in LDS (20 KB): sobol_uint becomes 4 LDS reads + 3 XORs instead of 32 x (bfe, and, xor).
+#define SKH_SOBOL_LUT_WORDS (5 * 4 * 256)
+__device__ uint32_t g_sobol_lut[SKH_SOBOL_LUT_WORDS];
 
 SKH_DI uint32_t hash_murmur(uint32_t x) // RandomSampler.h:86-95
 {
@@ -267,13 +271,27 @@ SKH_DI Sampler init_sampler(uint32_t px, uint32_t py, uint32_t pixelSampleIndex,
     s.depth = 0;
     return s;
 }
+static_assert(DIM_COUNT % 5 == 0, "(dim + depth * DIM_COUNT) % 5 == dim % 5 needs DIM_COUNT to be a multiple of 5");
 // random<Dim>(state): RandomSampler.h:213-226, including the (Dim + depth*10) % 5 aliasing of dimensions
+// ((dim + depth * 10) % 5 == dim % 5: written that way so that aliased dimensions are visibly the same value)
 SKH_DI float sampler_random(const Sampler& s, uint32_t dim)
 {
-    const uint32_t dimension = (dim + s.depth * (uint32_t)DIM_COUNT) % 5u;
+    const uint32_t dimension = dim % 5u;
     uint32_t seed = hash_murmur(s.seed + s.depth);
     const uint32_t index = nested_uniform_scramble(s.sampleIdx, seed);
     const uint32_t r = nested_uniform_scramble(sobol_uint(index, dimension), hash_combine(seed, dimension));
+    return fminf((float)r * 0x1p-32f, SKH_ONE_MINUS_EPS);
+}
+
+// same value as sampler_random, Sobol point from the byte-folded table (lut = LDS copy of g_sobol_lut)
+SKH_DI float sampler_random_lut(const Sampler& s, uint32_t dim, const uint32_t* lut)
+{
+    const uint32_t dimension = dim % 5u;
+    uint32_t seed = hash_murmur(s.seed + s.depth);
+    const uint32_t index = nested_uniform_scramble(s.sampleIdx, seed);
+    const uint32_t* t = lut + dimension * 1024u;
+    const uint32_t X = t[index & 255u] ^ t[256u + ((index >> 8) & 255u)] ^ t[512u + ((index >> 16) & 255u)] ^ t[768u + (index >> 24)];
+    const uint32_t r = nested_uniform_scramble(X, hash_combine(seed, dimension));
     return fminf((float)r * 0x1p-32f, SKH_ONE_MINUS_EPS);
 }
 

@@ -1082,19 +1082,26 @@ SKH_DI SurfaceHit fill_curve(const DevScene& sc, const HostInstance& hi, const f
 // k_shade: __miss__ms (OptixRender.cu:250-257), __closesthit__light (:315-341), __closesthit__radiance
 // (closest_hit.cu:456-606) and the tail of the raygen bounce loop (OptixRender.cu:131-153) for one bounce.
 // ------------------------------------------------------------------------------------------------------------
+#ifndef SKH_SHADE_ATTR
+#define SKH_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(4, 4))) // 128 VGPRs (4 spilled dwords): four 256-thread blocks per CU
+#endif
 #ifndef SKH_SHADE_BLOCK
 #define SKH_SHADE_BLOCK 256 // 132 VGPRs = 3 waves/SIMD: 256-thread blocks (1 wave per SIMD) fill all three, 512-thread blocks only two
 #endif
-__global__ void __launch_bounds__(SKH_SHADE_BLOCK)
+__global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
     k_shade(DevScene sc, FrameP fp, uint32_t sampleOffset, uint32_t depth, const uint32_t* __restrict__ tileXY, RayQ rq,
             const uint32_t* __restrict__ countPtr, HitQ hq, PathS ps, RayQ nextQ, uint32_t* __restrict__ nextCount, RayQ shadowQ,
             float* __restrict__ contrib, uint32_t* __restrict__ shadowCount)
 {
     __shared__ uint32_t s_wave[SKH_COMPACT_MAX_WAVES + 1];
+    __shared__ uint32_t s_sobol[SKH_SOBOL_LUT_WORDS];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = *countPtr;
     if (blockIdx.x * blockDim.x >= n)
         return; // whole block past the end of the queue
+    for (uint32_t k = threadIdx.x; k < SKH_SOBOL_LUT_WORDS / 4; k += blockDim.x)
+        reinterpret_cast<uint4*>(s_sobol)[k] = reinterpret_cast<const uint4*>(g_sobol_lut)[k];
+    __syncthreads();
     const bool valid = i < n;
     bool emitNext = false, emitShadow = false;
     v3 nextO = mk3(0.0f), nextD = mk3(0.0f), shO = mk3(0.0f), shD = mk3(0.0f), shC = mk3(0.0f);
@@ -1167,8 +1174,8 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK)
                 {
                     const uint32_t mid = hi.material == 0xffffffffu ? 0u : hi.material; // OptixRender.cpp:768
                     const Material mat = sc.materials[mid < sc.numMaterials ? mid : 0u];
-                    const float xi0 = sampler_random(smp, DIM_BSDF0), xi1 = sampler_random(smp, DIM_BSDF1),
-                                xi2 = sampler_random(smp, DIM_BSDF2);
+                    const float xi0 = sampler_random_lut(smp, DIM_BSDF0, s_sobol), xi1 = sampler_random_lut(smp, DIM_BSDF1, s_sobol),
+                                xi2 = sampler_random_lut(smp, DIM_BSDF2, s_sobol);
                     const v3 k1 = -rayD;
                     BsdfSample bs;
                     bsdf_sample(mat, sh.normal, sh.geom_normal, k1, xi0, xi1, xi2, inside, bs);
@@ -1199,11 +1206,11 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK)
                             float distToLight = 0.0f;
                             if (sc.numLights > 0)
                             {
-                                const float u = sampler_random(smp, DIM_LIGHT_ID);
+                                const float u = sampler_random_lut(smp, DIM_LIGHT_ID, s_sobol);
                                 const uint32_t lightId = (uint32_t)((float)sc.numLights * u);
                                 const float lightSelectionPdf = 1.0f / (float)sc.numLights;
                                 const Light& light = sc.lights[lightId];
-                                const float ux = sampler_random(smp, DIM_LIGHT_X), uy = sampler_random(smp, DIM_LIGHT_Y);
+                                const float ux = sampler_random_lut(smp, DIM_LIGHT_X, s_sobol), uy = sampler_random_lut(smp, DIM_LIGHT_Y, s_sobol);
                                 LightSample d;
                                 d.pointOnLight = mk3(0.0f);
                                 d.pdf = 0.0f;
@@ -1291,7 +1298,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK)
         if (prdDepth > 3)
         {
             const float p = fmaxf(throughput.x, fmaxf(throughput.y, throughput.z));
-            if (sampler_random(smp, DIM_RR) > p)
+            if (sampler_random_lut(smp, DIM_RR, s_sobol) > p)
                 alive = false;
             else
                 throughput = throughput * (1.0f / (p + 1e-5f));

@@ -686,7 +686,19 @@ skh_status skh_create(int device_ordinal, skh_context** out_ctx)
         c->numCUs = prop.multiProcessorCount;
     uint32_t tab[5][32];
     init_sobol_table(tab);
-    if (hipMemcpyToSymbol(HIP_SYMBOL(c_sobol), tab, sizeof(tab)) != hipSuccess)
+    std::vector<uint32_t> lut(SKH_SOBOL_LUT_WORDS);
+    for (uint32_t d = 0; d < 5; ++d)
+        for (uint32_t b = 0; b < 4; ++b)
+            for (uint32_t v = 0; v < 256; ++v)
+            {
+                uint32_t x = 0;
+                for (uint32_t j = 0; j < 8; ++j)
+                    if ((v >> j) & 1u)
+                        x ^= tab[d][8 * b + j];
+                lut[(d * 4 + b) * 256 + v] = x;
+            }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_sobol), tab, sizeof(tab)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(g_sobol_lut), lut.data(), lut.size() * sizeof(uint32_t)) != hipSuccess)
     {
         delete c;
         return SKH_FAIL;
