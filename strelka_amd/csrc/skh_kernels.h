@@ -40,7 +40,8 @@ struct DevScene
     const uint32_t* tlasInst; // leaf order -> instance id
     int tlasRoot;
     uint32_t numInstances;
-    const DevInstance* inst;
+    const DevInstance* inst; // per instance (shading side, flattening)
+    const DevInstance* tinst; // per TLAS leaf: (instance, BLAS subtree) after opening; pad = instance id
     const Node4* triNodes;
     const float4* tris; // 3 x float4 per triangle, leaf order
     const Node4* segNodes;
@@ -116,6 +117,8 @@ struct FrameP // skh_frame_params + launch geometry
 #define SKH_STACK_OVF 104
 #define SKH_TRACE_BLOCK 64
 
+typedef float pk2 __attribute__((ext_vector_type(2))); // operand of the packed fp32 VALU ops (v_pk_fma_f32)
+
 struct TraceCounters
 {
     uint32_t nodes, prims, segs, insts;
@@ -176,6 +179,15 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 #ifndef SKH_POP_IN_LOOP
 #define SKH_POP_IN_LOOP 1
 #endif
+#ifndef SKH_ONE_TRI_PER_PASS
+#define SKH_ONE_TRI_PER_PASS 0 // measured: -4 % (the lagging lane costs more than the better-filled triangle block gains)
+#endif
+#ifndef SKH_TRACE_ATTR
+#define SKH_TRACE_ATTR
+#endif
+#ifndef SKH_PK_FMA
+#define SKH_PK_FMA 0
+#endif
 #ifndef SKH_FETCH_MIN
 #define SKH_FETCH_MIN 20 // refill the wave from the ray queue when at least this many lanes are idle
 #endif
@@ -194,7 +206,7 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 // the result does not depend on the BVH or on the traversal order (DESIGN.md "determinism").
 // ------------------------------------------------------------------------------------------------------------
 template <bool ANY_HIT, bool COUNT, bool CURVES>
-__global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WAVES)
+__global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WAVES) SKH_TRACE_ATTR
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
             uint32_t fetchArg /* refill threshold | node-break threshold << 16 */, const uint32_t* __restrict__ perm /*optional: sorted order -> queue index*/,
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
@@ -362,6 +374,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                 const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
                 if (COUNT)
                     tc.nodes++;
+                SKH_LP(if (!inBlas) tc.segs++;) // (profile build: TLAS share of the node visits, reported as "segs")
                 const uint32_t exps = __float_as_uint(w0.w);
                 // per axis: plane t = q * (cell * inv) + (o_node - o_ray) * inv; near/far bytes picked by the sign of inv
                 const float ax = __uint_as_float((exps & 0xffu) << 23) * inv.x, bx = (w0.x - o.x) * inv.x;
@@ -374,6 +387,27 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                 float tn[4];
                 int rf[4];
                 rf[0] = __float_as_int(w3.x), rf[1] = __float_as_int(w3.y), rf[2] = __float_as_int(w3.z), rf[3] = __float_as_int(w3.w);
+#if SKH_PK_FMA
+                // two children per v_pk_fma_f32 (same fused multiply-add per element as fmaf)
+                const pk2 pax = { ax, ax }, pbx = { bx, bx }, pay = { ay, ay }, pby = { by, by }, paz = { az, az }, pbz = { bz, bz };
+#pragma unroll
+                for (int k = 0; k < 4; k += 2)
+                {
+#define SKH_Q2(w) pk2{ (float)(((w) >> (8 * k)) & 0xffu), (float)(((w) >> (8 * k + 8)) & 0xffu) }
+                    const pk2 nx = __builtin_elementwise_fma(SKH_Q2(nxw), pax, pbx), fx = __builtin_elementwise_fma(SKH_Q2(fxw), pax, pbx);
+                    const pk2 ny = __builtin_elementwise_fma(SKH_Q2(nyw), pay, pby), fy = __builtin_elementwise_fma(SKH_Q2(fyw), pay, pby);
+                    const pk2 nz = __builtin_elementwise_fma(SKH_Q2(nzw), paz, pbz), fz = __builtin_elementwise_fma(SKH_Q2(fzw), paz, pbz);
+#undef SKH_Q2
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                    {
+                        const float tnear = fmaxf(fmaxf(nx[j], ny[j]), fmaxf(nz[j], tmin));
+                        const float tfar = fminf(fminf(fx[j], fy[j]), fminf(fz[j], best.t));
+                        const bool hit = rf[k + j] != SKH_REF_INVALID && tnear <= tfar * 1.0000002384185791015625f;
+                        tn[k + j] = hit ? tnear : INFINITY;
+                    }
+                }
+#else
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                 {
@@ -385,6 +419,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                     const bool hit = rf[k] != SKH_REF_INVALID && tnear <= tfar * 1.0000002384185791015625f;
                     tn[k] = hit ? tnear : INFINITY;
                 }
+#endif
 #ifdef SKH_DEBUG_PRINT
                 if (ridx == 0)
                     printf("ray o %g %g %g inv %g %g %g ax %g bx %g ay %g by %g az %g bz %g nxw %08x fxw %08x\n", o.x, o.y, o.z, inv.x, inv.y, inv.z, ax, bx, ay, by, az, bz, nxw, fxw);
@@ -409,12 +444,26 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                     SKH_CSWAP(0, 2)
                     SKH_CSWAP(1, 3)
                     SKH_CSWAP(1, 2)
-                    if (tn[3] < INFINITY)
-                        SKH_PUSH(rf[3]);
-                    if (tn[2] < INFINITY)
-                        SKH_PUSH(rf[2]);
-                    if (tn[1] < INFINITY)
-                        SKH_PUSH(rf[1]);
+                    if (sp + 3 <= SKH_STACK_LDS)
+                    {
+                        // the c hit children among rf[1..3] go to slots sp .. sp+c-1 (farthest first); the writes are
+                        // unconditional (what lands above the new top is never read): no branch per push
+                        const int c = (tn[1] < INFINITY ? 1 : 0) + (tn[2] < INFINITY ? 1 : 0) + (tn[3] < INFINITY ? 1 : 0);
+                        int* p = lds + sp * SKH_TRACE_BLOCK;
+                        p[0] = c == 3 ? rf[3] : (c == 2 ? rf[2] : rf[1]);
+                        p[SKH_TRACE_BLOCK] = c == 3 ? rf[2] : rf[1];
+                        p[2 * SKH_TRACE_BLOCK] = rf[1];
+                        sp += c;
+                    }
+                    else
+                    {
+                        if (tn[3] < INFINITY)
+                            SKH_PUSH(rf[3]);
+                        if (tn[2] < INFINITY)
+                            SKH_PUSH(rf[2]);
+                        if (tn[1] < INFINITY)
+                            SKH_PUSH(rf[1]);
+                    }
                     cur = tn[0] < INFINITY ? rf[0] : SKH_REF_INVALID;
                 }
                 else
@@ -462,8 +511,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                 if (!inBlas)
                 {
                     // TLAS leaves hold exactly one instance
-                    const uint32_t id = first; // TLAS leaves hold exactly one instance: `first` IS the instance id
-                    const float4* ip = reinterpret_cast<const float4*>(sc.inst + id);
+                    const float4* ip = reinterpret_cast<const float4*>(sc.tinst + first); // `first` = TLAS leaf number
                     const float4 i3 = ip[3];
                     if (__float_as_uint(i3.y) & rayMask)
                     {
@@ -475,7 +523,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                         d = xform_vector(m, dw);
                         inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                         sh = make_shear(d);
-                        curInst = id;
+                        curInst = __float_as_uint(i3.w); // the instance this leaf belongs to
                         curType = __float_as_uint(i3.z);
                         nodes = (CURVES && curType == 2) ? sc.segNodes : sc.triNodes;
                         inBlas = true;
@@ -515,7 +563,18 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                 }
                 else
                 {
+#if SKH_ONE_TRI_PER_PASS
+                    // one triangle per pass of the outer loop: a lane with more triangles in its leaf keeps the leaf
+                    // (advanced by one) and meets the other lanes' triangles again in the next pass
+                    if (count > 1u)
+                    {
+                        cur = ~(int)(((first + 1u) << 3) | (count - 2u));
+                        entered = true; // (do not pop)
+                    }
+                    for (uint32_t k = 0; k < 1u; ++k)
+#else
                     for (uint32_t k = 0; k < count; ++k)
+#endif
                     {
                         const float4* tp = sc.tris + 3 * (size_t)(first + k);
                         const float4 a = tp[0], b = tp[1], c = tp[2];

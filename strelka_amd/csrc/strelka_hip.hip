@@ -65,7 +65,7 @@ struct skh_context
     DevBuf dVerts, dIndices, dMeshes, dPoints, dRadii, dInstances, dLights, dMaterials;
     DevBuf dCurveSegBase, dSegStartAll;
     // accel
-    DevBuf dTriNodes, dTris, dSegNodes, dSegs, dSegPrim, dTlasNodes, dTlasInst, dDevInst;
+    DevBuf dTriNodes, dTris, dSegNodes, dSegs, dSegPrim, dTlasNodes, dTlasInst, dDevInst, dTravInst;
     int tlasRoot = SKH_REF_INVALID;
     bool accelBuilt = false;
     uint32_t nTris = 0, nSegs = 0;
@@ -77,6 +77,7 @@ struct skh_context
     DevBuf dTileXY, dAccum, dDiffuse, dSpecular, dDiffCnt, dSpecCnt, dSums, dPath, dRayQ[2], dHits, dShadowQ, dContrib, dCounts,
         dOvf, dStats, dScratchImage;
     uint32_t traceBlocks = 0;
+    uint32_t numTlasLeaves = 0;
     bool countTraversal = false, timing = false;
     // measured on MI355X (kitchen C3, 16 sub-frames per pass): 24 resident waves/CU; refill thresholds 32 (closest) / 44 (any-hit)
     uint32_t wavesPerCU = 24;
@@ -92,6 +93,7 @@ struct skh_context
     int wRoot = SKH_REF_INVALID;
     uint32_t wTriCount = 0, wSegCount = 0;
     uint32_t subframeBatch = 0, batchCapacity = 1; // option subframe_batch: 0 = auto
+    uint32_t tlasOpen = 1; // TLAS opening: up to tlasOpen x numInstances leaves; 1 = one leaf per instance (default: on the kitchen stand-in 2..16 were 4-9 % slower, more instance entries for no fewer nodes)
     uint32_t leafMaxTris = 2; // measured on MI355X: 2 beats 1, 3, 4, 6, 8 (the kernel is ALU bound, wasted triangle tests cost more than extra nodes)
     uint32_t buildQuality = 1; // 0: Karras radix tree (fastest build), 1: PLOC clustering (SAH-class quality)
     float sceneLo[3] = { 0, 0, 0 }, sceneHi[3] = { 1, 1, 1 };
@@ -720,7 +722,7 @@ void skh_destroy(skh_context* c)
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : { &c->dVerts, &c->dIndices, &c->dMeshes, &c->dPoints, &c->dRadii, &c->dInstances, &c->dLights, &c->dMaterials,
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
-                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
+                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
                        &c->dCounts, &c->dOvf, &c->dStats, &c->dScratchImage, &c->dSortKeys[0], &c->dSortKeys[1], &c->dSortVals[0],
                        &c->dSortVals[1], &c->dSortHist, &c->dWNodes, &c->dWTris, &c->dWSegs, &c->dWSegMeta })
@@ -1141,30 +1143,132 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
             cleanup();
             return SKH_FAIL;
         }
-        std::vector<HostBox> hb(nInst);
+        std::vector<HostBox> hb;
         std::vector<uint32_t> ids;
+        std::vector<DevInstance> tinst; // traversal records, one per TLAS leaf; pad = id of the instance it belongs to
         float slo[3] = { INFINITY, INFINITY, INFINITY }, shi[3] = { -INFINITY, -INFINITY, -INFINITY };
-        for (uint32_t i = 0; i < nInst; ++i)
         {
-            hb[i] = HostBox{ { hlo[i].x, hlo[i].y, hlo[i].z }, { hhi[i].x, hhi[i].y, hhi[i].z } };
-            if (hinst[i].mask != 0)
+            // ---- TLAS opening (partial re-braiding) ----
+            // A TLAS leaf is (instance, BLAS subtree).  Starting from one leaf per instance, the leaf with the largest world
+            // box is replaced by the children of its subtree's root until the budget is used: big instances that contain or
+            // overlap others (rooms, floors, rotated boxes) stop dragging every ray through their whole box.  Results do not
+            // depend on it (closest hit = min t, ties by (instance, primitive)); only nodes / instance entries per ray do.
+            std::vector<Node4> hTri, hSeg;
+            const bool open = c->tlasOpen > 1;
+            if (open)
             {
-                ids.push_back(i);
-                for (int k = 0; k < 3; ++k)
+                hTri.resize(triOut.numNodes);
+                hSeg.resize(segOut.numNodes);
+                if ((triOut.numNodes && hipMemcpy(hTri.data(), c->dTriNodes.p, sizeof(Node4) * hTri.size(), hipMemcpyDeviceToHost) != hipSuccess) ||
+                    (segOut.numNodes && hipMemcpy(hSeg.data(), c->dSegNodes.p, sizeof(Node4) * hSeg.size(), hipMemcpyDeviceToHost) != hipSuccess))
                 {
-                    slo[k] = std::min(slo[k], hb[i].lo[k]);
-                    shi[k] = std::max(shi[k], hb[i].hi[k]);
+                    c->err = "skh_build_accel: BLAS node read-back failed";
+                    cleanup();
+                    return SKH_FAIL;
                 }
             }
+            struct Ref
+            {
+                uint32_t inst;
+                int node;
+                HostBox box;
+                float area;
+            };
+            auto areaOf = [](const HostBox& b) { return hb_half_area(b.lo, b.hi); };
+            auto cmp = [](const Ref& a, const Ref& b) { return a.area < b.area || (a.area == b.area && a.inst > b.inst); };
+            std::vector<Ref> heap, done;
+            uint32_t nValid = 0;
+            for (uint32_t i = 0; i < nInst; ++i)
+                if (hinst[i].mask != 0)
+                {
+                    Ref r{ i, hinst[i].rootRef, HostBox{ { hlo[i].x, hlo[i].y, hlo[i].z }, { hhi[i].x, hhi[i].y, hhi[i].z } }, 0.0f };
+                    r.area = areaOf(r.box);
+                    heap.push_back(r);
+                    ++nValid;
+                }
+            std::make_heap(heap.begin(), heap.end(), cmp);
+            const size_t budget = open ? (size_t)nValid * c->tlasOpen : (size_t)nValid;
+            while (!heap.empty())
+            {
+                std::pop_heap(heap.begin(), heap.end(), cmp);
+                const Ref r = heap.back();
+                heap.pop_back();
+                const std::vector<Node4>& bn = hinst[r.inst].type == 2 ? hSeg : hTri;
+                if (!open || r.node < 0 || r.node == SKH_REF_INVALID || (size_t)r.node >= bn.size() || heap.size() + done.size() + 4 > budget)
+                {
+                    done.push_back(r);
+                    continue;
+                }
+                const Node4& nd = bn[(size_t)r.node];
+                const float* M = c->instances[r.inst].transform; // object -> world, 3x4 row-major
+                for (int ch = 0; ch < 4; ++ch)
+                {
+                    if (nd.child[ch] == SKH_REF_INVALID)
+                        continue;
+                    // child box in object space (decoded as the traversal kernel sees it), padded, then the box of its
+                    // eight transformed corners, padded again and clipped to the parent leaf's box
+                    double lo[3], hi[3];
+                    for (int a = 0; a < 3; ++a)
+                    {
+                        const double cell = std::ldexp(1.0, (int)((nd.exps >> (8 * a)) & 0xffu) - 127);
+                        lo[a] = (double)nd.o[a] + cell * (double)((nd.qlo[a] >> (8 * ch)) & 0xffu);
+                        hi[a] = (double)nd.o[a] + cell * (double)((nd.qhi[a] >> (8 * ch)) & 0xffu);
+                        const double pad = (std::fabs(lo[a]) + std::fabs(hi[a])) * 0x1p-20 + 1e-30;
+                        lo[a] -= pad;
+                        hi[a] += pad;
+                    }
+                    Ref q{ r.inst, nd.child[ch], HostBox{ { INFINITY, INFINITY, INFINITY }, { -INFINITY, -INFINITY, -INFINITY } }, 0.0f };
+                    for (int k = 0; k < 8; ++k)
+                    {
+                        const double x = (k & 1) ? hi[0] : lo[0], y = (k & 2) ? hi[1] : lo[1], z = (k & 4) ? hi[2] : lo[2];
+                        for (int a = 0; a < 3; ++a)
+                        {
+                            const double w = (double)M[4 * a] * x + (double)M[4 * a + 1] * y + (double)M[4 * a + 2] * z + (double)M[4 * a + 3];
+                            const double pad = std::fabs(w) * 0x1p-20 + 1e-30;
+                            q.box.lo[a] = std::min(q.box.lo[a], (float)(w - pad));
+                            q.box.hi[a] = std::max(q.box.hi[a], (float)(w + pad));
+                        }
+                    }
+                    for (int a = 0; a < 3; ++a)
+                    {
+                        q.box.lo[a] = std::max(q.box.lo[a], r.box.lo[a]);
+                        q.box.hi[a] = std::min(q.box.hi[a], r.box.hi[a]);
+                        if (q.box.hi[a] < q.box.lo[a])
+                            q.box.hi[a] = q.box.lo[a];
+                    }
+                    q.area = areaOf(q.box);
+                    heap.push_back(q);
+                    std::push_heap(heap.begin(), heap.end(), cmp);
+                }
+            }
+            // deterministic leaf numbering: by (instance, node)
+            std::sort(done.begin(), done.end(), [](const Ref& a, const Ref& b) { return a.inst < b.inst || (a.inst == b.inst && a.node < b.node); });
+            hb.resize(done.size());
+            tinst.resize(std::max<size_t>(1, done.size()));
+            for (size_t r = 0; r < done.size(); ++r)
+            {
+                hb[r] = done[r].box;
+                ids.push_back((uint32_t)r);
+                tinst[r] = hinst[done[r].inst];
+                tinst[r].rootRef = done[r].node;
+                tinst[r].pad = done[r].inst;
+                for (int k = 0; k < 3; ++k)
+                {
+                    slo[k] = std::min(slo[k], hb[r].lo[k]);
+                    shi[k] = std::max(shi[k], hb[r].hi[k]);
+                }
+            }
+            c->numTlasLeaves = (uint32_t)done.size();
         }
+        BA(dev_upload(c, c->dTravInst, tinst.data(), sizeof(DevInstance) * tinst.size()));
         std::vector<Node4> hnodes;
         std::vector<uint32_t> horder;
         c->tlasRoot = tlas_sah_build(hb, ids, hnodes, horder);
         if (getenv("SKH_DEBUG"))
         {
-            fprintf(stderr, "[skh] TLAS: %u instances, %zu valid, %zu nodes, root %d\n", nInst, ids.size(), hnodes.size(), c->tlasRoot);
-            for (uint32_t i = 0; i < std::min(nInst, 8u); ++i)
-                fprintf(stderr, "[skh]  inst %u mask %u root %d box %g %g %g .. %g %g %g\n", i, hinst[i].mask, hinst[i].rootRef, hb[i].lo[0], hb[i].lo[1], hb[i].lo[2], hb[i].hi[0], hb[i].hi[1], hb[i].hi[2]);
+            fprintf(stderr, "[skh] TLAS: %u instances, %zu leaves, %zu nodes, root %d\n", nInst, ids.size(), hnodes.size(), c->tlasRoot);
+            for (uint32_t i = 0; i < std::min((uint32_t)hb.size(), 8u); ++i)
+                fprintf(stderr, "[skh]  leaf %u inst %u root %d box %g %g %g .. %g %g %g\n", i, tinst[i].pad, tinst[i].rootRef, hb[i].lo[0], hb[i].lo[1], hb[i].lo[2], hb[i].hi[0], hb[i].hi[1], hb[i].hi[2]);
         }
         dev_free(c->dTlasNodes);
         dev_free(c->dTlasInst);
@@ -1180,6 +1284,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     {
         dev_free(c->dTlasNodes);
         dev_free(c->dTlasInst);
+        dev_free(c->dTravInst);
         c->tlasRoot = SKH_REF_INVALID;
     }
     hipError_t e = hipStreamSynchronize(st);
@@ -1334,6 +1439,7 @@ static DevScene make_dev_scene(const skh_context* c)
     sc.tlasRoot = c->tlasRoot;
     sc.numInstances = c->nInstances;
     sc.inst = c->dDevInst.as<DevInstance>();
+    sc.tinst = c->dTravInst.as<DevInstance>();
     sc.triNodes = c->dTriNodes.as<Node4>();
     sc.tris = c->dTris.as<float4>();
     sc.segNodes = c->dSegNodes.as<Node4>();
@@ -1860,6 +1966,13 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
             return SKH_INVALID_ARGUMENT;
         (n == "fetch_min_closest" ? c->fetchMinClosest : c->fetchMinShadow) = (uint32_t)value;
     }
+    else if (n == "tlas_open")
+    {
+        if (value < 0 || value > 64)
+            return SKH_INVALID_ARGUMENT;
+        c->tlasOpen = (uint32_t)value;
+        c->accelBuilt = false;
+    }
     else if (n == "node_break_closest" || n == "node_break_shadow")
     {
         if (value < 0 || value > 64)
@@ -1935,8 +2048,8 @@ skh_status skh_get_stats(skh_context* c, skh_stats* out)
     }
 #ifdef SKH_LANE_PROFILE
     for (int k = 0; k < 2; ++k)
-        fprintf(stderr, "[lane-profile] %s: rays %llu nodes %llu tris %llu insts %llu | wave: nodeIt %llu triIt %llu instBlk %llu outer %llu refills %llu refilled %llu\n",
-                k ? "shadow" : "closest", k ? sd.raysShadow : sd.raysRadiance, sd.nodes[k], sd.prims[k], sd.insts[k], sd.wave[k][0], sd.wave[k][1],
+        fprintf(stderr, "[lane-profile] %s: rays %llu nodes %llu (TLAS %llu) tris %llu insts %llu | wave: nodeIt %llu triIt %llu instBlk %llu outer %llu refills %llu refilled %llu\n",
+                k ? "shadow" : "closest", k ? sd.raysShadow : sd.raysRadiance, sd.nodes[k], sd.segs[k], sd.prims[k], sd.insts[k], sd.wave[k][0], sd.wave[k][1],
                 sd.wave[k][2], sd.wave[k][3], sd.wave[k][4], sd.wave[k][5]);
     for (int k = 0; k < 2; ++k)
         fprintf(stderr, "[lane-cycles] %s: refill %.3g node %.3g leaf %.3g pop %.3g write %.3g total %.3g\n", k ? "shadow" : "closest", (double)sd.cyc[k][0],
