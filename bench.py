@@ -84,8 +84,14 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("SKH_DIST_BACKEND", "nccl")  # "gloo": several ranks on ONE GPU (tests on a 1-GPU box)
+        if backend == "gloo":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
 
     from strelka_amd import build, capi, scene as S, scenes, tiles
@@ -155,10 +161,11 @@ def main():
     st = ctx.stats()
     rays_local = st["rays_radiance"] + st["rays_shadow"]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        rdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        rr = torch.tensor([float(rays_local)], dtype=torch.float64, device=dev)
+        rr = torch.tensor([float(rays_local)], dtype=torch.float64, device=rdev)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         rays_total = float(rr.item())
     else:
@@ -203,6 +210,12 @@ def main():
                                      "tris": round(cst["prims_tested"][0] / max(1, cst["rays_radiance"]), 2),
                                      "instances": round(cst["instances_entered"][0] / max(1, cst["rays_radiance"]), 2)}},
         }
+        if os.environ.get("SKH_BENCH_CHECKSUM"):
+            # CRC of the final accumulation image (tests: a tile-sharded N-rank run must reproduce the 1-rank image exactly)
+            import zlib
+
+            img = image.cpu().numpy() if world > 1 else ctx.read_accum()
+            out["image_crc32"] = zlib.crc32(np.ascontiguousarray(img[..., :3]).tobytes())
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(arr, cam, W, H, args.spp, args.depth, args.cpu_budget)
         print(json.dumps(out), flush=True)

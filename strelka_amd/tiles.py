@@ -35,8 +35,18 @@ def gather_tiles(local_tiles, world_size, rank, dist=None, dst=0):
 
     if world_size == 1 or dist is None:
         return [local_tiles]
+    if local_tiles.is_cuda and dist.get_backend() == "gloo":
+        # (test configuration: several ranks on one GPU, no RCCL) stage through the host
+        host = local_tiles.cpu()
+        out = [torch.empty_like(host) for _ in range(world_size)] if rank == dst else None
+        dist.gather(host, gather_list=out, dst=dst)
+        return [t.to(local_tiles.device) for t in out] if rank == dst else None
     out = [torch.empty_like(local_tiles) for _ in range(world_size)] if rank == dst else None
     dist.gather(local_tiles, gather_list=out, dst=dst)
+    if local_tiles.is_cuda:
+        # the collective runs on RCCL's stream and the consumer (skh_scatter_tiles) on the renderer's own stream:
+        # finish the gather before handing the buffers over
+        torch.cuda.current_stream().synchronize()
     return out
 
 

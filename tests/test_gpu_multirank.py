@@ -1,0 +1,33 @@
+"""N > 1 launch path of bench.py on a 1-GPU box: two ranks share cuda:0 (SKH_DIST_BACKEND=gloo stages the tile gather
+through the host, everything else -- tile assignment, per-rank rendering, gather, de-tiling scatter on the root, timing
+reduction -- is the code the driver runs with RCCL on 8 GPUs).  The gathered image must equal the 1-rank image bit for bit."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--scene", "cornell", "--width", "200", "--height", "136", "--spp", "5", "--depth", "4", "--steps", "1", "--warmup", "0",
+        "--no-cpu-baseline"]
+
+
+def _run(cmd, env):
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_two_ranks_reproduce_the_single_rank_image():
+    env = dict(os.environ, SKH_BENCH_CHECKSUM="1", SKH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, env)
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29533", "bench.py", "--gpus", "2"] + ARGS, env)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
+    assert two["image_crc32"] == one["image_crc32"]
+    assert two["scaling"] == "strong" and two["value"] > 0
