@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--tile", type=int, default=32)
-    ap.add_argument("--scene", default="kitchen")
+    ap.add_argument("--scene", default="kitchen", help="kitchen | cornell | hair | path to a .skscene dump or a .gltf file")
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to skh_set_option")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,9 +101,23 @@ def main():
         sc = scenes.kitchen_standin()
         workload = ("kitchen stand-in (SURVEY 8d C3): %d unique triangles, %d instances of %d meshes, "
                     "4 rect + 1 distant light, 60/25/10/5 %% diffuse/glossy/metal/glass")
-    else:
+    elif args.scene == "hair":
+        sc = scenes.hair_standin()
+        workload = "hair stand-in (SURVEY 8d C5): %d scalp triangles, %d instances of %d meshes + 100 k strands"
+    elif args.scene == "cornell":
         sc = scenes.cornell_box()
         workload = "cornell box (C2): %d triangles, %d instances of %d meshes"
+    else:
+        # a flat dump of a real bake (strelka_amd/scene_io.py) or a glTF file
+        from strelka_amd import scene_io
+
+        if args.scene.endswith((".gltf", ".glb")):
+            from strelka_amd import gltf
+
+            sc = gltf.load_gltf(args.scene)
+        else:
+            sc = scene_io.load_scene(args.scene)
+        workload = os.path.basename(args.scene) + ": %d triangles, %d instances of %d meshes"
     arr = sc.arrays()
     workload = workload % (len(arr["indices"]) // 3, len(arr["instances"]), len(arr["meshes"]))
     cam = sc.getCamera()

@@ -91,13 +91,30 @@ int main(int argc, char** argv)
 {
     if (argc < 3)
     {
-        fprintf(stderr, "usage: host_test cpu|gpu <outdir> [frames]\n");
+        fprintf(stderr, "usage: host_test cpu|gpu <outdir> [frames] | host_test load <outdir> <file.skscene>\n");
         return 2;
     }
     const std::string mode = argv[1], dir = argv[2];
     const int frames = argc > 3 ? atoi(argv[3]) : 6;
+    if (mode == "load")
+    {
+        // host_test load <outdir> <file.skscene>: read a dump (e.g. one written by strelka_amd/scene_io.py) and write it back
+        Scene loaded;
+        if (argc < 4 || !loaded.loadDump(argv[3]))
+        {
+            fprintf(stderr, "loadDump failed\n");
+            return 6;
+        }
+        if (!loaded.saveDump(dir + "/resaved.skscene"))
+            return 7;
+        printf("host_test load ok: %zu vertices, %zu instances, %zu lights, %u cameras\n", loaded.getVertices().size(), loaded.getInstances().size(),
+               loaded.getLights().size(), loaded.getCameraCount());
+        return 0;
+    }
     Scene scene;
     buildScene(scene);
+    if (!scene.saveDump(dir + "/scene.skscene"))
+        return 8;
     dump(dir, "vertices.bin", scene.getVertices().data(), scene.getVertices().size());
     dump(dir, "indices.bin", scene.getIndices().data(), scene.getIndices().size());
     dump(dir, "meshes.bin", scene.getMeshes().data(), scene.getMeshes().size());

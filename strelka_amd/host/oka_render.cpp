@@ -265,17 +265,8 @@ void Camera::setRotation(const quat& q)
     mOrientation = q;
     updateViewMatrix();
 }
-void Camera::lookAt(const float3& eye, const float3& target, const float3& up)
+quat quatFromRotationRows(float r00, float r01, float r02, float r10, float r11, float r12, float r20, float r21, float r22)
 {
-    auto sub = [](const float3& a, const float3& b) { return float3{ a.x - b.x, a.y - b.y, a.z - b.z }; };
-    auto crs = [](const float3& a, const float3& b) { return float3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; };
-    auto nrm = [](const float3& a) {
-        const float l = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
-        return float3{ a.x / l, a.y / l, a.z / l };
-    };
-    const float3 f = nrm(sub(target, eye)), s = nrm(crs(f, up)), u = crs(s, f);
-    // rotation matrix rows (s, u, -f) -> quaternion
-    const float r00 = s.x, r01 = s.y, r02 = s.z, r10 = u.x, r11 = u.y, r12 = u.z, r20 = -f.x, r21 = -f.y, r22 = -f.z;
     quat q;
     const float tr = r00 + r11 + r22;
     if (tr > 0)
@@ -310,6 +301,19 @@ void Camera::lookAt(const float3& eye, const float3& target, const float3& up)
         q.y = (r12 + r21) / S;
         q.z = 0.25f * S;
     }
+    return q;
+}
+void Camera::lookAt(const float3& eye, const float3& target, const float3& up)
+{
+    auto sub = [](const float3& a, const float3& b) { return float3{ a.x - b.x, a.y - b.y, a.z - b.z }; };
+    auto crs = [](const float3& a, const float3& b) { return float3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; };
+    auto nrm = [](const float3& a) {
+        const float l = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+        return float3{ a.x / l, a.y / l, a.z / l };
+    };
+    const float3 f = nrm(sub(target, eye)), s = nrm(crs(f, up)), u = crs(s, f);
+    // rotation matrix rows (s, u, -f) -> quaternion
+    const quat q = quatFromRotationRows(s.x, s.y, s.z, u.x, u.y, u.z, -f.x, -f.y, -f.z);
     mOrientation = q;
     position = eye;
     updateViewMatrix();
@@ -379,6 +383,220 @@ uint32_t Scene::addCamera(Camera& camera)
 {
     mCameras.push_back(camera);
     return (uint32_t)mCameras.size() - 1;
+}
+// ------------------------------------------------------------------------------------------------------
+// Flat binary scene dump (".skscene").  Format: strelka_amd/scene_io.py (the Python reader / writer of the
+// same file).  saveDump is the exporter a Strelka build runs after its USD / glTF bake: it
+// writes exactly what render() uploads on its first frame.
+// ------------------------------------------------------------------------------------------------------
+namespace
+{
+struct DumpCamera
+{
+    float view[16]; // world -> view, row-major
+    float fov, znear, zfar;
+    uint32_t pad[5];
+};
+static_assert(sizeof(DumpCamera) == 96, "camera record");
+void putSection(FILE* f, const char tag[4], uint32_t elemSize, uint64_t count, const void* data)
+{
+    fwrite(tag, 1, 4, f);
+    fwrite(&elemSize, 4, 1, f);
+    fwrite(&count, 8, 1, f);
+    const uint64_t bytes = (uint64_t)elemSize * count;
+    if (bytes)
+        fwrite(data, 1, bytes, f);
+    static const char zero[8] = { 0 };
+    fwrite(zero, 1, (size_t)((8 - bytes % 8) % 8), f);
+}
+std::vector<skh_instance> abiInstances(const std::vector<Instance>& in)
+{
+    std::vector<skh_instance> out(in.size());
+    for (size_t i = 0; i < in.size(); ++i)
+    {
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c)
+                out[i].transform[4 * r + c] = in[i].transform.m[c][r]; // glm::float3x4(glm::rowMajor4(transform)), OptixRender.cpp:438
+        out[i].type = (uint32_t)in[i].type;
+        out[i].geom_id = in[i].mMeshId;
+        out[i].material_id = in[i].mMaterialId;
+        out[i].light_id = in[i].mLightId;
+    }
+    return out;
+}
+} // namespace
+
+bool Scene::saveDump(const std::string& path) const
+{
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f)
+        return false;
+    const uint32_t version = 1, sections = 10 + (mCameras.empty() ? 0u : 1u);
+    fwrite("SKSCENE\0", 1, 8, f);
+    fwrite(&version, 4, 1, f);
+    fwrite(&sections, 4, 1, f);
+    putSection(f, "VERT", sizeof(Vertex), mVertices.size(), mVertices.data());
+    putSection(f, "INDX", 4, mIndices.size(), mIndices.data());
+    putSection(f, "MESH", sizeof(Mesh), mMeshes.size(), mMeshes.data());
+    putSection(f, "CPTS", sizeof(float3), mCurvePoints.size(), mCurvePoints.data());
+    putSection(f, "CWID", 4, mCurveWidths.size(), mCurveWidths.data());
+    putSection(f, "CVCN", 4, mCurveVertexCounts.size(), mCurveVertexCounts.data());
+    putSection(f, "CURV", sizeof(Curve), mCurves.size(), mCurves.data());
+    const std::vector<skh_instance> inst = abiInstances(mInstances);
+    putSection(f, "INST", sizeof(skh_instance), inst.size(), inst.data());
+    putSection(f, "LGHT", sizeof(Light), mLights.size(), mLights.data());
+    std::vector<skh_material> mats;
+    for (const MaterialDescription& m : mMaterialsDescs)
+        mats.push_back(m.args);
+    putSection(f, "MATL", sizeof(skh_material), mats.size(), mats.data());
+    if (!mCameras.empty())
+    {
+        std::vector<DumpCamera> cams(mCameras.size());
+        for (size_t k = 0; k < cams.size(); ++k)
+        {
+            memset(&cams[k], 0, sizeof(DumpCamera));
+            for (int r = 0; r < 4; ++r)
+                for (int c = 0; c < 4; ++c)
+                    cams[k].view[4 * r + c] = mCameras[k].matrices.view.m[c][r];
+            cams[k].fov = mCameras[k].fov;
+            cams[k].znear = mCameras[k].znear;
+            cams[k].zfar = mCameras[k].zfar;
+        }
+        putSection(f, "CAMR", sizeof(DumpCamera), cams.size(), cams.data());
+    }
+    const bool ok = !ferror(f);
+    return fclose(f) == 0 && ok;
+}
+
+bool Scene::loadDump(const std::string& path)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f)
+        return false;
+    std::vector<char> blob;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0)
+        blob.insert(blob.end(), buf, buf + n);
+    fclose(f);
+    if (blob.size() < 16 || memcmp(blob.data(), "SKSCENE\0", 8) != 0)
+        return false;
+    uint32_t version, sections;
+    memcpy(&version, &blob[8], 4);
+    memcpy(&sections, &blob[12], 4);
+    if (version != 1)
+        return false;
+    Scene fresh;
+    size_t off = 16;
+    auto take = [&](auto& vec, const char* data, uint32_t elemSize, uint64_t count) {
+        using T = typename std::remove_reference<decltype(vec)>::type::value_type;
+        if (elemSize != sizeof(T))
+            return false;
+        vec.resize((size_t)count);
+        if (count)
+            memcpy(vec.data(), data, (size_t)count * sizeof(T));
+        return true;
+    };
+    for (uint32_t s = 0; s < sections; ++s)
+    {
+        if (off + 16 > blob.size())
+            return false;
+        char tag[5] = { 0 };
+        uint32_t elemSize;
+        uint64_t count;
+        memcpy(tag, &blob[off], 4);
+        memcpy(&elemSize, &blob[off + 4], 4);
+        memcpy(&count, &blob[off + 8], 8);
+        off += 16;
+        const uint64_t bytes = (uint64_t)elemSize * count;
+        if (off + bytes > blob.size())
+            return false;
+        const char* data = blob.data() + off;
+        off += (size_t)(bytes + (8 - bytes % 8) % 8);
+        const std::string t(tag);
+        bool ok = true;
+        if (t == "VERT")
+            ok = take(fresh.mVertices, data, elemSize, count);
+        else if (t == "INDX")
+            ok = take(fresh.mIndices, data, elemSize, count);
+        else if (t == "MESH")
+            ok = take(fresh.mMeshes, data, elemSize, count);
+        else if (t == "CPTS")
+            ok = take(fresh.mCurvePoints, data, elemSize, count);
+        else if (t == "CWID")
+            ok = take(fresh.mCurveWidths, data, elemSize, count);
+        else if (t == "CVCN")
+            ok = take(fresh.mCurveVertexCounts, data, elemSize, count);
+        else if (t == "CURV")
+            ok = take(fresh.mCurves, data, elemSize, count);
+        else if (t == "LGHT")
+            ok = take(fresh.mLights, data, elemSize, count);
+        else if (t == "INST")
+        {
+            std::vector<skh_instance> in;
+            ok = take(in, data, elemSize, count);
+            for (const skh_instance& a : in)
+            {
+                Instance i;
+                i.transform = float4x4(1.0f);
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 4; ++c)
+                        i.transform.m[c][r] = a.transform[4 * r + c];
+                i.type = (Instance::Type)a.type;
+                i.mMeshId = a.geom_id;
+                i.mMaterialId = a.material_id;
+                i.mLightId = a.light_id;
+                fresh.mInstances.push_back(i);
+            }
+        }
+        else if (t == "MATL")
+        {
+            std::vector<skh_material> in;
+            ok = take(in, data, elemSize, count);
+            for (size_t k = 0; k < in.size(); ++k)
+                fresh.mMaterialsDescs.push_back(MaterialDescription{ "dumped_" + std::to_string(k), in[k] });
+        }
+        else if (t == "CAMR")
+        {
+            std::vector<DumpCamera> in;
+            ok = take(in, data, elemSize, count);
+            for (const DumpCamera& d : in)
+            {
+                Camera cam;
+                cam.name = "dumped camera";
+                cam.fov = d.fov;
+                cam.znear = d.znear;
+                cam.zfar = d.zfar;
+                // view = rotM * translate(-position): rotM = upper 3x3, position = -rotM^T * t
+                const float* v = d.view;
+                cam.mOrientation = quatFromRotationRows(v[0], v[1], v[2], v[4], v[5], v[6], v[8], v[9], v[10]);
+                cam.position = float3{ -(v[0] * v[3] + v[4] * v[7] + v[8] * v[11]), -(v[1] * v[3] + v[5] * v[7] + v[9] * v[11]),
+                                       -(v[2] * v[3] + v[6] * v[7] + v[10] * v[11]) };
+                cam.updateViewMatrix();
+                fresh.mCameras.push_back(cam);
+            }
+        }
+        if (!ok)
+            return false;
+    }
+    // range checks (the reference trusts its own loaders; a dump comes from outside)
+    for (const Mesh& m : fresh.mMeshes)
+        if ((uint64_t)m.mIndex + m.mCount > fresh.mIndices.size() || (uint64_t)m.mVbOffset + m.mVertexCount > fresh.mVertices.size() || m.mCount % 3)
+            return false;
+    for (const Instance& i : fresh.mInstances)
+    {
+        const bool curve = i.type == Instance::Type::eCurve;
+        if ((uint8_t)i.type > 2 || (curve ? i.mCurveId >= fresh.mCurves.size() : i.mMeshId >= fresh.mMeshes.size()))
+            return false;
+        if (i.type == Instance::Type::eLight && i.mLightId >= fresh.mLights.size())
+            return false;
+    }
+    for (const Curve& c : fresh.mCurves)
+        if ((uint64_t)c.mPointsStart + c.mPointsCount > fresh.mCurvePoints.size() || (uint64_t)c.mWidthsStart + c.mWidthsCount > fresh.mCurveWidths.size() ||
+            (uint64_t)c.mVertexCountsStart + c.mVertexCountsCount > fresh.mCurveVertexCounts.size())
+            return false;
+    *this = fresh;
+    return true;
 }
 uint32_t Scene::createRectLightMesh() // scene.cpp:119-145
 {

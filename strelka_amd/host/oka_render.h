@@ -50,6 +50,7 @@ struct float4x4
     bool operator!=(const float4x4& b) const;
 };
 quat quatFromEulerRadians(const float3& e); // glm::quat(vec3 eulerAngles)
+quat quatFromRotationRows(float r00, float r01, float r02, float r10, float r11, float r12, float r20, float r21, float r22);
 
 // ---- settings/settings.h ----
 class SettingsManager
@@ -244,6 +245,13 @@ public:
         return mCameras[index];
     }
     float4x4 getTransform(const UniformLightDesc& desc); // scene.h:331-343
+    // flat binary dump of the arrays render() uploads (".skscene"; format in strelka_amd/scene_io.py)
+    bool saveDump(const std::string& path) const;
+    bool loadDump(const std::string& path); // replaces the scene's content; false (scene untouched) on a malformed file
+    uint32_t getCameraCount() const
+    {
+        return (uint32_t)mCameras.size();
+    }
 
     std::vector<Vertex>& getVertices()
     {
