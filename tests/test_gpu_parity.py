@@ -377,3 +377,23 @@ def test_subframe_batching_is_exact(gpu):
     for other in imgs[1:]:
         for a, b in zip(imgs[0], other):
             assert np.array_equal(a, b)
+
+
+def test_gltf_scene_through_the_dump_format_matches_oracle(gpu, tmp_path):
+    """N2 end to end: glTF -> oka::Scene arrays -> .skscene -> renderer, image against the oracle on the same file
+    (default distant light of the loader, OmniPBR + OmniGlass conversion, instanced primitives, the file's camera)."""
+    import os
+
+    from strelka_amd import gltf, scene_io
+    from tests.test_gltf import make_gltf
+
+    path, _ = make_gltf(str(tmp_path), with_lights=True)
+    sc = gltf.load_gltf(path)
+    dump = os.path.join(str(tmp_path), "model.skscene")
+    scene_io.save_scene(dump, sc.arrays(), sc.getCamera(), sc.material_descriptions)
+    loaded = scene_io.load_scene(dump)
+    cam = loaded.getCamera()
+    cam.lookAt = None  # (a dumped camera is fixed)
+    o, want, got = _render_both(gpu, loaded, 80, 60, 6, 4)
+    _image_close(got, want, frac_tol=1e-2)
+    assert want[..., :3].max() > 0.0 and gpu.stats()["rays_radiance"] == o.stats()["rays_radiance"]
