@@ -123,8 +123,22 @@ typedef struct skh_material
     float metallic;
     float specular; /* specular_level, OmniPBR default 0.5 */
     float ior;
-    float reserved[8];
+    /* Texture ids (1-based index into skh_set_textures' list, 0 = none -- MDL numbers its resources from 1, 0 being the
+     * invalid texture: texture_support_cuda.h:300-304).  OmniPBR "diffuse_texture" / "normalmap_texture"
+     * (gltfloader.cpp:336-350): a valid diffuse texture replaces base_color, a valid normal map perturbs state.normal. */
+    uint32_t base_color_texture;
+    uint32_t normal_texture;
+    float reserved[6];
 } skh_material;
+
+/* One 2-D texture as the reference loads it: stbi_load(..., STBI_rgb_alpha) -> uchar4 array, sampled with
+ * cudaReadModeNormalizedFloat / cudaFilterModeLinear / cudaAddressModeWrap / normalized coordinates
+ * (OptixRender.cpp:1191-1264; lookup: texture_support_cuda.h:287-313).  Row 0 first, 4 bytes per texel. */
+typedef struct skh_texture
+{
+    const uint8_t* rgba8;
+    uint32_t width, height;
+} skh_texture;
 
 /* Per-launch constants == the subset of Params (OptixRenderParams.h:38-68) that render() fills
  * every call (OptixRender.cpp:936-1004). Matrices are ROW-major (OptixRender.cpp:953-954). */
@@ -214,6 +228,8 @@ skh_status skh_set_curves(skh_context* ctx, const float* points_xyz, uint32_t n_
                           const skh_curve* curves, uint32_t n_curves);
 skh_status skh_set_instances(skh_context* ctx, const skh_instance* instances, uint32_t n_instances);
 skh_status skh_set_lights(skh_context* ctx, const skh_light* lights, uint32_t n_lights);
+/* Replaces the texture list (count may be 0).  Host pointers need only live for the call. */
+skh_status skh_set_textures(skh_context* ctx, const skh_texture* textures, uint32_t count);
 skh_status skh_set_materials(skh_context* ctx, const skh_material* materials, uint32_t n_materials);
 
 /* ---- createAccelerationStructure (OptixRender.cpp:388-496): per-mesh / per-curve BLAS + one TLAS ---- */

@@ -39,7 +39,9 @@ struct Material // == skh_material, 64 B
     float metallic;
     float specular;
     float ior;
-    float reserved[8];
+    uint32_t base_color_texture; // 1-based index into the texture list, 0 = none (MDL texture ids: 0 is the invalid texture)
+    uint32_t normal_texture;
+    float reserved[6];
 };
 static_assert(sizeof(Material) == 64, "Material layout");
 

@@ -479,6 +479,50 @@ static inline f2 unpack_uv(uint32_t val) // closest_hit.cu:247-254
     return uv;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 2-D texture lookup.  The reference samples through a CUDA texture object created by loadTextureFromFile
+// (OptixRender.cpp:1191-1264): uchar4 array, cudaReadModeNormalizedFloat (byte / 255), cudaFilterModeLinear,
+// cudaAddressModeWrap, normalized coordinates; tex_lookup_float4_2d (texture_support_cuda.h:287-313) passes the
+// coordinate through unchanged for the default wrap_repeat / crop (0,1) that OmniPBR uses.  The filter itself is
+// hardware; restated here from the CUDA C Programming Guide, "Texture Fetching / Linear Filtering":
+//   x = N * frac(u);  xB = x - 0.5;  i = floor(xB);  alpha = frac(xB) kept in 1.8 fixed point;
+//   tex = (1-a)(1-b) T[i,j] + a(1-b) T[i+1,j] + (1-a) b T[i,j+1] + a b T[i+1,j+1],  indices wrapped modulo N
+// (8 fractional bits, round to nearest -- the guide does not state the rounding; parity vs. NVIDIA hardware is unpinned,
+// GPU == oracle is exact).  Row 0 of the image is v = 0 (stbi_load order).
+// ------------------------------------------------------------------------------------------------
+struct OTexture
+{
+    uint32_t offset, width, height, pad; // offset in texels into the shared RGBA8 array
+};
+static inline void tex_axis(float u, uint32_t n, uint32_t& i0, uint32_t& i1, float& a)
+{
+    const float x = (u - floorf(u)) * (float)n - 0.5f;
+    const float fl = floorf(x);
+    a = floorf((x - fl) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    int i = (int)fl; // -1 .. n-1  (frac() == 1.0f cannot happen: u - floorf(u) < 1 in fp32 except for tiny negative u, handled by the modulo)
+    i = i < 0 ? i + (int)n : i;
+    i0 = (uint32_t)i % n;
+    i1 = (i0 + 1u) % n;
+}
+static inline f4 texel_rgba8(uint32_t t)
+{
+    return f4{ (float)(t & 0xffu) / 255.0f, (float)((t >> 8) & 0xffu) / 255.0f, (float)((t >> 16) & 0xffu) / 255.0f,
+               (float)(t >> 24) / 255.0f };
+}
+static inline f4 tex_lookup_rgba8(const uint32_t* texels, const OTexture& t, float u, float v)
+{
+    uint32_t x0, x1, y0, y1;
+    float a, b;
+    tex_axis(u, t.width, x0, x1, a);
+    tex_axis(v, t.height, y0, y1, b);
+    const uint32_t* base = texels + t.offset;
+    const f4 t00 = texel_rgba8(base[y0 * t.width + x0]), t10 = texel_rgba8(base[y0 * t.width + x1]);
+    const f4 t01 = texel_rgba8(base[y1 * t.width + x0]), t11 = texel_rgba8(base[y1 * t.width + x1]);
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return f4{ ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x, ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y,
+               ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z, ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w };
+}
+
 // offset_ray: closest_hit.cu:218-233 (Waechter & Binder, Ray Tracing Gems ch. 6)
 static inline f3 offset_ray(const f3& p, const f3& n)
 {

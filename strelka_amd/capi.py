@@ -21,7 +21,7 @@ STATS = np.dtype([("rays_radiance", np.uint64), ("rays_shadow", np.uint64), ("no
                   ("launches_shade", np.uint32), ("launches_other", np.uint32)])
 
 SYMBOLS = ["skh_create", "skh_destroy", "skh_last_error", "skh_abi_version", "skh_set_geometry", "skh_set_curves",
-           "skh_set_instances", "skh_set_lights", "skh_set_materials", "skh_build_accel", "skh_resize", "skh_set_tiles",
+           "skh_set_instances", "skh_set_lights", "skh_set_textures", "skh_set_materials", "skh_build_accel", "skh_resize", "skh_set_tiles",
            "skh_render_subframe", "skh_render_subframes", "skh_tonemap", "skh_read_accum", "skh_read_aov",
            "skh_buffer_alloc", "skh_buffer_free", "skh_buffer_download", "skh_copy_accum", "skh_copy_accum_tiles", "skh_scatter_tiles", "skh_trace", "skh_trace_device",
            "skh_set_option", "skh_get_stats", "skh_reset_stats", "skh_synchronize", "skh_get_stream"]
@@ -55,7 +55,7 @@ def load():
     lib.skh_abi_version.restype = u32
     lib.skh_set_geometry.argtypes = [vp, vp, u32, vp, u32, vp, u32]
     lib.skh_set_curves.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, u32]
-    for n in ("skh_set_instances", "skh_set_lights", "skh_set_materials"):
+    for n in ("skh_set_instances", "skh_set_lights", "skh_set_textures", "skh_set_materials"):
         getattr(lib, n).argtypes = [vp, vp, u32]
     lib.skh_build_accel.argtypes = [vp, u32]
     lib.skh_resize.argtypes = [vp, u32, u32]
@@ -131,9 +131,25 @@ class Context:
                      "skh_set_curves")
         self._ck(L.skh_set_instances(self.h, _p(arr["instances"]), len(arr["instances"])), "skh_set_instances")
         self._ck(L.skh_set_lights(self.h, _p(arr["lights"]), len(arr["lights"])), "skh_set_lights")
+        self.set_textures(arr.get("textures") or [])
         self._ck(L.skh_set_materials(self.h, _p(arr["materials"]), len(arr["materials"])), "skh_set_materials")
         if build:
             self.build_accel(flags)
+
+    def set_textures(self, textures):
+        """textures: list of HxWx4 uint8 images (rows top to bottom).  skh_texture = {const uint8_t* rgba8; u32 width, height}."""
+
+        class SkhTexture(C.Structure):
+            _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+        keep = [np.ascontiguousarray(t, np.uint8) for t in textures]
+        for t in keep:
+            if t.ndim != 3 or t.shape[2] != 4:
+                raise ValueError("textures must be HxWx4 uint8")
+        recs = (SkhTexture * max(1, len(keep)))()
+        for k, t in enumerate(keep):
+            recs[k].rgba8, recs[k].width, recs[k].height = t.ctypes.data, t.shape[1], t.shape[0]
+        self._ck(self.lib.skh_set_textures(self.h, C.cast(recs, C.c_void_p), len(keep)), "skh_set_textures")
 
     def build_accel(self, flags=0):
         self._ck(self.lib.skh_build_accel(self.h, flags), "skh_build_accel")

@@ -564,6 +564,41 @@ SKH_DI v3 unpack_normal(uint32_t val) // closest_hit.cu:236-244
     n.x = (float)(val & 0x000003ffu) / 511.99999f * 2.0f - 1.0f;
     return n;
 }
+SKH_DI void unpack_uv(uint32_t val, float& u, float& v) // closest_hit.cu:247-254
+{
+    v = (float)((val & 0xffff0000u) >> 16) / 16383.99999f * 20.0f - 10.0f;
+    u = (float)(val & 0x0000ffffu) / 16383.99999f * 20.0f - 10.0f;
+}
+// 2-D texture lookup = tex2D<float4> of the reference's texture objects (uchar4, normalized float, linear filter, wrap,
+// normalized coordinates: OptixRender.cpp:1191-1264, texture_support_cuda.h:287-313), restated from the CUDA programming
+// guide's linear-filtering formula with 1.8 fixed-point weights.
+SKH_DI void tex_axis(float u, uint32_t n, uint32_t& i0, uint32_t& i1, float& a)
+{
+    const float x = (u - floorf(u)) * (float)n - 0.5f;
+    const float fl = floorf(x);
+    a = floorf((x - fl) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    int i = (int)fl;
+    i = i < 0 ? i + (int)n : i;
+    i0 = (uint32_t)i % n;
+    i1 = (i0 + 1u) % n;
+}
+SKH_DI v4 texel_rgba8(uint32_t t)
+{
+    return mk4((float)(t & 0xffu) / 255.0f, (float)((t >> 8) & 0xffu) / 255.0f, (float)((t >> 16) & 0xffu) / 255.0f, (float)(t >> 24) / 255.0f);
+}
+SKH_DI v4 tex_lookup_rgba8(const uint32_t* __restrict__ texels, const uint4 desc /*offset, width, height*/, float u, float v)
+{
+    uint32_t x0, x1, y0, y1;
+    float a, b;
+    tex_axis(u, desc.y, x0, x1, a);
+    tex_axis(v, desc.z, y0, y1, b);
+    const uint32_t* base = texels + desc.x;
+    const v4 t00 = texel_rgba8(base[y0 * desc.y + x0]), t10 = texel_rgba8(base[y0 * desc.y + x1]);
+    const v4 t01 = texel_rgba8(base[y1 * desc.y + x0]), t11 = texel_rgba8(base[y1 * desc.y + x1]);
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return mk4(((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x, ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y,
+               ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z, ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w);
+}
 SKH_DI v3 interpolate_attrib(const v3& a1, const v3& a2, const v3& a3, float bx, float by) // closest_hit.cu:199-205
 {
     return a1 * (1.0f - bx - by) + a2 * bx + a3 * by;
@@ -833,7 +868,8 @@ struct Material // skh_material, 64 B
     uint32_t type;
     float base_color[3];
     float roughness, metallic, specular, ior;
-    float reserved[8];
+    uint32_t base_color_texture, normal_texture; // 1-based texture ids, 0 = none
+    float reserved[6];
 };
 struct BsdfSample
 {

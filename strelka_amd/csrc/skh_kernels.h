@@ -67,6 +67,9 @@ struct DevScene
     uint32_t numLights;
     const Material* materials;
     uint32_t numMaterials;
+    const uint32_t* texels; // RGBA8 texels of all textures
+    const uint4* texDesc; // per texture: {offset in texels, width, height, 0}
+    uint32_t numTextures;
 };
 
 struct RayQ // SoA planes of `stride` elements: ox oy oz dx dy dz tmin tmax pathId  (36 B / ray)
@@ -1084,11 +1087,15 @@ struct SurfaceHit
 {
     v3 position, normal, geom_normal;
 };
+struct SurfaceTex // state.text_coords[0], tangent_u[0], tangent_v[0]: only textured materials consume them
+{
+    float u, v;
+    v3 tangent_u, tangent_v;
+};
 
-// fillTriangleGeomData: closest_hit.cu:365-421 (position / shading normal / geometric normal; UVs and tangents are
-// only consumed by textured MDL materials, which this build does not have yet)
+// fillTriangleGeomData: closest_hit.cu:365-421.  UVs / tangent frame are computed only when `tex` is given.
 SKH_DI SurfaceHit fill_triangle(const DevScene& sc, const HostInstance& hi, const float* w2o, uint32_t prim, float bu,
-                                float bv, bool inside)
+                                float bv, bool inside, SurfaceTex* tex)
 {
     const uint4 me = sc.meshes[hi.geom];
     const uint32_t i0 = sc.indices[me.x + prim * 3 + 0];
@@ -1110,6 +1117,20 @@ SKH_DI SurfaceHit fill_triangle(const DevScene& sc, const HostInstance& hi, cons
     const float flip = inside ? -1.0f : 1.0f;
     s.geom_normal = geomNormal * flip;
     s.normal = worldNormal * flip;
+    if (tex)
+    {
+        float u0, v0u, u1, v1u, u2, v2u;
+        unpack_uv(__float_as_uint(a1.y), u0, v0u);
+        unpack_uv(__float_as_uint(b1.y), u1, v1u);
+        unpack_uv(__float_as_uint(c1.y), u2, v2u);
+        const float bw = 1.0f - bu - bv;
+        tex->u = (u0 * bw + u1 * bu) + u2 * bv;
+        tex->v = (v0u * bw + v1u * bu) + v2u * bv;
+        const v3 t0 = unpack_normal(__float_as_uint(a0.w)), t1 = unpack_normal(__float_as_uint(b0.w)), t2 = unpack_normal(__float_as_uint(c0.w));
+        // the tangent goes through the NORMAL transform in the reference (closest_hit.cu:399-400)
+        tex->tangent_u = normalize(xform_normal(w2o, interpolate_attrib(t0, t1, t2, bu, bv)));
+        tex->tangent_v = cross(s.normal, tex->tangent_u); // worldBinormal, with the already flipped normal (:404)
+    }
     return s;
 }
 // fillCurveGeomData: closest_hit.cu:423-454
@@ -1225,14 +1246,35 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
             else
             {
                 // __closesthit__radiance
-                const SurfaceHit sh = hi.type == 2 ? fill_curve(sc, hi, w2o, hprim, hu, ht, rayO, rayD, inside) :
-                                                     fill_triangle(sc, hi, w2o, hprim, hu, hv, inside);
+                const uint32_t mid = hi.material == 0xffffffffu ? 0u : hi.material; // OptixRender.cpp:768
+                Material mat = sc.materials[mid < sc.numMaterials ? mid : 0u];
+                // mdlcode_init (closest_hit.cu:507): texture lookups of the material, triangle hits only.  OmniPBR: a valid
+                // diffuse_texture replaces the constant colour; a valid normalmap_texture replaces state.normal by
+                // normalize(tu x + tv y + n z), (x, y, z) = 2 rgb - 1 (base::tangent_space_normal_texture, factor 1)
+                const bool useBase = mat.base_color_texture != 0u && mat.base_color_texture <= sc.numTextures;
+                const bool useNormal = mat.normal_texture != 0u && mat.normal_texture <= sc.numTextures;
+                const bool textured = hi.type != 2 && (useBase || useNormal);
+                SurfaceTex st;
+                SurfaceHit sh = hi.type == 2 ? fill_curve(sc, hi, w2o, hprim, hu, ht, rayO, rayD, inside) :
+                                               fill_triangle(sc, hi, w2o, hprim, hu, hv, inside, textured ? &st : nullptr);
+                if (textured)
+                {
+                    if (useBase)
+                    {
+                        const v4 c = tex_lookup_rgba8(sc.texels, sc.texDesc[mat.base_color_texture - 1u], st.u, st.v);
+                        mat.base_color[0] = c.x, mat.base_color[1] = c.y, mat.base_color[2] = c.z;
+                    }
+                    if (useNormal)
+                    {
+                        const v4 c = tex_lookup_rgba8(sc.texels, sc.texDesc[mat.normal_texture - 1u], st.u, st.v);
+                        const v3 ts = mk3(c.x * 2.0f - 1.0f, c.y * 2.0f - 1.0f, c.z * 2.0f - 1.0f);
+                        sh.normal = normalize((st.tangent_u * ts.x + st.tangent_v * ts.y) + sh.normal * ts.z);
+                    }
+                }
                 if (fp.debug == 1)
                     radiance = (sh.normal + mk3(1.0f)) * 0.5f;
                 else
                 {
-                    const uint32_t mid = hi.material == 0xffffffffu ? 0u : hi.material; // OptixRender.cpp:768
-                    const Material mat = sc.materials[mid < sc.numMaterials ? mid : 0u];
                     const float xi0 = sampler_random_lut(smp, DIM_BSDF0, s_sobol), xi1 = sampler_random_lut(smp, DIM_BSDF1, s_sobol),
                                 xi2 = sampler_random_lut(smp, DIM_BSDF2, s_sobol);
                     const v3 k1 = -rayD;

@@ -65,6 +65,8 @@ struct skh_context
     DevBuf dVerts, dIndices, dMeshes, dPoints, dRadii, dInstances, dLights, dMaterials;
     DevBuf dCurveSegBase, dSegStartAll;
     // accel
+    DevBuf dTexels, dTexDesc;
+    uint32_t nTextures = 0;
     DevBuf dTriNodes, dTris, dSegNodes, dSegs, dSegPrim, dTlasNodes, dTlasInst, dDevInst, dTravInst;
     int tlasRoot = SKH_REF_INVALID;
     bool accelBuilt = false;
@@ -722,7 +724,7 @@ void skh_destroy(skh_context* c)
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : { &c->dVerts, &c->dIndices, &c->dMeshes, &c->dPoints, &c->dRadii, &c->dInstances, &c->dLights, &c->dMaterials,
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
-                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
+                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
                        &c->dCounts, &c->dOvf, &c->dStats, &c->dScratchImage, &c->dSortKeys[0], &c->dSortKeys[1], &c->dSortVals[0],
                        &c->dSortVals[1], &c->dSortHist, &c->dWNodes, &c->dWTris, &c->dWSegs, &c->dWSegMeta })
@@ -807,6 +809,37 @@ skh_status skh_set_lights(skh_context* c, const skh_light* lights, uint32_t n)
     return dev_upload(c, c->dLights, lights, sizeof(skh_light) * (size_t)n);
 }
 
+skh_status skh_set_textures(skh_context* c, const skh_texture* textures, uint32_t n)
+{
+    if (!c || (n && !textures))
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    std::vector<uint4> desc(n);
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < n; ++k)
+    {
+        if (!textures[k].rgba8 || textures[k].width == 0 || textures[k].height == 0)
+        {
+            c->err = "skh_set_textures: texture " + std::to_string(k) + " is empty";
+            return SKH_INVALID_ARGUMENT;
+        }
+        desc[k] = make_uint4((uint32_t)total, textures[k].width, textures[k].height, 0u);
+        total += (uint64_t)textures[k].width * textures[k].height;
+        if (total >= (1ull << 32))
+        {
+            c->err = "skh_set_textures: more than 2^32 texels";
+            return SKH_INVALID_ARGUMENT;
+        }
+    }
+    std::vector<uint32_t> texels((size_t)total);
+    for (uint32_t k = 0; k < n; ++k)
+        memcpy(texels.data() + desc[k].x, textures[k].rgba8, (size_t)textures[k].width * textures[k].height * 4);
+    skh_status s = dev_upload(c, c->dTexels, texels.data(), sizeof(uint32_t) * texels.size());
+    if (s == SKH_OK)
+        s = dev_upload(c, c->dTexDesc, desc.data(), sizeof(uint4) * desc.size());
+    c->nTextures = s == SKH_OK ? n : 0;
+    return s;
+}
 skh_status skh_set_materials(skh_context* c, const skh_material* materials, uint32_t n)
 {
     if (!c || (n && !materials))
@@ -1463,6 +1496,9 @@ static DevScene make_dev_scene(const skh_context* c)
     sc.numLights = c->nLights;
     sc.materials = c->dMaterials.as<Material>();
     sc.numMaterials = c->nMaterials;
+    sc.texels = c->dTexels.as<uint32_t>();
+    sc.texDesc = c->dTexDesc.as<uint4>();
+    sc.numTextures = c->nTextures;
     return sc;
 }
 

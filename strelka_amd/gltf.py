@@ -151,11 +151,20 @@ class GltfScene(S.Scene):
     def __init__(self):
         super().__init__()
         self.material_descriptions = []
-        self.texture_uris = []
+        self.texture_ids = {}  # uri -> texture id (1-based), loaded relative to the model like resource/searchPath
 
     def arrays(self):
         arr = super().arrays()
-        arr["materials"] = scene_io.materials_from_descriptions(self.material_descriptions)
+        mats = scene_io.materials_from_descriptions(self.material_descriptions)
+        # eTexture parameters (OptixRender.cpp:1352-1377): each uri becomes a texture resource of the material
+        for k, d in enumerate(self.material_descriptions):
+            for p in d.get("params", []):
+                if p.get("type") == "texture" and p.get("value") in self.texture_ids:
+                    if p["name"] == "diffuse_texture":
+                        mats[k]["base_color_texture"] = self.texture_ids[p["value"]]
+                    elif p["name"] == "normalmap_texture":
+                        mats[k]["normal_texture"] = self.texture_ids[p["value"]]
+        arr["materials"] = mats
         return arr
 
 
@@ -185,6 +194,34 @@ def _load_materials(doc, sc):
             sc.material_descriptions.append({"file": "OmniGlass.mdl", "name": "OmniGlass", "params": [
                 {"name": "enable_opacity", "type": "bool", "value": True}, {"name": "thin_walled", "type": "bool", "value": False},
                 {"name": "frosting_roughness", "type": "float", "value": rough}]})
+
+
+def _load_textures(path, sc):
+    """The reference resolves texture uris against `resource/searchPath` and loads them with stb_image; here: PNG files next
+    to the model (strelka_amd/png.py).  A texture that cannot be read is reported and left out (the reference logs an error
+    and binds an empty texture, OptixRender.cpp:1195-1199) -- the material then keeps its constant colour."""
+    from . import png
+
+    base = os.path.dirname(os.path.abspath(path))
+    for d in sc.material_descriptions:
+        for p in d.get("params", []):
+            if p.get("type") != "texture" or p["value"] in sc.texture_ids:
+                continue
+            uri = p["value"]
+            try:
+                if uri.startswith("data:"):
+                    import tempfile
+
+                    with tempfile.NamedTemporaryFile(suffix=".png") as tmp:
+                        tmp.write(base64.b64decode(uri.split(",", 1)[1]))
+                        tmp.flush()
+                        img = png.load_png(tmp.name)
+                else:
+                    img = png.load_png(os.path.join(base, uri))
+            except (OSError, ValueError) as e:
+                print(f"[gltf] unable to load texture {uri[:60]}: {e}")
+                continue
+            sc.texture_ids[uri] = sc.addTexture(img)
 
 
 def _load_lights(path, sc):
@@ -270,7 +307,7 @@ def load_gltf(path):
     doc, buffers = _read_model(path)
     sc = GltfScene()
     _load_materials(doc, sc)
-    sc.texture_uris = [im.get("uri") for im in doc.get("images", [])]
+    _load_textures(path, sc)
     _load_lights(path, sc)
     _load_cameras(doc, sc)
     scenes = doc.get("scenes", [])

@@ -379,6 +379,15 @@ uint32_t Scene::createCurve(Curve::Type, const std::vector<uint32_t>& vertexCoun
     mCurves.push_back(c);
     return (uint32_t)mCurves.size() - 1;
 }
+uint32_t Scene::addTexture(uint32_t width, uint32_t height, const uint8_t* rgba8)
+{
+    Texture t;
+    t.width = width;
+    t.height = height;
+    t.rgba8.assign(rgba8, rgba8 + (size_t)width * height * 4);
+    mTextures.push_back(std::move(t));
+    return (uint32_t)mTextures.size();
+}
 uint32_t Scene::addCamera(Camera& camera)
 {
     mCameras.push_back(camera);
@@ -431,7 +440,7 @@ bool Scene::saveDump(const std::string& path) const
     FILE* f = fopen(path.c_str(), "wb");
     if (!f)
         return false;
-    const uint32_t version = 1, sections = 10 + (mCameras.empty() ? 0u : 1u);
+    const uint32_t version = 1, sections = 10 + (mCameras.empty() ? 0u : 1u) + (mTextures.empty() ? 0u : 2u);
     fwrite("SKSCENE\0", 1, 8, f);
     fwrite(&version, 4, 1, f);
     fwrite(&sections, 4, 1, f);
@@ -449,6 +458,19 @@ bool Scene::saveDump(const std::string& path) const
     for (const MaterialDescription& m : mMaterialsDescs)
         mats.push_back(m.args);
     putSection(f, "MATL", sizeof(skh_material), mats.size(), mats.data());
+    if (!mTextures.empty())
+    {
+        std::vector<uint32_t> desc, texels;
+        for (const Texture& t : mTextures)
+        {
+            desc.insert(desc.end(), { (uint32_t)texels.size(), t.width, t.height, 0u });
+            const size_t n = (size_t)t.width * t.height;
+            texels.resize(texels.size() + n);
+            memcpy(texels.data() + texels.size() - n, t.rgba8.data(), n * 4);
+        }
+        putSection(f, "TXDS", 16, mTextures.size(), desc.data());
+        putSection(f, "TXEL", 4, texels.size(), texels.data());
+    }
     if (!mCameras.empty())
     {
         std::vector<DumpCamera> cams(mCameras.size());
@@ -487,6 +509,7 @@ bool Scene::loadDump(const std::string& path)
     if (version != 1)
         return false;
     Scene fresh;
+    std::vector<uint32_t> texDesc, texels;
     size_t off = 16;
     auto take = [&](auto& vec, const char* data, uint32_t elemSize, uint64_t count) {
         using T = typename std::remove_reference<decltype(vec)>::type::value_type;
@@ -556,6 +579,16 @@ bool Scene::loadDump(const std::string& path)
             for (size_t k = 0; k < in.size(); ++k)
                 fresh.mMaterialsDescs.push_back(MaterialDescription{ "dumped_" + std::to_string(k), in[k] });
         }
+        else if (t == "TXDS")
+        {
+            if (elemSize != 16)
+                return false;
+            texDesc.resize((size_t)count * 4);
+            if (count)
+                memcpy(texDesc.data(), data, (size_t)count * 16);
+        }
+        else if (t == "TXEL")
+            ok = take(texels, data, elemSize, count);
         else if (t == "CAMR")
         {
             std::vector<DumpCamera> in;
@@ -579,7 +612,17 @@ bool Scene::loadDump(const std::string& path)
         if (!ok)
             return false;
     }
+    for (size_t k = 0; k + 3 < texDesc.size(); k += 4)
+    {
+        const uint64_t o = texDesc[k], n = (uint64_t)texDesc[k + 1] * texDesc[k + 2];
+        if (n == 0 || o + n > texels.size())
+            return false;
+        fresh.addTexture(texDesc[k + 1], texDesc[k + 2], reinterpret_cast<const uint8_t*>(texels.data() + o));
+    }
     // range checks (the reference trusts its own loaders; a dump comes from outside)
+    for (const MaterialDescription& m : fresh.mMaterialsDescs)
+        if (m.args.base_color_texture > fresh.mTextures.size() || m.args.normal_texture > fresh.mTextures.size())
+            return false;
     for (const Mesh& m : fresh.mMeshes)
         if ((uint64_t)m.mIndex + m.mCount > fresh.mIndices.size() || (uint64_t)m.mVbOffset + m.mVertexCount > fresh.mVertices.size() || m.mCount % 3)
             return false;
@@ -846,6 +889,10 @@ void HipRender::uploadScene()
     }
     check(skh_set_instances(mCtx, inst.data(), (uint32_t)inst.size()), "skh_set_instances");
     check(skh_set_lights(mCtx, reinterpret_cast<const skh_light*>(sc.getLights().data()), (uint32_t)sc.getLights().size()), "skh_set_lights");
+    std::vector<skh_texture> tex; // OptixRender.cpp:1352-1377: one texture object per eTexture parameter
+    for (const Scene::Texture& t : sc.getTextures())
+        tex.push_back(skh_texture{ t.rgba8.data(), t.width, t.height });
+    check(skh_set_textures(mCtx, tex.data(), (uint32_t)tex.size()), "skh_set_textures");
     std::vector<skh_material> mats;
     for (const auto& m : sc.getMaterials())
         mats.push_back(m.args);

@@ -235,6 +235,18 @@ public:
     uint32_t createInstance(Instance::Type type, uint32_t geomId, uint32_t materialId, const float4x4& transform,
                             uint32_t lightId = (uint32_t)-1); // scene.cpp:51-87
     uint32_t addMaterial(const MaterialDescription& material); // scene.cpp:89-95
+    // RGBA8 image as stbi_load(..., STBI_rgb_alpha) returns it (OptixRender.cpp:1191-1264).  Returns the texture id that
+    // skh_material::base_color_texture / normal_texture refer to (1-based; 0 = none).
+    struct Texture
+    {
+        uint32_t width = 0, height = 0;
+        std::vector<uint8_t> rgba8;
+    };
+    uint32_t addTexture(uint32_t width, uint32_t height, const uint8_t* rgba8);
+    const std::vector<Texture>& getTextures() const
+    {
+        return mTextures;
+    }
     uint32_t createCurve(Curve::Type type, const std::vector<uint32_t>& vertexCounts, const std::vector<float3>& points,
                          const std::vector<float>& widths);
     uint32_t createLight(const UniformLightDesc& desc); // scene.cpp:306-351
@@ -306,6 +318,7 @@ private:
     std::vector<Light> mLights;
     std::vector<UniformLightDesc> mLightDesc;
     std::vector<MaterialDescription> mMaterialsDescs;
+    std::vector<Texture> mTextures;
     std::vector<Camera> mCameras;
     int mRectLightMeshId = -1, mSphereLightMeshId = -1, mDiskLightMeshId = -1;
     uint32_t createRectLightMesh();

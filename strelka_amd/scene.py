@@ -22,7 +22,9 @@ LIGHT = np.dtype([("points", np.float32, (4, 4)), ("color", np.float32, 4), ("no
                   ("type", np.int32), ("half_angle", np.float32), ("pad0", np.float32), ("pad1", np.float32)])  # 112 B
 MATERIAL = np.dtype([("type", np.uint32), ("base_color", np.float32, 3), ("roughness", np.float32),
                      ("metallic", np.float32), ("specular", np.float32), ("ior", np.float32),
-                     ("reserved", np.float32, 8)])  # 64 B
+                     ("base_color_texture", np.uint32), ("normal_texture", np.uint32),  # texture ids: 1-based, 0 = none
+                     ("reserved", np.float32, 6)])  # 64 B
+TEXTURE_DESC = np.dtype([("offset", np.uint32), ("width", np.uint32), ("height", np.uint32), ("pad", np.uint32)])
 FRAME_PARAMS = np.dtype([("view_to_world", np.float32, 16), ("clip_to_view", np.float32, 16),
                          ("subframe_index", np.uint32), ("samples_this_launch", np.uint32), ("spp_total", np.uint32),
                          ("max_depth", np.uint32), ("rect_light_sampling_method", np.uint32),
@@ -155,6 +157,7 @@ class Scene:
         self.mLights = []
         self.mLightDesc = []
         self.mMaterials = []
+        self.mTextures = []
         self.mCameras = []
         self._nverts = 0
         self._nidx = 0
@@ -184,9 +187,18 @@ class Scene:
         return inst_id
 
     # -- scene.cpp:89-95.  `material` is a dict of the fixed-layout argument block (skh_material)
-    def addMaterial(self, type=MAT_DIFFUSE, base_color=(0.8, 0.8, 0.8), roughness=0.5, metallic=0.0, specular=0.5, ior=1.5):
-        self.mMaterials.append((type, tuple(base_color), roughness, metallic, specular, ior))
+    def addMaterial(self, type=MAT_DIFFUSE, base_color=(0.8, 0.8, 0.8), roughness=0.5, metallic=0.0, specular=0.5, ior=1.5,
+                    base_color_texture=0, normal_texture=0):
+        self.mMaterials.append((type, tuple(base_color), roughness, metallic, specular, ior, base_color_texture, normal_texture))
         return len(self.mMaterials) - 1
+
+    def addTexture(self, rgba8):
+        """RGBA8 image, rows top to bottom as stbi_load returns them (OptixRender.cpp:1191-1264).  Returns the texture ID
+        materials refer to (1-based; 0 = no texture, as MDL's invalid texture)."""
+        t = np.ascontiguousarray(rgba8, np.uint8)
+        assert t.ndim == 3 and t.shape[2] == 4 and t.shape[0] > 0 and t.shape[1] > 0
+        self.mTextures.append(t)
+        return len(self.mTextures)
 
     def addCamera(self, camera):
         self.mCameras.append(camera)
@@ -342,9 +354,10 @@ class Scene:
         mats = np.zeros(max(1, len(self.mMaterials)), MATERIAL)
         if not self.mMaterials:  # material 0 = default.mdl::default_material (OptixRender.cpp:1090-1097)
             mats[0]["base_color"] = 0.8
-        for i, (ty, bc, r, me, sp, ior) in enumerate(self.mMaterials):
+        for i, (ty, bc, r, me, sp, ior, bt, nt) in enumerate(self.mMaterials):
             mats[i]["type"], mats[i]["base_color"], mats[i]["roughness"] = ty, bc, r
             mats[i]["metallic"], mats[i]["specular"], mats[i]["ior"] = me, sp, ior
+            mats[i]["base_color_texture"], mats[i]["normal_texture"] = bt, nt
         return {
             "vertices": cat(self.mVertices, VERTEX),
             "indices": cat(self.mIndices, np.uint32),
@@ -356,7 +369,21 @@ class Scene:
             "instances": inst,
             "lights": lights,
             "materials": mats,
+            "textures": list(self.mTextures),
         }
+
+
+def pack_textures(textures):
+    """list of HxWx4 uint8 images -> (TEXTURE_DESC array, uint32 texel array) in the packed form the renderer keeps on the device"""
+    desc = np.zeros(len(textures), TEXTURE_DESC)
+    off, parts = 0, []
+    for k, t in enumerate(textures):
+        t = np.ascontiguousarray(t, np.uint8)
+        desc[k] = (off, t.shape[1], t.shape[0], 0)
+        parts.append(t.reshape(-1, 4).view(np.uint32).reshape(-1))
+        off += t.shape[0] * t.shape[1]
+    texels = np.concatenate(parts) if parts else np.zeros(0, np.uint32)
+    return desc, np.ascontiguousarray(texels, np.uint32)
 
 
 def make_vertices(positions, normals=None, uvs=None, tangents=None):

@@ -26,7 +26,9 @@ Layout (little endian)::
     MDSC  u8 JSON text: the original MaterialDescription list [{"file", "name", "params": [{"name", "type", "value"}]}]
           (optional; `materials_from_descriptions` turns it into MATL when MATL is absent)
     CAMR  96 B {float view[16] (world -> view, row-major); float fov_deg, znear, zfar; u32 pad[5]}   Camera::matrices.view, fov
-Unknown tags are skipped, so the format can grow (textures: section 8f N3).
+    TXDS  4 x u32 {offset (texels), width, height, 0} per texture; materials refer to texture k as id k + 1 (0 = none)
+    TXEL  u32 RGBA8 texel (R in the low byte), rows top to bottom as stbi_load returns them (OptixRender.cpp:1191-1264)
+Unknown tags are skipped, so the format can grow.
 """
 import json
 import struct
@@ -71,6 +73,10 @@ def save_scene(path, arrays, camera=None, material_descriptions=None):
             if dt.shape:
                 a = a.reshape((-1,) + dt.shape)
             sections.append((tag, dt.itemsize, len(a), a.tobytes()))
+    if arrays.get("textures"):
+        desc, texels = S.pack_textures(arrays["textures"])
+        sections.append((b"TXDS", S.TEXTURE_DESC.itemsize, len(desc), desc.tobytes()))
+        sections.append((b"TXEL", 4, len(texels), texels.tobytes()))
     if material_descriptions is not None:
         text = json.dumps(material_descriptions).encode()
         sections.append((b"MDSC", 1, len(text), text))
@@ -120,6 +126,7 @@ def load_scene(path):
     known = {tag: (key, dt) for tag, key, dt in _SECTIONS}
     arrays = {key: np.zeros((0,) + dt.shape, dt.base if dt.shape else dt) for _, key, dt in _SECTIONS}
     cameras, descs = [], None
+    tex_desc, texels = np.zeros(0, S.TEXTURE_DESC), np.zeros(0, np.uint32)
     off = 16
     for _ in range(nsec):
         if off + 16 > len(blob):
@@ -143,7 +150,17 @@ def load_scene(path):
                 cameras.append(LoadedCamera(rec["view"], float(rec["fov"]), float(rec["znear"]), float(rec["zfar"])))
         elif tag == b"MDSC":
             descs = json.loads(bytes(data).decode())
+        elif tag == b"TXDS" and esz == S.TEXTURE_DESC.itemsize:
+            tex_desc = np.frombuffer(data, dtype=S.TEXTURE_DESC).copy()
+        elif tag == b"TXEL" and esz == 4:
+            texels = np.frombuffer(data, dtype=np.uint32).copy()
         # unknown tags: skipped
+    arrays["textures"] = []
+    for k, d in enumerate(tex_desc):
+        n = int(d["width"]) * int(d["height"])
+        if n == 0 or int(d["offset"]) + n > len(texels):
+            raise ValueError(f"{path}: texture {k} reaches outside the texel section")
+        arrays["textures"].append(texels[int(d["offset"]):int(d["offset"]) + n].view(np.uint8).reshape(int(d["height"]), int(d["width"]), 4).copy())
     if len(arrays["materials"]) == 0:
         arrays["materials"] = materials_from_descriptions(descs or [])
     if not cameras:
@@ -170,6 +187,10 @@ def validate(arrays):
         if t == S.INSTANCE_LIGHT and int(i["light_id"]) >= nl:
             raise ValueError(f"instance {k}: light {int(i['light_id'])} does not exist")
     npts, nw, nvc = len(arrays["curve_points"]), len(arrays["curve_radii"]), len(arrays["curve_vertex_counts"])
+    nt = len(arrays.get("textures") or [])
+    for k, m in enumerate(arrays["materials"]):
+        if int(m["base_color_texture"]) > nt or int(m["normal_texture"]) > nt:
+            raise ValueError(f"material {k} refers to a texture that does not exist")
     for k, c in enumerate(arrays["curves"]):
         if (int(c["points_start"]) + int(c["points_count"]) > npts or int(c["widths_start"]) + int(c["widths_count"]) > nw or
                 int(c["vertex_counts_start"]) + int(c["vertex_counts_count"]) > nvc):

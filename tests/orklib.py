@@ -49,6 +49,11 @@ class Oracle:
         L.ork_set_instances(self.ctx, fptr(scene["instances"]), len(scene["instances"]))
         L.ork_set_lights(self.ctx, fptr(scene["lights"]), len(scene["lights"]))
         L.ork_set_materials(self.ctx, fptr(scene["materials"]), len(scene["materials"]))
+        from strelka_amd import scene as S
+
+        desc, texels = S.pack_textures(scene.get("textures") or [])
+        if L.ork_set_textures(self.ctx, fptr(desc), len(desc), fptr(texels), C.c_uint64(len(texels))) != 0:
+            raise ValueError("ork_set_textures: descriptor outside the texel array")
         L.ork_build_accel(self.ctx)
 
     def resize(self, w, h):

@@ -13,6 +13,11 @@ import pytest
 from strelka_amd import gltf, scene as S, scene_io
 
 
+def flat_bytes(v):
+    """array, or list of arrays (textures): shape-tagged bytes for equality checks"""
+    return v.tobytes() if hasattr(v, "tobytes") else b"".join(repr(t.shape).encode() + t.tobytes() for t in v)
+
+
 def _pad4(b):
     return b + b"\0" * (-len(b) % 4)
 
@@ -159,7 +164,7 @@ def test_light_file_and_external_buffer(tmp_path):
     scene_io.save_scene(dump, arr, sc.getCamera(), sc.material_descriptions)
     back = scene_io.load_scene(dump).arrays()
     for k in arr:
-        assert arr[k].tobytes() == back[k].tobytes(), k
+        assert flat_bytes(arr[k]) == flat_bytes(back[k]), k
 
 
 def test_glb_container_and_rejections(tmp_path):
@@ -178,7 +183,7 @@ def test_glb_container_and_rejections(tmp_path):
         f.write(struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(blob), 0x004E4942) + blob)
     a, b = gltf.load_gltf(path).arrays(), gltf.load_gltf(glb).arrays()
     for k in a:
-        assert a[k].tobytes() == b[k].tobytes(), k
+        assert flat_bytes(a[k]) == flat_bytes(b[k]), k
     # non-indexed primitive: the reference asserts (gltfloader.cpp:158)
     doc = json.load(open(path))
     del doc["meshes"][1]["primitives"][0]["indices"]

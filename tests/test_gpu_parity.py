@@ -397,3 +397,48 @@ def test_gltf_scene_through_the_dump_format_matches_oracle(gpu, tmp_path):
     o, want, got = _render_both(gpu, loaded, 80, 60, 6, 4)
     _image_close(got, want, frac_tol=1e-2)
     assert want[..., :3].max() > 0.0 and gpu.stats()["rays_radiance"] == o.stats()["rays_radiance"]
+
+
+def test_textured_materials_match_oracle(gpu):
+    """N3: diffuse texture + normal map through the GPU's texture fetch (same 1.8 fixed-point bilinear arithmetic as the
+    oracle): the normal AOV (debug view 1 = state.normal after the material's init) agrees to float rounding, the image within
+    the render tolerance; a scene whose material names a missing texture falls back to the constant colour on both sides."""
+    from tests.test_textures import checker, textured_scene
+
+    rs = np.random.RandomState(11)
+    bumps = rs.randint(96, 160, (16, 16, 4)).astype(np.uint8)
+    bumps[..., 2] = 255
+    sc = textured_scene(base_tex=checker(8), normal_tex=bumps)
+    import torch
+
+    from tests import orklib
+
+    arr = sc.arrays()
+    o = orklib.new_context()
+    o.set_scene(arr)
+    o.resize(96, 72)
+    gpu.set_scene(arr)
+    gpu.resize(96, 72)
+    img = torch.zeros((72, 96, 4), dtype=torch.float32, device="cuda")
+    p = S.frame_params(sc.getCamera(), 96, 72, subframe_index=0, spp_total=1, max_depth=3, debug=1)
+    o.render_subframe(p)
+    gpu.render_subframe(p, img.data_ptr())
+    want, got = o.read_image(), img.cpu().numpy()  # debug views go to the output image, not to the accumulator
+    hit = want[..., :3].sum(-1) > 0
+    assert hit.mean() > 0.3 and np.allclose(got[..., :3], want[..., :3], atol=2e-6)
+    assert np.ptp(want[..., 0][hit]) > 0.05  # the normal map really varies across the floor
+    o, want, got = _render_both(gpu, sc, 96, 72, 6, 4)
+    _image_close(got, want, frac_tol=1e-2)
+    assert gpu.stats()["rays_radiance"] == o.stats()["rays_radiance"]
+    plain = textured_scene()
+    _, want_plain, _ = _render_both(gpu, plain, 96, 72, 6, 4)
+    assert np.abs(want[..., :3] - want_plain[..., :3]).max() > 1e-2  # textures change the picture
+    # texture ids beyond the list are ignored (OmniPBR checks texture_isvalid): same as untextured
+    arr = plain.arrays()
+    arr["materials"] = arr["materials"].copy()
+    arr["materials"]["base_color_texture"][0] = 7
+    gpu.set_scene(arr)
+    gpu.resize(96, 72)
+    for i in range(6):
+        gpu.render_subframe(S.frame_params(plain.getCamera(), 96, 72, subframe_index=i, spp_total=6, max_depth=4))
+    assert gpu.read_accum().tobytes() == _render_both(gpu, plain, 96, 72, 6, 4)[2].tobytes()

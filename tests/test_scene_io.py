@@ -13,10 +13,18 @@ from strelka_amd import scene as S, scene_io, scenes
 from tests.test_host_cpp import python_recipe, run_host
 
 
+def flat_bytes(v):
+    """array, or list of arrays (textures): shape-tagged bytes for equality checks"""
+    return v.tobytes() if hasattr(v, "tobytes") else b"".join(repr(t.shape).encode() + t.tobytes() for t in v)
+
+
 def same(a, b):
     assert set(a) == set(b)
     for k in a:
-        assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and a[k].tobytes() == b[k].tobytes(), k
+        if isinstance(a[k], list):
+            assert flat_bytes(a[k]) == flat_bytes(b[k]), k
+        else:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and a[k].tobytes() == b[k].tobytes(), k
 
 
 def test_python_round_trip_with_curves(tmp_path):
