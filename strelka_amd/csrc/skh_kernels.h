@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
     // per-lane traversal state
     bool hasRay = false, pending = false;
     uint32_t ridx = 0;
-    v3 ow = mk3(0.0f), dw = mk3(0.0f), o = mk3(0.0f), d = mk3(0.0f), inv = mk3(0.0f);
+    v3 ow = mk3(0.0f), dw = mk3(0.0f), o = mk3(0.0f), d = mk3(0.0f), inv = mk3(0.0f), invw = mk3(0.0f);
     float tmin = 0.0f, tmax = 0.0f;
     RayShear sh;
     sh.perm = 0;
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                 tmax = rq.plane(7)[ridx];
                 o = ow;
                 d = dw;
-                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                inv = invw = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 nodes = sc.tlasNodes;
                 inBlas = false;
                 sp = 0;
@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
             {
                 o = ow;
                 d = dw;
-                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                inv = invw; // (three IEEE divisions saved per instance exit)
                 nodes = sc.tlasNodes;
                 inBlas = false;
                 cur = SKH_REF_INVALID;
@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                     {
                         o = ow;
                         d = dw;
-                        inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        inv = invw;
                         nodes = sc.tlasNodes;
                         inBlas = false;
                         continue;
