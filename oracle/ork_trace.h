@@ -73,9 +73,9 @@ static inline RayShear make_shear(const f3& d)
         s.ky = t;
     }
     const float dz = comp(d, s.kz);
-    s.Sx = comp(d, s.kx) / dz;
-    s.Sy = comp(d, s.ky) / dz;
-    s.Sz = 1.0f / dz;
+    s.Sz = 1.0f / dz; // one division; the shear factors use the reciprocal (own definition, identical on the GPU)
+    s.Sx = comp(d, s.kx) * s.Sz;
+    s.Sy = comp(d, s.ky) * s.Sz;
     return s;
 }
 static inline bool intersect_triangle(const f3& o, const RayShear& s, float tmin, float tmax, const f3& p0, const f3& p1,

@@ -722,9 +722,9 @@ SKH_DI RayShear make_shear(const v3& d)
     const float dkz = kz == 0 ? d.x : (kz == 1 ? d.y : d.z);
     s.perm = kz | (dkz < 0.0f ? 4 : 0);
     const v3 dp = shear_permute(d, s.perm);
-    s.Sx = dp.x / dp.z;
-    s.Sy = dp.y / dp.z;
-    s.Sz = 1.0f / dp.z;
+    s.Sz = 1.0f / dp.z; // one division; the shear factors use the reciprocal (same definition in the oracle)
+    s.Sx = dp.x * s.Sz;
+    s.Sy = dp.y * s.Sz;
     return s;
 }
 // watertight edge-function test (Woop, Benthin, Wald 2013); accepts tmin < t <= tmax
