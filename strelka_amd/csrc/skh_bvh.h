@@ -932,20 +932,62 @@ __global__ void k_gather_tris(const uint8_t* __restrict__ verts, const uint32_t*
 __global__ void k_gather_segs(const float* __restrict__ points, const float* __restrict__ radii,
                               const uint32_t* __restrict__ segStart, const uint32_t* __restrict__ segLocal,
                               const uint32_t* __restrict__ sortedVals, uint32_t n, float4* __restrict__ out,
-                              uint32_t* __restrict__ outPrim)
+                              uint32_t* __restrict__ outPrim, float4* __restrict__ outBound)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n)
         return;
     const uint32_t i = sortedVals[j];
     const uint32_t s = segStart[i];
+    float4 q[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
         const float* p = points + 3 * (size_t)(s + k);
-        out[4 * (size_t)j + k] = make_float4(p[0], p[1], p[2], radii[s + k]);
+        q[k] = make_float4(p[0], p[1], p[2], radii[s + k]);
+        out[4 * (size_t)j + k] = q[k];
     }
     outPrim[j] = segLocal[i];
+    // Conservative bounding cylinder (infinite) of the swept segment, for a cheap rejection test in front of the iterative
+    // intersector: the curve is a convex combination of its control points and so is its radius, hence every surface point
+    // lies within  max_i dist(q_i, L) + max_i r_i  of ANY line L.  L = the line through the segment's end points
+    // C(0) = (q0 + 4 q1 + q2) / 6 and C(1) = (q1 + 4 q2 + q3) / 6.  Record: {A.xyz, R}, {unit axis.xyz, 0}; a degenerate
+    // chord gives axis = 0 and R = the radius of a bounding sphere around A (dist to a "line" of direction 0 = dist to A).
+    const float ax = (q[0].x + 4.0f * q[1].x + q[2].x) / 6.0f, ay = (q[0].y + 4.0f * q[1].y + q[2].y) / 6.0f, az = (q[0].z + 4.0f * q[1].z + q[2].z) / 6.0f;
+    const float bx = (q[1].x + 4.0f * q[2].x + q[3].x) / 6.0f, by = (q[1].y + 4.0f * q[2].y + q[3].y) / 6.0f, bz = (q[1].z + 4.0f * q[2].z + q[3].z) / 6.0f;
+    float ux = bx - ax, uy = by - ay, uz = bz - az;
+    const float len = sqrtf(ux * ux + uy * uy + uz * uz);
+    if (len > 1e-20f)
+        ux /= len, uy /= len, uz /= len;
+    else
+        ux = uy = uz = 0.0f;
+    // distances of the segment's BEZIER control points to the line (the same cubic in Bezier form: b0 = C(0),
+    // b1 = (2 q1 + q2) / 3, b2 = (q1 + 2 q2) / 3, b3 = C(1); their hull is far tighter than the B-spline points' hull)
+    float dmax = 0.0f, rmax = 0.0f, cmax = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+    {
+        const float4 qa = q[1 + k], qb = q[2 - k];
+        const float vx = (2.0f * qa.x + qb.x) / 3.0f - ax, vy = (2.0f * qa.y + qb.y) / 3.0f - ay, vz = (2.0f * qa.z + qb.z) / 3.0f - az;
+        const float t = vx * ux + vy * uy + vz * uz;
+        const float px = vx - t * ux, py = vy - t * uy, pz = vz - t * uz;
+        dmax = fmaxf(dmax, sqrtf(px * px + py * py + pz * pz));
+    }
+    if (len <= 1e-20f) // degenerate chord: bounding sphere around A over all B-spline control points
+        for (int k = 0; k < 4; ++k)
+        {
+            const float vx = q[k].x - ax, vy = q[k].y - ay, vz = q[k].z - az;
+            dmax = fmaxf(dmax, sqrtf(vx * vx + vy * vy + vz * vz));
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+        rmax = fmaxf(rmax, fabsf(q[k].w)); // (the radius is a convex combination of the four radii)
+        cmax = fmaxf(cmax, fmaxf(fabsf(q[k].x), fmaxf(fabsf(q[k].y), fabsf(q[k].z))));
+    }
+    const float R = (dmax + rmax) * 1.001f + cmax * 4e-6f + 1e-30f; // rounding of A, the axis and the distances
+    outBound[2 * (size_t)j] = make_float4(ax, ay, az, R);
+    outBound[2 * (size_t)j + 1] = make_float4(ux, uy, uz, 0.0f);
 }
 
 } // namespace skh

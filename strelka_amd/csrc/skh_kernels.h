@@ -47,6 +47,7 @@ struct DevScene
     const Node4* segNodes;
     const float4* segs; // 4 x float4 per segment, leaf order
     const uint32_t* segPrim; // leaf order -> segment index inside its curve set
+    const float4* segBound; // 2 x float4 per segment, leaf order: bounding cylinder {A, R}, {unit axis, 0}
     // flattened world-space hierarchy (default): one tree over every instanced primitive
     const Node4* wNodes;
     int wRoot;
@@ -539,6 +540,15 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                 {
                     for (uint32_t k = 0; k < count; ++k)
                     {
+                        // cheap conservative rejection: (distance between the ray's line and the segment's bounding cylinder
+                        // axis)^2 = ((A - o) . n)^2 / |n|^2, n = d x axis; a long thin diagonal hair fills a tiny part of its box
+                        const float4 b0 = sc.segBound[2 * (size_t)(first + k)], b1 = sc.segBound[2 * (size_t)(first + k) + 1];
+                        const v3 w = mk3(b0.x - o.x, b0.y - o.y, b0.z - o.z);
+                        const v3 nn = cross(d, mk3(b1.x, b1.y, b1.z));
+                        const float n2 = dot(nn, nn), wn = dot(w, nn);
+                        const float Rm = b0.w + (fabsf(w.x) + fabsf(w.y) + fabsf(w.z)) * 4e-6f; // cancellation in w . n
+                        if (n2 > 1e-12f * dot(d, d) && wn * wn > Rm * Rm * n2 * 1.0001f)
+                            continue;
                         const float4* cp = sc.segs + 4 * (size_t)(first + k);
                         const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
                         if (COUNT)

@@ -65,7 +65,7 @@ struct skh_context
     DevBuf dVerts, dIndices, dMeshes, dPoints, dRadii, dInstances, dLights, dMaterials;
     DevBuf dCurveSegBase, dSegStartAll;
     // accel
-    DevBuf dTexels, dTexDesc;
+    DevBuf dTexels, dTexDesc, dSegBound;
     uint32_t nTextures = 0;
     DevBuf dTriNodes, dTris, dSegNodes, dSegs, dSegPrim, dTlasNodes, dTlasInst, dDevInst, dTravInst;
     int tlasRoot = SKH_REF_INVALID;
@@ -724,7 +724,7 @@ void skh_destroy(skh_context* c)
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : { &c->dVerts, &c->dIndices, &c->dMeshes, &c->dPoints, &c->dRadii, &c->dInstances, &c->dLights, &c->dMaterials,
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
-                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
+                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
                        &c->dCounts, &c->dOvf, &c->dStats, &c->dScratchImage, &c->dSortKeys[0], &c->dSortKeys[1], &c->dSortVals[0],
                        &c->dSortVals[1], &c->dSortHist, &c->dWNodes, &c->dWTris, &c->dWSegs, &c->dWSegMeta })
@@ -1141,10 +1141,11 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     BA(lbvh_build(c, nSegs, nCurves, curveSegCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), 2, usePloc, segOut));
     BA(dev_alloc(c, c->dSegs, sizeof(float4) * 4 * (size_t)std::max(1u, nSegs)));
     BA(dev_alloc(c, c->dSegPrim, sizeof(uint32_t) * (size_t)std::max(1u, nSegs)));
+    BA(dev_alloc(c, c->dSegBound, sizeof(float4) * 2 * (size_t)std::max(1u, nSegs)));
     if (nSegs)
         k_gather_segs<<<(nSegs + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), c->dSegStartAll.as<uint32_t>(),
                                                         dSegLocal.as<uint32_t>(), segOut.sortedVals.as<uint32_t>(), nSegs,
-                                                        c->dSegs.as<float4>(), c->dSegPrim.as<uint32_t>());
+                                                        c->dSegs.as<float4>(), c->dSegPrim.as<uint32_t>(), c->dSegBound.as<float4>());
     dev_free(c->dSegNodes);
     c->dSegNodes = segOut.nodes;
     // ---- instances -> TLAS ----
@@ -1478,6 +1479,7 @@ static DevScene make_dev_scene(const skh_context* c)
     sc.segNodes = c->dSegNodes.as<Node4>();
     sc.segs = c->dSegs.as<float4>();
     sc.segPrim = c->dSegPrim.as<uint32_t>();
+    sc.segBound = c->dSegBound.as<float4>();
     sc.wNodes = c->dWNodes.as<Node4>();
     sc.wRoot = c->wRoot;
     sc.wTriCount = c->wTriCount;

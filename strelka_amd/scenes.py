@@ -273,7 +273,7 @@ def hair_standin(seed=77, n_strands=100000, n_cp=16):
     cid = sc.createCurve(counts, pts.reshape(-1, 3), rad.reshape(-1))
     sc.createInstance(S.INSTANCE_CURVE, cid, hair, np.eye(4))
     for pos, rot in [((2.5, 2.5, 2.5), (-45, 45, 0)), ((-3.0, 1.5, 1.0), (-20, -70, 0))]:
-        xf = S.translate(pos) @ S.rotate((0, 1, 0), math.radians(rot[1])) @ S.rotate((1, 0, 0), math.radians(rot[0] + 180))
+        xf = S.translate(pos) @ S.rotate((0, 1, 0), math.radians(rot[1])) @ S.rotate((1, 0, 0), math.radians(rot[0]))  # local -Z (the emitting side) towards the head
         sc.createLight({"type": 0, "xform": xf, "useXform": True, "width": 1.5, "height": 1.5, "color": (1, 1, 1),
                         "intensity": 25.0})
     cam = S.Camera(fov=40.0)

@@ -1,0 +1,109 @@
+"""BASELINE.json's full-size configurations on the GPU: bit-exact hit records against the oracle on
+a ray sample traced through the FULL scene (1.7 M unique triangles in 2022 instances; 1.4 M curve segments), and the
+size-independent properties at 1920x1080: two runs give identical bits, sub-frame batching == one sub-frame per pass,
+tile-sharded accumulation == the full frame, ray counts of both sides agree."""
+import numpy as np
+import pytest
+
+from strelka_amd import scene as S, scenes, tiles
+from tests.test_gpu_parity import camera_rays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kitchen():
+    sc = scenes.kitchen_standin()
+    return sc, sc.arrays()
+
+
+def test_kitchen_full_scene_hits_bit_exact(kitchen):
+    from strelka_amd import capi
+    from tests import orklib
+
+    sc, arr = kitchen
+    rays = np.concatenate([camera_rays(sc, 1920, 1080, 60000, 3), scenes.random_rays(20000, 4, -5.0, 5.0)])
+    o = orklib.new_context()
+    o.set_scene(arr)
+    want = o.trace(rays, 0)
+    ctx = capi.Context(0)
+    ctx.set_scene(arr)
+    got = ctx.trace(rays, 0)
+    assert (want["instance_id"] != 0xFFFFFFFF).mean() > 0.5
+    assert got.tobytes() == want.tobytes()
+    sh = rays.copy()
+    sh["tmax"] = 3.0
+    assert np.array_equal(ctx.trace(sh, 1), o.trace(sh, 1))
+    ctx.close()
+
+
+def test_kitchen_1080p_properties(kitchen):
+    from strelka_amd import capi
+
+    sc, arr = kitchen
+    W, H, SPP, DEPTH = 1920, 1080, 3, 4
+
+    def frame(options, tile_xy=None):
+        ctx = capi.Context(0)
+        for k, v in options.items():
+            ctx.set_option(k, v)
+        ctx.set_scene(arr)
+        ctx.set_tiles(32, tile_xy)
+        ctx.resize(W, H)
+        p = S.frame_params(sc.getCamera(), W, H, subframe_index=0, samples_this_launch=1, spp_total=SPP, max_depth=DEPTH)
+        ctx.render_subframes(p, SPP, None)
+        st = ctx.stats()
+        acc = ctx.read_accum() if tile_xy is None else None
+        import torch
+
+        tile_acc = None
+        if tile_xy is not None:
+            buf = torch.zeros((len(tile_xy), 32 * 32, 4), dtype=torch.float32, device="cuda")
+            ctx.copy_accum_tiles(buf.data_ptr())
+            tile_acc = buf.cpu().numpy()
+        ctx.close()
+        return acc, st, tile_acc
+
+    base, st, _ = frame({})
+    assert np.isfinite(base).all() and base[..., :3].max() > 0
+    again, st2, _ = frame({})
+    assert again.tobytes() == base.tobytes() and st2["rays_radiance"] == st["rays_radiance"] and st2["rays_shadow"] == st["rays_shadow"]
+    single, st1, _ = frame({"subframe_batch": 1})  # the reference's schedule: one sub-frame per launch
+    assert single.tobytes() == base.tobytes() and st1["rays_radiance"] == st["rays_radiance"]
+    # paths: every pixel starts one per sample; radiance segments never exceed paths x depth
+    assert W * H * SPP <= st["rays_radiance"] <= W * H * SPP * DEPTH and st["rays_shadow"] <= st["rays_radiance"]
+    # two of eight ranks' tile sets reproduce their pixels of the full frame bit for bit
+    for rank in (0, 5):
+        t = tiles.assign_tiles(W, H, 32, 8, rank)
+        _, _, tacc = frame({}, t)
+        part = tiles.detile_numpy(tacc, t, 32, W, H)
+        mask = tiles.detile_numpy(np.ones_like(tacc), t, 32, W, H)[..., 0] > 0
+        assert mask.mean() == pytest.approx(1 / 8, abs=0.02)
+        assert part[mask].tobytes() == base[mask].tobytes()
+
+
+def test_hair_full_scene_hits_bit_exact():
+    from strelka_amd import capi
+    from tests import orklib
+
+    sc = scenes.hair_standin()
+    arr = sc.arrays()
+    assert len(arr["curve_points"]) >= 1_000_000
+    rays = camera_rays(sc, 1920, 1080, 30000, 8)
+    o = orklib.new_context()
+    o.set_scene(arr)
+    want = o.trace(rays, 0)
+    ctx = capi.Context(0)
+    ctx.set_scene(arr)
+    got = ctx.trace(rays, 0)
+    assert (want["instance_id"] != 0xFFFFFFFF).mean() > 0.2
+    assert got.tobytes() == want.tobytes()
+    # one 1080p sub-frame renders and is repeatable
+    ctx.resize(1920, 1080)
+    p = S.frame_params(sc.getCamera(), 1920, 1080, subframe_index=0, spp_total=1, max_depth=3)
+    ctx.render_subframe(p)
+    a = ctx.read_accum()
+    ctx.resize(1920, 1080)
+    ctx.render_subframe(p)
+    assert np.isfinite(a).all() and a[..., :3].max() > 0 and ctx.read_accum().tobytes() == a.tobytes()
+    ctx.close()
