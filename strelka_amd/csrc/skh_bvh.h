@@ -142,27 +142,77 @@ __global__ void k_tri_boxes(const uint8_t* __restrict__ verts /*32 B stride*/, c
     grp[i] = m;
 }
 // curve segments: box of the 4 B-spline control points (convex hull property) grown by the largest radius
+// ---- curve segments, optionally cut into K parameter sub-ranges ("sub-segments") --------------------------------
+// A long thin diagonal hair fills a tiny part of its box; K sub-ranges give K boxes that hug the curve.  Sub-primitive p of a
+// curve set = (segment p / K, sub-range p % K).  Every sub-leaf runs the SAME full-segment intersector (so (t, u) are the bits
+// the unsplit segment gives) and keeps the hit only when u falls into its own sub-range: the nearest hit is found by exactly
+// the leaf that owns its u.  For that leaf's box to contain the hit point P: P lies on the sphere of some u* near u with
+// |C(u*) - C(u)| <= r for |dr/ds| <= 1, i.e. within 2 r of C(u); the box is the hull of the sub-curve's Bezier points over the
+// sub-range widened by SKH_SUBSEG_PAD on both sides, grown by 2 r_max (and rounding slack).
+#define SKH_SUBSEG_PAD 0.02f
+SKH_DI float4 lerp4(const float4& a, const float4& b, float t)
+{
+    return make_float4(a.x + (b.x - a.x) * t, a.y + (b.y - a.y) * t, a.z + (b.z - a.z) * t, a.w + (b.w - a.w) * t);
+}
+SKH_DI float4 bezier_blossom(const float4* b, float t0, float t1, float t2)
+{
+    const float4 l0 = lerp4(b[0], b[1], t0), l1 = lerp4(b[1], b[2], t0), l2 = lerp4(b[2], b[3], t0);
+    const float4 m0 = lerp4(l0, l1, t1), m1 = lerp4(l1, l2, t1);
+    return lerp4(m0, m1, t2);
+}
+// Bezier control points (xyz, radius) of the part [u0, u1] of the uniform cubic B-spline segment q[0..3]
+SKH_DI void subcurve_bezier(const float4* q, float u0, float u1, float4* c)
+{
+    float4 b[4];
+    b[0] = make_float4((q[0].x + 4.0f * q[1].x + q[2].x) / 6.0f, (q[0].y + 4.0f * q[1].y + q[2].y) / 6.0f, (q[0].z + 4.0f * q[1].z + q[2].z) / 6.0f,
+                       (q[0].w + 4.0f * q[1].w + q[2].w) / 6.0f);
+    b[1] = make_float4((2.0f * q[1].x + q[2].x) / 3.0f, (2.0f * q[1].y + q[2].y) / 3.0f, (2.0f * q[1].z + q[2].z) / 3.0f, (2.0f * q[1].w + q[2].w) / 3.0f);
+    b[2] = make_float4((q[1].x + 2.0f * q[2].x) / 3.0f, (q[1].y + 2.0f * q[2].y) / 3.0f, (q[1].z + 2.0f * q[2].z) / 3.0f, (q[1].w + 2.0f * q[2].w) / 3.0f);
+    b[3] = make_float4((q[1].x + 4.0f * q[2].x + q[3].x) / 6.0f, (q[1].y + 4.0f * q[2].y + q[3].y) / 6.0f, (q[1].z + 4.0f * q[2].z + q[3].z) / 6.0f,
+                       (q[1].w + 4.0f * q[2].w + q[3].w) / 6.0f);
+    c[0] = bezier_blossom(b, u0, u0, u0);
+    c[1] = bezier_blossom(b, u0, u0, u1);
+    c[2] = bezier_blossom(b, u0, u1, u1);
+    c[3] = bezier_blossom(b, u1, u1, u1);
+}
+SKH_DI void subseg_range(uint32_t sub, uint32_t K, float& u0, float& u1)
+{
+    u0 = K > 1u ? fmaxf((float)sub / (float)K - SKH_SUBSEG_PAD, 0.0f) : 0.0f;
+    u1 = K > 1u ? fminf((float)(sub + 1u) / (float)K + SKH_SUBSEG_PAD, 1.0f) : 1.0f;
+}
 __global__ void k_seg_boxes(const float* __restrict__ points, const float* __restrict__ radii,
-                            const uint32_t* __restrict__ segStart, const uint32_t* __restrict__ segCurve, uint32_t n,
-                            float4* __restrict__ boxLo, float4* __restrict__ boxHi, uint32_t* __restrict__ grp)
+                            const uint32_t* __restrict__ segStart, const uint32_t* __restrict__ segCurve, uint32_t n /*segments x K*/,
+                            uint32_t K, float4* __restrict__ boxLo, float4* __restrict__ boxHi, uint32_t* __restrict__ grp)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
-    const uint32_t s = segStart[i];
-    v3 lo = mk3(INFINITY), hi = mk3(-INFINITY);
-    float rmax = 0.0f;
+    const uint32_t seg = i / K, sub = i - seg * K;
+    const uint32_t s = segStart[seg];
+    float4 q[4], c[4];
+    float rmax = 0.0f, cmax = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
         const float* p = points + 3 * (size_t)(s + k);
-        lo = mk3(fminf(lo.x, p[0]), fminf(lo.y, p[1]), fminf(lo.z, p[2]));
-        hi = mk3(fmaxf(hi.x, p[0]), fmaxf(hi.y, p[1]), fmaxf(hi.z, p[2]));
-        rmax = fmaxf(rmax, radii[s + k]);
+        q[k] = make_float4(p[0], p[1], p[2], radii[s + k]);
+        rmax = fmaxf(rmax, fabsf(q[k].w));
+        cmax = fmaxf(cmax, fmaxf(fabsf(p[0]), fmaxf(fabsf(p[1]), fabsf(p[2]))));
     }
-    boxLo[i] = make_float4(lo.x - rmax, lo.y - rmax, lo.z - rmax, 0.0f);
-    boxHi[i] = make_float4(hi.x + rmax, hi.y + rmax, hi.z + rmax, 0.0f);
-    grp[i] = segCurve[i];
+    float u0, u1;
+    subseg_range(sub, K, u0, u1);
+    subcurve_bezier(q, u0, u1, c);
+    v3 lo = mk3(INFINITY), hi = mk3(-INFINITY);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+        lo = mk3(fminf(lo.x, c[k].x), fminf(lo.y, c[k].y), fminf(lo.z, c[k].z));
+        hi = mk3(fmaxf(hi.x, c[k].x), fmaxf(hi.y, c[k].y), fmaxf(hi.z, c[k].z));
+    }
+    const float m = (K > 1u ? 2.0f : 1.0f) * rmax * 1.01f + cmax * 4e-6f;
+    boxLo[i] = make_float4(lo.x - m, lo.y - m, lo.z - m, 0.0f);
+    boxHi[i] = make_float4(hi.x + m, hi.y + m, hi.z + m, 0.0f);
+    grp[i] = segCurve[seg];
 }
 
 __global__ void k_init_group_bounds(uint32_t* __restrict__ gb, uint32_t nGroups)
@@ -929,63 +979,57 @@ __global__ void k_gather_tris(const uint8_t* __restrict__ verts, const uint32_t*
     out[3 * (size_t)j + 2] = r[2];
 }
 // gather curve segments into leaf order: 64 B records (4 x {xyz, radius}) + the segment's primitive index
+// leaf order -> leaf records.  out: the segment's four control points (duplicated per sub-range: one 64-byte fetch per test);
+// outPrim: segment index inside its curve set | sub-range << 28; outBound: conservative bounding cylinder of the (padded)
+// sub-range for the cheap rejection test in front of the iterative intersector: {A.xyz, R}, {unit axis.xyz, 0}.  The curve
+// part is inside the hull of its Bezier points, so every accepted hit point lies within  max_i dist(c_i, L) + 2 r_max  of the
+// line L through the part's end points (r_max for the unsplit segment, see k_seg_boxes); a degenerate chord gives axis = 0,
+// which switches the test off.
 __global__ void k_gather_segs(const float* __restrict__ points, const float* __restrict__ radii,
                               const uint32_t* __restrict__ segStart, const uint32_t* __restrict__ segLocal,
-                              const uint32_t* __restrict__ sortedVals, uint32_t n, float4* __restrict__ out,
+                              const uint32_t* __restrict__ sortedVals, uint32_t n /*segments x K*/, uint32_t K, float4* __restrict__ out,
                               uint32_t* __restrict__ outPrim, float4* __restrict__ outBound)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n)
         return;
     const uint32_t i = sortedVals[j];
-    const uint32_t s = segStart[i];
-    float4 q[4];
+    const uint32_t seg = i / K, sub = i - seg * K;
+    const uint32_t s = segStart[seg];
+    float4 q[4], c[4];
+    float rmax = 0.0f, cmax = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
         const float* p = points + 3 * (size_t)(s + k);
         q[k] = make_float4(p[0], p[1], p[2], radii[s + k]);
         out[4 * (size_t)j + k] = q[k];
+        rmax = fmaxf(rmax, fabsf(q[k].w));
+        cmax = fmaxf(cmax, fmaxf(fabsf(p[0]), fmaxf(fabsf(p[1]), fabsf(p[2]))));
     }
-    outPrim[j] = segLocal[i];
-    // Conservative bounding cylinder (infinite) of the swept segment, for a cheap rejection test in front of the iterative
-    // intersector: the curve is a convex combination of its control points and so is its radius, hence every surface point
-    // lies within  max_i dist(q_i, L) + max_i r_i  of ANY line L.  L = the line through the segment's end points
-    // C(0) = (q0 + 4 q1 + q2) / 6 and C(1) = (q1 + 4 q2 + q3) / 6.  Record: {A.xyz, R}, {unit axis.xyz, 0}; a degenerate
-    // chord gives axis = 0 and R = the radius of a bounding sphere around A (dist to a "line" of direction 0 = dist to A).
-    const float ax = (q[0].x + 4.0f * q[1].x + q[2].x) / 6.0f, ay = (q[0].y + 4.0f * q[1].y + q[2].y) / 6.0f, az = (q[0].z + 4.0f * q[1].z + q[2].z) / 6.0f;
-    const float bx = (q[1].x + 4.0f * q[2].x + q[3].x) / 6.0f, by = (q[1].y + 4.0f * q[2].y + q[3].y) / 6.0f, bz = (q[1].z + 4.0f * q[2].z + q[3].z) / 6.0f;
-    float ux = bx - ax, uy = by - ay, uz = bz - az;
+    outPrim[j] = segLocal[seg] | (sub << 28);
+    float u0, u1;
+    subseg_range(sub, K, u0, u1);
+    subcurve_bezier(q, u0, u1, c);
+    const float ax = c[0].x, ay = c[0].y, az = c[0].z;
+    float ux = c[3].x - ax, uy = c[3].y - ay, uz = c[3].z - az;
     const float len = sqrtf(ux * ux + uy * uy + uz * uz);
+    float dmax = 0.0f;
     if (len > 1e-20f)
+    {
         ux /= len, uy /= len, uz /= len;
+#pragma unroll
+        for (int k = 1; k < 3; ++k)
+        {
+            const float vx = c[k].x - ax, vy = c[k].y - ay, vz = c[k].z - az;
+            const float t = vx * ux + vy * uy + vz * uz;
+            const float px = vx - t * ux, py = vy - t * uy, pz = vz - t * uz;
+            dmax = fmaxf(dmax, sqrtf(px * px + py * py + pz * pz));
+        }
+    }
     else
         ux = uy = uz = 0.0f;
-    // distances of the segment's BEZIER control points to the line (the same cubic in Bezier form: b0 = C(0),
-    // b1 = (2 q1 + q2) / 3, b2 = (q1 + 2 q2) / 3, b3 = C(1); their hull is far tighter than the B-spline points' hull)
-    float dmax = 0.0f, rmax = 0.0f, cmax = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-    {
-        const float4 qa = q[1 + k], qb = q[2 - k];
-        const float vx = (2.0f * qa.x + qb.x) / 3.0f - ax, vy = (2.0f * qa.y + qb.y) / 3.0f - ay, vz = (2.0f * qa.z + qb.z) / 3.0f - az;
-        const float t = vx * ux + vy * uy + vz * uz;
-        const float px = vx - t * ux, py = vy - t * uy, pz = vz - t * uz;
-        dmax = fmaxf(dmax, sqrtf(px * px + py * py + pz * pz));
-    }
-    if (len <= 1e-20f) // degenerate chord: bounding sphere around A over all B-spline control points
-        for (int k = 0; k < 4; ++k)
-        {
-            const float vx = q[k].x - ax, vy = q[k].y - ay, vz = q[k].z - az;
-            dmax = fmaxf(dmax, sqrtf(vx * vx + vy * vy + vz * vz));
-        }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-    {
-        rmax = fmaxf(rmax, fabsf(q[k].w)); // (the radius is a convex combination of the four radii)
-        cmax = fmaxf(cmax, fmaxf(fabsf(q[k].x), fmaxf(fabsf(q[k].y), fabsf(q[k].z))));
-    }
-    const float R = (dmax + rmax) * 1.001f + cmax * 4e-6f + 1e-30f; // rounding of A, the axis and the distances
+    const float R = (dmax + (K > 1u ? 2.0f : 1.0f) * rmax) * 1.001f + cmax * 4e-6f + 1e-30f;
     outBound[2 * (size_t)j] = make_float4(ax, ay, az, R);
     outBound[2 * (size_t)j + 1] = make_float4(ux, uy, uz, 0.0f);
 }

@@ -47,7 +47,8 @@ struct DevScene
     const Node4* segNodes;
     const float4* segs; // 4 x float4 per segment, leaf order
     const uint32_t* segPrim; // leaf order -> segment index inside its curve set
-    const float4* segBound; // 2 x float4 per segment, leaf order: bounding cylinder {A, R}, {unit axis, 0}
+    const float4* segBound; // 2 x float4 per leaf record: bounding cylinder {A, R}, {unit axis, 0}
+    uint32_t curveSplit; // parameter sub-ranges per segment (sub-range in segPrim >> 28)
     // flattened world-space hierarchy (default): one tree over every instanced primitive
     const Node4* wNodes;
     int wRoot;
@@ -561,7 +562,11 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                         float t, u;
                         if (intersect_curve_segment(o, d, tmin, best.t, q, t, u) && t < tmax)
                         {
-                            const uint32_t prim = sc.segPrim[first + k];
+                            const uint32_t sp = sc.segPrim[first + k];
+                            const uint32_t prim = sp & 0x0fffffffu;
+                            // a sub-range leaf keeps the hit only if u is its own (the leaf that owns u reports the same bits)
+                            if (min((uint32_t)(u * (float)sc.curveSplit), sc.curveSplit - 1u) != (sp >> 28))
+                                continue;
                             if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
                             {
                                 best.t = t;

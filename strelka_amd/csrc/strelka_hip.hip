@@ -79,6 +79,7 @@ struct skh_context
     DevBuf dTileXY, dAccum, dDiffuse, dSpecular, dDiffCnt, dSpecCnt, dSums, dPath, dRayQ[2], dHits, dShadowQ, dContrib, dCounts,
         dOvf, dStats, dScratchImage;
     uint32_t traceBlocks = 0;
+    uint32_t curveSplitBuilt = 1;
     uint32_t numTlasLeaves = 0;
     bool countTraversal = false, timing = false;
     // measured on MI355X (kitchen C3, 16 sub-frames per pass): 24 resident waves/CU; refill thresholds 32 (closest) / 44 (any-hit)
@@ -95,6 +96,7 @@ struct skh_context
     int wRoot = SKH_REF_INVALID;
     uint32_t wTriCount = 0, wSegCount = 0;
     uint32_t subframeBatch = 0, batchCapacity = 1; // option subframe_batch: 0 = auto
+    uint32_t curveSplit = 2; // parameter sub-ranges per curve segment in the curve BLAS (1 = off; hair stand-in, ms per 1080p sub-frame: 1: 61.6, 2: 52.1, 4: 49.7, 8: 50.1 -- build time and leaf memory grow with it)
     uint32_t tlasOpen = 1; // TLAS opening: up to tlasOpen x numInstances leaves; 1 = one leaf per instance (default: on the kitchen stand-in 2..16 were 4-9 % slower, more instance entries for no fewer nodes)
     uint32_t leafMaxTris = 2; // measured on MI355X: 2 beats 1, 3, 4, 6, 8 (the kernel is ALU bound, wasted triangle tests cost more than extra nodes)
     uint32_t buildQuality = 1; // 0: Karras radix tree (fastest build), 1: PLOC clustering (SAH-class quality)
@@ -1131,21 +1133,33 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     BA(dev_upload(c, c->dCurveSegBase, curveSegBase.data(), sizeof(uint32_t) * (size_t)nCurves));
     BA(dev_upload(c, dSegCurve, segCurve.data(), sizeof(uint32_t) * (size_t)nSegs));
     BA(dev_upload(c, dSegLocal, segLocal.data(), sizeof(uint32_t) * (size_t)nSegs));
-    BA(dev_alloc(c, dBoxLo, sizeof(float4) * (size_t)std::max(nSegs, std::max(1u, c->nInstances))));
-    BA(dev_alloc(c, dBoxHi, sizeof(float4) * (size_t)std::max(nSegs, std::max(1u, c->nInstances))));
-    BA(dev_alloc(c, dGrp, sizeof(uint32_t) * (size_t)std::max(nSegs, std::max(1u, c->nInstances))));
-    if (nSegs)
-        k_seg_boxes<<<(nSegs + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), c->dSegStartAll.as<uint32_t>(),
-                                                      dSegCurve.as<uint32_t>(), nSegs, dBoxLo.as<float4>(), dBoxHi.as<float4>(),
+    const uint32_t K = std::max(1u, std::min(c->curveSplit, 8u));
+    if ((uint64_t)nSegs * K >= (1ull << 28))
+    {
+        c->err = "skh_build_accel: more than 2^28 curve sub-segments (lower the curve_split option)";
+        cleanup();
+        return SKH_INVALID_ARGUMENT;
+    }
+    const uint32_t nSub = nSegs * K;
+    std::vector<uint32_t> curveSubCount(nCurves);
+    for (uint32_t ci = 0; ci < nCurves; ++ci)
+        curveSubCount[ci] = curveSegCount[ci] * K;
+    BA(dev_alloc(c, dBoxLo, sizeof(float4) * (size_t)std::max(nSub, std::max(1u, c->nInstances))));
+    BA(dev_alloc(c, dBoxHi, sizeof(float4) * (size_t)std::max(nSub, std::max(1u, c->nInstances))));
+    BA(dev_alloc(c, dGrp, sizeof(uint32_t) * (size_t)std::max(nSub, std::max(1u, c->nInstances))));
+    if (nSub)
+        k_seg_boxes<<<(nSub + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), c->dSegStartAll.as<uint32_t>(),
+                                                      dSegCurve.as<uint32_t>(), nSub, K, dBoxLo.as<float4>(), dBoxHi.as<float4>(),
                                                       dGrp.as<uint32_t>());
-    BA(lbvh_build(c, nSegs, nCurves, curveSegCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), 2, usePloc, segOut));
-    BA(dev_alloc(c, c->dSegs, sizeof(float4) * 4 * (size_t)std::max(1u, nSegs)));
-    BA(dev_alloc(c, c->dSegPrim, sizeof(uint32_t) * (size_t)std::max(1u, nSegs)));
-    BA(dev_alloc(c, c->dSegBound, sizeof(float4) * 2 * (size_t)std::max(1u, nSegs)));
-    if (nSegs)
-        k_gather_segs<<<(nSegs + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), c->dSegStartAll.as<uint32_t>(),
-                                                        dSegLocal.as<uint32_t>(), segOut.sortedVals.as<uint32_t>(), nSegs,
+    BA(lbvh_build(c, nSub, nCurves, curveSubCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), 2, usePloc, segOut));
+    BA(dev_alloc(c, c->dSegs, sizeof(float4) * 4 * (size_t)std::max(1u, nSub)));
+    BA(dev_alloc(c, c->dSegPrim, sizeof(uint32_t) * (size_t)std::max(1u, nSub)));
+    BA(dev_alloc(c, c->dSegBound, sizeof(float4) * 2 * (size_t)std::max(1u, nSub)));
+    if (nSub)
+        k_gather_segs<<<(nSub + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), c->dSegStartAll.as<uint32_t>(),
+                                                        dSegLocal.as<uint32_t>(), segOut.sortedVals.as<uint32_t>(), nSub, K,
                                                         c->dSegs.as<float4>(), c->dSegPrim.as<uint32_t>(), c->dSegBound.as<float4>());
+    c->curveSplitBuilt = K;
     dev_free(c->dSegNodes);
     c->dSegNodes = segOut.nodes;
     // ---- instances -> TLAS ----
@@ -1480,6 +1494,7 @@ static DevScene make_dev_scene(const skh_context* c)
     sc.segs = c->dSegs.as<float4>();
     sc.segPrim = c->dSegPrim.as<uint32_t>();
     sc.segBound = c->dSegBound.as<float4>();
+    sc.curveSplit = c->curveSplitBuilt;
     sc.wNodes = c->dWNodes.as<Node4>();
     sc.wRoot = c->wRoot;
     sc.wTriCount = c->wTriCount;
@@ -2003,6 +2018,13 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 1 || value > 64)
             return SKH_INVALID_ARGUMENT;
         (n == "fetch_min_closest" ? c->fetchMinClosest : c->fetchMinShadow) = (uint32_t)value;
+    }
+    else if (n == "curve_split")
+    {
+        if (value < 1 || value > 8)
+            return SKH_INVALID_ARGUMENT;
+        c->curveSplit = (uint32_t)value;
+        c->accelBuilt = false;
     }
     else if (n == "tlas_open")
     {
