@@ -1386,7 +1386,7 @@ static skh_status alloc_frame(skh_context* c)
     AF(dev_alloc(c, c->dHits, sizeof(float) * 5 * N));
     AF(dev_alloc(c, c->dShadowQ, sizeof(float) * 9 * N));
     AF(dev_alloc(c, c->dContrib, sizeof(float) * 3 * N));
-    AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * (512 + 16 * 130)));
+    AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * (512 + 16 * SKH_FETCH_STRIDE * 130)));
     for (int k = 0; k < 2; ++k)
     {
         AF(dev_alloc(c, c->dSortKeys[k], sizeof(uint64_t) * N));
@@ -1641,12 +1641,12 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     RayQ shq{ c->dShadowQ.as<float>(), N };
     HitQ hq{ c->dHits.as<float>(), N };
     HitQ nohq{ nullptr, 0 };
-    // dCounts: [0, 260) queue lengths (2 per bounce), [512, 512 + 16 * 129) ray-fetch cursors (8 per trace launch)
+    // dCounts: [0, 260) queue lengths (2 per bounce), then the ray-fetch cursors: 8 per trace launch, one 128-byte line each
     uint32_t* counts = c->dCounts.as<uint32_t>();
     uint32_t* fetch = counts + 512;
     for (uint32_t s = 0; s < fp.samplesThisLaunch; ++s)
     {
-        SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (512 + 16 * (fp.maxDepth + 1)), st));
+        SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (512 + 16 * SKH_FETCH_STRIDE * (fp.maxDepth + 1)), st));
         {
             SpanGuard g(c, KC_RAYGEN);
             k_raygen<<<(NP + 511) / 512, 512, 0, st>>>(fp, tiles, s, rq[0], counts, ps);
@@ -1662,9 +1662,9 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
             {
                 SpanGuard g(c, KC_TRACE_CLOSEST);
                 if (c->countTraversal)
-                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b, fetch + 16 * b, permC, hq, ps, nullptr, 0);
+                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b, fetch + 16 * b * SKH_FETCH_STRIDE, permC, hq, ps, nullptr, 0);
                 else
-                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b, fetch + 16 * b, permC, hq, ps, nullptr, 0);
+                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b, fetch + 16 * b * SKH_FETCH_STRIDE, permC, hq, ps, nullptr, 0);
             }
             {
                 SpanGuard g(c, KC_SHADE);
@@ -1680,9 +1680,9 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
             {
                 SpanGuard g(c, KC_TRACE_SHADOW);
                 if (c->countTraversal)
-                    launch_trace<true, true>(c, sc, shq, counts + 2 * b + 1, fetch + 16 * b + 8, permS, nohq, ps, c->dContrib.as<float>(), N);
+                    launch_trace<true, true>(c, sc, shq, counts + 2 * b + 1, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, permS, nohq, ps, c->dContrib.as<float>(), N);
                 else
-                    launch_trace<true, false>(c, sc, shq, counts + 2 * b + 1, fetch + 16 * b + 8, permS, nohq, ps, c->dContrib.as<float>(), N);
+                    launch_trace<true, false>(c, sc, shq, counts + 2 * b + 1, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, permS, nohq, ps, c->dContrib.as<float>(), N);
             }
             if (fp.debug == 1)
                 break;
@@ -1922,7 +1922,7 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
         dev_free(cnt);
     };
     if ((s = dev_alloc(c, q, sizeof(float) * 9 * (size_t)n_rays)) != SKH_OK || (s = dev_alloc(c, h, sizeof(float) * 5 * (size_t)n_rays)) != SKH_OK ||
-        (s = dev_alloc(c, cnt, sizeof(uint32_t) * 16)) != SKH_OK)
+        (s = dev_alloc(c, cnt, sizeof(uint32_t) * (SKH_FETCH_STRIDE + 8 * SKH_FETCH_STRIDE))) != SKH_OK)
     {
         cleanup();
         return s;
@@ -1938,13 +1938,13 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
     HitQ hq{ h.as<float>(), n_rays };
     PathS ps{ nullptr, 0 };
     uint32_t* dcount = cnt.as<uint32_t>();
-    uint32_t* dfetch = dcount + 8;
+    uint32_t* dfetch = dcount + SKH_FETCH_STRIDE;
     SKH_TRY(c, hipMemcpyAsync(dcount, &n_rays, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     const DevScene sc = make_dev_scene(c);
     k_rays_aos_to_soa<<<(n_rays + 255) / 256, 256, 0, c->stream>>>(reinterpret_cast<const skh_ray*>(d_rays), n_rays, rq);
     for (uint32_t r = 0; r < std::max(1u, repeat); ++r)
     {
-        (void)hipMemsetAsync(dfetch, 0, sizeof(uint32_t) * 8, c->stream);
+        (void)hipMemsetAsync(dfetch, 0, sizeof(uint32_t) * 8 * SKH_FETCH_STRIDE, c->stream);
         SpanGuard g(c, mode == SKH_TRACE_SHADOW ? KC_TRACE_SHADOW : KC_TRACE_CLOSEST);
         if (mode == SKH_TRACE_SHADOW)
         {
