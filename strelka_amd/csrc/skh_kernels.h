@@ -193,6 +193,7 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 // The 8 ray-fetch cursors of a launch sit in separate 128-byte lines: returning atomics on ONE line serialise at ~88 per
 // microsecond chip-wide (measured), which eight cursors in the same line would share.
 #define SKH_FETCH_STRIDE 32
+#define SKH_COUNT_STRIDE 32 // same for the queue-length words the compaction atomics hit
 #ifndef SKH_PK_FMA
 #define SKH_PK_FMA 0
 #endif
@@ -1653,8 +1654,8 @@ __global__ void k_add_stats(const uint32_t* __restrict__ counts, uint32_t numBou
         unsigned long long r = 0, s = 0;
         for (uint32_t b = 0; b < numBounces; ++b)
         {
-            r += counts[2 * b];
-            s += counts[2 * b + 1];
+            r += counts[2 * b * SKH_COUNT_STRIDE];
+            s += counts[(2 * b + 1) * SKH_COUNT_STRIDE];
         }
         stats->raysRadiance += r;
         stats->raysShadow += s;

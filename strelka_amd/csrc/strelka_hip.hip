@@ -84,7 +84,7 @@ struct skh_context
     bool countTraversal = false, timing = false;
     // measured on MI355X (kitchen C3, 16 sub-frames per pass): 24 resident waves/CU; refill thresholds 32 (closest) / 44 (any-hit)
     uint32_t wavesPerCU = 24;
-    uint32_t fetchMinClosest = 40, fetchMinShadow = 52;
+    uint32_t fetchMinClosest = 16, fetchMinShadow = 24;
     uint32_t nodeBreakClosest = 20, nodeBreakShadow = 20; // leave the node loop when fewer than x/64 of the wave's rays are still descending
     // ray re-ordering (per bounce): 0 = off, else Morton bits per axis of the origin cell (key = octant : morton)
     uint32_t sortBitsClosest = 0, sortBitsShadow = 0, sortFirstBounce = 1;
@@ -1386,7 +1386,7 @@ static skh_status alloc_frame(skh_context* c)
     AF(dev_alloc(c, c->dHits, sizeof(float) * 5 * N));
     AF(dev_alloc(c, c->dShadowQ, sizeof(float) * 9 * N));
     AF(dev_alloc(c, c->dContrib, sizeof(float) * 3 * N));
-    AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * (512 + 16 * SKH_FETCH_STRIDE * 130)));
+    AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * (SKH_COUNT_STRIDE * 2 * 130 + 16 * SKH_FETCH_STRIDE * 130)));
     for (int k = 0; k < 2; ++k)
     {
         AF(dev_alloc(c, c->dSortKeys[k], sizeof(uint64_t) * N));
@@ -1641,12 +1641,13 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     RayQ shq{ c->dShadowQ.as<float>(), N };
     HitQ hq{ c->dHits.as<float>(), N };
     HitQ nohq{ nullptr, 0 };
-    // dCounts: [0, 260) queue lengths (2 per bounce), then the ray-fetch cursors: 8 per trace launch, one 128-byte line each
+    // dCounts: 260 queue-length words (2 per bounce), then the ray-fetch cursors (8 per trace launch); every word that is the
+    // target of atomics has a 128-byte line of its own (returning atomics on one line serialise at ~88 per microsecond)
     uint32_t* counts = c->dCounts.as<uint32_t>();
-    uint32_t* fetch = counts + 512;
+    uint32_t* fetch = counts + SKH_COUNT_STRIDE * 2 * 130;
     for (uint32_t s = 0; s < fp.samplesThisLaunch; ++s)
     {
-        SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (512 + 16 * SKH_FETCH_STRIDE * (fp.maxDepth + 1)), st));
+        SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (SKH_COUNT_STRIDE * 2 * 130 + 16 * SKH_FETCH_STRIDE * (fp.maxDepth + 1)), st));
         {
             SpanGuard g(c, KC_RAYGEN);
             k_raygen<<<(NP + 511) / 512, 512, 0, st>>>(fp, tiles, s, rq[0], counts, ps);
@@ -1657,32 +1658,32 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
             if (b >= c->sortFirstBounce && c->sortBitsClosest)
             {
                 SpanGuard g(c, KC_SORT);
-                permC = sort_rays(c, rq[b & 1], counts + 2 * b, c->sortBitsClosest);
+                permC = sort_rays(c, rq[b & 1], counts + 2 * b * SKH_COUNT_STRIDE, c->sortBitsClosest);
             }
             {
                 SpanGuard g(c, KC_TRACE_CLOSEST);
                 if (c->countTraversal)
-                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b, fetch + 16 * b * SKH_FETCH_STRIDE, permC, hq, ps, nullptr, 0);
+                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b * SKH_COUNT_STRIDE, fetch + 16 * b * SKH_FETCH_STRIDE, permC, hq, ps, nullptr, 0);
                 else
-                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b, fetch + 16 * b * SKH_FETCH_STRIDE, permC, hq, ps, nullptr, 0);
+                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b * SKH_COUNT_STRIDE, fetch + 16 * b * SKH_FETCH_STRIDE, permC, hq, ps, nullptr, 0);
             }
             {
                 SpanGuard g(c, KC_SHADE);
-                k_shade<<<(NP + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b, hq, ps, rq[(b + 1) & 1],
-                                                   counts + 2 * (b + 1), shq, c->dContrib.as<float>(), counts + 2 * b + 1);
+                k_shade<<<(NP + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b * SKH_COUNT_STRIDE, hq, ps, rq[(b + 1) & 1],
+                                                   counts + 2 * (b + 1) * SKH_COUNT_STRIDE, shq, c->dContrib.as<float>(), counts + (2 * b + 1) * SKH_COUNT_STRIDE);
             }
             const uint32_t* permS = nullptr;
             if (c->sortBitsShadow)
             {
                 SpanGuard g(c, KC_SORT);
-                permS = sort_rays(c, shq, counts + 2 * b + 1, c->sortBitsShadow);
+                permS = sort_rays(c, shq, counts + (2 * b + 1) * SKH_COUNT_STRIDE, c->sortBitsShadow);
             }
             {
                 SpanGuard g(c, KC_TRACE_SHADOW);
                 if (c->countTraversal)
-                    launch_trace<true, true>(c, sc, shq, counts + 2 * b + 1, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, permS, nohq, ps, c->dContrib.as<float>(), N);
+                    launch_trace<true, true>(c, sc, shq, counts + (2 * b + 1) * SKH_COUNT_STRIDE, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, permS, nohq, ps, c->dContrib.as<float>(), N);
                 else
-                    launch_trace<true, false>(c, sc, shq, counts + 2 * b + 1, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, permS, nohq, ps, c->dContrib.as<float>(), N);
+                    launch_trace<true, false>(c, sc, shq, counts + (2 * b + 1) * SKH_COUNT_STRIDE, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, permS, nohq, ps, c->dContrib.as<float>(), N);
             }
             if (fp.debug == 1)
                 break;
