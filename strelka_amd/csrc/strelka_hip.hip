@@ -1364,10 +1364,11 @@ static skh_status alloc_frame(skh_context* c)
     }
     c->numTiles = (uint32_t)(c->tileXY.size() / 2);
     c->numSlots = c->numTiles * T * T;
-    // sub-frame batching: aim at ~32 M paths per wavefront pass.  The persistent trace kernels have a long tail (a few
-    // rays walk 10x the average number of nodes); at 2 M rays per launch the tail is half of the kernel time, at 32 M it
-    // is amortised (measured: 1104 -> 2055 Mray/s at 1080p).  ~270 B per path: 9 GB of 288 GB at the default.
-    c->batchCapacity = c->subframeBatch ? c->subframeBatch : std::min(64u, std::max(1u, (1u << 25) / std::max(1u, c->numSlots)));
+    // sub-frame batching: aim at ~64 M paths per wavefront pass.  The persistent trace kernels have a long tail (a few
+    // rays walk 10x the average number of nodes); at 2 M rays per launch the tail is half of the kernel time, at 64 M it
+    // is amortised (measured at 1080p, Mray/s: 1 sub-frame per pass 1104, 16: 1942, 64: 2055 before the kernel work; with
+    // the final kernels 8: 3455, 16: 3579, 32: 3678).  ~270 B per path: 18 GB of 288 GB at the default.
+    c->batchCapacity = c->subframeBatch ? c->subframeBatch : std::min(64u, std::max(1u, (1u << 26) / std::max(1u, c->numSlots)));
     const size_t N1 = std::max(1u, c->numSlots);
     const size_t N = N1 * c->batchCapacity;
 #define AF(expr)                \
