@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
             StatsDev* __restrict__ stats)
 {
     __shared__ int s_stack[SKH_STACK_LDS * SKH_TRACE_BLOCK];
-    const uint32_t fetchMin = fetchArg & 0xffffu, nodeBreak = fetchArg >> 16;
+    const uint32_t fetchMin = fetchArg & 0xffffu, nodeBreak = (fetchArg >> 16) & 0xffu, leafMin = fetchArg >> 24;
     const uint32_t lane = threadIdx.x;
     const uint32_t n = *countPtr;
     if (n == 0)
@@ -513,7 +513,20 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
             // ---- leaf ----
             SKH_LP({ const unsigned long long t = __builtin_readcyclecounter(); cy[1] += t - cyA; cyA = t; })
             bool entered = false;
-            if (cur < 0 && cur != SKH_REF_SENTINEL)
+            // Two kinds of leaf work (instance entry, primitive tests) are two branches of the same wave.  When one of them has
+            // only a few takers it is postponed: those lanes keep their leaf and meet the next pass's takers (leafMin = 0/1: off)
+            bool isLeaf = cur < 0 && cur != SKH_REF_SENTINEL;
+            if (leafMin > 1u)
+            {
+                const uint32_t nI = (uint32_t)__popcll(__ballot(isLeaf && !inBlas)), nT = (uint32_t)__popcll(__ballot(isLeaf && inBlas));
+                const bool runI = nI >= nT || nI >= leafMin, runT = nT > nI || nT >= leafMin;
+                if (isLeaf && !(inBlas ? runT : runI))
+                {
+                    isLeaf = false;
+                    entered = true; // (keeps `cur`: no pop)
+                }
+            }
+            if (isLeaf)
             {
                 const uint32_t enc = (uint32_t)~cur;
                 const uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
