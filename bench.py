@@ -139,16 +139,24 @@ def main():
     max_tiles = tiles.max_tiles_per_rank(W, H, args.tile, world)
     tile_buf = torch.zeros((max_tiles, args.tile * args.tile, 4), dtype=torch.float32, device=dev)
     image = torch.zeros((H, W, 4), dtype=torch.float32, device=dev) if rank == 0 else None
+    # root: one receive buffer for all ranks' tiles and ONE de-tiling launch per frame; a rank with fewer tiles than
+    # max_tiles sends padding, which gets an origin outside the image and is dropped by the scatter kernel
+    all_tiles = torch.zeros((world, max_tiles, args.tile * args.tile, 4), dtype=torch.float32, device=dev) if rank == 0 and world > 1 else None
+    all_xy = None
+    if rank == 0 and world > 1:
+        all_xy = np.full((world, max_tiles, 2), max(W, H), np.uint32)
+        for r in range(world):
+            t = tiles.assign_tiles(W, H, args.tile, world, r)
+            all_xy[r, :len(t)] = t
+        all_xy = np.ascontiguousarray(all_xy.reshape(-1, 2))
 
     def frame():
-        ctx.render_subframes(params, args.spp, None)  # 64 sub-frames of 1 spp, one device sync at the end
+        ctx.render_subframes(params, args.spp, None)  # all sub-frames of the frame, one device sync at the end
         if world > 1:
             ctx.copy_accum_tiles(tile_buf.data_ptr())
-            parts = tiles.gather_tiles(tile_buf, world, rank, dist)
+            tiles.gather_tiles(tile_buf, world, rank, dist, out=all_tiles)
             if rank == 0:
-                for r, part in enumerate(parts):
-                    t = tiles.assign_tiles(W, H, args.tile, world, r)
-                    ctx.scatter_tiles(part.data_ptr(), t, args.tile, image.data_ptr(), W, H)
+                ctx.scatter_tiles(all_tiles.data_ptr(), all_xy, args.tile, image.data_ptr(), W, H)
 
     def barrier():
         if world > 1:

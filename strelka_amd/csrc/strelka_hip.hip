@@ -65,7 +65,7 @@ struct skh_context
     DevBuf dVerts, dIndices, dMeshes, dPoints, dRadii, dInstances, dLights, dMaterials;
     DevBuf dCurveSegBase, dSegStartAll;
     // accel
-    DevBuf dTexels, dTexDesc, dSegBound;
+    DevBuf dTexels, dTexDesc, dSegBound, dScatterXY;
     uint32_t nTextures = 0;
     DevBuf dTriNodes, dTris, dSegNodes, dSegs, dSegPrim, dTlasNodes, dTlasInst, dDevInst, dTravInst;
     int tlasRoot = SKH_REF_INVALID;
@@ -727,7 +727,7 @@ void skh_destroy(skh_context* c)
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : { &c->dVerts, &c->dIndices, &c->dMeshes, &c->dPoints, &c->dRadii, &c->dInstances, &c->dLights, &c->dMaterials,
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
-                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
+                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dScatterXY, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
                        &c->dCounts, &c->dOvf, &c->dStats, &c->dScratchImage, &c->dSortKeys[0], &c->dSortKeys[1], &c->dSortVals[0],
                        &c->dSortVals[1], &c->dSortHist, &c->dWNodes, &c->dWTris, &c->dWSegs, &c->dWSegMeta })
@@ -1851,18 +1851,18 @@ skh_status skh_scatter_tiles(skh_context* c, const void* d_src_tiles, const uint
     if (!c || !d_src_tiles || !tile_xy || !d_dst || (tile_size & (tile_size - 1)))
         return SKH_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
-    DevBuf t;
-    skh_status s = dev_upload(c, t, tile_xy, sizeof(uint32_t) * 2 * (size_t)n_tiles);
+    // (tile list kept in a context buffer: no allocation per call; tiles whose origin lies outside the image -- the padding
+    // of a gathered multi-rank tile set -- write nothing)
+    skh_status s = dev_upload(c, c->dScatterXY, tile_xy, sizeof(uint32_t) * 2 * (size_t)n_tiles);
     if (s != SKH_OK)
         return s;
     uint32_t shift = 0;
     while ((1u << shift) < tile_size)
         ++shift;
     const uint32_t slots = n_tiles * tile_size * tile_size;
-    k_detile<<<(slots + 255) / 256, 256, 0, c->stream>>>(reinterpret_cast<const float4*>(d_src_tiles), t.as<uint32_t>(), slots, shift,
+    k_detile<<<(slots + 255) / 256, 256, 0, c->stream>>>(reinterpret_cast<const float4*>(d_src_tiles), c->dScatterXY.as<uint32_t>(), slots, shift,
                                                         width, height, reinterpret_cast<float4*>(d_dst));
     hipError_t e = hipStreamSynchronize(c->stream);
-    dev_free(t);
     if (e != hipSuccess)
     {
         c->err = std::string("skh_scatter_tiles: ") + hipGetErrorString(e);

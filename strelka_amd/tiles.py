@@ -27,10 +27,11 @@ def max_tiles_per_rank(width, height, tile_size, world_size):
     return (n + world_size - 1) // world_size
 
 
-def gather_tiles(local_tiles, world_size, rank, dist=None, dst=0):
+def gather_tiles(local_tiles, world_size, rank, dist=None, dst=0, out=None):
     """One gather of equally sized (padded) tile-accumulator tensors to `dst`.
     local_tiles: torch tensor [max_tiles, tile*tile, 4] float32 (rows past this rank's tile count are padding).
-    Returns the list of per-rank tensors on dst, None elsewhere."""
+    out: optional preallocated [world_size, max_tiles, tile*tile, 4] tensor on dst (the parts are written into its slices,
+    so the root can de-tile everything with one launch).  Returns the list of per-rank tensors on dst, None elsewhere."""
     import torch
 
     if world_size == 1 or dist is None:
@@ -38,16 +39,25 @@ def gather_tiles(local_tiles, world_size, rank, dist=None, dst=0):
     if local_tiles.is_cuda and dist.get_backend() == "gloo":
         # (test configuration: several ranks on one GPU, no RCCL) stage through the host
         host = local_tiles.cpu()
-        out = [torch.empty_like(host) for _ in range(world_size)] if rank == dst else None
-        dist.gather(host, gather_list=out, dst=dst)
-        return [t.to(local_tiles.device) for t in out] if rank == dst else None
-    out = [torch.empty_like(local_tiles) for _ in range(world_size)] if rank == dst else None
-    dist.gather(local_tiles, gather_list=out, dst=dst)
+        parts = [torch.empty_like(host) for _ in range(world_size)] if rank == dst else None
+        dist.gather(host, gather_list=parts, dst=dst)
+        if rank != dst:
+            return None
+        if out is not None:
+            for r, p in enumerate(parts):
+                out[r].copy_(p)
+            return [out[r] for r in range(world_size)]
+        return [t.to(local_tiles.device) for t in parts]
+    if rank == dst:
+        parts = [out[r] for r in range(world_size)] if out is not None else [torch.empty_like(local_tiles) for _ in range(world_size)]
+    else:
+        parts = None
+    dist.gather(local_tiles, gather_list=parts, dst=dst)
     if local_tiles.is_cuda:
         # the collective runs on RCCL's stream and the consumer (skh_scatter_tiles) on the renderer's own stream:
         # finish the gather before handing the buffers over
         torch.cuda.current_stream().synchronize()
-    return out
+    return parts
 
 
 def detile_numpy(tiles_rgba, tile_xy, tile_size, width, height, out=None):
