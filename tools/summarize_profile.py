@@ -75,6 +75,42 @@ def main():
                       open(os.path.join(dst, "traffic_k_trace_closest.json"), "w"), indent=1)
             print("traffic", r)
     print(open(os.path.join(dst, f"{tag}_pmc_hbm.csv")).read())
+    sq_summaries(src, dst, tag)
+
+
+def sq_summaries(src, dst, tag):
+    """optional passes (tools/profile.sh does not run them by default): <src>/pmc_inst with SQ_WAVES SQ_INSTS_*, and
+    <src>/pmc_util with SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"""
+    def collect(sub, key):
+        acc = defaultdict(lambda: defaultdict(float))
+        cnt = defaultdict(int)
+        for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                k = short(row["Kernel_Name"])
+                acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+                if row["Counter_Name"] == key:
+                    cnt[k] += 1
+        return acc, cnt
+
+    acc, cnt = collect("pmc_inst", "SQ_WAVES")
+    if acc:
+        with open(os.path.join(dst, f"{tag}_pmc_instructions.csv"), "w") as fo:
+            fo.write("kernel,launches,waves_per_launch,VALU_per_wave,SALU_per_wave,VMEM_per_wave,LDS_per_wave\n")
+            for k, a in sorted(acc.items()):
+                w = a["SQ_WAVES"]
+                if w and cnt[k]:
+                    fo.write('"%s",%d,%.0f,%.0f,%.0f,%.1f,%.1f\n' % (k, cnt[k], w / cnt[k], a["SQ_INSTS_VALU"] / w, a["SQ_INSTS_SALU"] / w,
+                                                                 a["SQ_INSTS_VMEM"] / w, a["SQ_INSTS_LDS"] / w))
+    acc, cnt = collect("pmc_util", "SQ_BUSY_CYCLES")
+    if acc:
+        with open(os.path.join(dst, f"{tag}_pmc_sq_utilisation.csv"), "w") as fo:
+            fo.write("kernel,launches,SQ_BUSY_CYCLES,SQ_WAVE_CYCLES,SQ_ACTIVE_INST_VALU,SQ_THREAD_CYCLES_VALU,SQ_WAIT_INST_ANY,lanes_per_valu_inst\n")
+            for k, a in sorted(acc.items()):
+                n = cnt[k]
+                if n and a["SQ_ACTIVE_INST_VALU"]:
+                    fo.write('"%s",%d,%.4g,%.4g,%.4g,%.4g,%.4g,%.1f\n' % (k, n, a["SQ_BUSY_CYCLES"] / n, a["SQ_WAVE_CYCLES"] / n, a["SQ_ACTIVE_INST_VALU"] / n,
+                                                                        a["SQ_THREAD_CYCLES_VALU"] / n, a["SQ_WAIT_INST_ANY"] / n,
+                                                                        a["SQ_THREAD_CYCLES_VALU"] / a["SQ_ACTIVE_INST_VALU"]))
 
 
 if __name__ == "__main__":
