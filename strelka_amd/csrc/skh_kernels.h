@@ -122,8 +122,6 @@ struct FrameP // skh_frame_params + launch geometry
 #define SKH_STACK_OVF 104
 #define SKH_TRACE_BLOCK 64
 
-typedef float pk2 __attribute__((ext_vector_type(2))); // operand of the packed fp32 VALU ops (v_pk_fma_f32)
-
 struct TraceCounters
 {
     uint32_t nodes, prims, segs, insts;
@@ -181,12 +179,6 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 #ifndef SKH_SORT_ANYHIT
 #define SKH_SORT_ANYHIT 0
 #endif
-#ifndef SKH_POP_IN_LOOP
-#define SKH_POP_IN_LOOP 1
-#endif
-#ifndef SKH_ONE_TRI_PER_PASS
-#define SKH_ONE_TRI_PER_PASS 0 // measured: -4 % (the lagging lane costs more than the better-filled triangle block gains)
-#endif
 #ifndef SKH_TRACE_ATTR
 #define SKH_TRACE_ATTR
 #endif
@@ -194,12 +186,6 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 // microsecond chip-wide (measured), which eight cursors in the same line would share.
 #define SKH_FETCH_STRIDE 32
 #define SKH_COUNT_STRIDE 32 // same for the queue-length words the compaction atomics hit
-#ifndef SKH_PK_FMA
-#define SKH_PK_FMA 0
-#endif
-#ifndef SKH_FETCH_MIN
-#define SKH_FETCH_MIN 20 // refill the wave from the ray queue when at least this many lanes are idle
-#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // k_trace: persistent waves over the ray queue, two-level BVH traversal (TLAS -> instance -> BLAS).
@@ -207,7 +193,7 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 // Work distribution: the queue is cut into 8 contiguous ranges, one per XCD label (blockIdx % 8; blocks b and b+8
 // share an XCD under the observed round-robin placement, so neighbouring rays -- similar BVH working set -- land in
 // one XCD's L2).  A wave pulls rays from its range through one returning atomic per refill and steals from the next
-// ranges when its own is empty.  Lanes whose ray has terminated are refilled as soon as SKH_FETCH_MIN lanes are idle
+// ranges when its own is empty.  Lanes whose ray has terminated are refilled as soon as `fetchMin` lanes are idle
 // ("persistent while-while with dynamic fetch"), which keeps the 64-wide wave populated when ray lengths diverge.
 // Placement and fetch order only affect speed: every ray's result is independent of scheduling.
 //
@@ -396,27 +382,6 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                 float tn[4];
                 int rf[4];
                 rf[0] = __float_as_int(w3.x), rf[1] = __float_as_int(w3.y), rf[2] = __float_as_int(w3.z), rf[3] = __float_as_int(w3.w);
-#if SKH_PK_FMA
-                // two children per v_pk_fma_f32 (same fused multiply-add per element as fmaf)
-                const pk2 pax = { ax, ax }, pbx = { bx, bx }, pay = { ay, ay }, pby = { by, by }, paz = { az, az }, pbz = { bz, bz };
-#pragma unroll
-                for (int k = 0; k < 4; k += 2)
-                {
-#define SKH_Q2(w) pk2{ (float)(((w) >> (8 * k)) & 0xffu), (float)(((w) >> (8 * k + 8)) & 0xffu) }
-                    const pk2 nx = __builtin_elementwise_fma(SKH_Q2(nxw), pax, pbx), fx = __builtin_elementwise_fma(SKH_Q2(fxw), pax, pbx);
-                    const pk2 ny = __builtin_elementwise_fma(SKH_Q2(nyw), pay, pby), fy = __builtin_elementwise_fma(SKH_Q2(fyw), pay, pby);
-                    const pk2 nz = __builtin_elementwise_fma(SKH_Q2(nzw), paz, pbz), fz = __builtin_elementwise_fma(SKH_Q2(fzw), paz, pbz);
-#undef SKH_Q2
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                    {
-                        const float tnear = fmaxf(fmaxf(nx[j], ny[j]), fmaxf(nz[j], tmin));
-                        const float tfar = fminf(fminf(fx[j], fy[j]), fminf(fz[j], best.t));
-                        const bool hit = rf[k + j] != SKH_REF_INVALID && tnear <= tfar * 1.0000002384185791015625f;
-                        tn[k + j] = hit ? tnear : INFINITY;
-                    }
-                }
-#else
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                 {
@@ -428,13 +393,6 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                     const bool hit = rf[k] != SKH_REF_INVALID && tnear <= tfar * 1.0000002384185791015625f;
                     tn[k] = hit ? tnear : INFINITY;
                 }
-#endif
-#ifdef SKH_DEBUG_PRINT
-                if (ridx == 0)
-                    printf("ray o %g %g %g inv %g %g %g ax %g bx %g ay %g by %g az %g bz %g nxw %08x fxw %08x\n", o.x, o.y, o.z, inv.x, inv.y, inv.z, ax, bx, ay, by, az, bz, nxw, fxw);
-                if (ridx == 0)
-                    printf("node %d inBlas %d o %g %g %g exps %08x tn %g %g %g %g rf %d %d %d %d best.t %g tmin %g\n", cur, (int)inBlas, w0.x, w0.y, w0.z, exps, tn[0], tn[1], tn[2], tn[3], rf[0], rf[1], rf[2], rf[3], best.t, tmin);
-#endif
                 // sort the four candidates by entry distance (5-comparator network), nearest first
 #define SKH_CSWAP(a, b)                      \
     {                                        \
@@ -489,17 +447,14 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                         }
                 }
 #undef SKH_CSWAP
-#if SKH_POP_IN_LOOP
                 // a lane whose node had no hit child takes its next stack entry right here instead of idling until
                 // the whole wave leaves the node loop
                 if (cur == SKH_REF_INVALID && sp > 0)
                     SKH_POP(cur);
-#endif
                 // few lanes still descending while the rest wait at their leaves: let the leaves go first
                 if ((uint32_t)__popcll(__ballot(cur >= 0 && cur != SKH_REF_INVALID)) < breakBelow)
                     break;
             }
-#if SKH_POP_IN_LOOP
             if (cur == SKH_REF_SENTINEL)
             {
                 o = ow;
@@ -509,7 +464,6 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                 inBlas = false;
                 cur = SKH_REF_INVALID;
             }
-#endif
             // ---- leaf ----
             SKH_LP({ const unsigned long long t = __builtin_readcyclecounter(); cy[1] += t - cyA; cyA = t; })
             bool entered = false;
@@ -598,18 +552,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                 }
                 else
                 {
-#if SKH_ONE_TRI_PER_PASS
-                    // one triangle per pass of the outer loop: a lane with more triangles in its leaf keeps the leaf
-                    // (advanced by one) and meets the other lanes' triangles again in the next pass
-                    if (count > 1u)
-                    {
-                        cur = ~(int)(((first + 1u) << 3) | (count - 2u));
-                        entered = true; // (do not pop)
-                    }
-                    for (uint32_t k = 0; k < 1u; ++k)
-#else
                     for (uint32_t k = 0; k < count; ++k)
-#endif
                     {
                         const float4* tp = sc.tris + 3 * (size_t)(first + k);
                         const float4 a = tp[0], b = tp[1], c = tp[2];
