@@ -72,6 +72,7 @@ struct DevScene
     const uint32_t* texels; // RGBA8 texels of all textures
     const uint4* texDesc; // per texture: {offset in texels, width, height, 0}
     uint32_t numTextures;
+    struct StatsDev* profile; // (lane-profile build only)
 };
 
 struct RayQ // SoA planes of `stride` elements: ox oy oz dx dy dz tmin tmax pathId  (36 B / ray)
@@ -153,6 +154,7 @@ struct StatsDev
     // wave-level event counts of k_trace (profile build only): [0] node-loop iterations, [1] triangle-loop iterations,
     // [2] instance-entry blocks, [3] outer iterations, [4] refills, [5] lanes refilled, [6] leaf blocks, [7] pop blocks
     unsigned long long wave[2][8];
+    unsigned long long shade[8]; // k_shade cycle split (SKH_SP marks)
     unsigned long long cyc[2][8]; // summed over waves: [0] refill [1] node loop [2] leaf [3] pop [4] result write [5] whole kernel
 #endif
 };
@@ -1015,6 +1017,43 @@ SKH_DI uint32_t block_compact(bool emit, uint32_t* counter, uint32_t* s_wave /*[
     __syncthreads(); // s_wave is reused by the next call
     return r;
 }
+// Two compactions with one round of barriers and both queue-tail atomics in flight together (k_shade emits a continuation
+// ray and a shadow ray per path).  s_wave2: [2][SKH_COMPACT_MAX_WAVES + 1].
+SKH_DI void block_compact2(bool emitA, uint32_t* counterA, bool emitB, uint32_t* counterB, uint32_t* s_wave2, uint32_t& ia, uint32_t& ib)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const unsigned long long ma = __ballot(emitA), mb = __ballot(emitB);
+    uint32_t* sa = s_wave2;
+    uint32_t* sb = s_wave2 + SKH_COMPACT_MAX_WAVES + 1;
+    if (lane == 0)
+    {
+        sa[wave] = (uint32_t)__popcll(ma);
+        sb[wave] = (uint32_t)__popcll(mb);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 || threadIdx.x == 64)
+    {
+        uint32_t* sw = threadIdx.x == 0 ? sa : sb; // wave 0 serves queue A, wave 1 queue B (a one-wave block: thread 0 does both)
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < nw; ++w)
+        {
+            const uint32_t cnt = sw[w];
+            sw[w] = tot;
+            tot += cnt;
+        }
+        sw[SKH_COMPACT_MAX_WAVES] = tot ? atomicAdd(threadIdx.x == 0 ? counterA : counterB, tot) : 0u;
+    }
+    if (nw == 1 && threadIdx.x == 0)
+    {
+        uint32_t tot = sb[0];
+        sb[0] = 0;
+        sb[SKH_COMPACT_MAX_WAVES] = tot ? atomicAdd(counterB, tot) : 0u;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    ia = sa[SKH_COMPACT_MAX_WAVES] + sa[wave] + (uint32_t)__popcll(ma & below);
+    ib = sb[SKH_COMPACT_MAX_WAVES] + sb[wave] + (uint32_t)__popcll(mb & below);
+}
 
 __global__ void __launch_bounds__(512) k_raygen(FrameP fp, const uint32_t* __restrict__ tileXY, uint32_t sampleOffset, RayQ rq,
                                                uint32_t* __restrict__ counter, PathS ps)
@@ -1148,12 +1187,23 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
             const uint32_t* __restrict__ countPtr, HitQ hq, PathS ps, RayQ nextQ, uint32_t* __restrict__ nextCount, RayQ shadowQ,
             float* __restrict__ contrib, uint32_t* __restrict__ shadowCount)
 {
-    __shared__ uint32_t s_wave[SKH_COMPACT_MAX_WAVES + 1];
+    __shared__ uint32_t s_wave[2 * (SKH_COMPACT_MAX_WAVES + 1)];
     __shared__ uint32_t s_sobol[SKH_SOBOL_LUT_WORDS];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = *countPtr;
     if (blockIdx.x * blockDim.x >= n)
         return; // whole block past the end of the queue
+#ifdef SKH_LANE_PROFILE
+    unsigned long long spc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, spT = __builtin_readcyclecounter();
+#define SKH_SP(k)                                                    \
+    {                                                                \
+        const unsigned long long t_ = __builtin_readcyclecounter();  \
+        spc[k] += t_ - spT;                                          \
+        spT = t_;                                                    \
+    }
+#else
+#define SKH_SP(k)
+#endif
     for (uint32_t k = threadIdx.x; k < SKH_SOBOL_LUT_WORDS / 4; k += blockDim.x)
         reinterpret_cast<uint4*>(s_sobol)[k] = reinterpret_cast<const uint4*>(g_sobol_lut)[k];
     __syncthreads();
@@ -1197,6 +1247,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
         }
         else
         {
+            SKH_SP(0) // queue / path-state loads, sampler
             const HostInstance hi = sc.instances[hinst];
             const float* w2o = sc.inst[hinst].w2o;
             if (hi.type == 1)
@@ -1254,7 +1305,9 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
                                 xi2 = sampler_random_lut(smp, DIM_BSDF2, s_sobol);
                     const v3 k1 = -rayD;
                     BsdfSample bs;
+                    SKH_SP(1) // hit reconstruction, material, textures, bsdf randoms
                     bsdf_sample(mat, sh.normal, sh.geom_normal, k1, xi0, xi1, xi2, inside, bs);
+                    SKH_SP(2) // bsdf_sample
                     if (bs.event_type == EV_ABSORB)
                     {
                         if (depth == 0)
@@ -1332,7 +1385,9 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
                                 if (isNextEventValid)
                                 {
                                     BsdfEval ev;
+                                    SKH_SP(3) // light sampling
                                     bsdf_evaluate(mat, sh.normal, sh.geom_normal, k1, toLight, ev);
+                                    SKH_SP(4) // bsdf_evaluate
                                     if (isnan3(ev.bsdf_diffuse) || isnan3(ev.bsdf_glossy))
                                     {
                                         radiance = mk3(10000.0f, 0.0f, 0.0f);
@@ -1369,6 +1424,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
                 }
             }
         }
+        SKH_SP(5) // rest of the hit program
         // tail of the bounce loop: OptixRender.cu:131-153
         bool alive = true;
         if (prdDepth > 3)
@@ -1403,8 +1459,10 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
         reinterpret_cast<uint32_t*>(P)[pid + 7 * S] =
             (inside ? PF_INSIDE : 0u) | (specularBounce ? PF_SPECULAR : 0u) | (firstEvent << PF_EVENT_SHIFT);
     }
-    // stream compaction of live paths / shadow rays: one atomic per wave
-    const uint32_t ni = block_compact(emitNext, nextCount, s_wave);
+    SKH_SP(6) // bounce tail + path-state write
+    // stream compaction of live paths / shadow rays: one atomic per queue per workgroup, both in flight together
+    uint32_t ni, si;
+    block_compact2(emitNext, nextCount, emitShadow, shadowCount, s_wave, ni, si);
     if (emitNext)
     {
         nextQ.plane(0)[ni] = nextO.x;
@@ -1417,7 +1475,6 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
         nextQ.plane(7)[ni] = 1e16f;
         nextQ.ids()[ni] = pid;
     }
-    const uint32_t si = block_compact(emitShadow, shadowCount, s_wave);
     if (emitShadow)
     {
         shadowQ.plane(0)[si] = shO.x;
@@ -1433,6 +1490,16 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
         contrib[si + shadowQ.stride] = shC.y;
         contrib[si + 2 * (size_t)shadowQ.stride] = shC.z;
     }
+#ifdef SKH_LANE_PROFILE
+    SKH_SP(7) // compaction + queue writes
+    for (int k = 0; k < 8; ++k)
+    {
+        const uint32_t hi32 = wave_max((uint32_t)(spc[k] >> 4));
+        if ((threadIdx.x & 63u) == 0)
+            atomicAdd(&sc.profile->shade[k], (unsigned long long)hi32 << 4);
+    }
+#endif
+#undef SKH_SP
 }
 
 // ------------------------------------------------------------------------------------------------------------

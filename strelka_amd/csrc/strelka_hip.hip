@@ -1518,6 +1518,7 @@ static DevScene make_dev_scene(const skh_context* c)
     sc.texels = c->dTexels.as<uint32_t>();
     sc.texDesc = c->dTexDesc.as<uint4>();
     sc.numTextures = c->nTextures;
+    sc.profile = c->dStats.as<StatsDev>();
     return sc;
 }
 
@@ -2120,6 +2121,14 @@ skh_status skh_get_stats(skh_context* c, skh_stats* out)
         fprintf(stderr, "[lane-profile] %s: rays %llu nodes %llu (TLAS %llu) tris %llu insts %llu | wave: nodeIt %llu triIt %llu instBlk %llu outer %llu refills %llu refilled %llu\n",
                 k ? "shadow" : "closest", k ? sd.raysShadow : sd.raysRadiance, sd.nodes[k], sd.segs[k], sd.prims[k], sd.insts[k], sd.wave[k][0], sd.wave[k][1],
                 sd.wave[k][2], sd.wave[k][3], sd.wave[k][4], sd.wave[k][5]);
+    {
+        double tot = 0;
+        for (int k = 0; k < 8; ++k)
+            tot += (double)sd.shade[k];
+        fprintf(stderr, "[shade-cycles] load %.1f%% hit+material %.1f%% bsdf_sample %.1f%% light %.1f%% bsdf_eval %.1f%% rest-of-hit %.1f%% tail+state %.1f%% compaction+queues %.1f%%\n",
+                100 * sd.shade[0] / tot, 100 * sd.shade[1] / tot, 100 * sd.shade[2] / tot, 100 * sd.shade[3] / tot, 100 * sd.shade[4] / tot, 100 * sd.shade[5] / tot,
+                100 * sd.shade[6] / tot, 100 * sd.shade[7] / tot);
+    }
     for (int k = 0; k < 2; ++k)
         fprintf(stderr, "[lane-cycles] %s: refill %.3g node %.3g leaf %.3g pop %.3g write %.3g total %.3g\n", k ? "shadow" : "closest", (double)sd.cyc[k][0],
                 (double)sd.cyc[k][1], (double)sd.cyc[k][2], (double)sd.cyc[k][3], (double)sd.cyc[k][4], (double)sd.cyc[k][5]);
