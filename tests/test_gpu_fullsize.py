@@ -107,3 +107,28 @@ def test_hair_full_scene_hits_bit_exact():
     ctx.render_subframe(p)
     assert np.isfinite(a).all() and a[..., :3].max() > 0 and ctx.read_accum().tobytes() == a.tobytes()
     ctx.close()
+
+
+def test_kitchen_1080p_subframe_image_matches_oracle(kitchen):
+    """One full-resolution sub-frame of the bench configuration (1920x1080, depth 4) against the oracle rendering the same
+    sub-frame on the host cores: same tolerance as the small-scene render tests, same number of radiance rays."""
+    from strelka_amd import capi
+    from tests import orklib
+    from tests.test_gpu_parity import _image_close
+
+    sc, arr = kitchen
+    W, H = 1920, 1080
+    p = S.frame_params(sc.getCamera(), W, H, subframe_index=0, samples_this_launch=1, spp_total=64, max_depth=4)
+    o = orklib.new_context()
+    o.set_scene(arr)
+    o.resize(W, H)
+    o.render_subframe(p)
+    want = o.read_accum()
+    ctx = capi.Context(0)
+    ctx.set_scene(arr)
+    ctx.resize(W, H)
+    ctx.render_subframe(p)
+    got = ctx.read_accum()
+    _image_close(got, want, frac_tol=1e-2)
+    assert ctx.stats()["rays_radiance"] == o.stats()["rays_radiance"]
+    ctx.close()
