@@ -240,6 +240,56 @@ def test_curve_hits_bit_exact(gpu):
     assert np.array_equal(gpu.trace(rays, 1)["t"], o.trace(rays, 1)["t"])
 
 
+def thick_curves(seed=3, n_strands=60, n_cp=9):
+    """tubes whose radius is comparable to the segment length and varies along the strand: the hard case for the curve
+    BLAS's parameter sub-ranges (a hit point can be a whole radius away from C(u))"""
+    rs = np.random.RandomState(seed)
+    sc = S.Scene()
+    mat = sc.addMaterial(S.MAT_HAIR, (0.5, 0.4, 0.3))
+    pts, rad = [], []
+    for _ in range(n_strands):
+        p = rs.uniform(-1.0, 1.0, 3)
+        d = rs.normal(size=3)
+        d /= np.linalg.norm(d)
+        strand = [p]
+        for _k in range(n_cp - 1):
+            d = d + 0.6 * rs.normal(size=3)
+            d /= np.linalg.norm(d)
+            strand.append(strand[-1] + d * rs.uniform(0.08, 0.25))
+        strand = np.array(strand)
+        r = rs.uniform(0.03, 0.15, n_cp)
+        pts.append(np.concatenate([strand[:1], strand, strand[-1:]]))  # phantom points as BasisCurves.cpp:189-232
+        rad.append(np.concatenate([r[:1], r, r[-1:]]))
+    counts = np.full(n_strands, n_cp + 2, np.uint32)
+    cid = sc.createCurve(counts, np.concatenate(pts), np.concatenate(rad))
+    sc.createInstance(S.INSTANCE_CURVE, cid, mat, S.translate((0.1, -0.2, 0.0)) @ S.rotate((0, 1, 0), 0.7) @ S.scale((1.3, 0.8, 1.1)))
+    cam = S.Camera(fov=50.0)
+    cam.lookAt((0.0, 0.5, 4.5), (0.0, 0.0, 0.0))
+    sc.addCamera(cam)
+    return sc
+
+
+@pytest.mark.parametrize("split", [1, 2, 5, 8])
+def test_thick_varying_radius_curves_bit_exact_for_every_sub_range_count(split):
+    from strelka_amd import capi
+    from tests import orklib
+
+    sc = thick_curves()
+    arr = sc.arrays()
+    o = orklib.new_context()
+    o.set_scene(arr)
+    rays = np.concatenate([camera_rays(sc, 64, 64, 20000, 5), scenes.random_rays(20000, 6, -2.5, 2.5)])
+    want = o.trace(rays, 0)
+    assert (want["instance_id"] != 0xFFFFFFFF).mean() > 0.15
+    ctx = capi.Context(0)
+    ctx.set_option("curve_split", split)
+    ctx.set_scene(arr)
+    assert_hits_equal(ctx.trace(rays, 0), want)
+    rays["tmax"] = 2.0
+    assert np.array_equal(ctx.trace(rays, 1)["t"], o.trace(rays, 1)["t"])
+    ctx.close()
+
+
 def test_render_hair_matches_oracle(gpu):
     sc = small_hair()
     o, want, got = _render_both(gpu, sc, 96, 64, 4, 3)
