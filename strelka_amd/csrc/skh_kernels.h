@@ -123,6 +123,17 @@ struct FrameP // skh_frame_params + launch geometry
 #define SKH_STACK_OVF 104
 #define SKH_TRACE_BLOCK 64
 
+// Reciprocal ray direction for the SLAB tests only: v_rcp_f32 (1 ulp) instead of the ten-instruction IEEE division.  Box
+// tests need to be conservative, not exact -- hit records come from the primitive tests, which never see `inv` -- and the
+// acceptance slack below covers the extra ulp: per plane the computed t carries a relative error <= 2^-23 (rcp) + 3 * 2^-24
+// (difference, product, fma), entry and exit of different axes can err in opposite directions, so tnear <= tfar * (1 + 2^-19)
+// keeps every box the exact arithmetic would accept (plus the 2^-20 relative inflation of the stored boxes).
+SKH_DI v3 rcp3(const v3& d)
+{
+    return mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+}
+#define SKH_SLAB_SLACK 1.0000019073486328125f // 1 + 2^-19
+
 struct TraceCounters
 {
     uint32_t nodes, prims, segs, insts;
@@ -339,7 +350,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                 tmax = rq.plane(7)[ridx];
                 o = ow;
                 d = dw;
-                inv = invw = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                inv = invw = rcp3(d);
                 nodes = sc.tlasNodes;
                 inBlas = false;
                 sp = 0;
@@ -392,7 +403,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                     const float nz = fmaf((float)((nzw >> (8 * k)) & 0xffu), az, bz), fz = fmaf((float)((fzw >> (8 * k)) & 0xffu), az, bz);
                     const float tnear = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
                     const float tfar = fminf(fminf(fx, fy), fminf(fz, best.t));
-                    const bool hit = rf[k] != SKH_REF_INVALID && tnear <= tfar * 1.0000002384185791015625f;
+                    const bool hit = rf[k] != SKH_REF_INVALID && tnear <= tfar * SKH_SLAB_SLACK;
                     tn[k] = hit ? tnear : INFINITY;
                 }
                 // sort the four candidates by entry distance (5-comparator network), nearest first
@@ -499,7 +510,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                         const float m[12] = { i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w };
                         o = xform_point(m, ow);
                         d = xform_vector(m, dw);
-                        inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        inv = rcp3(d);
                         sh = make_shear(d);
                         curInst = __float_as_uint(i3.w); // the instance this leaf belongs to
                         curType = __float_as_uint(i3.z);
