@@ -284,7 +284,8 @@ skh_status skh_trace_device(skh_context* ctx, const void* d_rays, uint32_t n_ray
  *   measurement   count_traversal 0|1 (counter build of the trace kernels), timing 0|1 (per-kernel hipEvent spans)
  *   scheduling    waves_per_cu (24), fetch_min_closest / fetch_min_shadow (16 / 24: idle lanes before a wave refills),
  *                 node_break_closest / node_break_shadow (20: leave the node loop below x/64 descending rays),
- *                 leaf_min (16: lanes for the minority kind of leaf work), subframe_batch (0 = auto: ~64 M paths per pass),
+ *                 leaf_min (16: lanes for the minority kind of leaf work), curve_min (48: lanes parked in front of the
+ *                 curve intersector before it runs), subframe_batch (0 = auto: ~64 M paths per pass),
  *                 sort_bits_closest / sort_bits_shadow / sort_first_bounce (ray re-ordering, off)
  *   build         build_quality 1|0 (PLOC | Karras radix tree), leaf_max_tris (2), curve_split (2: parameter sub-ranges
  *                 per curve segment), tlas_open (1: TLAS leaves per instance budget), flatten 0|1 (one world-space tree)

@@ -186,6 +186,9 @@ SKH_DI uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+#ifndef SKH_CURVE_MIN_WAVES
+#define SKH_CURVE_MIN_WAVES 4 // 128 VGPRs for the build with the inlined curve intersector (hair stand-in: +4 % over 3 waves)
+#endif
 #ifndef SKH_TRACE_MIN_WAVES
 #define SKH_TRACE_MIN_WAVES 1
 #endif
@@ -214,14 +217,14 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 // the result does not depend on the BVH or on the traversal order (DESIGN.md "determinism").
 // ------------------------------------------------------------------------------------------------------------
 template <bool ANY_HIT, bool COUNT, bool CURVES>
-__global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WAVES) SKH_TRACE_ATTR
+__global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES : SKH_TRACE_MIN_WAVES) SKH_TRACE_ATTR
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
-            uint32_t fetchArg /* refill threshold | node-break threshold << 16 */, const uint32_t* __restrict__ perm /*optional: sorted order -> queue index*/,
+            uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, const uint32_t* __restrict__ perm /*optional: sorted order -> queue index*/,
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
             StatsDev* __restrict__ stats)
 {
     __shared__ int s_stack[SKH_STACK_LDS * SKH_TRACE_BLOCK];
-    const uint32_t fetchMin = fetchArg & 0xffffu, nodeBreak = (fetchArg >> 16) & 0xffu, leafMin = fetchArg >> 24;
+    const uint32_t fetchMin = fetchArg & 0xffu, curveMin = (fetchArg >> 8) & 0xffu, nodeBreak = (fetchArg >> 16) & 0xffu, leafMin = fetchArg >> 24;
     const uint32_t lane = threadIdx.x;
     const uint32_t n = *countPtr;
     if (n == 0)
@@ -246,6 +249,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
 
     // per-lane traversal state
     bool hasRay = false, pending = false;
+    uint32_t pend = 0; // (curve build) segments of the current leaf that passed the cheap test and wait for the full one
     uint32_t ridx = 0;
     v3 ow = mk3(0.0f), dw = mk3(0.0f), o = mk3(0.0f), d = mk3(0.0f), inv = mk3(0.0f), invw = mk3(0.0f);
     float tmin = 0.0f, tmax = 0.0f;
@@ -359,6 +363,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                 best.inst = best.prim = 0xffffffffu;
                 best.u = best.v = 0.0f;
                 best.found = false;
+                pend = 0;
                 hasRay = true;
             }
         }
@@ -483,6 +488,57 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
             // Two kinds of leaf work (instance entry, primitive tests) are two branches of the same wave.  When one of them has
             // only a few takers it is postponed: those lanes keep their leaf and meet the next pass's takers (leafMin = 0/1: off)
             bool isLeaf = cur < 0 && cur != SKH_REF_SENTINEL;
+            if (CURVES)
+            {
+                // The iterative curve intersector costs ~1000 instructions; run for the one or two lanes that happen to need it, it
+                // owns the wave (measured on the hair stand-in: 89 % of the kernel time at ~3 active lanes).  Lanes whose segment
+                // passed the cheap cylinder test PARK in front of it (`pend`) and the block runs once `curveMin` lanes wait, or
+                // when no other lane of the wave can make progress.
+                const uint32_t nParked = (uint32_t)__popcll(__ballot(pend != 0u)), nActive = (uint32_t)__popcll(__ballot(pend == 0u));
+                if (pend != 0u)
+                {
+                    isLeaf = false;
+                    if (nParked >= curveMin || nActive == 0u)
+                    {
+                        const uint32_t first = ((uint32_t)~cur) >> 3;
+                        for (uint32_t k = 0; k < 8u; ++k)
+                        {
+                            if (!((pend >> k) & 1u))
+                                continue;
+                            const float4* cp = sc.segs + 4 * (size_t)(first + k);
+                            const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+                            if (COUNT)
+                                tc.segs++;
+                            v4 q[4];
+                            q[0] = mk4(c0.x, c0.y, c0.z, c0.w);
+                            q[1] = mk4(c1.x, c1.y, c1.z, c1.w);
+                            q[2] = mk4(c2.x, c2.y, c2.z, c2.w);
+                            q[3] = mk4(c3.x, c3.y, c3.z, c3.w);
+                            float t, u;
+                            if (intersect_curve_segment(o, d, tmin, best.t, q, t, u) && t < tmax)
+                            {
+                                const uint32_t sp = sc.segPrim[first + k];
+                                const uint32_t prim = sp & 0x0fffffffu;
+                                // a sub-range leaf keeps the hit only if u is its own (the leaf that owns u reports the same bits)
+                                if (min((uint32_t)(u * (float)sc.curveSplit), sc.curveSplit - 1u) != (sp >> 28))
+                                    continue;
+                                if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
+                                {
+                                    best.t = t;
+                                    best.inst = curInst;
+                                    best.prim = prim;
+                                    best.u = u;
+                                    best.v = 0.0f;
+                                    best.found = true;
+                                }
+                            }
+                        }
+                        pend = 0u; // leaf done: falls through to the pop below
+                    }
+                    else
+                        entered = true; // keep waiting (no pop)
+                }
+            }
             if (leafMin > 1u)
             {
                 const uint32_t nI = (uint32_t)__popcll(__ballot(isLeaf && !inBlas)), nT = (uint32_t)__popcll(__ballot(isLeaf && inBlas));
@@ -534,34 +590,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
                         const float Rm = b0.w + (fabsf(w.x) + fabsf(w.y) + fabsf(w.z)) * 4e-6f; // cancellation in w . n
                         if (n2 > 1e-12f * dot(d, d) && wn * wn > Rm * Rm * n2 * 1.0001f)
                             continue;
-                        const float4* cp = sc.segs + 4 * (size_t)(first + k);
-                        const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
-                        if (COUNT)
-                            tc.segs++;
-                        v4 q[4];
-                        q[0] = mk4(c0.x, c0.y, c0.z, c0.w);
-                        q[1] = mk4(c1.x, c1.y, c1.z, c1.w);
-                        q[2] = mk4(c2.x, c2.y, c2.z, c2.w);
-                        q[3] = mk4(c3.x, c3.y, c3.z, c3.w);
-                        float t, u;
-                        if (intersect_curve_segment(o, d, tmin, best.t, q, t, u) && t < tmax)
-                        {
-                            const uint32_t sp = sc.segPrim[first + k];
-                            const uint32_t prim = sp & 0x0fffffffu;
-                            // a sub-range leaf keeps the hit only if u is its own (the leaf that owns u reports the same bits)
-                            if (min((uint32_t)(u * (float)sc.curveSplit), sc.curveSplit - 1u) != (sp >> 28))
-                                continue;
-                            if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
-                            {
-                                best.t = t;
-                                best.inst = curInst;
-                                best.prim = prim;
-                                best.u = u;
-                                best.v = 0.0f;
-                                best.found = true;
-                            }
-                        }
+                        pend |= 1u << k;
                     }
+                    if (pend != 0u)
+                        entered = true; // parks in front of the full intersector (see above); `cur` keeps the leaf
                 }
                 else
                 {
@@ -672,12 +704,12 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WA
 // intersection arithmetic and hence every hit record stay identical to the two-level formulation.
 // ------------------------------------------------------------------------------------------------------------
 template <bool ANY_HIT, bool COUNT, bool CURVES>
-__global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? 1 : SKH_TRACE_MIN_WAVES)
+__global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES : SKH_TRACE_MIN_WAVES)
     k_trace_flat(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch, uint32_t fetchMin,
                  const uint32_t* __restrict__ perm, HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride,
                  int* __restrict__ ovfBase, StatsDev* __restrict__ stats)
 {
-    fetchMin &= 0xffffu;
+    fetchMin &= 0xffu;
     __shared__ int s_stack[SKH_STACK_LDS * SKH_TRACE_BLOCK];
     const uint32_t lane = threadIdx.x;
     const uint32_t n = *countPtr;

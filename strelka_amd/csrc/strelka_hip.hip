@@ -86,6 +86,7 @@ struct skh_context
     uint32_t wavesPerCU = 24;
     uint32_t fetchMinClosest = 16, fetchMinShadow = 24;
     uint32_t nodeBreakClosest = 20, nodeBreakShadow = 20;
+    uint32_t curveMin = 48; // lanes parked in front of the curve intersector before it runs (hair stand-in, Mray/s: 1: 113, 16: 225, 32: 310, 48: 334, 64: 321)
     uint32_t leafMin = 16; // postpone the minority kind of leaf work unless it has this many lanes (0 = never postpone; measured +1.5 % at 16) // leave the node loop when fewer than x/64 of the wave's rays are still descending
     // ray re-ordering (per bounce): 0 = off, else Morton bits per axis of the origin cell (key = octant : morton)
     uint32_t sortBitsClosest = 0, sortBitsShadow = 0, sortFirstBounce = 1;
@@ -1582,7 +1583,7 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
                          HitQ hq, PathS ps, const float* contrib, uint32_t contribStride)
 {
     // scenes without curve instances run the build of the kernel that has no curve intersector in it (fewer VGPRs)
-    const uint32_t fm = (ANY ? c->fetchMinShadow : c->fetchMinClosest) | ((ANY ? c->nodeBreakShadow : c->nodeBreakClosest) << 16) | (c->leafMin << 24);
+    const uint32_t fm = (ANY ? c->fetchMinShadow : c->fetchMinClosest) | (c->curveMin << 8) | ((ANY ? c->nodeBreakShadow : c->nodeBreakClosest) << 16) | (c->leafMin << 24);
     int* ovf = c->dOvf.as<int>();
     StatsDev* sd = c->dStats.as<StatsDev>();
     if (c->flatten)
@@ -2022,6 +2023,12 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 1 || value > 64)
             return SKH_INVALID_ARGUMENT;
         (n == "fetch_min_closest" ? c->fetchMinClosest : c->fetchMinShadow) = (uint32_t)value;
+    }
+    else if (n == "curve_min")
+    {
+        if (value < 1 || value > 64)
+            return SKH_INVALID_ARGUMENT;
+        c->curveMin = (uint32_t)value;
     }
     else if (n == "leaf_min")
     {
