@@ -375,7 +375,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
         }
         bool terminated = false;
         SKH_LP(uint32_t itN = 0, itT = 0; { const unsigned long long t = __builtin_readcyclecounter(); cy[0] += t - cyA; cyA = t; })
-        const uint32_t breakBelow = ((uint32_t)__popcll(__ballot(hasRay)) * nodeBreak) >> 6;
+        // (lanes parked in front of the curve intersector do not count: they are not waiting for the node loop to end)
+        const uint32_t breakBelow = ((uint32_t)__popcll(__ballot(hasRay && !(CURVES && pend != 0u))) * nodeBreak) >> 6;
         if (hasRay)
         {
             // ---- descend through internal nodes ----
