@@ -1099,17 +1099,23 @@ SKH_DI void block_compact2(bool emitA, uint32_t* counterA, bool emitB, uint32_t*
     ib = sb[SKH_COMPACT_MAX_WAVES] + sb[wave] + (uint32_t)__popcll(mb & below);
 }
 
+// Ray generation without atomics: which slots of a tile set fall inside the image is known on the host, so the first queue
+// position of every 512-slot block (`blockBase`, exclusive prefix of the per-block valid counts) and the number of valid
+// pixels per sub-frame (`validPerSub`) are tables; inside a block the rank comes from ballots.  The queue order is the slot
+// order (tile-major, Morton inside a tile), sub-frame after sub-frame -- and one returning atomic per block less (a single
+// queue-tail word takes ~88 of those per microsecond: a 64 M-path launch was bound by exactly that).
 __global__ void __launch_bounds__(512) k_raygen(FrameP fp, const uint32_t* __restrict__ tileXY, uint32_t sampleOffset, RayQ rq,
-                                               uint32_t* __restrict__ counter, PathS ps)
+                                               uint32_t* __restrict__ counter, PathS ps, const uint32_t* __restrict__ blockBase,
+                                               uint32_t blocksPerSub, uint32_t validPerSub)
 {
     __shared__ uint32_t s_wave[SKH_COMPACT_MAX_WAVES + 1];
     // several sub-frames can be in flight at once (fp.batch): path = sub * numSlots + slot.  Paths of different
     // sub-frames are independent; only the accumulation (k_finalize_batch) has to respect their order.
-    const uint32_t path = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t sub = path / fp.numSlots;
-    const uint32_t slot = path - sub * fp.numSlots;
+    const uint32_t sub = blockIdx.x / blocksPerSub, bi = blockIdx.x - sub * blocksPerSub;
+    const uint32_t slot = bi * blockDim.x + threadIdx.x;
+    const uint32_t path = sub * fp.numSlots + slot;
     uint32_t px = 0, py = 0;
-    const bool active = sub < fp.batch && slot_to_pixel(fp, tileXY, slot, px, py);
+    const bool active = sub < fp.batch && slot < fp.numSlots && slot_to_pixel(fp, tileXY, slot, px, py);
     v3 o = mk3(0.0f), d = mk3(0.0f);
     if (active)
     {
@@ -1126,7 +1132,17 @@ __global__ void __launch_bounds__(512) k_raygen(FrameP fp, const uint32_t* __res
         ps.base[path + 6 * (size_t)ps.stride] = 0.0f; // lastBsdfPdf
         reinterpret_cast<uint32_t*>(ps.base)[path + 7 * (size_t)ps.stride] = 0u; // flags: outside, eUndef
     }
-    const uint32_t idx = block_compact(active, counter, s_wave);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(active);
+    if (lane == 0)
+        s_wave[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w)
+        before += s_wave[w];
+    const uint32_t idx = sub * validPerSub + blockBase[bi] + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *counter = validPerSub * fp.batch; // the queue length the next kernels read
     if (active)
     {
         rq.plane(0)[idx] = o.x;

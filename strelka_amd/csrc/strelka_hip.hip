@@ -65,7 +65,8 @@ struct skh_context
     DevBuf dVerts, dIndices, dMeshes, dPoints, dRadii, dInstances, dLights, dMaterials;
     DevBuf dCurveSegBase, dSegStartAll;
     // accel
-    DevBuf dTexels, dTexDesc, dSegBound, dScatterXY;
+    DevBuf dTexels, dTexDesc, dSegBound, dScatterXY, dRaygenBase;
+    uint32_t raygenBlocksPerSub = 0, raygenValidPerSub = 0;
     uint32_t nTextures = 0;
     DevBuf dTriNodes, dTris, dSegNodes, dSegs, dSegPrim, dTlasNodes, dTlasInst, dDevInst, dTravInst;
     int tlasRoot = SKH_REF_INVALID;
@@ -728,7 +729,7 @@ void skh_destroy(skh_context* c)
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : { &c->dVerts, &c->dIndices, &c->dMeshes, &c->dPoints, &c->dRadii, &c->dInstances, &c->dLights, &c->dMaterials,
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
-                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dScatterXY, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
+                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
                        &c->dCounts, &c->dOvf, &c->dStats, &c->dScratchImage, &c->dSortKeys[0], &c->dSortKeys[1], &c->dSortVals[0],
                        &c->dSortVals[1], &c->dSortHist, &c->dWNodes, &c->dWTris, &c->dWSegs, &c->dWSegMeta })
@@ -1377,6 +1378,35 @@ static skh_status alloc_frame(skh_context* c)
     if ((s = (expr)) != SKH_OK) \
         return s;
     AF(dev_upload(c, c->dTileXY, c->tileXY.data(), sizeof(uint32_t) * c->tileXY.size()));
+    {
+        // k_raygen's tables: valid (inside the image) slots per 512-slot block, as an exclusive prefix sum
+        auto compact = [](uint32_t x) {
+            x &= 0x55555555u;
+            x = (x ^ (x >> 1)) & 0x33333333u;
+            x = (x ^ (x >> 2)) & 0x0f0f0f0fu;
+            x = (x ^ (x >> 4)) & 0x00ff00ffu;
+            x = (x ^ (x >> 8)) & 0x0000ffffu;
+            return x;
+        };
+        const uint32_t blocks = (c->numSlots + 511u) / 512u;
+        std::vector<uint32_t> base(std::max(1u, blocks), 0u);
+        const uint32_t shift2 = 2 * c->tileShift, mask = (1u << shift2) - 1u;
+        uint32_t total = 0;
+        for (uint32_t b = 0; b < blocks; ++b)
+        {
+            base[b] = total;
+            const uint32_t end = std::min(c->numSlots, (b + 1) * 512u);
+            for (uint32_t slot = b * 512u; slot < end; ++slot)
+            {
+                const uint32_t tile = slot >> shift2, m = slot & mask;
+                const uint32_t px = c->tileXY[2 * tile] + compact(m), py = c->tileXY[2 * tile + 1] + compact(m >> 1);
+                total += (px < c->width && py < c->height) ? 1u : 0u;
+            }
+        }
+        c->raygenBlocksPerSub = blocks;
+        c->raygenValidPerSub = total;
+        AF(dev_upload(c, c->dRaygenBase, base.data(), sizeof(uint32_t) * base.size()));
+    }
     AF(dev_alloc(c, c->dAccum, sizeof(float4) * N1));
     AF(dev_alloc(c, c->dDiffuse, sizeof(float4) * N1));
     AF(dev_alloc(c, c->dSpecular, sizeof(float4) * N1));
@@ -1654,7 +1684,8 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
         SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (SKH_COUNT_STRIDE * 2 * 130 + 16 * SKH_FETCH_STRIDE * (fp.maxDepth + 1)), st));
         {
             SpanGuard g(c, KC_RAYGEN);
-            k_raygen<<<(NP + 511) / 512, 512, 0, st>>>(fp, tiles, s, rq[0], counts, ps);
+            k_raygen<<<c->raygenBlocksPerSub * fp.batch, 512, 0, st>>>(fp, tiles, s, rq[0], counts, ps, c->dRaygenBase.as<uint32_t>(),
+                                                                       c->raygenBlocksPerSub, c->raygenValidPerSub);
         }
         for (uint32_t b = 0; b < fp.maxDepth; ++b)
         {
