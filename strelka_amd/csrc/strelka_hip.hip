@@ -83,12 +83,12 @@ struct skh_context
     uint32_t curveSplitBuilt = 1;
     uint32_t numTlasLeaves = 0;
     bool countTraversal = false, timing = false;
-    // measured on MI355X (kitchen C3, 16 sub-frames per pass): 24 resident waves/CU; refill thresholds 32 (closest) / 44 (any-hit)
-    uint32_t wavesPerCU = 24;
-    uint32_t fetchMinClosest = 16, fetchMinShadow = 24;
-    uint32_t nodeBreakClosest = 20, nodeBreakShadow = 20;
+    // scheduling of the persistent trace kernels, measured on MI355X (kitchen C3, 32 sub-frames per pass):
+    uint32_t wavesPerCU = 24; // resident waves per CU (6 per SIMD at <= 80 VGPRs)
+    uint32_t fetchMinClosest = 16, fetchMinShadow = 24; // idle lanes before a wave pulls new rays from the queue
+    uint32_t nodeBreakClosest = 20, nodeBreakShadow = 20; // leave the node loop when fewer than x/64 of the wave's rays are still descending
     uint32_t curveMin = 48; // lanes parked in front of the curve intersector before it runs (hair stand-in, Mray/s: 1: 113, 16: 225, 32: 310, 48: 334, 64: 321)
-    uint32_t leafMin = 16; // postpone the minority kind of leaf work unless it has this many lanes (0 = never postpone; measured +1.5 % at 16) // leave the node loop when fewer than x/64 of the wave's rays are still descending
+    uint32_t leafMin = 16; // postpone the minority kind of leaf work unless it has this many lanes (0 = never postpone; measured +1.5 % at 16)
     // ray re-ordering (per bounce): 0 = off, else Morton bits per axis of the origin cell (key = octant : morton)
     uint32_t sortBitsClosest = 0, sortBitsShadow = 0, sortFirstBounce = 1;
     // flatten = true: one world-space tree over all instanced primitives instead of TLAS + per-mesh BLAS.  Measured
