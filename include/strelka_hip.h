@@ -288,7 +288,8 @@ skh_status skh_trace_device(skh_context* ctx, const void* d_rays, uint32_t n_ray
  *                 curve intersector before it runs), subframe_batch (0 = auto: ~64 M paths per pass),
  *                 sort_bits_closest / sort_bits_shadow / sort_first_bounce (ray re-ordering, off)
  *   build         build_quality 1|0 (PLOC | Karras radix tree), leaf_max_tris (2), curve_split (2: parameter sub-ranges
- *                 per curve segment), tlas_open (1: TLAS leaves per instance budget), flatten 0|1 (one world-space tree)
+ *                 per curve segment), tlas_open (1: TLAS leaves per instance budget), tight_instance_boxes 1|0, flatten 0|1 (one
+ *                 world-space tree)
  * Unknown names and out-of-range values return SKH_INVALID_ARGUMENT. */
 skh_status skh_set_option(skh_context* ctx, const char* name, int64_t value);
 skh_status skh_get_stats(skh_context* ctx, skh_stats* out);

@@ -1851,4 +1851,52 @@ __global__ void k_instance_boxes(const HostInstance* __restrict__ instances, con
     grp[i] = 0;
 }
 
+// Tight world box of a mesh instance: the box of its transformed VERTICES instead of the box of the eight transformed corners
+// of the object-space box (for a round object turned by 45 degrees the latter has twice the footprint).  One workgroup per
+// instance; the result only ever SHRINKS the corner box (component-wise intersection) and is padded like it.  Instances of
+// very large meshes keep the corner box (maxVerts), curve instances too.
+__global__ void __launch_bounds__(256) k_instance_tight_boxes(const HostInstance* __restrict__ instances, const DevInstance* __restrict__ dev,
+                                                              const uint4* __restrict__ meshes, const uint8_t* __restrict__ verts, uint32_t nMeshes,
+                                                              uint32_t maxVerts, float4* __restrict__ boxLo, float4* __restrict__ boxHi)
+{
+    __shared__ float s_red[6][256];
+    const uint32_t i = blockIdx.x;
+    const HostInstance in = instances[i];
+    if (in.type == 2 || in.geom >= nMeshes || dev[i].mask == 0)
+        return;
+    const uint4 me = meshes[in.geom];
+    if (me.w == 0 || me.w > maxVerts)
+        return;
+    v3 lo = mk3(INFINITY), hi = mk3(-INFINITY);
+    for (uint32_t v = threadIdx.x; v < me.w; v += blockDim.x)
+    {
+        const float4 p = *reinterpret_cast<const float4*>(verts + (size_t)(me.z + v) * 32);
+        const v3 w = xform_point(in.o2w, mk3(p.x, p.y, p.z));
+        lo = mk3(fminf(lo.x, w.x), fminf(lo.y, w.y), fminf(lo.z, w.z));
+        hi = mk3(fmaxf(hi.x, w.x), fmaxf(hi.y, w.y), fmaxf(hi.z, w.z));
+    }
+    s_red[0][threadIdx.x] = lo.x, s_red[1][threadIdx.x] = lo.y, s_red[2][threadIdx.x] = lo.z;
+    s_red[3][threadIdx.x] = hi.x, s_red[4][threadIdx.x] = hi.y, s_red[5][threadIdx.x] = hi.z;
+    __syncthreads();
+    for (uint32_t st = 128; st >= 1; st >>= 1)
+    {
+        if (threadIdx.x < st)
+            for (int k = 0; k < 6; ++k)
+                s_red[k][threadIdx.x] = k < 3 ? fminf(s_red[k][threadIdx.x], s_red[k][threadIdx.x + st]) : fmaxf(s_red[k][threadIdx.x], s_red[k][threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        float4 tlo = make_float4(s_red[0][0], s_red[1][0], s_red[2][0], 0.0f), thi = make_float4(s_red[3][0], s_red[4][0], s_red[5][0], 0.0f);
+        // same padding as the corner box (BLAS boxes inflated by 2^-20 relative, transform rounding), once more for the
+        // difference between the forward transform used here and the inverse the traversal applies to the ray
+        inflate_box(tlo, thi);
+        inflate_box(tlo, thi);
+        inflate_box(tlo, thi);
+        const float4 clo = boxLo[i], chi = boxHi[i];
+        boxLo[i] = make_float4(fmaxf(clo.x, tlo.x), fmaxf(clo.y, tlo.y), fmaxf(clo.z, tlo.z), 0.0f);
+        boxHi[i] = make_float4(fminf(chi.x, thi.x), fminf(chi.y, thi.y), fminf(chi.z, thi.z), 0.0f);
+    }
+}
+
 } // namespace skh

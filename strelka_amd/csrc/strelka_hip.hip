@@ -99,6 +99,7 @@ struct skh_context
     int wRoot = SKH_REF_INVALID;
     uint32_t wTriCount = 0, wSegCount = 0;
     uint32_t subframeBatch = 0, batchCapacity = 1; // option subframe_batch: 0 = auto
+    bool tightInstanceBoxes = true; // TLAS leaf boxes from the transformed vertices, not from the transformed object box
     uint32_t curveSplit = 2; // parameter sub-ranges per curve segment in the curve BLAS (1 = off; hair stand-in, ms per 1080p sub-frame: 1: 61.6, 2: 52.1, 4: 49.7, 8: 50.1 -- build time and leaf memory grow with it)
     uint32_t tlasOpen = 1; // TLAS opening: up to tlasOpen x numInstances leaves; 1 = one leaf per instance (default: on the kitchen stand-in 2..16 were 4-9 % slower, more instance entries for no fewer nodes)
     uint32_t leafMaxTris = 2; // measured on MI355X: 2 beats 1, 3, 4, 6, 8 (the kernel is ALU bound, wasted triangle tests cost more than extra nodes)
@@ -1180,6 +1181,9 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
                                                            segOut.groupBounds.as<float>(), segOut.groupRoot.as<int>(), nMeshes, nCurves,
                                                            nInst, c->dDevInst.as<DevInstance>(), dBoxLo.as<float4>(),
                                                            dBoxHi.as<float4>(), dGrp.as<uint32_t>());
+    if (nInst > 0 && c->tightInstanceBoxes)
+        k_instance_tight_boxes<<<nInst, 256, 0, st>>>(c->dInstances.as<HostInstance>(), c->dDevInst.as<DevInstance>(), c->dMeshes.as<uint4>(),
+                                                      c->dVerts.as<uint8_t>(), nMeshes, 1u << 22, dBoxLo.as<float4>(), dBoxHi.as<float4>());
     if (nInst > 0)
     {
         // instance boxes were produced on the device (k_instance_boxes); the sweep runs on the host
@@ -2066,6 +2070,11 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 0 || value > 64)
             return SKH_INVALID_ARGUMENT;
         c->leafMin = (uint32_t)value;
+    }
+    else if (n == "tight_instance_boxes")
+    {
+        c->tightInstanceBoxes = value != 0;
+        c->accelBuilt = false;
     }
     else if (n == "curve_split")
     {
