@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from strelka_amd import scene as S
-from strelka_amd import scenes
+from strelka_amd import scenes, tiles
 
 pytestmark = pytest.mark.gpu
 
@@ -492,3 +492,51 @@ def test_textured_materials_match_oracle(gpu):
     for i in range(6):
         gpu.render_subframe(S.frame_params(plain.getCamera(), 96, 72, subframe_index=i, spp_total=6, max_depth=4))
     assert gpu.read_accum().tobytes() == _render_both(gpu, plain, 96, 72, 6, 4)[2].tobytes()
+
+
+@pytest.mark.parametrize("w,h,tile", [(37, 21, 8), (130, 70, 16), (96, 96, 32), (200, 120, 64), (65, 257, 128), (19, 11, 256)])
+def test_odd_resolutions_and_tile_sizes(w, h, tile):
+    """Image sizes that are not multiples of the tile, tiles smaller and larger than the 512-slot blocks of the ray
+    generator's prefix table, a custom (shuffled, partial) tile list: every pixel gets exactly its own sample (same image as
+    the oracle), sub-frame batching stays exact, a subset of tiles reproduces its pixels of the full frame."""
+    from strelka_amd import capi
+    from tests import orklib
+
+    sc = scenes.cornell_box()
+    arr = sc.arrays()
+    o = orklib.new_context()
+    o.set_scene(arr)
+    o.resize(w, h)
+    spp = 3
+    for i in range(spp):
+        o.render_subframe(S.frame_params(sc.getCamera(), w, h, subframe_index=i, spp_total=spp, max_depth=3))
+    want = o.read_accum()
+    ctx = capi.Context(0)
+    ctx.set_scene(arr)
+    ctx.set_tiles(tile, None)
+    ctx.resize(w, h)
+    p0 = S.frame_params(sc.getCamera(), w, h, subframe_index=0, spp_total=spp, max_depth=3)
+    ctx.render_subframes(p0, spp, None)
+    got = ctx.read_accum()
+    _image_close(got, want, frac_tol=2e-2)
+    assert ctx.stats()["rays_radiance"] == o.stats()["rays_radiance"]
+    ctx.set_option("subframe_batch", 1)
+    ctx.resize(w, h)
+    ctx.render_subframes(p0, spp, None)
+    assert ctx.read_accum().tobytes() == got.tobytes()
+    ctx.set_option("subframe_batch", 0)
+    # a shuffled third of the tiles
+    import torch
+
+    grid = tiles.tile_grid(w, h, tile)
+    rs = np.random.RandomState(w * h + tile)
+    mine = np.ascontiguousarray(grid[rs.permutation(len(grid))[:max(1, len(grid) // 3)]])
+    ctx.set_tiles(tile, mine)
+    ctx.resize(w, h)
+    ctx.render_subframes(p0, spp, None)
+    buf = torch.zeros((len(mine), tile * tile, 4), dtype=torch.float32, device="cuda")
+    ctx.copy_accum_tiles(buf.data_ptr())
+    part = tiles.detile_numpy(buf.cpu().numpy(), mine, tile, w, h)
+    mask = tiles.detile_numpy(np.ones((len(mine), tile * tile, 4), np.float32), mine, tile, w, h)[..., 0] > 0
+    assert mask.any() and part[mask].tobytes() == got[mask].tobytes()
+    ctx.close()
