@@ -52,6 +52,9 @@ struct skh_context
 {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr; // any-hit launches when `overlap` is on: shadow[b] runs beside closest[b+1] and fills its tail
+    int overlap = 1; // 0 off, 1 for small passes only (<= 8 M paths: the interactive one-sub-frame-per-call mode, +7 %), 2 always
+    hipEvent_t evShade = nullptr, evShadow = nullptr;
     std::string err;
     int numCUs = 256;
 
@@ -78,7 +81,7 @@ struct skh_context
     std::vector<uint32_t> tileXY;
     bool customTiles = false;
     DevBuf dTileXY, dAccum, dDiffuse, dSpecular, dDiffCnt, dSpecCnt, dSums, dPath, dRayQ[2], dHits, dShadowQ, dContrib, dCounts,
-        dOvf, dStats, dScratchImage;
+        dOvf, dOvf2, dStats, dScratchImage;
     uint32_t traceBlocks = 0;
     uint32_t curveSplitBuilt = 1;
     uint32_t numTlasLeaves = 0;
@@ -686,7 +689,8 @@ skh_status skh_create(int device_ordinal, skh_context** out_ctx)
         return SKH_FAIL; // no GPU: the product path fails loudly, there is no CPU fallback
     skh_context* c = new skh_context();
     c->device = device_ordinal;
-    if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess)
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evShade, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evShadow, hipEventDisableTiming) != hipSuccess)
     {
         delete c;
         return SKH_FAIL;
@@ -732,12 +736,18 @@ void skh_destroy(skh_context* c)
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
                        &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
-                       &c->dCounts, &c->dOvf, &c->dStats, &c->dScratchImage, &c->dSortKeys[0], &c->dSortKeys[1], &c->dSortVals[0],
+                       &c->dCounts, &c->dOvf, &c->dOvf2, &c->dStats, &c->dScratchImage, &c->dSortKeys[0], &c->dSortKeys[1], &c->dSortVals[0],
                        &c->dSortVals[1], &c->dSortHist, &c->dWNodes, &c->dWTris, &c->dWSegs, &c->dWSegMeta })
         dev_free(*b);
     for (hipEvent_t e : c->eventPool)
         (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
+    if (c->stream2)
+        (void)hipStreamDestroy(c->stream2);
+    if (c->evShade)
+        (void)hipEventDestroy(c->evShade);
+    if (c->evShadow)
+        (void)hipEventDestroy(c->evShadow);
     delete c;
 }
 
@@ -1432,6 +1442,7 @@ static skh_status alloc_frame(skh_context* c)
     AF(dev_alloc(c, c->dSortHist, sizeof(uint32_t) * 256 * ((N + SKH_RS_THREADS * SKH_RS_ITEMS - 1) / (SKH_RS_THREADS * SKH_RS_ITEMS))));
     c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
     AF(dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * c->traceBlocks * SKH_TRACE_BLOCK));
+    AF(dev_alloc(c, c->dOvf2, sizeof(int) * (size_t)SKH_STACK_OVF * c->traceBlocks * SKH_TRACE_BLOCK));
 #undef AF
     SKH_TRY(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(float4) * N1, c->stream));
     SKH_TRY(c, hipMemsetAsync(c->dDiffuse.p, 0, sizeof(float4) * N1, c->stream));
@@ -1485,13 +1496,14 @@ struct SpanGuard
     skh_context* c;
     int cls;
     hipEvent_t a = nullptr;
-    SpanGuard(skh_context* c_, int cls_) : c(c_), cls(cls_)
+    hipStream_t st;
+    SpanGuard(skh_context* c_, int cls_, hipStream_t st_ = nullptr) : c(c_), cls(cls_), st(st_ ? st_ : c_->stream)
     {
         c->launches[cls]++;
         if (c->timing)
         {
             a = next_event(c);
-            (void)hipEventRecord(a, c->stream);
+            (void)hipEventRecord(a, st);
         }
     }
     ~SpanGuard()
@@ -1499,7 +1511,7 @@ struct SpanGuard
         if (c->timing)
         {
             hipEvent_t b = next_event(c);
-            (void)hipEventRecord(b, c->stream);
+            (void)hipEventRecord(b, st);
             c->spans.push_back(TimedSpan{ cls, a, b });
         }
     }
@@ -1614,26 +1626,28 @@ static const uint32_t* sort_rays(skh_context* c, RayQ rq, const uint32_t* countP
 
 template <bool ANY, bool COUNT>
 static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint32_t* countPtr, uint32_t* fetch, const uint32_t* perm,
-                         HitQ hq, PathS ps, const float* contrib, uint32_t contribStride)
+                         HitQ hq, PathS ps, const float* contrib, uint32_t contribStride, hipStream_t st = nullptr)
 {
     // scenes without curve instances run the build of the kernel that has no curve intersector in it (fewer VGPRs)
     const uint32_t fm = (ANY ? c->fetchMinShadow : c->fetchMinClosest) | (c->curveMin << 8) | ((ANY ? c->nodeBreakShadow : c->nodeBreakClosest) << 16) | (c->leafMin << 24);
-    int* ovf = c->dOvf.as<int>();
+    if (!st)
+        st = c->stream;
+    int* ovf = st == c->stream ? c->dOvf.as<int>() : c->dOvf2.as<int>(); // (two trace kernels may be in flight)
     StatsDev* sd = c->dStats.as<StatsDev>();
     if (c->flatten)
     {
         if (c->wSegCount)
-            k_trace_flat<ANY, COUNT, true><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib,
+            k_trace_flat<ANY, COUNT, true><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib,
                                                                                                contribStride, ovf, sd);
         else
-            k_trace_flat<ANY, COUNT, false><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib,
+            k_trace_flat<ANY, COUNT, false><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib,
                                                                                                 contribStride, ovf, sd);
     }
     else if (c->nSegs)
-        k_trace<ANY, COUNT, true><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride,
+        k_trace<ANY, COUNT, true><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride,
                                                                                       ovf, sd);
     else
-        k_trace<ANY, COUNT, false><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, c->stream>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride,
+        k_trace<ANY, COUNT, false><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride,
                                                                                        ovf, sd);
 }
 
@@ -1683,6 +1697,9 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     // target of atomics has a 128-byte line of its own (returning atomics on one line serialise at ~88 per microsecond)
     uint32_t* counts = c->dCounts.as<uint32_t>();
     uint32_t* fetch = counts + SKH_COUNT_STRIDE * 2 * 130;
+    // shadow[b] on a second stream: it depends on shade[b] only, and so does closest[b+1]; each fills the other's tail.  Ray
+    // sorting shares scratch buffers between the two and keeps everything on one stream.
+    const bool useOverlap = (c->overlap == 2 || (c->overlap == 1 && NP <= (1u << 23))) && !c->sortBitsClosest && !c->sortBitsShadow && fp.debug != 1;
     for (uint32_t s = 0; s < fp.samplesThisLaunch; ++s)
     {
         SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (SKH_COUNT_STRIDE * 2 * 130 + 16 * SKH_FETCH_STRIDE * (fp.maxDepth + 1)), st));
@@ -1706,6 +1723,8 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                 else
                     launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b * SKH_COUNT_STRIDE, fetch + 16 * b * SKH_FETCH_STRIDE, permC, hq, ps, nullptr, 0);
             }
+            if (useOverlap && b > 0)
+                (void)hipStreamWaitEvent(st, c->evShadow, 0); // shade[b] reads the radiance shadow[b-1] adds to and reuses its queue
             {
                 SpanGuard g(c, KC_SHADE);
                 k_shade<<<(NP + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b * SKH_COUNT_STRIDE, hq, ps, rq[(b + 1) & 1],
@@ -1718,15 +1737,27 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                 permS = sort_rays(c, shq, counts + (2 * b + 1) * SKH_COUNT_STRIDE, c->sortBitsShadow);
             }
             {
-                SpanGuard g(c, KC_TRACE_SHADOW);
-                if (c->countTraversal)
-                    launch_trace<true, true>(c, sc, shq, counts + (2 * b + 1) * SKH_COUNT_STRIDE, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, permS, nohq, ps, c->dContrib.as<float>(), N);
-                else
-                    launch_trace<true, false>(c, sc, shq, counts + (2 * b + 1) * SKH_COUNT_STRIDE, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, permS, nohq, ps, c->dContrib.as<float>(), N);
+                hipStream_t sst = useOverlap ? c->stream2 : st;
+                if (useOverlap)
+                {
+                    (void)hipEventRecord(c->evShade, st);
+                    (void)hipStreamWaitEvent(sst, c->evShade, 0);
+                }
+                {
+                    SpanGuard g(c, KC_TRACE_SHADOW, sst);
+                    if (c->countTraversal)
+                        launch_trace<true, true>(c, sc, shq, counts + (2 * b + 1) * SKH_COUNT_STRIDE, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, permS, nohq, ps, c->dContrib.as<float>(), N, sst);
+                    else
+                        launch_trace<true, false>(c, sc, shq, counts + (2 * b + 1) * SKH_COUNT_STRIDE, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, permS, nohq, ps, c->dContrib.as<float>(), N, sst);
+                }
+                if (useOverlap)
+                    (void)hipEventRecord(c->evShadow, sst);
             }
             if (fp.debug == 1)
                 break;
         }
+        if (useOverlap)
+            (void)hipStreamWaitEvent(st, c->evShadow, 0);
         {
             SpanGuard g(c, KC_ACCUM);
             k_add_stats<<<1, 64, 0, st>>>(counts, fp.maxDepth, c->dStats.as<StatsDev>());
@@ -2070,6 +2101,12 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 0 || value > 64)
             return SKH_INVALID_ARGUMENT;
         c->leafMin = (uint32_t)value;
+    }
+    else if (n == "overlap")
+    {
+        if (value < 0 || value > 2)
+            return SKH_INVALID_ARGUMENT;
+        c->overlap = (int)value;
     }
     else if (n == "tight_instance_boxes")
     {
