@@ -210,12 +210,24 @@ def material_from_description(desc):
     default.mdl::default_material.diffuse_color (OptixRender.cpp:1090-1097, RenderPass.cpp:222-245) -> diffuse;
     OmniPBR.{diffuse_color_constant, reflection_roughness_constant, metallic_constant} (gltfloader.cpp:304-352) -> PBR;
     OmniGlass (gltfloader.cpp:354-406: enable_opacity, thin_walled, frosting_roughness; glass_ior when present) -> glass;
-    names containing "hair" -> the hair BSDF slot.  Unknown materials fall back to the default diffuse 0.8 grey."""
+    UsdPreviewSurface parameter sets (HdStrelka's eMaterialX descriptions) -> PBR / glass; names containing "hair" -> the hair
+    BSDF slot.  Unknown materials fall back to the default diffuse 0.8 grey."""
     m = np.zeros(1, S.MATERIAL)[0]
     m["base_color"], m["roughness"], m["specular"], m["ior"] = 0.8, 0.5, 0.5, 1.5
     name = (desc.get("name") or "") + " " + (desc.get("file") or "")
     low = name.lower()
-    if "omniglass" in low or "glass" in low:
+    pnames = {p.get("name") for p in desc.get("params", [])}
+    if pnames & {"diffuseColor", "useSpecularWorkflow", "specularColor", "clearcoat", "emissiveColor"}:
+        # UsdPreviewSurface: HdStrelkaMaterial copies the node's parameters under their USD names (Material.cpp:52-150) and hands
+        # the network to MaterialX -> MDL (RenderPass.cpp:164-172, type eMaterialX).  Spec defaults: diffuseColor 0.18,
+        # roughness 0.5, metallic 0, ior 1.5, opacity 1; an opacity below 0.5 is treated as glass.
+        opacity = float(_param(desc, "opacity", 1.0))
+        m["type"] = S.MAT_GLASS if opacity < 0.5 else S.MAT_PBR
+        m["base_color"] = _param(desc, "diffuseColor", (0.18, 0.18, 0.18))
+        m["roughness"] = float(_param(desc, "roughness", 0.5))
+        m["metallic"] = float(_param(desc, "metallic", 0.0))
+        m["ior"] = float(_param(desc, "ior", 1.5))
+    elif "omniglass" in low or "glass" in low:
         m["type"] = S.MAT_GLASS
         m["base_color"] = _param(desc, "glass_color", (1.0, 1.0, 1.0))
         m["roughness"] = float(_param(desc, "frosting_roughness", 0.0))

@@ -105,9 +105,15 @@ def test_material_descriptions_map_to_the_argument_block(tmp_path):
             {"name": "enable_opacity", "type": "bool", "value": True}, {"name": "thin_walled", "type": "bool", "value": False},
             {"name": "frosting_roughness", "type": "float", "value": 0.0}]},
         {"file": "unknown.mdl", "name": "something_else", "params": []},
+        {"file": "", "name": "Kitchen_set_Material_12", "params": [  # UsdPreviewSurface via HdStrelka (Material.cpp:52-150)
+            {"name": "diffuseColor", "type": "float3", "value": f3((0.3, 0.25, 0.2))}, {"name": "roughness", "type": "float", "value": 0.7},
+            {"name": "metallic", "type": "float", "value": 0.0}, {"name": "useSpecularWorkflow", "type": "int", "value": 0}]},
+        {"file": "", "name": "window_glass", "params": [{"name": "diffuseColor", "type": "float3", "value": f3((1, 1, 1))},
+                                                         {"name": "opacity", "type": "float", "value": 0.1}, {"name": "ior", "type": "float", "value": 1.45}]},
     ]
     m = scene_io.materials_from_descriptions(descs)
-    assert list(m["type"]) == [S.MAT_DIFFUSE, S.MAT_PBR, S.MAT_GLASS, S.MAT_DIFFUSE]
+    assert list(m["type"]) == [S.MAT_DIFFUSE, S.MAT_PBR, S.MAT_GLASS, S.MAT_DIFFUSE, S.MAT_PBR, S.MAT_GLASS]
+    assert np.allclose(m["base_color"][4], (0.3, 0.25, 0.2)) and m["roughness"][4] == np.float32(0.7) and m["ior"][5] == np.float32(1.45)
     assert np.allclose(m["base_color"][0], (0.1, 0.2, 0.3)) and np.allclose(m["base_color"][1], (0.9, 0.5, 0.1))
     assert m["roughness"][1] == np.float32(0.25) and m["metallic"][1] == 1.0 and m["ior"][2] == np.float32(1.491)
     assert np.allclose(m["base_color"][3], 0.8)
