@@ -498,8 +498,7 @@ struct HostBin // internal node of the host-side binary tree
     int left, right; // >= 0 HostBin index, < 0 leaf ref
     float lo[3], hi[3];
 };
-static void hb_box_of_ref(int ref, const std::vector<HostBin>& bin, const std::vector<HostBox>& boxes, const std::vector<uint32_t>& order,
-                          float* lo, float* hi)
+static void hb_box_of_ref(int ref, const std::vector<HostBin>& bin, const std::vector<HostBox>& boxes, float* lo, float* hi)
 {
     if (ref >= 0)
     {
@@ -655,7 +654,7 @@ static int tlas_sah_build(const std::vector<HostBox>& boxes, const std::vector<u
         int refs[4];
         for (int k = 0; k < cnt; ++k)
         {
-            hb_box_of_ref(slot[k], bin, boxes, order, clo[k], chi[k]);
+            hb_box_of_ref(slot[k], bin, boxes, clo[k], chi[k]);
             if (slot[k] >= 0)
             {
                 refs[k] = (int)nodes.size();

@@ -614,8 +614,8 @@ bool Scene::loadDump(const std::string& path)
     }
     for (size_t k = 0; k + 3 < texDesc.size(); k += 4)
     {
-        const uint64_t o = texDesc[k], n = (uint64_t)texDesc[k + 1] * texDesc[k + 2];
-        if (n == 0 || o + n > texels.size())
+        const uint64_t o = texDesc[k], texelCount = (uint64_t)texDesc[k + 1] * texDesc[k + 2];
+        if (texelCount == 0 || o + texelCount > texels.size())
             return false;
         fresh.addTexture(texDesc[k + 1], texDesc[k + 2], reinterpret_cast<const uint8_t*>(texels.data() + o));
     }
