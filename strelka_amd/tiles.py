@@ -58,27 +58,3 @@ def gather_tiles(local_tiles, world_size, rank, dist=None, dst=0, out=None):
         # finish the gather before handing the buffers over
         torch.cuda.current_stream().synchronize()
     return parts
-
-
-def detile_numpy(tiles_rgba, tile_xy, tile_size, width, height, out=None):
-    """Host reference of the de-tiling scatter (tests only; on the GPU the root uses skh_scatter_tiles).
-    Slot order inside a tile is Morton(xl, yl) (skh_kernels.h: slot_to_pixel)."""
-    t = np.asarray(tiles_rgba).reshape(len(tile_xy), tile_size * tile_size, 4)
-    if out is None:
-        out = np.zeros((height, width, 4), np.float32)
-    m = np.arange(tile_size * tile_size, dtype=np.uint32)
-
-    def compact(v):
-        v = v & 0x55555555
-        v = (v ^ (v >> 1)) & 0x33333333
-        v = (v ^ (v >> 2)) & 0x0F0F0F0F
-        v = (v ^ (v >> 4)) & 0x00FF00FF
-        v = (v ^ (v >> 8)) & 0x0000FFFF
-        return v
-
-    xl, yl = compact(m), compact(m >> 1)
-    for k, (x0, y0) in enumerate(np.asarray(tile_xy, np.int64)):
-        px, py = x0 + xl, y0 + yl
-        ok = (px < width) & (py < height)
-        out[py[ok], px[ok]] = t[k][ok]
-    return out

@@ -3,6 +3,8 @@ a ray sample traced through the FULL scene (1.7 M unique triangles in 2022 insta
 size-independent properties at 1920x1080: two runs give identical bits, sub-frame batching == one sub-frame per pass,
 tile-sharded accumulation == the full frame, ray counts of both sides agree."""
 import numpy as np
+
+from tests.tilehelp import detile_numpy
 import pytest
 
 from strelka_amd import scene as S, scenes, tiles
@@ -76,8 +78,8 @@ def test_kitchen_1080p_properties(kitchen):
     for rank in (0, 5):
         t = tiles.assign_tiles(W, H, 32, 8, rank)
         _, _, tacc = frame({}, t)
-        part = tiles.detile_numpy(tacc, t, 32, W, H)
-        mask = tiles.detile_numpy(np.ones_like(tacc), t, 32, W, H)[..., 0] > 0
+        part = detile_numpy(tacc, t, 32, W, H)
+        mask = detile_numpy(np.ones_like(tacc), t, 32, W, H)[..., 0] > 0
         assert mask.mean() == pytest.approx(1 / 8, abs=0.02)
         assert part[mask].tobytes() == base[mask].tobytes()
 

@@ -7,6 +7,8 @@ device library, and a 1-ulp direction change can flip a hit on an edge, so a tin
 in one sample).
 """
 import numpy as np
+
+from tests.tilehelp import detile_numpy
 import pytest
 
 from strelka_amd import scene as S
@@ -536,7 +538,7 @@ def test_odd_resolutions_and_tile_sizes(w, h, tile):
     ctx.render_subframes(p0, spp, None)
     buf = torch.zeros((len(mine), tile * tile, 4), dtype=torch.float32, device="cuda")
     ctx.copy_accum_tiles(buf.data_ptr())
-    part = tiles.detile_numpy(buf.cpu().numpy(), mine, tile, w, h)
-    mask = tiles.detile_numpy(np.ones((len(mine), tile * tile, 4), np.float32), mine, tile, w, h)[..., 0] > 0
+    part = detile_numpy(buf.cpu().numpy(), mine, tile, w, h)
+    mask = detile_numpy(np.ones((len(mine), tile * tile, 4), np.float32), mine, tile, w, h)[..., 0] > 0
     assert mask.any() and part[mask].tobytes() == got[mask].tobytes()
     ctx.close()

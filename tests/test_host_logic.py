@@ -5,6 +5,8 @@ import math
 
 import numpy as np
 
+from tests.tilehelp import detile_numpy
+
 from strelka_amd import scene as S
 from strelka_amd import scenes, tiles
 
@@ -145,6 +147,6 @@ def test_tile_assignment_partitions_the_frame():
     assert len(seen) == len(grid)
     # detile reference: slot order inside a tile is Morton
     data = np.arange(2 * 16 * 16 * 4, dtype=np.float32).reshape(2, 256, 4)
-    img = tiles.detile_numpy(data, np.array([(0, 0), (16, 0)]), 16, 24, 16)
+    img = detile_numpy(data, np.array([(0, 0), (16, 0)]), 16, 24, 16)
     assert img[0, 0, 0] == 0 and img[0, 1, 0] == 4 and img[1, 0, 0] == 8 and img[1, 1, 0] == 12  # z-order
     assert img[0, 16, 0] == 256 * 4 and (img[:, 24:] == 0).all() if img.shape[1] > 24 else True

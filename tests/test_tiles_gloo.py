@@ -4,6 +4,8 @@ import os
 import socket
 
 import numpy as np
+
+from tests.tilehelp import detile_numpy
 import pytest
 import torch
 import torch.distributed as dist
@@ -51,7 +53,7 @@ def worker(rank, world, port, ret):
         img = np.zeros((H, W, 4), np.float32)
         for r, part in enumerate(parts):
             tr = tiles.assign_tiles(W, H, T, world, r)
-            tiles.detile_numpy(part.numpy()[: len(tr)], tr, T, W, H, out=img)
+            detile_numpy(part.numpy()[: len(tr)], tr, T, W, H, out=img)
         yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
         ok = np.array_equal(img, pixel_value(xx, yy)) and float(t.item()) == float(world)
         ret.put(bool(ok))
