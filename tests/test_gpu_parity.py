@@ -542,3 +542,45 @@ def test_odd_resolutions_and_tile_sizes(w, h, tile):
     mask = detile_numpy(np.ones((len(mine), tile * tile, 4), np.float32), mine, tile, w, h)[..., 0] > 0
     assert mask.any() and part[mask].tobytes() == got[mask].tobytes()
     ctx.close()
+
+
+def test_error_paths_leave_the_context_usable(gpu):
+    """The C ABI never aborts (the reference logs + assert(0) and carries on: OptixRender.cpp:61-103): bad arguments come back
+    as an error code + message, and the context keeps working afterwards."""
+    from strelka_amd import capi
+
+    sc = scenes.cornell_box()
+    gpu.set_scene(sc.arrays())
+    gpu.resize(32, 24)
+    with pytest.raises(capi.SkhError):
+        gpu.set_option("no_such_option", 1)
+    with pytest.raises(capi.SkhError):
+        gpu.set_option("leaf_max_tris", 99)
+    with pytest.raises(capi.SkhError):
+        gpu.set_option("curve_split", 0)
+    p = S.frame_params(sc.getCamera(), 32, 24, subframe_index=0, spp_total=1, max_depth=4)
+    bad = p.copy()
+    bad["max_depth"] = 1000  # > MAX_BOUNCES (RandomSampler.h:35)
+    with pytest.raises(capi.SkhError):
+        gpu.render_subframe(bad)
+    bad = p.copy()
+    bad["samples_this_launch"] = 0
+    with pytest.raises(capi.SkhError):
+        gpu.render_subframe(bad)
+    with pytest.raises((capi.SkhError, ValueError)):
+        gpu.set_textures([np.zeros((0, 4, 4), np.uint8)])
+    with pytest.raises(capi.SkhError):
+        gpu.set_tiles(24, None)  # not a power of two
+    arr = sc.arrays()
+    broken = dict(arr)
+    broken["meshes"] = arr["meshes"].copy()
+    broken["meshes"]["index_count"][0] = 10 ** 7  # reaches outside the index buffer
+    with pytest.raises(capi.SkhError):
+        gpu.set_scene(broken)
+    # still alive and correct
+    gpu.set_tiles(32, None)
+    gpu.set_scene(arr)
+    gpu.resize(32, 24)
+    gpu.render_subframe(p)
+    a = gpu.read_accum()
+    assert np.isfinite(a).all() and a[..., :3].max() > 0
