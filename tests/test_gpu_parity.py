@@ -613,3 +613,30 @@ def test_multi_sample_launches_match_oracle(gpu):
     for i in range(6):
         gpu.render_subframe(S.frame_params(sc.getCamera(), 64, 40, subframe_index=i, samples_this_launch=1, spp_total=6, max_depth=4))
     assert not np.array_equal(gpu.read_accum(), o.read_accum())
+
+
+@pytest.mark.parametrize("kw", [{"rect_light_sampling_method": 1}, {"enable_accumulation": 0}, {"shadow_ray_tmin": 0.05, "material_ray_tmin": 0.02},
+                                {"exposure": np.float32([1e-3, 2e-3, 5e-4])}])
+def test_frame_parameters_match_oracle(gpu, kw):
+    """The Params fields render() fills from the settings (OptixRender.cpp:936-1004): spherical-rectangle light sampling
+    (render/pt/rectLightSamplingMethod = 1, Lights.h:245-275), accumulation off (image = this launch's mean), non-zero ray
+    tmins (render/pt/dev/*), per-channel exposure in the LDR-space accumulator."""
+    import torch
+
+    from tests import orklib
+
+    sc = small_kitchen()
+    arr = sc.arrays()
+    o = orklib.new_context()
+    o.set_scene(arr)
+    o.resize(72, 48)
+    gpu.set_scene(arr)
+    gpu.resize(72, 48)
+    img = torch.zeros((48, 72, 4), dtype=torch.float32, device="cuda")
+    for i in range(4):
+        p = S.frame_params(sc.getCamera(), 72, 48, subframe_index=i, spp_total=4, max_depth=4, **kw)
+        o.render_subframe(p)
+        gpu.render_subframe(p, img.data_ptr())
+    _image_close(img.cpu().numpy(), o.read_image(), frac_tol=1.5e-2)
+    if kw.get("enable_accumulation", 1):
+        _image_close(gpu.read_accum(), o.read_accum(), frac_tol=1.5e-2)
