@@ -27,6 +27,7 @@ import json
 import math
 import os
 import struct
+import sys
 
 import numpy as np
 
@@ -175,7 +176,11 @@ def _load_materials(doc, sc):
         if not info or info.get("index", -1) < 0:
             return None
         src = textures[info["index"]].get("source", -1)
-        return images[src].get("uri") if 0 <= src < len(images) else None
+        if not 0 <= src < len(images):
+            return None
+        if images[src].get("uri") is None and "bufferView" in images[src]:
+            return f"bufferView:{images[src]['bufferView']}"  # image stored inside a buffer (.glb); tinygltf decodes those too
+        return images[src].get("uri")
 
     for m in doc.get("materials", []):
         pbr = m.get("pbrMetallicRoughness", {})
@@ -196,7 +201,7 @@ def _load_materials(doc, sc):
                 {"name": "frosting_roughness", "type": "float", "value": rough}]})
 
 
-def _load_textures(path, sc):
+def _load_textures(path, sc, doc=None, buffers=None):
     """The reference resolves texture uris against `resource/searchPath` and loads them with stb_image; here: PNG files next
     to the model (strelka_amd/png.py).  A texture that cannot be read is reported and left out (the reference logs an error
     and binds an empty texture, OptixRender.cpp:1195-1199) -- the material then keeps its constant colour."""
@@ -210,16 +215,15 @@ def _load_textures(path, sc):
             uri = p["value"]
             try:
                 if uri.startswith("data:"):
-                    import tempfile
-
-                    with tempfile.NamedTemporaryFile(suffix=".png") as tmp:
-                        tmp.write(base64.b64decode(uri.split(",", 1)[1]))
-                        tmp.flush()
-                        img = png.load_png(tmp.name)
+                    img = png.decode_png(base64.b64decode(uri.split(",", 1)[1]), "data: uri")
+                elif uri.startswith("bufferView:") and doc is not None:
+                    view = doc["bufferViews"][int(uri.split(":")[1])]
+                    start = view.get("byteOffset", 0)
+                    img = png.decode_png(bytes(buffers[view["buffer"]][start:start + view["byteLength"]]), uri)
                 else:
                     img = png.load_png(os.path.join(base, uri))
-            except (OSError, ValueError) as e:
-                print(f"[gltf] unable to load texture {uri[:60]}: {e}")
+            except (OSError, ValueError, KeyError, IndexError) as e:
+                print(f"[gltf] unable to load texture {uri[:60]}: {e}", file=sys.stderr)
                 continue
             sc.texture_ids[uri] = sc.addTexture(img)
 
@@ -307,7 +311,7 @@ def load_gltf(path):
     doc, buffers = _read_model(path)
     sc = GltfScene()
     _load_materials(doc, sc)
-    _load_textures(path, sc)
+    _load_textures(path, sc, doc, buffers)
     _load_lights(path, sc)
     _load_cameras(doc, sc)
     scenes = doc.get("scenes", [])

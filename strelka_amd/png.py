@@ -26,7 +26,11 @@ def _paeth(a, b, c):
 
 def load_png(path):
     with open(path, "rb") as f:
-        blob = f.read()
+        return decode_png(f.read(), path)
+
+
+def decode_png(blob, path="<memory>"):
+    """PNG file content (bytes) -> HxWx4 uint8"""
     if blob[:8] != _SIG:
         raise PngError(f"{path}: not a PNG file")
     off, idat, palette, trns, hdr = 8, [], None, None, None

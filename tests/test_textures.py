@@ -175,6 +175,32 @@ def test_gltf_loader_binds_png_textures(tmp_path):
     assert len(arr2["textures"]) == 0 and arr2["materials"]["base_color_texture"][0] == 0
 
 
+def test_gltf_images_inside_buffers_and_data_uris(tmp_path):
+    import base64
+
+    path, _ = make_gltf(str(tmp_path), embed=False, name="bv")
+    png.save_png(os.path.join(tmp_path, "albedo.png"), checker(4))
+    blob_png = open(os.path.join(tmp_path, "albedo.png"), "rb").read()
+    os.remove(os.path.join(tmp_path, "albedo.png"))
+    doc = json.load(open(path))
+    # (a) data: uri
+    doc["images"][0] = {"uri": "data:image/png;base64," + base64.b64encode(blob_png).decode()}
+    json.dump(doc, open(path, "w"))
+    a = gltf.load_gltf(path).arrays()
+    assert len(a["textures"]) == 1 and np.array_equal(a["textures"][0], checker(4)) and a["materials"]["base_color_texture"][0] == 1
+    # (b) image bytes appended to the binary buffer, referenced through a bufferView (what .glb files do)
+    binp = os.path.join(tmp_path, "bv.bin")
+    data = open(binp, "rb").read()
+    off = len(data) + (-len(data) % 4)
+    open(binp, "wb").write(data + b"\0" * (off - len(data)) + blob_png)
+    doc["buffers"][0]["byteLength"] = off + len(blob_png)
+    doc["bufferViews"].append({"buffer": 0, "byteOffset": off, "byteLength": len(blob_png)})
+    doc["images"][0] = {"bufferView": len(doc["bufferViews"]) - 1, "mimeType": "image/png"}
+    json.dump(doc, open(path, "w"))
+    b = gltf.load_gltf(path).arrays()
+    assert len(b["textures"]) == 1 and np.array_equal(b["textures"][0], checker(4)) and b["materials"]["base_color_texture"][0] == 1
+
+
 def test_png_round_trip_and_screenshot_orientation(tmp_path):
     rs = np.random.RandomState(2)
     img = rs.randint(0, 256, (9, 14, 4)).astype(np.uint8)
