@@ -202,10 +202,14 @@ def _load_materials(doc, sc):
 
 
 def _load_textures(path, sc, doc=None, buffers=None):
-    """The reference resolves texture uris against `resource/searchPath` and loads them with stb_image; here: PNG files next
-    to the model (strelka_amd/png.py).  A texture that cannot be read is reported and left out (the reference logs an error
-    and binds an empty texture, OptixRender.cpp:1195-1199) -- the material then keeps its constant colour."""
-    from . import png
+    """The reference resolves texture uris against `resource/searchPath` and loads them with stb_image; here: PNG and
+    baseline JPEG (strelka_amd/png.py, jpeg.py), from files next to the model, data: URIs or bufferViews.  A texture that
+    cannot be read is reported and left out (the reference logs an error and binds an empty texture,
+    OptixRender.cpp:1195-1199) -- the material then keeps its constant colour."""
+    from . import jpeg, png
+
+    def decode(blob, name):
+        return jpeg.decode_jpeg(blob, name) if blob[:2] == b"\xff\xd8" else png.decode_png(blob, name)
 
     base = os.path.dirname(os.path.abspath(path))
     for d in sc.material_descriptions:
@@ -215,13 +219,14 @@ def _load_textures(path, sc, doc=None, buffers=None):
             uri = p["value"]
             try:
                 if uri.startswith("data:"):
-                    img = png.decode_png(base64.b64decode(uri.split(",", 1)[1]), "data: uri")
+                    img = decode(base64.b64decode(uri.split(",", 1)[1]), "data: uri")
                 elif uri.startswith("bufferView:") and doc is not None:
                     view = doc["bufferViews"][int(uri.split(":")[1])]
                     start = view.get("byteOffset", 0)
-                    img = png.decode_png(bytes(buffers[view["buffer"]][start:start + view["byteLength"]]), uri)
+                    img = decode(bytes(buffers[view["buffer"]][start:start + view["byteLength"]]), uri)
                 else:
-                    img = png.load_png(os.path.join(base, uri))
+                    with open(os.path.join(base, uri), "rb") as f:
+                        img = decode(f.read(), uri)
             except (OSError, ValueError, KeyError, IndexError) as e:
                 print(f"[gltf] unable to load texture {uri[:60]}: {e}", file=sys.stderr)
                 continue

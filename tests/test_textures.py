@@ -215,3 +215,37 @@ def test_png_round_trip_and_screenshot_orientation(tmp_path):
     with pytest.raises(png.PngError):
         open(p, "wb").write(b"not a png")
         png.load_png(p)
+
+
+def test_baseline_jpeg_reader(tmp_path):
+    """JPEG textures (what stbi_load decodes for most glTF assets): the reader against images written by the module's own
+    baseline encoder -- 4:4:4 and 4:2:0, with and without restart intervals, sizes that are not multiples of the MCU -- within
+    the quantisation error; progressive files and non-JPEG data are rejected."""
+    from strelka_amd import jpeg
+
+    rs = np.random.RandomState(4)
+    yy, xx = np.mgrid[0:45, 0:61]
+    img = np.stack([127 + 100 * np.sin(xx / 7.0) * np.cos(yy / 5.0), 127 + 90 * np.cos(xx / 11.0), 60 + 3 * yy + rs.randint(0, 8, (45, 61))],
+                   -1).clip(0, 255).astype(np.uint8)
+    p = os.path.join(tmp_path, "t.jpg")
+    for sub, ri, tol in ((False, 0, 2.5), (False, 5, 2.5), (True, 0, 5.0), (True, 2, 5.0)):
+        jpeg.save_jpeg(p, img, quality_scale=0.25, subsample=sub, restart_interval=ri)
+        out = jpeg.load_jpeg(p)
+        assert out.shape == (45, 61, 4) and (out[..., 3] == 255).all()
+        err = np.abs(out[..., :3].astype(int) - img.astype(int))
+        assert err.mean() < tol and err.max() < 40, (sub, ri, err.mean(), err.max())
+    flat = np.full((16, 16, 3), 200, np.uint8)
+    jpeg.save_jpeg(p, flat, quality_scale=0.1)
+    assert np.abs(jpeg.load_jpeg(p)[..., :3].astype(int) - 200).max() <= 1  # DC only: exact up to rounding
+    blob = bytearray(open(p, "rb").read())
+    blob[blob.index(b"\xff\xc0") + 1] = 0xC2  # pretend progressive
+    with pytest.raises(jpeg.JpegError):
+        jpeg.decode_jpeg(bytes(blob))
+    with pytest.raises(jpeg.JpegError):
+        jpeg.decode_jpeg(b"\x89PNG....")
+    # the glTF loader picks the decoder by the file's magic bytes
+    path, _ = make_gltf(str(tmp_path), name="jp")
+    jpeg.save_jpeg(os.path.join(tmp_path, "albedo.png"), checker(16)[..., :3], quality_scale=0.1)  # JPEG content under the model's uri
+    arr = gltf.load_gltf(path).arrays()
+    assert len(arr["textures"]) == 1 and arr["textures"][0].shape == (16, 16, 4)
+    assert np.abs(arr["textures"][0][..., :3].astype(int) - checker(16)[..., :3].astype(int)).mean() < 12
