@@ -173,6 +173,11 @@ static inline bool intersect_curve_segment(const f3& o, const f3& d, float tmin,
     const f4 e0 = poly.position4(0.0f);
     const f4 e1 = poly.position4(1.0f);
     float tstart = (e1.z - e0.z) > 0.0f ? 0.0f : 1.0f;
+    // Both ends are always tried and the NEARER accepted root wins.  The roots the two passes converge to do not depend on
+    // [tmin, tmax]; returning the first accepted one would make the closest hit depend on the order in which segments are
+    // visited (a first pass that converges to the far side of a thick tube is accepted under tmax = 1e16 and rejected
+    // once a nearer hit elsewhere has shrunk the interval).
+    bool found = false;
     for (int ep = 0; ep < 2; ++ep)
     {
         float t = tstart;
@@ -189,13 +194,13 @@ static inline bool intersect_curve_segment(const f3& o, const f3& d, float tmin,
             if (!phantom && fabsf(rci.dt) < 5e-5f)
             {
                 const float s = (rci.s + rci.c0.z) * inv_dlen;
-                if (s > tmin && s <= tmax && t >= 0.0f && t <= 1.0f)
+                if (s > tmin && s <= tmax && t >= 0.0f && t <= 1.0f && (!found || s < t_out))
                 {
                     t_out = s;
                     u_out = t;
-                    return true;
+                    found = true;
                 }
-                break; // converged to a point outside the ray interval: try the other end
+                break; // converged: try the other end
             }
             rci.dt = fminf(rci.dt, 0.5f);
             rci.dt = fmaxf(rci.dt, -0.5f);
@@ -221,7 +226,7 @@ static inline bool intersect_curve_segment(const f3& o, const f3& d, float tmin,
         }
         tstart = 1.0f - tstart;
     }
-    return false;
+    return found;
 }
 
 // ---------------------------------------------------------------------------------------------

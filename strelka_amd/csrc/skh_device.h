@@ -786,6 +786,9 @@ SKH_DI bool intersect_curve_segment(const v3& o, const v3& d, float tmin, float 
     const v4 e0 = cubic_position(poly, 0.0f);
     const v4 e1 = cubic_position(poly, 1.0f);
     float tstart = (e1.z - e0.z) > 0.0f ? 0.0f : 1.0f;
+    // both ends are always tried and the nearer accepted root wins: the roots do not depend on [tmin, tmax], so the closest
+    // hit does not depend on the order in which segments are visited (returning the first accepted root did)
+    bool found = false;
     for (int ep = 0; ep < 2; ++ep)
     {
         float t = tstart;
@@ -815,11 +818,11 @@ SKH_DI bool intersect_curve_segment(const v3& o, const v3& d, float tmin, float 
             if (!phantom && fabsf(dt) < 5e-5f)
             {
                 const float sw = (s + c0.z) * inv_dlen;
-                if (sw > tmin && sw <= tmax && t >= 0.0f && t <= 1.0f)
+                if (sw > tmin && sw <= tmax && t >= 0.0f && t <= 1.0f && (!found || sw < t_out))
                 {
                     t_out = sw;
                     u_out = t;
-                    return true;
+                    found = true;
                 }
                 break;
             }
@@ -847,7 +850,7 @@ SKH_DI bool intersect_curve_segment(const v3& o, const v3& d, float tmin, float 
         }
         tstart = 1.0f - tstart;
     }
-    return false;
+    return found;
 }
 
 // =================================================================================================

@@ -1,0 +1,52 @@
+"""Randomised hit-record parity: procedural scenes of all kinds (instanced triangle meshes, thin hair, thick varying-radius tubes, many small
+instances) with random extra rotations / non-uniform scales, camera + random + degenerate rays, random build options; GPU closest-hit and any-hit
+results must equal the oracle bit for bit.  usage: python tools/fuzz_hits.py <first seed> <last seed>  (run on the GPU box)."""
+import sys, numpy as np, time
+sys.path.insert(0, ".")
+from strelka_amd import capi, scene as S, scenes
+from tests import orklib
+from tests.test_gpu_parity import camera_rays, thick_curves
+bad = 0; total = 0
+t0 = time.time()
+for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+    rs = np.random.RandomState(seed)
+    kind = seed % 4
+    if kind == 0:
+        sc = scenes.kitchen_standin(seed=seed, n_meshes=10 + seed % 7, n_instances=40 + 13 * (seed % 5), tri_lo=50, tri_hi=3000)
+    elif kind == 1:
+        sc = scenes.hair_standin(seed=seed, n_strands=400 + 50 * (seed % 9), n_cp=6 + seed % 5)
+    elif kind == 2:
+        sc = thick_curves(seed=seed, n_strands=30 + seed % 40, n_cp=5 + seed % 6)
+    else:
+        sc = scenes.kitchen_standin(seed=seed, n_meshes=4, n_instances=300, tri_lo=20, tri_hi=200)
+    arr = sc.arrays()
+    # random extra transforms on the instances: non-uniform scale, rotation about a random axis, large offsets
+    inst = arr["instances"].copy()
+    for k in range(len(inst)):
+        if rs.rand() < 0.5 and inst["type"][k] != S.INSTANCE_LIGHT:
+            m = np.eye(4); m[:3] = inst["transform"][k].reshape(3, 4)
+            ax = rs.normal(size=3); r = S.rotate(ax, rs.uniform(0, 6.28)) @ S.scale(rs.uniform(0.3, 2.5, 3))
+            m2 = S.translate(rs.uniform(-0.5, 0.5, 3)) @ m @ r
+            inst["transform"][k] = m2[:3].astype(np.float32).reshape(12)
+    arr = dict(arr); arr["instances"] = inst
+    rays = np.concatenate([camera_rays(sc, 64, 64, 15000, seed), scenes.random_rays(15000, seed + 1, -4.0, 4.0)])
+    # some nasty rays: axis-parallel directions, zero components, origins far away
+    nasty = rays[:3000].copy()
+    nasty["dir"][:1000, 1] = 0.0; nasty["dir"][1000:2000, [0, 2]] = 0.0; nasty["dir"][1000:2000, 1] = -1.0
+    nasty["origin"][2000:] *= 300.0
+    d = nasty["dir"]; n = np.linalg.norm(d, axis=1, keepdims=True); nasty["dir"] = np.where(n > 0, d / np.maximum(n, 1e-30), [[0, 0, 1]])
+    rays = np.concatenate([rays, nasty])
+    o = orklib.new_context(); o.set_scene(arr); want = o.trace(rays, 0)
+    ctx = capi.Context(0)
+    ctx.set_option("curve_split", 1 + seed % 4); ctx.set_option("leaf_max_tris", 1 + seed % 4)
+    ctx.set_scene(arr); got = ctx.trace(rays, 0)
+    sh = rays.copy(); sh["tmax"] = rs.uniform(0.5, 5.0)
+    ws, gs = o.trace(sh, 1)["t"], ctx.trace(sh, 1)["t"]
+    ctx.close()
+    m1 = int((got.view(np.uint8).reshape(len(got), -1) != want.view(np.uint8).reshape(len(want), -1)).any(1).sum())
+    m2 = int((ws != gs).sum())
+    total += len(rays) * 2
+    if m1 or m2:
+        bad += 1
+        print("seed", seed, "kind", kind, "closest mismatches", m1, "shadow mismatches", m2, flush=True)
+print("fuzz done: %d seeds, %d rays, %d seeds with mismatches, %.0f s" % (int(sys.argv[2]) - int(sys.argv[1]), total, bad, time.time() - t0))
