@@ -1,0 +1,59 @@
+"""Randomised render parity: small procedural scenes (all stand-in kinds, random extra instance transforms, optional textures),
+random resolution / spp / depth / frame parameters; the GPU image must match the oracle's within the render tolerance and the
+two sides must trace (almost) the same number of rays.  usage: python tools/fuzz_render.py <first seed> <last seed>  (GPU box)."""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from strelka_amd import capi, scene as S, scenes  # noqa: E402
+from tests import orklib  # noqa: E402
+from tests.test_gpu_parity import thick_curves  # noqa: E402
+from tests.test_textures import checker, textured_scene  # noqa: E402
+
+bad = 0
+t0 = time.time()
+for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+    rs = np.random.RandomState(seed)
+    kind = seed % 5
+    if kind == 0:
+        sc = scenes.kitchen_standin(seed=seed, n_meshes=8 + seed % 7, n_instances=30 + 11 * (seed % 5), tri_lo=50, tri_hi=2000)
+    elif kind == 1:
+        sc = scenes.hair_standin(seed=seed, n_strands=300 + 40 * (seed % 9), n_cp=6 + seed % 5)
+    elif kind == 2:
+        sc = thick_curves(seed=seed, n_strands=20 + seed % 30, n_cp=5 + seed % 6)
+        sc.createLight({"type": 0, "useXform": False, "position": (0.0, 3.0, 1.0), "orientation": (-70.0, 0.0, 0.0), "width": 2.0, "height": 2.0,
+                        "color": (1.0, 1.0, 1.0), "intensity": 20.0})
+    elif kind == 3:
+        sc = scenes.cornell_box()
+    else:
+        bumps = rs.randint(90, 170, (8, 8, 4)).astype(np.uint8)
+        bumps[..., 2] = 255
+        sc = textured_scene(base_tex=checker(4 + seed % 5), normal_tex=bumps if seed % 2 else None)
+    arr = dict(sc.arrays())
+    w, h = int(rs.randint(17, 120)), int(rs.randint(11, 90))
+    spp, depth = int(rs.randint(1, 6)), int(rs.randint(1, 7))
+    kw = {"rect_light_sampling_method": int(rs.randint(0, 2)), "max_depth": depth}
+    o = orklib.new_context()
+    o.set_scene(arr)
+    o.resize(w, h)
+    ctx = capi.Context(0)
+    ctx.set_option("subframe_batch", int(rs.choice([0, 1, 2])))
+    ctx.set_scene(arr)
+    ctx.set_tiles(int(rs.choice([8, 16, 32, 64])), None)
+    ctx.resize(w, h)
+    p0 = S.frame_params(sc.getCamera(), w, h, subframe_index=0, spp_total=spp, **kw)
+    for i in range(spp):
+        o.render_subframe(S.frame_params(sc.getCamera(), w, h, subframe_index=i, spp_total=spp, **kw))
+    ctx.render_subframes(p0, spp, None)
+    want, got = o.read_accum()[..., :3].astype(np.float64), ctx.read_accum()[..., :3].astype(np.float64)
+    ro, rg = o.stats()["rays_radiance"], ctx.stats()["rays_radiance"]
+    ctx.close()
+    l2 = np.sqrt(((got - want) ** 2).sum()) / max(np.sqrt((want ** 2).sum()), 1e-12)
+    frac = (np.abs(got - want).max(-1) > 2e-3 * (np.abs(want).max(-1) + 1e-3)).mean()
+    ok = np.isfinite(got).all() and l2 < 2e-2 and frac < 2e-2 and abs(int(ro) - int(rg)) <= max(2, ro // 2000)
+    if not ok:
+        bad += 1
+        print("seed", seed, "kind", kind, w, h, spp, depth, "L2 %.3g frac %.3g rays %d vs %d" % (l2, frac, ro, rg), flush=True)
+print("fuzz done: %d seeds, %d failures, %.0f s" % (int(sys.argv[2]) - int(sys.argv[1]), bad, time.time() - t0))
