@@ -739,9 +739,24 @@ SKH_DI bool intersect_triangle(const v3& o, const RayShear& s, float tmin, float
     const float By = B.y - s.Sy * Bkz;
     const float Cx = C.x - s.Sx * Ckz;
     const float Cy = C.y - s.Sy * Ckz;
-    const float U = Cx * By - Cy * Bx;
-    const float V = Ax * Cy - Ay * Cx;
-    const float W = Bx * Ay - By * Ax;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f)
+    {
+        // Woop et al.'s fallback: an edge function that rounds to zero is re-evaluated in fp64, where the products of two
+        // floats are exact and the sign of their difference is therefore exact.  Without it a triangle seen exactly edge-on
+        // (projected vertices collinear with the ray) passes the sign test on rounding noise and reports a "hit" far outside
+        // its own bounding box -- which conservative box tests cull, i.e. the result would depend on the hierarchy.
+        const double Ud = (double)Cx * (double)By - (double)Cy * (double)Bx;
+        const double Vd = (double)Ax * (double)Cy - (double)Ay * (double)Cx;
+        const double Wd = (double)Bx * (double)Ay - (double)By * (double)Ax;
+        if ((Ud < 0.0 || Vd < 0.0 || Wd < 0.0) && (Ud > 0.0 || Vd > 0.0 || Wd > 0.0))
+            return false;
+        U = (float)Ud;
+        V = (float)Vd;
+        W = (float)Wd;
+    }
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f))
         return false;
     const float det = (U + V) + W;

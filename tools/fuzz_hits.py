@@ -36,6 +36,27 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     nasty["origin"][2000:] *= 300.0
     d = nasty["dir"]; n = np.linalg.norm(d, axis=1, keepdims=True); nasty["dir"] = np.where(n > 0, d / np.maximum(n, 1e-30), [[0, 0, 1]])
     rays = np.concatenate([rays, nasty])
+    # rays aimed exactly at mesh vertices and edge midpoints (ties between the triangles that share them: the smaller
+    # (instance, primitive) key must win on both sides) and along triangle edges
+    mesh_inst = np.nonzero(inst["type"] == S.INSTANCE_MESH)[0]
+    if len(mesh_inst) and len(arr["indices"]):
+        aim = np.zeros(4000, S.RAY)
+        for j in range(len(aim)):
+            k = mesh_inst[rs.randint(len(mesh_inst))]
+            me = arr["meshes"][inst["geom_id"][k]]
+            tri = rs.randint(me["index_count"] // 3)
+            vi = arr["indices"][me["index_offset"] + 3 * tri:me["index_offset"] + 3 * tri + 3] + me["vertex_offset"]
+            P = arr["vertices"]["pos"][vi].astype(np.float64)
+            M = inst["transform"][k].reshape(3, 4).astype(np.float64)
+            Pw = P @ M[:, :3].T + M[:, 3]
+            mode = j % 3
+            target = Pw[0] if mode == 0 else (0.5 * (Pw[0] + Pw[1]) if mode == 1 else Pw[2])
+            org = rs.uniform(-3, 3, 3) if mode != 2 else Pw[0] + (Pw[0] - Pw[2]) * rs.uniform(0.1, 2.0)  # mode 2: along an edge
+            dvec = target - org
+            aim["origin"][j] = org
+            aim["dir"][j] = dvec / max(np.linalg.norm(dvec), 1e-30)
+            aim["tmax"][j] = 1e16
+        rays = np.concatenate([rays, aim])
     o = orklib.new_context(); o.set_scene(arr); want = o.trace(rays, 0)
     ctx = capi.Context(0)
     ctx.set_option("curve_split", 1 + seed % 4); ctx.set_option("leaf_max_tris", 1 + seed % 4)
