@@ -742,6 +742,8 @@ SKH_DI bool intersect_triangle(const v3& o, const RayShear& s, float tmin, float
     float U = Cx * By - Cy * Bx;
     float V = Ax * Cy - Ay * Cx;
     float W = Bx * Ay - By * Ax;
+    // >= the sum of the absolute values of the six products above: bounds the cancellation in U, V, W (used below)
+    const float S = ((fabsf(Ax) + fabsf(Bx)) + fabsf(Cx)) * ((fabsf(Ay) + fabsf(By)) + fabsf(Cy));
     if (U == 0.0f || V == 0.0f || W == 0.0f)
     {
         // Woop et al.'s fallback: an edge function that rounds to zero is re-evaluated in fp64, where the products of two
@@ -764,6 +766,15 @@ SKH_DI bool intersect_triangle(const v3& o, const RayShear& s, float tmin, float
         return false;
     const float Az = s.Sz * Akz, Bz = s.Sz * Bkz, Cz = s.Sz * Ckz;
     const float T = (U * Az + V * Bz) + W * Cz;
+    // A depth closer to the start of the ray than the rounding noise of its own evaluation is rejected: the sign of
+    // t - tmin would be arbitrary there (an origin lying on the triangle; worst for sliver triangles, whose barycentric weights
+    // are ill-conditioned), while the boxes around the triangle decide by geometry -- the hit would exist in one hierarchy and
+    // not in another.  S bounds the cancellation in the edge functions; for a well-shaped triangle the threshold is a few
+    // 2^-20 of the parametric distance to the farthest vertex.
+    const float noise = 0x1p-20f * (S * fmaxf(fmaxf(fabsf(Az), fabsf(Bz)), fabsf(Cz)));
+    const float q = T - tmin * det;
+    if (!((det > 0.0f ? q : -q) > noise))
+        return false;
     const float rcpDet = 1.0f / det;
     const float t = T * rcpDet;
     if (!(t > tmin && t <= tmax))

@@ -190,7 +190,7 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 #define SKH_CURVE_MIN_WAVES 4 // 128 VGPRs for the build with the inlined curve intersector (hair stand-in: +4 % over 3 waves)
 #endif
 #ifndef SKH_TRACE_MIN_WAVES
-#define SKH_TRACE_MIN_WAVES 1
+#define SKH_TRACE_MIN_WAVES 6 // 80 VGPRs: the launch runs 24 one-wave blocks per CU; the closest-hit variant would take 81 (4 dwords spill instead)
 #endif
 #ifndef SKH_SORT_ANYHIT
 #define SKH_SORT_ANYHIT 0

@@ -57,6 +57,39 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             aim["dir"][j] = dvec / max(np.linalg.norm(dvec), 1e-30)
             aim["tmax"][j] = 1e16
         rays = np.concatenate([rays, aim])
+    if len(mesh_inst) and len(arr["indices"]):
+        # secondary-ray situations: origins exactly ON a surface (tmin = 0, open interval), going anywhere; and segments that
+        # end exactly on another surface point (shadow rays to a surface)
+        on = np.zeros(6000, S.RAY)
+        pts = np.zeros((len(on), 3))
+        for j in range(len(on)):
+            k = mesh_inst[rs.randint(len(mesh_inst))]
+            me = arr["meshes"][inst["geom_id"][k]]
+            tri = rs.randint(me["index_count"] // 3)
+            vi = arr["indices"][me["index_offset"] + 3 * tri:me["index_offset"] + 3 * tri + 3] + me["vertex_offset"]
+            M = inst["transform"][k].reshape(3, 4).astype(np.float64)
+            Pw = arr["vertices"]["pos"][vi].astype(np.float64) @ M[:, :3].T + M[:, 3]
+            b = rs.dirichlet((1, 1, 1))
+            pts[j] = b @ Pw
+        dirs = rs.normal(size=(len(on), 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        on["origin"] = pts; on["dir"] = dirs; on["tmax"] = 1e16
+        seg = on[:3000].copy()
+        dv = pts[3000:6000] - pts[:3000]; ln = np.linalg.norm(dv, axis=1, keepdims=True)
+        seg["dir"] = dv / np.maximum(ln, 1e-30); seg["tmax"] = ln[:, 0]
+        rays = np.concatenate([rays, on, seg])
+    if seed % 3 == 0:
+        # precision stress: the whole scene far from the origin and / or at an odd scale (rays follow)
+        sc_f, off = float(rs.choice([1e-3, 1.0, 250.0])), rs.uniform(-1, 1, 3) * float(rs.choice([0.0, 100.0, 3000.0]))
+        off = off * sc_f # relative to the scene's size: an instance must stay larger than the float spacing at its position
+        G = S.translate(off) @ S.scale((sc_f, sc_f, sc_f))
+        inst2 = inst.copy()
+        for k in range(len(inst2)):
+            m = np.eye(4); m[:3] = inst2["transform"][k].reshape(3, 4)
+            inst2["transform"][k] = (G @ m)[:3].astype(np.float32).reshape(12)
+        arr = dict(arr); arr["instances"] = inst2
+        rays = rays.copy()
+        rays["origin"] = (rays["origin"].astype(np.float64) * sc_f + off).astype(np.float32)
+        rays["tmax"] = np.where(rays["tmax"] < 1e15, rays["tmax"] * np.float32(sc_f), rays["tmax"]).astype(np.float32)
     o = orklib.new_context(); o.set_scene(arr); want = o.trace(rays, 0)
     ctx = capi.Context(0)
     ctx.set_option("curve_split", 1 + seed % 4); ctx.set_option("leaf_max_tris", 1 + seed % 4)
