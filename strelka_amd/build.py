@@ -34,10 +34,22 @@ def build_variant(out_path, defines, verbose=False):
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-o", LIB, SRC]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # several ranks of one job may get here at the same time (bench.py under torch.distributed.run): one compiles, into a
+    # temporary file that is renamed into place, the others wait on the lock and find the library up to date
+    import fcntl
+
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or needs_build():
+                tmp = "%s.tmp.%d" % (LIB, os.getpid())
+                cmd = [hipcc()] + FLAGS + ["-o", tmp, SRC]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
+                os.replace(tmp, LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
