@@ -287,7 +287,8 @@ skh_status skh_trace_device(skh_context* ctx, const void* d_rays, uint32_t n_ray
  *                 leaf_min (16: lanes for the minority kind of leaf work), curve_min (48: lanes parked in front of the
  *                 curve intersector before it runs), subframe_batch (0 = auto: ~64 M paths per pass),
  *                 overlap 0|1|2 (any-hit launches on a second stream beside the next closest-hit launch: off | small passes |
- *                 always), sort_bits_closest / sort_bits_shadow / sort_first_bounce (ray re-ordering, off)
+ *                 always), small_waves_closest / small_waves_shadow (16 / 16: waves per CU of the two overlapped launches),
+ *                 sort_bits_closest / sort_bits_shadow / sort_first_bounce (ray re-ordering, off)
  *   build         build_quality 1|0 (PLOC | Karras radix tree), leaf_max_tris (2), curve_split (2: parameter sub-ranges
  *                 per curve segment), tlas_open (1: TLAS leaves per instance budget), tight_instance_boxes 1|0, flatten 0|1 (one
  *                 world-space tree)

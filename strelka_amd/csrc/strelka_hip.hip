@@ -88,6 +88,8 @@ struct skh_context
     bool countTraversal = false, timing = false;
     // scheduling of the persistent trace kernels, measured on MI355X (kitchen C3, 32 sub-frames per pass):
     uint32_t wavesPerCU = 24; // resident waves per CU (6 per SIMD at <= 80 VGPRs)
+    uint32_t smallWavesClosest = 16, smallWavesShadow = 16; // overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24
+    uint32_t gridOverride = 0; // set by render_one around its launches
     uint32_t fetchMinClosest = 16, fetchMinShadow = 24; // idle lanes before a wave pulls new rays from the queue
     uint32_t nodeBreakClosest = 20, nodeBreakShadow = 20; // leave the node loop when fewer than x/64 of the wave's rays are still descending
     uint32_t curveMin = 48; // lanes parked in front of the curve intersector before it runs (hair stand-in, Mray/s: 1: 113, 16: 225, 32: 310, 48: 334, 64: 321)
@@ -1633,20 +1635,21 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
         st = c->stream;
     int* ovf = st == c->stream ? c->dOvf.as<int>() : c->dOvf2.as<int>(); // (two trace kernels may be in flight)
     StatsDev* sd = c->dStats.as<StatsDev>();
+    const uint32_t blocks = c->gridOverride ? std::min(c->gridOverride, c->traceBlocks) : c->traceBlocks;
     if (c->flatten)
     {
         if (c->wSegCount)
-            k_trace_flat<ANY, COUNT, true><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib,
+            k_trace_flat<ANY, COUNT, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib,
                                                                                                contribStride, ovf, sd);
         else
-            k_trace_flat<ANY, COUNT, false><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib,
+            k_trace_flat<ANY, COUNT, false><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib,
                                                                                                 contribStride, ovf, sd);
     }
     else if (c->nSegs)
-        k_trace<ANY, COUNT, true><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride,
+        k_trace<ANY, COUNT, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride,
                                                                                       ovf, sd);
     else
-        k_trace<ANY, COUNT, false><<<c->traceBlocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride,
+        k_trace<ANY, COUNT, false><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride,
                                                                                        ovf, sd);
 }
 
@@ -1717,6 +1720,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
             }
             {
                 SpanGuard g(c, KC_TRACE_CLOSEST);
+                c->gridOverride = useOverlap ? c->smallWavesClosest * (uint32_t)c->numCUs : 0u;
                 if (c->countTraversal)
                     launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b * SKH_COUNT_STRIDE, fetch + 16 * b * SKH_FETCH_STRIDE, permC, hq, ps, nullptr, 0);
                 else
@@ -1744,11 +1748,13 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                 }
                 {
                     SpanGuard g(c, KC_TRACE_SHADOW, sst);
+                    c->gridOverride = useOverlap ? c->smallWavesShadow * (uint32_t)c->numCUs : 0u;
                     if (c->countTraversal)
                         launch_trace<true, true>(c, sc, shq, counts + (2 * b + 1) * SKH_COUNT_STRIDE, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, permS, nohq, ps, c->dContrib.as<float>(), N, sst);
                     else
                         launch_trace<true, false>(c, sc, shq, counts + (2 * b + 1) * SKH_COUNT_STRIDE, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, permS, nohq, ps, c->dContrib.as<float>(), N, sst);
                 }
+                c->gridOverride = 0;
                 if (useOverlap)
                     (void)hipEventRecord(c->evShadow, sst);
             }
@@ -2157,6 +2163,12 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
             return SKH_INVALID_ARGUMENT;
         c->leafMaxTris = (uint32_t)value;
         c->accelBuilt = false;
+    }
+    else if (n == "small_waves_closest" || n == "small_waves_shadow")
+    {
+        if (value < 0 || value > 64)
+            return SKH_INVALID_ARGUMENT;
+        (n == "small_waves_closest" ? c->smallWavesClosest : c->smallWavesShadow) = (uint32_t)value;
     }
     else if (n == "build_quality")
     {

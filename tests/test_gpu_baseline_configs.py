@@ -1,0 +1,127 @@
+"""The remaining BASELINE.json configurations as parity cases (the bench line is C3, tests/test_gpu_fullsize.py):
+  C1  coffeemaker stand-in, 512x512, 2 bounces, 16 spp   -- the whole configuration on both sides
+  C2  Cornell box, 1024x1024, 4 bounces, 256 spp          -- oracle on 2 spp at full resolution; 256 spp through properties
+  C4  kitchen stand-in, 3840x2160, 6 bounces, 8 tile sets -- Russian roulette (depth > 3) and the 8-rank tile split at 4K
+  C5  hair stand-in, 1920x1080, 3 bounces                 -- full-resolution properties (hit parity is in test_gpu_fullsize)
+Tolerances are the ones of tests/test_gpu_parity.py (_image_close); ray counts and tile-sharded images are exact."""
+import numpy as np
+import pytest
+
+from strelka_amd import scene as S, scenes, tiles
+from tests.tilehelp import detile_numpy
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_frame(arr, cam, W, H, spp, depth, first=0, total=None):
+    from tests import orklib
+
+    o = orklib.new_context()
+    o.set_scene(arr)
+    o.resize(W, H)
+    for i in range(spp):
+        o.render_subframe(S.frame_params(cam, W, H, subframe_index=first + i, samples_this_launch=1, spp_total=total or spp, max_depth=depth))
+    return o.read_accum(), o.stats()
+
+
+def _gpu_frame(arr, cam, W, H, spp, depth, options=None, tile_xy=None, total=None):
+    import torch
+    from strelka_amd import capi
+
+    ctx = capi.Context(0)
+    for k, v in (options or {}).items():
+        ctx.set_option(k, v)
+    ctx.set_scene(arr)
+    ctx.set_tiles(32, tile_xy)
+    ctx.resize(W, H)
+    ctx.render_subframes(S.frame_params(cam, W, H, subframe_index=0, samples_this_launch=1, spp_total=total or spp, max_depth=depth), spp, None)
+    st = ctx.stats()
+    if tile_xy is None:
+        out = ctx.read_accum()
+    else:
+        buf = torch.zeros((len(tile_xy), 32 * 32, 4), dtype=torch.float32, device="cuda")
+        ctx.copy_accum_tiles(buf.data_ptr())
+        out = buf.cpu().numpy()
+    ctx.close()
+    return out, st
+
+
+def test_c1_coffeemaker_512_whole_configuration_matches_oracle():
+    from tests.test_gpu_parity import _image_close
+
+    sc = scenes.coffeemaker_standin()
+    arr = sc.arrays()
+    assert 40_000 <= len(arr["indices"]) // 3 <= 70_000
+    W = H = 512
+    want, so = _oracle_frame(arr, sc.getCamera(), W, H, 16, 2)
+    got, st = _gpu_frame(arr, sc.getCamera(), W, H, 16, 2)
+    _image_close(got, want)
+    assert st["rays_radiance"] == so["rays_radiance"] and W * H * 16 <= st["rays_radiance"] <= W * H * 16 * 2
+    assert want[..., :3].max() > 0
+
+
+def test_c2_cornell_1024_oracle_on_two_samples_and_256_spp_properties():
+    from tests.test_gpu_parity import _image_close
+
+    sc = scenes.cornell_box()
+    arr = sc.arrays()
+    W = H = 1024
+    want, so = _oracle_frame(arr, sc.getCamera(), W, H, 2, 4, total=256)
+    got, st = _gpu_frame(arr, sc.getCamera(), W, H, 2, 4, total=256)
+    _image_close(got, want)
+    assert st["rays_radiance"] == so["rays_radiance"]
+    # the whole 256-spp frame: the same bits whatever the pass size, every pixel finite and non-negative
+    full, stf = _gpu_frame(arr, sc.getCamera(), W, H, 256, 4)
+    again, _ = _gpu_frame(arr, sc.getCamera(), W, H, 256, 4, options={"subframe_batch": 8})
+    assert full.tobytes() == again.tobytes()
+    assert np.isfinite(full).all() and 0.0 <= full[..., :3].min() and full[..., :3].max() > 1.0  # the emitter is in view
+    assert W * H * 256 <= stf["rays_radiance"] <= W * H * 256 * 4
+    # converged enough to be compared with the 2-sample image in the mean
+    assert abs(full[..., :3].mean() - got[..., :3].mean()) < 0.1 * full[..., :3].mean()
+
+
+def test_c4_kitchen_4k_depth6_roulette_and_eight_rank_tiles():
+    from tests.test_gpu_parity import _image_close
+
+    sc = scenes.kitchen_standin()
+    arr = sc.arrays()
+    W, H, DEPTH = 3840, 2160, 6
+    base, st = _gpu_frame(arr, sc.getCamera(), W, H, 2, DEPTH, total=256)
+    assert np.isfinite(base).all() and base[..., :3].max() > 0
+    # depth 6 goes past the Russian-roulette threshold (OptixRender.cu:131-146): some paths are longer than 4 segments
+    _, st4 = _gpu_frame(arr, sc.getCamera(), W, H, 2, 4, total=256)
+    assert st["rays_radiance"] > st4["rays_radiance"]
+    # the 8-rank tile split of C4: ranks 0, 3 and 7 reproduce their pixels of the full frame bit for bit
+    for rank in (0, 3, 7):
+        t = tiles.assign_tiles(W, H, 32, 8, rank)
+        tacc, _ = _gpu_frame(arr, sc.getCamera(), W, H, 2, DEPTH, tile_xy=t, total=256)
+        part = detile_numpy(tacc, t, 32, W, H)
+        mask = detile_numpy(np.ones_like(tacc), t, 32, W, H)[..., 0] > 0
+        assert mask.mean() == pytest.approx(1 / 8, abs=0.01)
+        assert part[mask].tobytes() == base[mask].tobytes()
+    # a band of the 4K frame against the oracle (32 rows of both sub-frames on the host cores)
+    from tests import orklib
+
+    o = orklib.new_context()
+    o.set_scene(arr)
+    o.resize(W, H)
+    r0, r1 = 1024, 1056
+    for i in range(2):
+        o.render_subframe(S.frame_params(sc.getCamera(), W, H, subframe_index=i, samples_this_launch=1, spp_total=256, max_depth=DEPTH), rows=(r0, r1))
+    _image_close(base[r0:r1], o.read_accum()[r0:r1], frac_tol=1e-2)
+
+
+def test_c5_hair_1080p_depth3_properties():
+    sc = scenes.hair_standin()
+    arr = sc.arrays()
+    W, H = 1920, 1080
+    a, st = _gpu_frame(arr, sc.getCamera(), W, H, 4, 3, total=1024)
+    b, st2 = _gpu_frame(arr, sc.getCamera(), W, H, 4, 3, total=1024, options={"subframe_batch": 1, "curve_split": 3})
+    assert np.isfinite(a).all() and a[..., :3].max() > 0
+    assert a.tobytes() == b.tobytes() and st["rays_radiance"] == st2["rays_radiance"] and st["rays_shadow"] == st2["rays_shadow"]
+    assert W * H * 4 <= st["rays_radiance"] <= W * H * 4 * 3
+    t = tiles.assign_tiles(W, H, 32, 8, 5)
+    tacc, _ = _gpu_frame(arr, sc.getCamera(), W, H, 4, 3, tile_xy=t, total=1024)
+    part = detile_numpy(tacc, t, 32, W, H)
+    mask = detile_numpy(np.ones_like(tacc), t, 32, W, H)[..., 0] > 0
+    assert part[mask].tobytes() == a[mask].tobytes()
