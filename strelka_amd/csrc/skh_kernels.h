@@ -409,7 +409,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                     const float nz = fmaf((float)((nzw >> (8 * k)) & 0xffu), az, bz), fz = fmaf((float)((fzw >> (8 * k)) & 0xffu), az, bz);
                     const float tnear = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
                     const float tfar = fminf(fminf(fx, fy), fminf(fz, best.t));
-                    const bool hit = rf[k] != SKH_REF_INVALID && tnear <= tfar * SKH_SLAB_SLACK;
+                    // (an empty slot is stored as the inverted box 255 > 0 on every axis and fails this test by itself; should rounding
+                    // ever let one through, its SKH_REF_INVALID is pushed and skipped when popped)
+                    const bool hit = tnear <= tfar * SKH_SLAB_SLACK;
                     tn[k] = hit ? tnear : INFINITY;
                 }
                 // sort the four candidates by entry distance (5-comparator network), nearest first
