@@ -57,7 +57,8 @@ struct DevScene
     const float4* wSegs; // 4 x float4 per instanced segment
     const uint2* wSegMeta; // {primId, instId}
     // shading side
-    const HostInstance* instances;
+    const HostInstance* instances; // shading copy: for mesh instances `light` holds the mesh's first record in shadeTris
+    const float4* shadeTris; // de-indexed shading vertices, 3 x 32 B per triangle, meshes back to back
     const uint8_t* verts;
     const uint32_t* indices;
     const uint4* meshes;
@@ -559,11 +560,12 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                 if (!inBlas)
                 {
                     // TLAS leaves hold exactly one instance
+                    // the whole 64-byte record in one round trip (loading the transform only after the mask test made it two)
                     const float4* ip = reinterpret_cast<const float4*>(sc.tinst + first); // `first` = TLAS leaf number
-                    const float4 i3 = ip[3];
+                    const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2], i3 = ip[3];
+                    asm volatile("" ::"v"(i0.x), "v"(i1.x), "v"(i2.x)); // (keeps the three loads above the branch: the compiler sinks them into it)
                     if (__float_as_uint(i3.y) & rayMask)
                     {
-                        const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2];
                         if (COUNT)
                             tc.insts++;
                         const float m[12] = { i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w };
@@ -1159,6 +1161,36 @@ __global__ void __launch_bounds__(512) k_raygen(FrameP fp, const uint32_t* __res
     }
 }
 
+// De-indexed shading vertices: the 3 x 32 B of every triangle, meshes back to back (meshTriBase = exclusive prefix of the
+// meshes' triangle counts).  165 MB for the 1.7 M triangles of the kitchen stand-in, of 288 GB.
+__global__ void __launch_bounds__(256) k_gather_shade_tris(const uint8_t* __restrict__ verts, const uint32_t* __restrict__ indices,
+                                                          const uint4* __restrict__ meshes, const uint32_t* __restrict__ meshTriBase,
+                                                          uint32_t nMeshes, uint32_t nTris, float4* __restrict__ out)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nTris)
+        return;
+    uint32_t lo = 0, hi = nMeshes; // meshTriBase[lo] <= g < meshTriBase[hi]
+    while (hi - lo > 1u)
+    {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (meshTriBase[mid] <= g)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint4 me = meshes[lo];
+    const uint32_t t = g - meshTriBase[lo];
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k)
+    {
+        const uint32_t idx = indices[me.x + 3u * t + k];
+        const float4* v = reinterpret_cast<const float4*>(verts + (size_t)(me.z + idx) * 32);
+        out[6 * (size_t)g + 2 * k] = v[0];
+        out[6 * (size_t)g + 2 * k + 1] = v[1];
+    }
+}
+
 struct SurfaceHit
 {
     v3 position, normal, geom_normal;
@@ -1173,14 +1205,11 @@ struct SurfaceTex // state.text_coords[0], tangent_u[0], tangent_v[0]: only text
 SKH_DI SurfaceHit fill_triangle(const DevScene& sc, const HostInstance& hi, const float* w2o, uint32_t prim, float bu,
                                 float bv, bool inside, SurfaceTex* tex)
 {
-    const uint4 me = sc.meshes[hi.geom];
-    const uint32_t i0 = sc.indices[me.x + prim * 3 + 0];
-    const uint32_t i1 = sc.indices[me.x + prim * 3 + 1];
-    const uint32_t i2 = sc.indices[me.x + prim * 3 + 2];
-    const float4* v0 = reinterpret_cast<const float4*>(sc.verts + (size_t)(me.z + i0) * 32);
-    const float4* v1 = reinterpret_cast<const float4*>(sc.verts + (size_t)(me.z + i1) * 32);
-    const float4* v2 = reinterpret_cast<const float4*>(sc.verts + (size_t)(me.z + i2) * 32);
-    const float4 a0 = v0[0], a1 = v0[1], b0 = v1[0], b1 = v1[1], c0 = v2[0], c1 = v2[1];
+    // the reference walks mesh -> 3 indices -> 3 vertices (closest_hit.cu:365-376); here the three vertices of every triangle
+    // sit de-indexed in one 96-byte record (k_gather_shade_tris) whose mesh base came with the instance record: one dependent
+    // fetch instead of three
+    const float4* tv = sc.shadeTris + 6 * (size_t)(hi.light + prim);
+    const float4 a0 = tv[0], a1 = tv[1], b0 = tv[2], b1 = tv[3], c0 = tv[4], c1 = tv[5];
     const v3 p0 = mk3(a0), p1 = mk3(b0), p2 = mk3(c0);
     const v3 n0 = unpack_normal(__float_as_uint(a1.x)), n1 = unpack_normal(__float_as_uint(b1.x)),
              n2 = unpack_normal(__float_as_uint(c1.x));

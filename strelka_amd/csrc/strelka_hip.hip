@@ -66,6 +66,7 @@ struct skh_context
     std::vector<skh_instance> instances;
 
     DevBuf dVerts, dIndices, dMeshes, dPoints, dRadii, dInstances, dLights, dMaterials;
+    DevBuf dShadeTris, dShadeInst; // shading side: de-indexed triangle records, instance records that carry their mesh's base
     DevBuf dCurveSegBase, dSegStartAll;
     // accel
     DevBuf dTexels, dTexDesc, dSegBound, dScatterXY, dRaygenBase;
@@ -733,7 +734,7 @@ void skh_destroy(skh_context* c)
         return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : { &c->dVerts, &c->dIndices, &c->dMeshes, &c->dPoints, &c->dRadii, &c->dInstances, &c->dLights, &c->dMaterials,
+    for (DevBuf* b : { &c->dShadeTris, &c->dShadeInst, &c->dVerts, &c->dIndices, &c->dMeshes, &c->dPoints, &c->dRadii, &c->dInstances, &c->dLights, &c->dMaterials,
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
                        &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
@@ -1049,11 +1050,52 @@ static skh_status build_world(skh_context* c, bool usePloc)
 #undef BW
 }
 
+// Shading-side tables (k_shade): one 96-byte record per triangle and a copy of the instance records whose unused light id (mesh
+// instances) holds the first record of the instance's mesh.
+static skh_status build_shading_tables(skh_context* c)
+{
+    const uint32_t nMeshes = (uint32_t)c->meshes.size();
+    std::vector<uint32_t> base(nMeshes + 1u, 0u);
+    for (uint32_t m = 0; m < nMeshes; ++m)
+        base[m + 1] = base[m] + c->meshes[m].index_count / 3u;
+    const uint32_t nTris = base[nMeshes];
+    skh_status s;
+    if ((s = dev_alloc(c, c->dShadeTris, std::max<size_t>(96, (size_t)nTris * 96))) != SKH_OK)
+        return s;
+    if (nTris)
+    {
+        DevBuf dBase;
+        if ((s = dev_upload(c, dBase, base.data(), sizeof(uint32_t) * base.size())) != SKH_OK)
+            return s;
+        k_gather_shade_tris<<<(nTris + 255u) / 256u, 256, 0, c->stream>>>(c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(), c->dMeshes.as<uint4>(),
+                                                                         dBase.as<uint32_t>(), nMeshes, nTris, c->dShadeTris.as<float4>());
+        const hipError_t e = hipStreamSynchronize(c->stream);
+        dev_free(dBase);
+        if (e != hipSuccess)
+        {
+            c->err = std::string("k_gather_shade_tris: ") + hipGetErrorString(e);
+            return SKH_FAIL;
+        }
+    }
+    std::vector<skh_instance> inst = c->instances;
+    for (skh_instance& i : inst)
+        if (i.type == SKH_INSTANCE_MESH)
+            i.light_id = i.geom_id < nMeshes ? base[i.geom_id] : 0u;
+    if (inst.empty())
+        inst.resize(1);
+    return dev_upload(c, c->dShadeInst, inst.data(), sizeof(skh_instance) * inst.size());
+}
+
 skh_status skh_build_accel(skh_context* c, uint32_t flags)
 {
     if (!c)
         return SKH_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
+    {
+        const skh_status ss = build_shading_tables(c);
+        if (ss != SKH_OK)
+            return ss;
+    }
     const bool usePloc = (flags & SKH_BUILD_SAH) != 0 || c->buildQuality != 0;
     const auto t0 = std::chrono::steady_clock::now();
     if (c->flatten)
@@ -1551,7 +1593,8 @@ static DevScene make_dev_scene(const skh_context* c)
     sc.wTris = c->dWTris.as<float4>();
     sc.wSegs = c->dWSegs.as<float4>();
     sc.wSegMeta = c->dWSegMeta.as<uint2>();
-    sc.instances = c->dInstances.as<HostInstance>();
+    sc.instances = c->dShadeInst.as<HostInstance>();
+    sc.shadeTris = c->dShadeTris.as<float4>();
     sc.verts = c->dVerts.as<uint8_t>();
     sc.indices = c->dIndices.as<uint32_t>();
     sc.meshes = c->dMeshes.as<uint4>();
