@@ -1202,13 +1202,11 @@ struct SurfaceTex // state.text_coords[0], tangent_u[0], tangent_v[0]: only text
 };
 
 // fillTriangleGeomData: closest_hit.cu:365-421.  UVs / tangent frame are computed only when `tex` is given.
-SKH_DI SurfaceHit fill_triangle(const DevScene& sc, const HostInstance& hi, const float* w2o, uint32_t prim, float bu,
-                                float bv, bool inside, SurfaceTex* tex)
+// The reference walks mesh -> 3 indices -> 3 vertices (closest_hit.cu:365-376); here the three vertices of every triangle sit
+// de-indexed in one 96-byte record (k_gather_shade_tris) whose mesh base came with the instance record -- one dependent fetch
+// instead of three -- and k_shade issues that fetch together with the material's (`tv` = the record).
+SKH_DI SurfaceHit fill_triangle(const HostInstance& hi, const float* w2o, const float4* tv, float bu, float bv, bool inside, SurfaceTex* tex)
 {
-    // the reference walks mesh -> 3 indices -> 3 vertices (closest_hit.cu:365-376); here the three vertices of every triangle
-    // sit de-indexed in one 96-byte record (k_gather_shade_tris) whose mesh base came with the instance record: one dependent
-    // fetch instead of three
-    const float4* tv = sc.shadeTris + 6 * (size_t)(hi.light + prim);
     const float4 a0 = tv[0], a1 = tv[1], b0 = tv[2], b1 = tv[3], c0 = tv[4], c1 = tv[5];
     const v3 p0 = mk3(a0), p1 = mk3(b0), p2 = mk3(c0);
     const v3 n0 = unpack_normal(__float_as_uint(a1.x)), n1 = unpack_normal(__float_as_uint(b1.x)),
@@ -1295,8 +1293,18 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
 #else
 #define SKH_SP(k)
 #endif
-    for (uint32_t k = threadIdx.x; k < SKH_SOBOL_LUT_WORDS / 4; k += blockDim.x)
-        reinterpret_cast<uint4*>(s_sobol)[k] = reinterpret_cast<const uint4*>(g_sobol_lut)[k];
+    {
+        // 20 KB table -> LDS: the block's five fetches go out together (a rolled loop waited for each in turn)
+        static_assert((SKH_SOBOL_LUT_WORDS / 4) % SKH_SHADE_BLOCK == 0, "table staging assumes whole passes");
+        constexpr int passes = (SKH_SOBOL_LUT_WORDS / 4) / SKH_SHADE_BLOCK;
+        uint4 lut[passes];
+#pragma unroll
+        for (int k = 0; k < passes; ++k)
+            lut[k] = reinterpret_cast<const uint4*>(g_sobol_lut)[threadIdx.x + k * SKH_SHADE_BLOCK];
+#pragma unroll
+        for (int k = 0; k < passes; ++k)
+            reinterpret_cast<uint4*>(s_sobol)[threadIdx.x + k * SKH_SHADE_BLOCK] = lut[k];
+    }
     __syncthreads();
     const bool valid = i < n;
     bool emitNext = false, emitShadow = false;
@@ -1341,6 +1349,8 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
             SKH_SP(0) // queue / path-state loads, sampler
             const HostInstance hi = sc.instances[hinst];
             const float* w2o = sc.inst[hinst].w2o;
+            // (the whole record now: the compiler sinks the loads of `material` / `light` below the type test = one more round trip)
+            asm volatile("" ::"v"(hi.type), "v"(hi.material), "v"(hi.light));
             if (hi.type == 1)
             {
                 // __closesthit__light
@@ -1365,6 +1375,16 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
                 // __closesthit__radiance
                 const uint32_t mid = hi.material == 0xffffffffu ? 0u : hi.material; // OptixRender.cpp:768
                 Material mat = sc.materials[mid < sc.numMaterials ? mid : 0u];
+                // the triangle's shading record goes out together with the material's (both hang off the instance record only);
+                // a curve hit fetches record 0 for nothing
+                float4 tv[6];
+                {
+                    const float4* tp = sc.shadeTris + 6 * (size_t)(hi.type == 2 ? 0u : hi.light + hprim);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                        tv[k] = tp[k];
+                }
+                asm volatile("" ::"v"(mat.type), "v"(tv[0].x), "v"(tv[2].x), "v"(tv[4].x));
                 // mdlcode_init (closest_hit.cu:507): texture lookups of the material, triangle hits only.  OmniPBR: a valid
                 // diffuse_texture replaces the constant colour; a valid normalmap_texture replaces state.normal by
                 // normalize(tu x + tv y + n z), (x, y, z) = 2 rgb - 1 (base::tangent_space_normal_texture, factor 1)
@@ -1373,7 +1393,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
                 const bool textured = hi.type != 2 && (useBase || useNormal);
                 SurfaceTex st;
                 SurfaceHit sh = hi.type == 2 ? fill_curve(sc, hi, w2o, hprim, hu, ht, rayO, rayD, inside) :
-                                               fill_triangle(sc, hi, w2o, hprim, hu, hv, inside, textured ? &st : nullptr);
+                                               fill_triangle(hi, w2o, tv, hu, hv, inside, textured ? &st : nullptr);
                 if (textured)
                 {
                     if (useBase)
