@@ -1449,7 +1449,11 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
                                 const float u = sampler_random_lut(smp, DIM_LIGHT_ID, s_sobol);
                                 const uint32_t lightId = (uint32_t)((float)sc.numLights * u);
                                 const float lightSelectionPdf = 1.0f / (float)sc.numLights;
-                                const Light& light = sc.lights[lightId];
+                                // the whole 112-byte record in one round trip (by reference its fields were fetched in three dependent
+                                // steps: type, then the branch's points, then colour / normal)
+                                const Light light = sc.lights[lightId];
+                                asm volatile("" ::"v"(light.points[0].x), "v"(light.points[1].x), "v"(light.points[2].x), "v"(light.points[3].x),
+                                             "v"(light.color.x), "v"(light.normal.x), "v"(light.type));
                                 const float ux = sampler_random_lut(smp, DIM_LIGHT_X, s_sobol), uy = sampler_random_lut(smp, DIM_LIGHT_Y, s_sobol);
                                 LightSample d;
                                 d.pointOnLight = mk3(0.0f);
