@@ -36,18 +36,20 @@ static_assert(sizeof(Node64) == 64, "node size");
 // halving the number of dependent memory round trips per ray relative to the binary layout (the traversal kernel is
 // latency bound, not bandwidth bound: DESIGN.md section 4).
 //   o[3]    node-box origin (min corner minus a safety margin)
-//   exps    one biased fp32 exponent byte per axis: cell size = 2^(e-127), chosen so that 255 cells cover the extent
+//   cell*   cell size per axis, a power of two 2^(e-127) chosen so that 255 cells cover the extent, stored as the float itself
+//           (cellz in the origin's fourth word, cellx / celly in the spare words of the two plane rows): the traversal multiplies
+//           them straight into the reciprocal direction
 //   qlo/qhi one byte per child per axis (byte c of word a = child c, axis a): child box = o + q * cell, with qlo rounded
 //           down and qhi rounded up, so the decoded box always contains the exact (inflated) child box
 //   child   >= 0 node index, < 0 leaf ~((first << 3) | (count - 1)), SKH_REF_INVALID for an empty slot (qlo 255 > qhi 0)
 struct Node4
 {
     float o[3];
-    uint32_t exps;
+    float cellz;
     uint32_t qlo[3];
-    uint32_t pad0;
+    float cellx;
     uint32_t qhi[3];
-    uint32_t pad1;
+    float celly;
     int child[4];
 };
 static_assert(sizeof(Node4) == 64, "node size");
@@ -60,8 +62,7 @@ SKH_HD void encode_node4(Node4& nd, const float* nlo, const float* nhi, const fl
     for (int a = 0; a < 3; ++a)
         m = fmaxf(m, fmaxf(fabsf(nlo[a]), fabsf(nhi[a])));
     const float margin = m * 0x1p-20f + 1e-30f;
-    nd.exps = 0;
-    nd.pad0 = nd.pad1 = 0;
+    nd.cellx = nd.celly = nd.cellz = 0.0f;
     for (int a = 0; a < 3; ++a)
     {
         const float o = nlo[a] - margin;
@@ -72,7 +73,7 @@ SKH_HD void encode_node4(Node4& nd, const float* nlo, const float* nhi, const fl
         biased = biased < 1 ? 1 : (biased > 254 ? 254 : biased);
         const float inv_cell = ldexpf(1.0f, 127 - biased);
         nd.o[a] = o;
-        nd.exps |= (uint32_t)biased << (8 * a);
+        (a == 0 ? nd.cellx : (a == 1 ? nd.celly : nd.cellz)) = ldexpf(1.0f, biased - 127);
         uint32_t wl = 0, wh = 0;
         for (int c = 0; c < 4; ++c)
         {

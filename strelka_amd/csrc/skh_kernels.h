@@ -390,11 +390,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                 if (COUNT)
                     tc.nodes++;
                 SKH_LP(if (!inBlas) tc.segs++;) // (profile build: TLAS share of the node visits, reported as "segs")
-                const uint32_t exps = __float_as_uint(w0.w);
-                // per axis: plane t = q * (cell * inv) + (o_node - o_ray) * inv; near/far bytes picked by the sign of inv
-                const float ax = __uint_as_float((exps & 0xffu) << 23) * inv.x, bx = (w0.x - o.x) * inv.x;
-                const float ay = __uint_as_float(((exps >> 8) & 0xffu) << 23) * inv.y, by = (w0.y - o.y) * inv.y;
-                const float az = __uint_as_float(((exps >> 16) & 0xffu) << 23) * inv.z, bz = (w0.z - o.z) * inv.z;
+                // per axis: plane t = q * (cell * inv) + (o_node - o_ray) * inv (cell sizes come as floats); near/far bytes picked by the sign of inv
+                const float ax = w1.w * inv.x, bx = (w0.x - o.x) * inv.x;
+                const float ay = w2.w * inv.y, by = (w0.y - o.y) * inv.y;
+                const float az = w0.w * inv.z, bz = (w0.z - o.z) * inv.z;
                 const bool px = inv.x >= 0.0f, py = inv.y >= 0.0f, pz = inv.z >= 0.0f;
                 const uint32_t nxw = __float_as_uint(px ? w1.x : w2.x), fxw = __float_as_uint(px ? w2.x : w1.x);
                 const uint32_t nyw = __float_as_uint(py ? w1.y : w2.y), fyw = __float_as_uint(py ? w2.y : w1.y);
@@ -839,10 +838,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                 const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
                 if (COUNT)
                     tc.nodes++;
-                const uint32_t exps = __float_as_uint(w0.w);
-                const float ax = __uint_as_float((exps & 0xffu) << 23) * inv.x, bx = (w0.x - o.x) * inv.x;
-                const float ay = __uint_as_float(((exps >> 8) & 0xffu) << 23) * inv.y, by = (w0.y - o.y) * inv.y;
-                const float az = __uint_as_float(((exps >> 16) & 0xffu) << 23) * inv.z, bz = (w0.z - o.z) * inv.z;
+                const float ax = w1.w * inv.x, bx = (w0.x - o.x) * inv.x;
+                const float ay = w2.w * inv.y, by = (w0.y - o.y) * inv.y;
+                const float az = w0.w * inv.z, bz = (w0.z - o.z) * inv.z;
                 const bool px = inv.x >= 0.0f, py = inv.y >= 0.0f, pz = inv.z >= 0.0f;
                 const uint32_t nxw = __float_as_uint(px ? w1.x : w2.x), fxw = __float_as_uint(px ? w2.x : w1.x);
                 const uint32_t nyw = __float_as_uint(py ? w1.y : w2.y), fyw = __float_as_uint(py ? w2.y : w1.y);

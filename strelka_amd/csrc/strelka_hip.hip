@@ -1318,7 +1318,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
                     double lo[3], hi[3];
                     for (int a = 0; a < 3; ++a)
                     {
-                        const double cell = std::ldexp(1.0, (int)((nd.exps >> (8 * a)) & 0xffu) - 127);
+                        const double cell = (double)(a == 0 ? nd.cellx : (a == 1 ? nd.celly : nd.cellz));
                         lo[a] = (double)nd.o[a] + cell * (double)((nd.qlo[a] >> (8 * ch)) & 0xffu);
                         hi[a] = (double)nd.o[a] + cell * (double)((nd.qhi[a] >> (8 * ch)) & 0xffu);
                         const double pad = (std::fabs(lo[a]) + std::fabs(hi[a])) * 0x1p-20 + 1e-30;
