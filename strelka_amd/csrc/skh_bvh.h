@@ -55,9 +55,37 @@ struct Node4
 static_assert(sizeof(Node4) == 64, "node size");
 
 #define SKH_HD __host__ __device__ inline
-SKH_HD void encode_node4(Node4& nd, const float* nlo, const float* nhi, const float clo[4][3], const float chi[4][3], const int* refs,
-                         int cnt)
+SKH_HD void encode_node4(Node4& nd, const float* nlo, const float* nhi, const float cloIn[4][3], const float chiIn[4][3],
+                         const int* refsIn, int cnt)
 {
+    // Children go into the slots by ascending surface area.  The closest-hit traversal orders them by entry distance anyway; the
+    // any-hit traversal visits slot 3 first, i.e. the child most likely to hold an occluder.
+    float clo[4][3], chi[4][3];
+    int refs[4];
+    {
+        int ord[4] = { 0, 1, 2, 3 };
+        float area[4];
+        for (int c = 0; c < 4; ++c)
+        {
+            const float ex = chiIn[c < cnt ? c : 0][0] - cloIn[c < cnt ? c : 0][0], ey = chiIn[c < cnt ? c : 0][1] - cloIn[c < cnt ? c : 0][1],
+                        ez = chiIn[c < cnt ? c : 0][2] - cloIn[c < cnt ? c : 0][2];
+            area[c] = c < cnt ? ex * ey + ey * ez + ez * ex : 3.0e38f; // (empty slots stay behind the used ones)
+        }
+        for (int i = 1; i < cnt; ++i) // insertion sort of the used slots
+            for (int j = i; j > 0 && area[ord[j]] < area[ord[j - 1]]; --j)
+            {
+                const int t = ord[j];
+                ord[j] = ord[j - 1];
+                ord[j - 1] = t;
+            }
+        for (int c = 0; c < 4; ++c)
+        {
+            const int sIdx = c < cnt ? ord[c] : 0;
+            for (int a = 0; a < 3; ++a)
+                clo[c][a] = cloIn[sIdx][a], chi[c][a] = chiIn[sIdx][a];
+            refs[c] = c < cnt ? refsIn[sIdx] : SKH_REF_INVALID;
+        }
+    }
     float m = 0.0f;
     for (int a = 0; a < 3; ++a)
         m = fmaxf(m, fmaxf(fabsf(nlo[a]), fabsf(nhi[a])));
