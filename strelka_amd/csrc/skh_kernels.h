@@ -119,7 +119,7 @@ struct FrameP // skh_frame_params + launch geometry
 };
 
 #ifndef SKH_STACK_LDS
-#define SKH_STACK_LDS 24 // per-lane stack entries kept in LDS (tests build a variant with 12 to exercise the overflow path)
+#define SKH_STACK_LDS 20 // per-lane stack entries kept in LDS: 5 KB per wave, 28 waves per CU fit 160 KB (tests build a variant with 12 to exercise the overflow path)
 #endif
 #define SKH_STACK_OVF 104
 #define SKH_TRACE_BLOCK 64
@@ -190,6 +190,9 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 #ifndef SKH_CURVE_MIN_WAVES
 #define SKH_CURVE_MIN_WAVES 4 // 128 VGPRs for the build with the inlined curve intersector (hair stand-in: +4 % over 3 waves)
 #endif
+#ifndef SKH_ANYHIT_MIN_WAVES
+#define SKH_ANYHIT_MIN_WAVES 7 // the any-hit build needs 71 VGPRs: 28 waves per CU (shadow 45.9 -> 43.4 ms over 24)
+#endif
 #ifndef SKH_TRACE_MIN_WAVES
 #define SKH_TRACE_MIN_WAVES 6 // 80 VGPRs: the launch runs 24 one-wave blocks per CU; the closest-hit variant would take 81 (4 dwords spill instead)
 #endif
@@ -218,7 +221,7 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 // the result does not depend on the BVH or on the traversal order (DESIGN.md "determinism").
 // ------------------------------------------------------------------------------------------------------------
 template <bool ANY_HIT, bool COUNT, bool CURVES>
-__global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES : SKH_TRACE_MIN_WAVES) SKH_TRACE_ATTR
+__global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES)) SKH_TRACE_ATTR
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
             uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, const uint32_t* __restrict__ perm /*optional: sorted order -> queue index*/,
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,

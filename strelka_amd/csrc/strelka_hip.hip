@@ -89,6 +89,7 @@ struct skh_context
     bool countTraversal = false, timing = false;
     // scheduling of the persistent trace kernels, measured on MI355X (kitchen C3, 32 sub-frames per pass):
     uint32_t wavesPerCU = 24; // resident waves per CU (6 per SIMD at <= 80 VGPRs)
+    uint32_t wavesPerCUShadow = 28; // the any-hit build of the triangle kernel fits 7 per SIMD
     uint32_t smallWavesClosest = 16, smallWavesShadow = 16; // overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24
     uint32_t gridOverride = 0; // set by render_one around its launches
     uint32_t fetchMinClosest = 16, fetchMinShadow = 24; // idle lanes before a wave pulls new rays from the queue
@@ -1484,8 +1485,8 @@ static skh_status alloc_frame(skh_context* c)
     }
     AF(dev_alloc(c, c->dSortHist, sizeof(uint32_t) * 256 * ((N + SKH_RS_THREADS * SKH_RS_ITEMS - 1) / (SKH_RS_THREADS * SKH_RS_ITEMS))));
     c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
-    AF(dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * c->traceBlocks * SKH_TRACE_BLOCK));
-    AF(dev_alloc(c, c->dOvf2, sizeof(int) * (size_t)SKH_STACK_OVF * c->traceBlocks * SKH_TRACE_BLOCK));
+    AF(dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * std::max(c->traceBlocks, (uint32_t)c->numCUs * c->wavesPerCUShadow) * SKH_TRACE_BLOCK));
+    AF(dev_alloc(c, c->dOvf2, sizeof(int) * (size_t)SKH_STACK_OVF * std::max(c->traceBlocks, (uint32_t)c->numCUs * c->wavesPerCUShadow) * SKH_TRACE_BLOCK));
 #undef AF
     SKH_TRY(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(float4) * N1, c->stream));
     SKH_TRY(c, hipMemsetAsync(c->dDiffuse.p, 0, sizeof(float4) * N1, c->stream));
@@ -1678,7 +1679,8 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
         st = c->stream;
     int* ovf = st == c->stream ? c->dOvf.as<int>() : c->dOvf2.as<int>(); // (two trace kernels may be in flight)
     StatsDev* sd = c->dStats.as<StatsDev>();
-    const uint32_t blocks = c->gridOverride ? std::min(c->gridOverride, c->traceBlocks) : c->traceBlocks;
+    const uint32_t fullGrid = (ANY && !c->nSegs && !c->flatten) ? (uint32_t)c->numCUs * c->wavesPerCUShadow : c->traceBlocks;
+    const uint32_t blocks = c->gridOverride ? std::min(c->gridOverride, fullGrid) : fullGrid;
     if (c->flatten)
     {
         if (c->wSegCount)
@@ -2048,7 +2050,7 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
     }
     if (!c->traceBlocks)
         c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
-    if ((s = dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * c->traceBlocks * SKH_TRACE_BLOCK)) != SKH_OK)
+    if ((s = dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * std::max(c->traceBlocks, (uint32_t)c->numCUs * c->wavesPerCUShadow) * SKH_TRACE_BLOCK)) != SKH_OK)
     {
         cleanup();
         return s;
@@ -2220,11 +2222,11 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
     }
     else if (n == "sort_first_bounce")
         c->sortFirstBounce = (uint32_t)std::max<int64_t>(0, value);
-    else if (n == "waves_per_cu")
+    else if (n == "waves_per_cu" || n == "waves_per_cu_shadow")
     {
         if (value < 1 || value > 32)
             return SKH_INVALID_ARGUMENT;
-        c->wavesPerCU = (uint32_t)value;
+        (n == "waves_per_cu" ? c->wavesPerCU : c->wavesPerCUShadow) = (uint32_t)value;
         if (c->width)
             return alloc_frame(c);
     }
