@@ -188,13 +188,14 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 }
 
 #ifndef SKH_CURVE_MIN_WAVES
-#define SKH_CURVE_MIN_WAVES 4 // 128 VGPRs for the build with the inlined curve intersector (hair stand-in: +4 % over 3 waves)
+#define SKH_CURVE_MIN_WAVES 6 // 80 VGPRs (29 dwords spilled) for the build with the inlined curve intersector: hair stand-in 425 / 455 / 478 / 480 Mray/s
+                              // at 4 / 5 / 6 / 7 waves per SIMD (the build needs 104 VGPRs unconstrained)
 #endif
 #ifndef SKH_ANYHIT_MIN_WAVES
 #define SKH_ANYHIT_MIN_WAVES 7 // the any-hit build needs 71 VGPRs: 28 waves per CU (shadow 45.9 -> 43.4 ms over 24)
 #endif
 #ifndef SKH_TRACE_MIN_WAVES
-#define SKH_TRACE_MIN_WAVES 6 // 80 VGPRs: the launch runs 24 one-wave blocks per CU; the closest-hit variant would take 81 (4 dwords spill instead)
+#define SKH_TRACE_MIN_WAVES 7 // 72 VGPRs (2 dwords spilled): the launch runs 28 one-wave blocks per CU (closest 103.3 -> 100.6 ms over 6 waves at 77 VGPRs)
 #endif
 #ifndef SKH_SORT_ANYHIT
 #define SKH_SORT_ANYHIT 0
@@ -255,8 +256,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
     bool hasRay = false, pending = false;
     uint32_t pend = 0; // (curve build) segments of the current leaf that passed the cheap test and wait for the full one
     uint32_t ridx = 0;
-    v3 ow = mk3(0.0f), dw = mk3(0.0f), o = mk3(0.0f), d = mk3(0.0f), inv = mk3(0.0f), invw = mk3(0.0f);
-    float tmin = 0.0f, tmax = 0.0f;
+    v3 ow = mk3(0.0f), dw = mk3(0.0f), o = mk3(0.0f), d = mk3(0.0f), inv = mk3(0.0f);
+    v3 invw = mk3(0.0f); // world-space reciprocal direction: kept by the any-hit build (67 VGPRs), recomputed at every instance exit by the
+                         // closest-hit build, which needs the three registers to stay at 72 = 7 waves per SIMD
+    float tmin = 0.0f;
     RayShear sh;
     sh.perm = 0;
     sh.Sx = sh.Sy = sh.Sz = 0.0f;
@@ -355,15 +358,16 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                 ow = mk3(rq.plane(0)[ridx], rq.plane(1)[ridx], rq.plane(2)[ridx]);
                 dw = mk3(rq.plane(3)[ridx], rq.plane(4)[ridx], rq.plane(5)[ridx]);
                 tmin = rq.plane(6)[ridx];
-                tmax = rq.plane(7)[ridx];
                 o = ow;
                 d = dw;
-                inv = invw = rcp3(d);
+                inv = rcp3(d);
+                if (ANY_HIT)
+                    invw = inv;
                 nodes = sc.tlasNodes;
                 inBlas = false;
                 sp = 0;
                 cur = sc.tlasRoot;
-                best.t = tmax;
+                best.t = rq.plane(7)[ridx];
                 best.inst = best.prim = 0xffffffffu;
                 best.u = best.v = 0.0f;
                 best.found = false;
@@ -483,7 +487,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
             {
                 o = ow;
                 d = dw;
-                inv = invw; // (three IEEE divisions saved per instance exit)
+                inv = ANY_HIT ? invw : rcp3(dw);
                 nodes = sc.tlasNodes;
                 inBlas = false;
                 cur = SKH_REF_INVALID;
@@ -521,7 +525,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                             q[2] = mk4(c2.x, c2.y, c2.z, c2.w);
                             q[3] = mk4(c3.x, c3.y, c3.z, c3.w);
                             float t, u;
-                            if (intersect_curve_segment(o, d, tmin, best.t, q, t, u) && t < tmax)
+                            if (intersect_curve_segment(o, d, tmin, best.t, q, t, u) && (best.found || t < best.t)) // (open at tmax: best.t is the ray's tmax until a hit is found)
                             {
                                 const uint32_t sp = sc.segPrim[first + k];
                                 const uint32_t prim = sp & 0x0fffffffu;
@@ -612,7 +616,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                             tc.prims++;
                         SKH_LP(itT++;)
                         float t, u, v;
-                        if (intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), t, u, v) && t < tmax)
+                        if (intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), t, u, v) && (best.found || t < best.t))
                         {
                             const uint32_t prim = __float_as_uint(a.w);
                             if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
@@ -646,7 +650,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                     {
                         o = ow;
                         d = dw;
-                        inv = invw;
+                        inv = ANY_HIT ? invw : rcp3(dw);
                         nodes = sc.tlasNodes;
                         inBlas = false;
                         continue;

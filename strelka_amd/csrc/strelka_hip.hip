@@ -88,7 +88,7 @@ struct skh_context
     uint32_t numTlasLeaves = 0;
     bool countTraversal = false, timing = false;
     // scheduling of the persistent trace kernels, measured on MI355X (kitchen C3, 32 sub-frames per pass):
-    uint32_t wavesPerCU = 24; // resident waves per CU (6 per SIMD at <= 80 VGPRs)
+    uint32_t wavesPerCU = 28; // resident waves per CU (7 per SIMD at <= 72 VGPRs; the curve build is resident 16 at a time whatever is asked: 128 VGPRs)
     uint32_t wavesPerCUShadow = 28; // the any-hit build of the triangle kernel fits 7 per SIMD
     uint32_t smallWavesClosest = 16, smallWavesShadow = 16; // overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24
     uint32_t gridOverride = 0; // set by render_one around its launches
