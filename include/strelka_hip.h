@@ -282,8 +282,8 @@ skh_status skh_trace_device(skh_context* ctx, const void* d_rays, uint32_t n_ray
  * None of the options changes a result: hit records and images are bit-identical for every setting
  * (tests/test_gpu_parity.py::test_results_do_not_depend_on_the_acceleration_structure_or_scheduling).
  *   measurement   count_traversal 0|1 (counter build of the trace kernels), timing 0|1 (per-kernel hipEvent spans)
- *   scheduling    waves_per_cu (28) / waves_per_cu_shadow (28) (7 waves per SIMD), fetch_min_closest / fetch_min_shadow (16 / 24: idle lanes before a wave refills),
- *                 node_break_closest / node_break_shadow (20: leave the node loop below x/64 descending rays),
+ *   scheduling    waves_per_cu (28) / waves_per_cu_shadow (28) (7 waves per SIMD), fetch_min_closest / fetch_min_shadow (24 / 32, scenes with curves 16 / 24: idle lanes before a wave refills),
+ *                 node_break_closest / node_break_shadow (24 / 20, curves 20 / 20: leave the node loop below x/64 descending rays),
  *                 leaf_min (16: lanes for the minority kind of leaf work), curve_min (48: lanes parked in front of the
  *                 curve intersector before it runs), subframe_batch (0 = auto: ~64 M paths per pass),
  *                 overlap 0|1|2 (any-hit launches on a second stream beside the next closest-hit launch: off | small passes |

@@ -92,8 +92,9 @@ struct skh_context
     uint32_t wavesPerCUShadow = 28; // the any-hit build of the triangle kernel fits 7 per SIMD
     uint32_t smallWavesClosest = 16, smallWavesShadow = 16; // overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24
     uint32_t gridOverride = 0; // set by render_one around its launches
-    uint32_t fetchMinClosest = 16, fetchMinShadow = 24; // idle lanes before a wave pulls new rays from the queue
-    uint32_t nodeBreakClosest = 20, nodeBreakShadow = 20; // leave the node loop when fewer than x/64 of the wave's rays are still descending
+    uint32_t fetchMinClosest = 24, fetchMinShadow = 32; // idle lanes before a wave pulls new rays from the queue (re-tuned at 7 waves/SIMD: was 16 / 24)
+    uint32_t curveFetchMinClosest = 16, curveFetchMinShadow = 24, curveNodeBreakClosest = 20; // the same three for the curve build (6 waves/SIMD): hair 482 vs 465 Mray/s
+    uint32_t nodeBreakClosest = 24, nodeBreakShadow = 20; // leave the node loop when fewer than x/64 of the wave's rays are still descending
     uint32_t curveMin = 48; // lanes parked in front of the curve intersector before it runs (hair stand-in, Mray/s: 1: 113, 16: 225, 32: 310, 48: 334, 64: 321)
     uint32_t leafMin = 16; // postpone the minority kind of leaf work unless it has this many lanes (0 = never postpone; measured +1.5 % at 16)
     // ray re-ordering (per bounce): 0 = off, else Morton bits per axis of the origin cell (key = octant : morton)
@@ -1674,7 +1675,10 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
                          HitQ hq, PathS ps, const float* contrib, uint32_t contribStride, hipStream_t st = nullptr)
 {
     // scenes without curve instances run the build of the kernel that has no curve intersector in it (fewer VGPRs)
-    const uint32_t fm = (ANY ? c->fetchMinShadow : c->fetchMinClosest) | (c->curveMin << 8) | ((ANY ? c->nodeBreakShadow : c->nodeBreakClosest) << 16) | (c->leafMin << 24);
+    const bool curveBuild = c->nSegs != 0 || (c->flatten && c->wSegCount);
+    const uint32_t fetchMin = ANY ? (curveBuild ? c->curveFetchMinShadow : c->fetchMinShadow) : (curveBuild ? c->curveFetchMinClosest : c->fetchMinClosest);
+    const uint32_t nodeBreak = ANY ? c->nodeBreakShadow : (curveBuild ? c->curveNodeBreakClosest : c->nodeBreakClosest);
+    const uint32_t fm = fetchMin | (c->curveMin << 8) | (nodeBreak << 16) | (c->leafMin << 24);
     if (!st)
         st = c->stream;
     int* ovf = st == c->stream ? c->dOvf.as<int>() : c->dOvf2.as<int>(); // (two trace kernels may be in flight)
@@ -2138,7 +2142,8 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
     {
         if (value < 1 || value > 64)
             return SKH_INVALID_ARGUMENT;
-        (n == "fetch_min_closest" ? c->fetchMinClosest : c->fetchMinShadow) = (uint32_t)value;
+        (n == "fetch_min_closest" ? c->fetchMinClosest : c->fetchMinShadow) = (uint32_t)value; // (an explicit value applies to both builds)
+        (n == "fetch_min_closest" ? c->curveFetchMinClosest : c->curveFetchMinShadow) = (uint32_t)value;
     }
     else if (n == "curve_min")
     {
@@ -2182,6 +2187,8 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 0 || value > 64)
             return SKH_INVALID_ARGUMENT;
         (n == "node_break_closest" ? c->nodeBreakClosest : c->nodeBreakShadow) = (uint32_t)value;
+        if (n == "node_break_closest")
+            c->curveNodeBreakClosest = (uint32_t)value;
     }
     else if (n == "sort_bits_closest" || n == "sort_bits_shadow")
     {
