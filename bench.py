@@ -67,6 +67,160 @@ def cpu_baseline(arr, cam, width, height, spp_total, depth, budget_s=12.0):
                       f"{rays} rays in {t_used:.2f} s; oracle BVH build {build_s:.2f} s not included"}
 
 
+PMC_RESULT = None  # filled by live_pmc() before this process touches the GPU
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),  # TCC: the two do not fit one pass (MI355X_MICROARCH.md "rocprofv3 PMC slots")
+              ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES",
+               "SQ_WAIT_INST_ANY"))
+CLOSEST = "void skh::k_trace<false, false"  # the timed build of the closest-hit kernel (the counting pass runs <false, true, ..>)
+
+
+def _pmc_per_launch(outdir, kernel_prefix):
+    """{counter: average over the kernel's dispatches of the summed Counter_Value} from rocprofv3's counter_collection.csv"""
+    import csv
+    import glob
+    from collections import defaultdict
+
+    per = defaultdict(lambda: defaultdict(float))
+    for f in glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Kernel_Name"].startswith(kernel_prefix):
+                per[row["Counter_Name"]][row.get("Dispatch_Id", "0")] += float(row["Counter_Value"])
+    return {c: sum(d.values()) / len(d) for c, d in per.items() if d}
+
+
+def pmc_figures(c, rays_per_launch, source):
+    """Counter averages of one launch -> the figures the roofline block quotes.  hbm bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB:
+    gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md "HBM"); calibrated on coalesced 16-byte
+    per lane streams, which is what a node / triangle fetch is per lane -- but lanes scatter, so read the absolute as +-2x."""
+    out = {"source": source, "rays_per_launch": rays_per_launch}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        out["hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        out["FETCH_SIZE_KiB"], out["WRITE_SIZE_KiB"] = c["FETCH_SIZE"], c["WRITE_SIZE"]
+    if c.get("SQ_INSTS_VALU"):
+        out["valu_per_launch"] = c["SQ_INSTS_VALU"]
+        out["salu_per_valu"] = round(c.get("SQ_INSTS_SALU", 0.0) / c["SQ_INSTS_VALU"], 3)
+        if c.get("SQ_ACTIVE_INST_VALU"):
+            out["lanes_per_valu_inst"] = round(c.get("SQ_THREAD_CYCLES_VALU", 0.0) / c["SQ_ACTIVE_INST_VALU"], 2)
+        if c.get("SQ_WAVE_CYCLES"):
+            out["wait_inst_any_frac"] = round(c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 3)
+    return out
+
+
+def live_pmc(argv, spp, keep_dir=None):
+    """The HBM-side and SQ counters of k_trace<closest>, measured NOW: this process (which has not touched the GPU yet) runs
+    `rocprofv3 --pmc <counters> -- python3 bench.py --pmc-child ...` once per counter group as child processes -- one frame of
+    one full batch each, so a launch there is a launch of the timed run -- and averages the kernel's dispatches.  Only --pmc,
+    never combined with a trace domain.  Returns None when rocprofv3 is missing or a pass fails (the committed profile is
+    quoted instead, with its tag as the source)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not rocprof:
+        return None
+    skip = {"--steps", "--warmup", "--spp", "--cpu-budget", "--gpus", "--pmc-keep", "--pmc-save"}
+    child, it = [], iter(argv)
+    for a in it:
+        if a in skip:
+            next(it, None)
+        elif a.split("=")[0] in skip or a in ("--no-cpu-baseline", "--no-pmc", "--no-drop-in"):
+            pass
+        else:
+            child.append(a)
+    child += ["--pmc-child", "--steps", "1", "--warmup", "0", "--spp", str(min(spp, 32)), "--no-cpu-baseline", "--no-pmc", "--no-drop-in"]
+    root = keep_dir or tempfile.mkdtemp(prefix="skh_pmc_", dir="/tmp")
+    os.makedirs(root, exist_ok=True)
+    counters, rays = {}, None
+    t0 = time.time()
+    for k, group in enumerate(PMC_PASSES):
+        outdir = os.path.join(root, "pass%d" % k)
+        cmd = [rocprof, "--pmc", *group, "--output-format", "csv", "-d", outdir, "--", sys.executable, os.path.abspath(__file__)] + child
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+        except (OSError, subprocess.TimeoutExpired):
+            return None
+        open(os.path.join(root, "pass%d.log" % k), "w").write(r.stdout[-4000:] + r.stderr[-4000:])
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        got = _pmc_per_launch(outdir, CLOSEST)
+        if r.returncode != 0 or not lines or not all(g in got for g in group):
+            return None
+        rays = json.loads(lines[-1])["roofline"]["rays_per_launch"]
+        counters.update(got)
+    fig = pmc_figures(counters, rays, "live: rocprofv3 --pmc child passes of this run (%s), %.0f s" % (" | ".join(" ".join(g) for g in PMC_PASSES), time.time() - t0))
+    if not keep_dir:
+        shutil.rmtree(root, ignore_errors=True)
+    return fig
+
+
+def committed_pmc(workload, resolution):
+    """Fallback when the counters cannot be collected in this run: the last committed profile of the same workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_k_trace_closest.json")
+    try:
+        j = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if j.get("workload") != workload or j.get("resolution") != resolution:
+        return None
+    j["source"] = "replayed from profiles/pmc_k_trace_closest.json (tag %s), not measured in this run" % j.get("tag")
+    return j
+
+
+def launch_command(gpus, argv, port=None):
+    """The command `python bench.py --gpus N ...` turns itself into when it was started WITHOUT a launcher: the driver's own
+    multi-rank line (one rank per GPU, rendezvous on 127.0.0.1)."""
+    port = port or int(os.environ.get("MASTER_PORT", "29541"))
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_self_launch(args, argv):
+    """--gpus N > 1 without WORLD_SIZE in the environment: start the N ranks as a CHILD process (torch.distributed.run) and
+    return its exit code.  Runs before torch is imported or the GPU is touched in this process, and never exec()s.  With a
+    launcher present, --gpus must agree with WORLD_SIZE: a silent 1-rank run labelled as N GPUs is the failure this guards."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is None:
+        if args.gpus <= 1:
+            return None
+        import subprocess
+
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        return subprocess.run(launch_command(args.gpus, argv), env=env).returncode
+    if int(ws) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws}: launch with --nproc-per-node {args.gpus} or pass --gpus {ws}\n")
+        return 2
+    return None
+
+
+def drop_in_leg(ctx, params, W, H, spp, torch, dev):
+    """The call pattern of the reference's caller, timed beside the batched headline: HdStrelkaRenderPass::_Execute calls
+    render(output) once per sub-frame and maps the image after every call (src/HdStrelka/RenderPass.cpp:441-447;
+    OptixBuffer::map = a D2H copy of the float4 image, OptixBuffer.cpp:37-43).  One frame = spp x (skh_render_subframe +
+    skh_buffer_download of W*H float4).  Same scene, same rays; the result is the same image (sub-frame batching is exact)."""
+    image = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    host = np.empty((H, W, 4), np.float32)
+    p = np.array(params, copy=True)
+    ctx.set_option("timing", 0)
+    res = {}
+    for with_map in (True, False):
+        for rep in range(2):  # first repetition = warm-up
+            ctx.reset_stats()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(spp):
+                p["subframe_index"] = i
+                ctx.render_subframe(p, image.data_ptr())  # synchronous, like OptiXRender::render (OptixRender.cpp:1012)
+                if with_map:
+                    ctx.buffer_download(image.data_ptr(), host)
+            dt = time.perf_counter() - t0
+        st = ctx.stats()
+        rays = st["rays_radiance"] + st["rays_shadow"]
+        res["with_map" if with_map else "without_map"] = {"value": round(rays / dt / 1e6, 1), "ms_per_frame": round(dt * 1e3, 2),
+                                                          "ms_per_subframe": round(dt * 1e3 / spp, 3)}
+    return {"unit": "Mray/s", "pattern": f"{spp} x (skh_render_subframe of 1 spp + map() = D2H of the {W}x{H} float4 image), the reference "
+            "caller's loop (RenderPass.cpp:441-447)", **res}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,10 +236,21 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to skh_set_option")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc child passes (roofline quotes the committed profile)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-keep", default=None, help="keep the rocprofv3 output of the child passes in this directory")
+    ap.add_argument("--pmc-save", default=None, metavar="TAG", help="write the live counter figures to profiles/pmc_k_trace_closest.json under this tag")
+    ap.add_argument("--no-drop-in", action="store_true", help="skip the one-render()+map()-per-sub-frame leg")
     args = ap.parse_args()
 
+    rc = maybe_self_launch(args, sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    global PMC_RESULT
+    if world == 1 and not args.no_pmc and not args.pmc_child:
+        PMC_RESULT = live_pmc(sys.argv[1:], args.spp, args.pmc_keep)  # child processes; nothing here has touched the GPU yet
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
 
@@ -160,6 +325,8 @@ def main():
             all_xy[r, :len(t)] = t
         all_xy = np.ascontiguousarray(all_xy.reshape(-1, 2))
 
+    gather_kind = "torch.distributed gather"
+
     def frame():
         ctx.render_subframes(params, args.spp, None)  # all sub-frames of the frame, one device sync at the end
         if world > 1:
@@ -203,45 +370,79 @@ def main():
     else:
         rays_total = float(rays_local)
 
+    drop_in = None
+    if rank == 0 and world == 1 and not args.no_drop_in and not args.pmc_child:
+        drop_in = drop_in_leg(ctx, params, W, H, args.spp, torch, dev)
     if rank == 0:
         K = max(1, args.steps)
-        # roofline of the dominant kernel: k_trace<closest>
+        # ---- roofline of the dominant kernel, k_trace<closest> ----
+        # Three figures, none of which can exceed 1:
+        #   frac (= frac_hbm)   HBM-side bytes per launch from the TCC counters / live launch time / 8 TB/s.  FETCH_SIZE counts
+        #                       Infinity-Cache hits too (MI355X_MICROARCH.md "HBM"), so this is an UPPER bound on HBM use.
+        #   frac_valu_issue     VALU wave-instructions per second / (SIMDs x clock / 2): a wave64 VALU op issues over 2 cycles.
+        #   cached_bw           SURVEY 8(d)'s algorithmic bytes / time: what L2 + Infinity Cache + HBM deliver together; it is
+        #                       NOT divided by the HBM peak (two thirds of those bytes never reach HBM).
         bytes_closest = algorithmic_bytes(cst["rays_radiance"], False, cst["nodes_visited"][0], cst["prims_tested"][0],
                                           cst["segs_tested"][0], cst["instances_entered"][0])
         launches = max(1, st["launches_trace_closest"])
         avg_ms = st["ms_trace_closest"] / launches
         bytes_per_launch = bytes_closest * K / launches
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_k_trace_closest.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                # PMC bytes per launch, measured on launches of `rays_per_launch` rays of the same workload; quoted per
-                # launch of THIS run (same figure when the launch sizes agree, which they do for the default config)
-                if tj.get("workload", workload) == workload and tj.get("resolution", f"{W}x{H}") == f"{W}x{H}":
-                    rpl = cst["rays_radiance"] * K / launches
-                    traffic = int(tj["hbm_bytes_per_launch"] * (rpl / tj["rays_per_launch"] if tj.get("rays_per_launch") else 1.0))
-            except Exception:
-                traffic = None
+        cached = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        rpl = cst["rays_radiance"] * K / launches
+        pmc = PMC_RESULT if PMC_RESULT else committed_pmc(workload, f"{W}x{H}")
+        traffic = achieved = frac = None
+        valu = None
+        if pmc and pmc.get("hbm_bytes_per_launch") and avg_ms > 0:
+            scale = rpl / pmc["rays_per_launch"] if pmc.get("rays_per_launch") else 1.0
+            traffic = int(pmc["hbm_bytes_per_launch"] * scale)
+            achieved = traffic / (avg_ms * 1e-3) / 1e9
+            frac = achieved / HBM_PEAK_GBS
+        if pmc and pmc.get("valu_per_launch") and avg_ms > 0:
+            scale = rpl / pmc["rays_per_launch"] if pmc.get("rays_per_launch") else 1.0
+            props = torch.cuda.get_device_properties(dev)
+            clock_ghz = props.clock_rate / 1e6  # kHz -> GHz (device maximum engine clock, read on this box)
+            simds = props.multi_processor_count * 4
+            peak_issue = simds * clock_ghz / 2.0  # G wave-instructions / s
+            rate = pmc["valu_per_launch"] * scale / (avg_ms * 1e-3) / 1e9
+            lanes = pmc.get("lanes_per_valu_inst")
+            valu = {"valu_wave_insts_per_launch": int(pmc["valu_per_launch"] * scale), "rate_G_per_s": round(rate, 1),
+                    "peak_G_per_s": round(peak_issue, 1), "clock_ghz": round(clock_ghz, 3), "simds": simds,
+                    "frac_valu_issue": round(rate / peak_issue, 4), "lanes_per_valu_inst": lanes,
+                    "frac_lane_throughput": round(rate / peak_issue * lanes / 64.0, 4) if lanes else None,
+                    "valu_per_ray": round(pmc["valu_per_launch"] / max(1, pmc.get("rays_per_launch") or rpl), 1),
+                    "salu_per_valu": pmc.get("salu_per_valu"), "wait_inst_any_frac": pmc.get("wait_inst_any_frac")}
+        for f in (frac, valu and valu["frac_valu_issue"]):
+            assert f is None or f <= 1.0, f"roofline fraction {f} > 1: the model or the counters are wrong"
+        nrs = max(1, cst["rays_shadow"])
         out = {
             "metric": "Mray/s", "value": round(rays_total / dt / 1e6, 3), "unit": "Mray/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "resolution": f"{W}x{H}", "bounces": args.depth, "spp": args.spp,
-                       "step": f"one frame = {args.spp} sub-frames of 1 spp", "tile": args.tile,
-                       "parallelism": f"pixel tiles round-robin over {world} GPU(s), 1 RCCL gather/frame" if world > 1
+                       "step": f"one frame = {args.spp} sub-frames of 1 spp", "tile": args.tile, "world_size": world,
+                       "parallelism": f"pixel tiles round-robin over {world} GPU(s), 1 gather/frame ({gather_kind})" if world > 1
                        else "single GPU", "rays_per_frame": int(rays_total / K), "bvh_build_ms": round(build_ms, 2)},
             "kernel_ms_per_frame": {k: round(st[k] / K, 3) for k in ("ms_trace_closest", "ms_trace_shadow", "ms_shade",
                                                                      "ms_raygen", "ms_accumulate", "ms_sort")},
-            "roofline": {"kernel": "k_trace<closest>", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                         "rays_per_launch": int(cst["rays_radiance"] * K / launches),
+            "roofline": {"kernel": "k_trace<closest>", "bound": "hbm", "achieved": None if achieved is None else round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if frac is None else round(frac, 5),
+                         "frac_is": "upper bound on HBM use: FETCH_SIZE counts Infinity-Cache hits",
+                         "traffic": traffic, "traffic_source": pmc.get("source") if pmc else None,
+                         "limiter": "valu_issue (divergence): see valu", "valu": valu,
+                         "cached_bw": {"GB/s": round(cached, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                                       "note": "SURVEY 8(d) bytes / time; served by L2 + Infinity Cache + HBM together, not an HBM fraction"},
+                         "avg_launch_ms": round(avg_ms, 4), "rays_per_launch": int(rpl),
                          "per_ray": {"nodes": round(cst["nodes_visited"][0] / max(1, cst["rays_radiance"]), 2),
                                      "tris": round(cst["prims_tested"][0] / max(1, cst["rays_radiance"]), 2),
-                                     "instances": round(cst["instances_entered"][0] / max(1, cst["rays_radiance"]), 2)}},
+                                     "instances": round(cst["instances_entered"][0] / max(1, cst["rays_radiance"]), 2)},
+                         "per_shadow_ray": {"nodes": round(cst["nodes_visited"][1] / nrs, 2), "tris": round(cst["prims_tested"][1] / nrs, 2),
+                                            "instances": round(cst["instances_entered"][1] / nrs, 2)}},
         }
+        if drop_in is not None:
+            out["drop_in"] = drop_in
+        if args.pmc_save and PMC_RESULT:
+            json.dump({**PMC_RESULT, "tag": args.pmc_save, "workload": workload, "resolution": f"{W}x{H}", "kernel": "k_trace<closest>"},
+                      open(os.path.join(ROOT, "profiles", "pmc_k_trace_closest.json"), "w"), indent=1)
         if os.environ.get("SKH_BENCH_CHECKSUM"):
             # CRC of the final accumulation image (tests: a tile-sharded N-rank run must reproduce the 1-rank image exactly)
             import zlib

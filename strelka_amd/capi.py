@@ -18,7 +18,8 @@ STATS = np.dtype([("rays_radiance", np.uint64), ("rays_shadow", np.uint64), ("no
                   ("ms_trace_closest", np.float64), ("ms_trace_shadow", np.float64), ("ms_shade", np.float64),
                   ("ms_raygen", np.float64), ("ms_accumulate", np.float64), ("ms_build", np.float64), ("ms_sort", np.float64),
                   ("launches_trace_closest", np.uint32), ("launches_trace_shadow", np.uint32),
-                  ("launches_shade", np.uint32), ("launches_other", np.uint32)])
+                  ("launches_shade", np.uint32), ("launches_other", np.uint32), ("stack_overflows", np.uint32),
+                  ("reserved0", np.uint32)])
 
 SYMBOLS = ["skh_create", "skh_destroy", "skh_last_error", "skh_abi_version", "skh_set_geometry", "skh_set_curves",
            "skh_set_instances", "skh_set_lights", "skh_set_textures", "skh_set_materials", "skh_build_accel", "skh_resize", "skh_set_tiles",
@@ -194,6 +195,10 @@ class Context:
         t = np.ascontiguousarray(tile_xy, np.uint32).reshape(-1, 2)
         self._ck(self.lib.skh_scatter_tiles(self.h, d_src, _p(t), len(t), tile_size, d_dst, width, height),
                  "skh_scatter_tiles")
+
+    def buffer_download(self, d_src, host):
+        """Buffer::map(): device -> host copy of a caller-owned device buffer into the numpy array `host`."""
+        self._ck(self.lib.skh_buffer_download(self.h, d_src, _p(host), host.nbytes), "skh_buffer_download")
 
     def tonemap(self, d_image, width, height, type_, exposure, gamma):
         e = np.ascontiguousarray(exposure, np.float32)
