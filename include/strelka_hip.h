@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SKH_ABI_VERSION 1
+#define SKH_ABI_VERSION 2
 
 /* mirrors oka::Result (include/render/common.h:30-35) */
 typedef enum skh_status
@@ -211,6 +211,10 @@ typedef struct skh_stats
     uint32_t launches_trace_shadow;
     uint32_t launches_shade;
     uint32_t launches_other;
+    /* render / trace calls since the last reset that returned SKH_FAIL because a traversal stack (20 LDS + 104 global entries per
+     * ray) overflowed and dropped a subtree -- a degenerate hierarchy; such a call's hits may be incomplete */
+    uint32_t stack_overflows;
+    uint32_t reserved0;
 } skh_stats;
 
 /* ---- lifetime: RenderFactory::createRender + Render::init (render.cpp:10-35, OptixRender.cpp:1059-1105) ---- */

@@ -74,6 +74,7 @@ struct DevScene
     const uint4* texDesc; // per texture: {offset in texels, width, height, 0}
     uint32_t numTextures;
     struct StatsDev* profile; // (lane-profile build only)
+    uint32_t* overflowFlag; // host-mapped word: set when a traversal stack had to drop an entry (checked after every render / trace call)
 };
 
 struct RayQ // SoA planes of `stride` elements: ox oy oz dx dy dz tmin tmax pathId  (36 B / ray)
@@ -121,7 +122,9 @@ struct FrameP // skh_frame_params + launch geometry
 #ifndef SKH_STACK_LDS
 #define SKH_STACK_LDS 20 // per-lane stack entries kept in LDS: 5 KB per wave, 28 waves per CU fit 160 KB (tests build a variant with 12 to exercise the overflow path)
 #endif
+#ifndef SKH_STACK_OVF
 #define SKH_STACK_OVF 104
+#endif
 #define SKH_TRACE_BLOCK 64
 
 // Reciprocal ray direction for the SLAB tests only: v_rcp_f32 (1 ulp) instead of the ten-instruction IEEE division.  Box
@@ -276,6 +279,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
             lds[sp * SKH_TRACE_BLOCK] = (v);                         \
         else if (sp < SKH_STACK_LDS + SKH_STACK_OVF)                 \
             ovf[(size_t)(sp - SKH_STACK_LDS) * ovfStride] = (v);     \
+        else                                                         \
+            *sc.overflowFlag = 1u; /* the entry is dropped: the call that launched this kernel returns SKH_FAIL, never silent */ \
         ++sp;                                                        \
     }
 #define SKH_POP(dst)                                                 \
@@ -754,6 +759,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
             lds[sp * SKH_TRACE_BLOCK] = (v);                         \
         else if (sp < SKH_STACK_LDS + SKH_STACK_OVF)                 \
             ovf[(size_t)(sp - SKH_STACK_LDS) * ovfStride] = (v);     \
+        else                                                         \
+            *sc.overflowFlag = 1u; /* the entry is dropped: the call that launched this kernel returns SKH_FAIL, never silent */ \
         ++sp;                                                        \
     }
 #define SKH_POP(dst)                                                 \
@@ -1359,7 +1366,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
             if (hi.type == 1)
             {
                 // __closesthit__light
-                const Light& l = sc.lights[hi.light];
+                const Light& l = sc.lights[hi.light < sc.numLights ? hi.light : 0u]; // (skh_build_accel validates it; the light list may have been replaced since)
                 const v3 hitPoint = rayO + ht * rayD;
                 const v3 lightNormal = calc_light_normal(l, hitPoint);
                 if (-dot(rayD, lightNormal) > 0.0f)

@@ -55,6 +55,8 @@ struct skh_context
     hipStream_t stream2 = nullptr; // any-hit launches when `overlap` is on: shadow[b] runs beside closest[b+1] and fills its tail
     int overlap = 1; // 0 off, 1 for small passes only (<= 8 M paths: the interactive one-sub-frame-per-call mode, +7 %), 2 always
     hipEvent_t evShade = nullptr, evShadow = nullptr;
+    uint32_t* hOverflow = nullptr; // pinned, device-visible: traversal-stack overflow flag (DevScene::overflowFlag)
+    uint32_t stackOverflows = 0; // calls that failed with it since the last skh_reset_stats
     std::string err;
     int numCUs = 256;
 
@@ -721,11 +723,14 @@ skh_status skh_create(int device_ordinal, skh_context** out_ctx)
         delete c;
         return SKH_FAIL;
     }
-    if (dev_alloc(c, c->dStats, sizeof(StatsDev)) != SKH_OK || hipMemset(c->dStats.p, 0, sizeof(StatsDev)) != hipSuccess)
+    if (dev_alloc(c, c->dStats, sizeof(StatsDev)) != SKH_OK || hipMemset(c->dStats.p, 0, sizeof(StatsDev)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&c->hOverflow), 64, hipHostMallocMapped) != hipSuccess)
     {
+        dev_free(c->dStats);
         delete c;
         return SKH_FAIL;
     }
+    *c->hOverflow = 0u;
     *out_ctx = c;
     return SKH_OK;
 }
@@ -752,6 +757,8 @@ void skh_destroy(skh_context* c)
         (void)hipEventDestroy(c->evShade);
     if (c->evShadow)
         (void)hipEventDestroy(c->evShadow);
+    if (c->hOverflow)
+        (void)hipHostFree(c->hOverflow);
     delete c;
 }
 
@@ -773,6 +780,17 @@ skh_status skh_set_geometry(skh_context* c, const skh_vertex* verts, uint32_t n_
             me.index_count % 3 != 0)
         {
             c->err = "skh_set_geometry: mesh " + std::to_string(m) + " is out of range";
+            return SKH_INVALID_ARGUMENT;
+        }
+        // indices are mesh-local (closest_hit.cu:365-376 adds mVbOffset): every one must address a vertex of its own mesh
+        const uint32_t* ib = indices + me.index_offset;
+        uint32_t worst = 0;
+        for (uint32_t k = 0; k < me.index_count; ++k)
+            worst = std::max(worst, ib[k]);
+        if (me.index_count && worst >= me.vertex_count)
+        {
+            c->err = "skh_set_geometry: mesh " + std::to_string(m) + " has index " + std::to_string(worst) + " >= its vertex_count " +
+                     std::to_string(me.vertex_count);
             return SKH_INVALID_ARGUMENT;
         }
     }
@@ -799,6 +817,21 @@ skh_status skh_set_curves(skh_context* c, const float* points_xyz, uint32_t n_po
         return SKH_INVALID_ARGUMENT;
     }
     (void)hipSetDevice(c->device);
+    for (uint32_t k = 0; k < n_curves; ++k)
+    {
+        // ranges of oka::Curve (scene.h:29-42) against the arrays they address; the strands of a set must fit its point range
+        const skh_curve& cu = curves[k];
+        bool ok = (uint64_t)cu.vertex_counts_start + cu.vertex_counts_count <= n_vertex_counts &&
+                  (uint64_t)cu.points_start + cu.points_count <= n_points && (uint64_t)cu.widths_start + cu.widths_count <= n_radii;
+        uint64_t used = 0;
+        for (uint32_t j = 0; ok && j < cu.vertex_counts_count; ++j)
+            used += vertex_counts[cu.vertex_counts_start + j];
+        if (!ok || used > cu.points_count)
+        {
+            c->err = "skh_set_curves: curve set " + std::to_string(k) + " addresses data outside the arrays passed in";
+            return SKH_INVALID_ARGUMENT;
+        }
+    }
     c->curves.assign(curves, curves + n_curves);
     c->curveVertexCounts.assign(vertex_counts, vertex_counts + n_vertex_counts);
     c->nPoints = n_points;
@@ -1097,6 +1130,23 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         const skh_status ss = build_shading_tables(c);
         if (ss != SKH_OK)
             return ss;
+    }
+    for (uint32_t i = 0; i < c->nInstances; ++i)
+    {
+        // what the kernels index with an instance's ids: a mesh / curve set (traversal, shading) and, for light proxies, a light
+        const skh_instance& in = c->instances[i];
+        const char* what = nullptr;
+        if (in.type > SKH_INSTANCE_CURVE)
+            what = "type";
+        else if (in.type == SKH_INSTANCE_CURVE ? in.geom_id >= c->curves.size() : in.geom_id >= c->meshes.size())
+            what = "geom_id";
+        else if (in.type == SKH_INSTANCE_LIGHT && in.light_id >= c->nLights)
+            what = "light_id";
+        if (what)
+        {
+            c->err = "skh_build_accel: instance " + std::to_string(i) + " has an out-of-range " + what;
+            return SKH_INVALID_ARGUMENT;
+        }
     }
     const bool usePloc = (flags & SKH_BUILD_SAH) != 0 || c->buildQuality != 0;
     const auto t0 = std::chrono::steady_clock::now();
@@ -1612,6 +1662,7 @@ static DevScene make_dev_scene(const skh_context* c)
     sc.texDesc = c->dTexDesc.as<uint4>();
     sc.numTextures = c->nTextures;
     sc.profile = c->dStats.as<StatsDev>();
+    sc.overflowFlag = c->hOverflow; // (hipHostMallocMapped memory: the host pointer is valid on the device)
     return sc;
 }
 
@@ -1700,6 +1751,18 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
     else
         k_trace<ANY, COUNT, false><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride,
                                                                                        ovf, sd);
+}
+
+// After a synchronisation: did any traversal of the calls since the last check drop a stack entry (its result may miss hits)?
+static skh_status check_stack_overflow(skh_context* c, const char* where)
+{
+    if (!*c->hOverflow)
+        return SKH_OK;
+    *c->hOverflow = 0u;
+    c->stackOverflows++;
+    c->err = std::string(where) + ": a traversal stack overflowed its " + std::to_string(SKH_STACK_LDS) + " LDS + " + std::to_string(SKH_STACK_OVF) +
+             " global entries and dropped a subtree: hits may be missing (degenerate hierarchy?)";
+    return SKH_FAIL;
 }
 
 // One wavefront pass: either one launch of p->samples_this_launch samples (batch = 1), or `batch` consecutive sub-frames
@@ -1868,7 +1931,7 @@ skh_status skh_render_subframes(skh_context* c, const skh_frame_params* params, 
     SKH_TRY(c, hipStreamSynchronize(c->stream)); // the reference's render() is synchronous (OptixRender.cpp:1012)
     if (c->timing)
         harvest_spans(c);
-    return SKH_OK;
+    return check_stack_overflow(c, "skh_render_subframes");
 }
 
 skh_status skh_render_subframe(skh_context* c, const skh_frame_params* params, void* d_image)
@@ -2096,7 +2159,7 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
     }
     if (c->timing)
         harvest_spans(c);
-    return SKH_OK;
+    return check_stack_overflow(c, "skh_trace");
 }
 
 skh_status skh_trace(skh_context* c, const skh_ray* rays, uint32_t n_rays, uint32_t mode, skh_hit* hits)
@@ -2291,6 +2354,7 @@ skh_status skh_get_stats(skh_context* c, skh_stats* out)
     out->launches_trace_shadow = c->launches[KC_TRACE_SHADOW];
     out->launches_shade = c->launches[KC_SHADE];
     out->launches_other = c->launches[KC_RAYGEN] + c->launches[KC_ACCUM];
+    out->stack_overflows = c->stackOverflows;
     return SKH_OK;
 }
 
@@ -2301,6 +2365,7 @@ skh_status skh_reset_stats(skh_context* c)
     (void)hipSetDevice(c->device);
     SKH_TRY(c, hipStreamSynchronize(c->stream));
     SKH_TRY(c, hipMemset(c->dStats.p, 0, sizeof(StatsDev)));
+    c->stackOverflows = 0;
     for (int k = 0; k < KC_COUNT; ++k)
     {
         c->msClass[k] = 0.0;

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(lib):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/strelka_hip.h but not exported"
     assert sorted(capi.SYMBOLS) == syms  # the Python binding covers the whole ABI
-    assert lib.skh_abi_version() == 1
+    assert lib.skh_abi_version() == 2
 
 
 def test_record_sizes_match_the_reference_layouts(ork):
