@@ -155,7 +155,7 @@ def kitchen_standin(seed=1234, n_meshes=150, n_instances=2000, tri_lo=200, tri_h
         elif k == 2:
             mats.append(sc.addMaterial(S.MAT_PBR, col, roughness=rs.uniform(0.1, 0.5), metallic=1.0, specular=0.5))
         else:
-            mats.append(sc.addMaterial(S.MAT_GLASS, (0.95, 0.97, 0.98), ior=1.5))
+            mats.append(sc.addMaterial(S.MAT_GLASS, (0.95, 0.97, 0.98), roughness=0.0, ior=1.5))  # clear glass (frosting_roughness 0)
     glass_mats = [m for m, k in zip(mats, kinds) if k == 3]
     # room shell (inward-facing), 12 triangles
     RX, RY, RZ = 5.0, 2.0, 3.0  # half extents: room 10 x 4 (height) x 6
@@ -304,6 +304,82 @@ def coffeemaker_standin(seed=1, target_tris=50000):
                     "intensity": 160.0})
     cam = S.Camera(fov=45.0)
     cam.lookAt((2.6, 2.2, 3.2), (0.0, 0.9, 0.0))
+    sc.addCamera(cam)
+    return sc
+
+
+def light_zoo(seed=11, with_rect=True):
+    """Every light type of include/render/Lights.h in one small room: a SPHERE light (type 2: uniform sampling over the whole
+    sphere with pdf 1/4pi, Lights.h:335-362; proxy = 16 x 16 UV sphere, scene.cpp:306-351), a DISK light (type 1: no sampler and
+    no pdf in the reference -- it only shines when a path hits its 16-gon proxy, Lights.h:239-242), a rect and a distant light.
+    A few objects of every material kind stand between them."""
+    rs = np.random.RandomState(seed)
+    sc = S.Scene()
+    white = sc.addMaterial(S.MAT_DIFFUSE, (0.75, 0.75, 0.72))
+    mats = [sc.addMaterial(S.MAT_DIFFUSE, (0.7, 0.3, 0.25)), sc.addMaterial(S.MAT_PBR, (0.3, 0.6, 0.3), roughness=0.3),
+            sc.addMaterial(S.MAT_PBR, (0.9, 0.8, 0.4), roughness=0.2, metallic=1.0), sc.addMaterial(S.MAT_GLASS, (0.95, 0.97, 0.98), roughness=0.0, ior=1.5)]
+    room = _add_mesh(sc, *_box_mesh((-2, 0, -2), (2, 3, 2), inward=True))
+    sc.createInstance(S.INSTANCE_MESH, room, white, np.eye(4))
+    meshes = []
+    for k, fn in enumerate([_sphere_fn(rs, 0.08), _torus_fn(rs), _lathe_fn(rs), _sphere_fn(rs, 0.0)]):
+        pos, tris = _grid_mesh(fn, 24, 16)
+        p = pos.astype(np.float64)
+        if np.einsum("ij,ij->i", p[tris[:, 0]], np.cross(p[tris[:, 1]], p[tris[:, 2]])).sum() < 0:
+            tris = tris[:, ::-1]
+        meshes.append(_add_mesh(sc, pos, tris))
+    for k in range(8):
+        x, z = -1.4 + 0.8 * (k % 4) + rs.uniform(-0.1, 0.1), (-0.6 if k < 4 else 0.7) + rs.uniform(-0.1, 0.1)
+        s = rs.uniform(0.22, 0.3)
+        xf = S.translate((x, 1.02 * s, z)) @ S.rotate((0, 1, 0), rs.uniform(0, 6.28)) @ S.scale((s, s, s))
+        sc.createInstance(S.INSTANCE_MESH, meshes[k % 4], mats[(k + k // 4) % 4], xf)
+    # (useXform: the proxy sphere is xform * scale(radius) and the sampler's centre xform * origin; without it the reference scales
+    # the proxy by width / height instead of the radius, scene.h:331-343)
+    sc.createLight({"type": 2, "xform": S.translate((-0.9, 2.2, 0.2)), "useXform": True, "radius": 0.25,
+                    "color": (1.0, 0.85, 0.7), "intensity": 40.0})
+    # disk normal = xform * (0,0,1) (scene.cpp:372-373); the light-hit test wants -dot(rayDir, normal) > 0 (OptixRender.cu:321-323):
+    # local +Z turned to world -Y, the side the room sees
+    xf = S.translate((1.0, 2.97, -0.3)) @ S.rotate((1, 0, 0), math.radians(90))
+    sc.createLight({"type": 1, "xform": xf, "useXform": True, "radius": 0.45, "color": (0.8, 0.9, 1.0), "intensity": 30.0})
+    if with_rect:
+        xf = S.translate((0.0, 2.98, 1.2)) @ S.rotate((1, 0, 0), math.radians(-90))
+        sc.createLight({"type": 0, "xform": xf, "useXform": True, "width": 0.8, "height": 0.5, "color": (1, 1, 1), "intensity": 12.0})
+        xf = S.rotate((0, 1, 0), math.radians(20)) @ S.rotate((1, 0, 0), math.radians(-60))
+        sc.createLight({"type": 3, "xform": xf, "useXform": True, "halfAngle": math.radians(3.0), "color": (1.0, 0.95, 0.85),
+                        "intensity": 1.0, "radius": 0.0})
+    cam = S.Camera(fov=55.0)
+    cam.lookAt((0.0, 1.7, 1.95), (0.0, 1.0, 0.0))
+    sc.addCamera(cam)
+    return sc
+
+
+def material_probe(kind, seed=5):
+    """One material everywhere (floor, walls, three objects): a wrong branch of ONE BSDF cannot hide behind the others.
+    kind: "diffuse" | "glossy" | "metal" | "glass" | "frosted" (OmniGlass with frosting_roughness, gltfloader.cpp:354-406)."""
+    rs = np.random.RandomState(seed)
+    sc = S.Scene()
+    mat = {"diffuse": lambda: sc.addMaterial(S.MAT_DIFFUSE, (0.7, 0.55, 0.4)),
+           "glossy": lambda: sc.addMaterial(S.MAT_PBR, (0.4, 0.6, 0.7), roughness=0.25, metallic=0.0),
+           "metal": lambda: sc.addMaterial(S.MAT_PBR, (0.95, 0.75, 0.4), roughness=0.15, metallic=1.0),
+           "glass": lambda: sc.addMaterial(S.MAT_GLASS, (0.9, 0.97, 0.95), roughness=0.0, ior=1.5),
+           "frosted": lambda: sc.addMaterial(S.MAT_GLASS, (0.9, 0.97, 0.95), roughness=0.45, ior=1.5)}[kind]()
+    room = _add_mesh(sc, *_box_mesh((-1.5, 0, -1.5), (1.5, 2.2, 1.5), inward=True))
+    # a glass room would let nothing back: the shell of the two glass probes is diffuse white, the objects carry the material
+    shell = mat if kind not in ("glass", "frosted") else sc.addMaterial(S.MAT_DIFFUSE, (0.75, 0.75, 0.75))
+    sc.createInstance(S.INSTANCE_MESH, room, shell, np.eye(4))
+    for k, fn in enumerate([_sphere_fn(rs, 0.0), _torus_fn(rs), _lathe_fn(rs)]):
+        pos, tris = _grid_mesh(fn, 28, 18)
+        p = pos.astype(np.float64)
+        if np.einsum("ij,ij->i", p[tris[:, 0]], np.cross(p[tris[:, 1]], p[tris[:, 2]])).sum() < 0:
+            tris = tris[:, ::-1]
+        m = _add_mesh(sc, pos, tris)
+        s = 0.33
+        sc.createInstance(S.INSTANCE_MESH, m, mat, S.translate((-0.8 + 0.8 * k, 1.02 * s + 0.02, -0.1 * k)) @ S.rotate((0, 1, 0), 0.7 * k) @ S.scale((s, s, s)))
+    xf = S.translate((0.0, 2.18, 0.3)) @ S.rotate((1, 0, 0), math.radians(-90))
+    sc.createLight({"type": 0, "xform": xf, "useXform": True, "width": 0.9, "height": 0.6, "color": (1.0, 0.97, 0.9), "intensity": 18.0})
+    sc.createLight({"type": 2, "xform": S.translate((-1.0, 1.6, 0.9)), "useXform": True, "radius": 0.12,
+                    "color": (0.9, 0.95, 1.0), "intensity": 60.0})
+    cam = S.Camera(fov=50.0)
+    cam.lookAt((0.0, 1.1, 1.45), (0.0, 0.55, -0.2))
     sc.addCamera(cam)
     return sc
 

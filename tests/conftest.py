@@ -18,3 +18,18 @@ def ork():
     from tests import orklib
 
     return orklib.load()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """measured image differences of every GPU-vs-oracle comparison (tests/test_gpu_parity.py::_image_close) -> gpurun_out/"""
+    mod = sys.modules.get("tests.test_gpu_parity")
+    log = getattr(mod, "PARITY_LOG", None)
+    if log:
+        import json
+
+        try:
+            d = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(d, exist_ok=True)
+            json.dump(log, open(os.path.join(d, "image_parity.json"), "w"), indent=0)
+        except OSError:
+            pass

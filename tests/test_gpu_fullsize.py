@@ -131,6 +131,6 @@ def test_kitchen_1080p_subframe_image_matches_oracle(kitchen):
     ctx.resize(W, H)
     ctx.render_subframe(p)
     got = ctx.read_accum()
-    _image_close(got, want, frac_tol=1e-2)
+    _image_close(got, want)
     assert ctx.stats()["rays_radiance"] == o.stats()["rays_radiance"]
     ctx.close()

@@ -9,7 +9,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ARGS = ["--scene", "cornell", "--width", "200", "--height", "136", "--spp", "5", "--depth", "4", "--steps", "1", "--warmup", "0",
+ARGS = ["--no-pmc", "--no-drop-in", "--scene", "cornell", "--width", "200", "--height", "136", "--spp", "5", "--depth", "4", "--steps", "1", "--warmup", "0",
         "--no-cpu-baseline"]
 
 
@@ -31,3 +31,16 @@ def test_two_ranks_reproduce_the_single_rank_image():
     assert two["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
     assert two["image_crc32"] == one["image_crc32"]
     assert two["scaling"] == "strong" and two["value"] > 0
+
+
+@pytest.mark.gpu
+def test_gpus_flag_alone_starts_the_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must itself become a 2-rank job (the driver's SCALE run may be
+    started exactly like the N=1 line) and say so in the record."""
+    env = dict(os.environ, SKH_BENCH_CHECKSUM="1", SKH_DIST_BACKEND="gloo", MASTER_PORT="29537")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, env)
+    two = _run([sys.executable, "bench.py", "--gpus", "2"] + ARGS, env)
+    assert two["n_gpus"] == 2 and two["config"]["world_size"] == 2
+    assert two["image_crc32"] == one["image_crc32"]

@@ -148,13 +148,22 @@ def _render_both(gpu, sc, w, h, spp, depth, **kw):
     return o, o.read_accum(), gpu.read_accum()
 
 
-def _image_close(got, want, frac_tol=2e-3, rel=2e-3):
+PARITY_LOG = []  # (test id, relative L2, fraction of pixels off) of every image comparison: tests/conftest.py writes it to gpurun_out/
+
+
+def _image_close(got, want, frac_tol=5e-4, rel=2e-3, l2_tol=1e-4):
+    """Image bar (set to what is measured, not 100x looser).  Default: relative L2 <= 1e-4 over the image and <= 0.05 %
+    of the pixels off by more than 2e-3 relative.  GPU and oracle run the same fp32 operation order; they differ only where libm
+    and the ROCm device library round sin/cos/acos differently (a few ulp), and a 1-ulp change of a direction can move ONE path
+    across a triangle edge -- that pixel is then off by a whole sample.  Tests whose scenes make that likelier (specular chains,
+    hair, few samples) state their own, measured, bar."""
     g, w = got[..., :3].astype(np.float64), want[..., :3].astype(np.float64)
     assert np.isfinite(g).all()
     l2 = np.sqrt(((g - w) ** 2).sum()) / max(np.sqrt((w ** 2).sum()), 1e-12)
     bad = (np.abs(g - w).max(axis=-1) > rel * (np.abs(w).max(axis=-1) + 1e-3)).mean()
-    assert l2 < 2e-2, f"relative L2 {l2}"
-    assert bad < frac_tol, f"{bad * 100:.3f}% of pixels differ by more than {rel} relative"
+    PARITY_LOG.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], float(l2), float(bad)))
+    assert l2 <= l2_tol, f"relative L2 {l2} > {l2_tol}"
+    assert bad <= frac_tol, f"{bad * 100:.3f}% of pixels differ by more than {rel} relative (allowed {frac_tol * 100:.3f}%)"
     return l2, bad
 
 
@@ -171,7 +180,50 @@ def test_render_cornell_matches_oracle(gpu):
 def test_render_mixed_materials_matches_oracle(gpu):
     sc = small_kitchen()
     o, want, got = _render_both(gpu, sc, 96, 64, 4, 5)
-    _image_close(got, want, frac_tol=1e-2)
+    _image_close(got, want)
+
+
+@pytest.mark.parametrize("rect_method", [0, 1])
+def test_render_every_light_type_matches_oracle(gpu, rect_method):
+    """A5 on hardware: sphere light sampling + pdf (Lights.h:335-362, :221-243), the disk light's hit-only emission and normal
+    (Lights.h:54-74,239-242), their proxy meshes (scene.cpp:119-250,306-351) next to a rect and a distant light.  Same paths
+    (equal radiance-ray counts), image at the default bar."""
+    sc = scenes.light_zoo()
+    arr = sc.arrays()
+    assert sorted(arr["lights"]["type"].tolist()) == [0, 1, 2, 3]
+    o, want, got = _render_both(gpu, sc, 120, 80, 8, 4, rect_light_sampling_method=rect_method)
+    _image_close(got, want)
+    st, so = gpu.stats(), o.stats()
+    assert st["rays_radiance"] == so["rays_radiance"] and st["rays_shadow"] <= so["rays_shadow"]
+    # the sphere and the disk are really hit by radiance rays (their proxies are geometry in the BVH with mask LIGHT)
+    li = np.nonzero(arr["instances"]["type"] == S.INSTANCE_LIGHT)[0]
+    rays = camera_rays(sc, 120, 80, 4000, 3)
+    rays["origin"] = (0.0, 0.4, 0.0)
+    rs = np.random.RandomState(2)
+    d = rs.normal(size=(len(rays), 3))
+    d[:, 1] = np.abs(d[:, 1])
+    rays["dir"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    hit = gpu.trace(rays, 0)["instance_id"]
+    for k in li[:2]:
+        assert (hit == k).sum() > 3, k
+
+
+def test_sphere_and_disk_lights_alone(gpu):
+    """only types 1 and 2 in the light list: every NEE sample is a sphere sample or a (pdf 0) disk pick"""
+    sc = scenes.light_zoo(with_rect=False)
+    o, want, got = _render_both(gpu, sc, 96, 64, 6, 3)
+    _image_close(got, want)
+    assert want[..., :3].mean() > 0.05
+    assert gpu.stats()["rays_radiance"] == o.stats()["rays_radiance"]
+
+
+@pytest.mark.parametrize("kind", ["diffuse", "glossy", "metal", "glass", "frosted"])
+def test_single_material_scenes_match_oracle(gpu, kind):
+    """One BSDF per scene (a wrong branch in a 5 %-share material could hide inside a mixed scene's tolerance)."""
+    sc = scenes.material_probe(kind)
+    o, want, got = _render_both(gpu, sc, 96, 72, 8, 5)
+    _image_close(got, want)
+    assert gpu.stats()["rays_radiance"] == o.stats()["rays_radiance"]
 
 
 def test_accumulation_is_order_dependent_and_resets(gpu):
@@ -297,7 +349,7 @@ def test_thick_varying_radius_curves_bit_exact_for_every_sub_range_count(split):
 def test_render_hair_matches_oracle(gpu):
     sc = small_hair()
     o, want, got = _render_both(gpu, sc, 96, 64, 4, 3)
-    _image_close(got, want, frac_tol=1e-2)
+    _image_close(got, want)
     assert gpu.stats()["rays_radiance"] == o.stats()["rays_radiance"]
 
 
@@ -322,9 +374,9 @@ def test_debug_views_and_aovs(gpu):
             gpu.render_subframe(p, img.data_ptr())
         want = o.read_image()
         got = img.cpu().numpy()
-        _image_close(got, want, frac_tol=2e-2)
+        _image_close(got, want)
     for which in (0, 1):
-        _image_close(gpu.read_aov(which), o.read_aov(which), frac_tol=2e-2)
+        _image_close(gpu.read_aov(which), o.read_aov(which))
 
 
 def test_tonemap_kernels_match_oracle(gpu, ork):
@@ -414,6 +466,90 @@ print("SPILL-OK")
     assert out.returncode == 0 and "SPILL-OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_stack_overflow_is_reported_not_silent(tmp_path, gpu):
+    """A traversal that runs out of stack drops a subtree; that must never pass silently.  A build with 2 LDS + 1
+    global stack entries per ray overflows on any real scene: skh_trace and skh_render_subframe then return SKH_FAIL with a
+    message, and skh_get_stats counts the failed calls.  The shipped build (20 + 104 entries) reports none on the same scene."""
+    import subprocess
+    import sys
+
+    from strelka_amd import build
+
+    lib = build.build_variant(str(tmp_path / "libstrelka_hip_tinystack.so"), ["SKH_STACK_LDS=2", "SKH_STACK_OVF=1"])
+    code = r'''
+import os, sys
+sys.path.insert(0, os.environ["SKH_ROOT"])
+import numpy as np
+from strelka_amd import capi, scene as S
+from tests.test_gpu_parity import small_kitchen, camera_rays
+sc = small_kitchen()
+ctx = capi.Context(0)
+ctx.set_scene(sc.arrays())
+rays = camera_rays(sc, 64, 64, 20000, 31)
+fails = 0
+try:
+    ctx.trace(rays, 0)
+except capi.SkhError as e:
+    assert "overflow" in str(e), e
+    fails += 1
+ctx.resize(64, 64)
+try:
+    ctx.render_subframe(S.frame_params(sc.getCamera(), 64, 64, subframe_index=0, spp_total=1, max_depth=3))
+except capi.SkhError as e:
+    assert "overflow" in str(e), e
+    fails += 1
+assert fails == 2 and ctx.stats()["stack_overflows"] == 2, (fails, ctx.stats()["stack_overflows"])
+print("OVERFLOW-REPORTED")
+'''
+    import os
+
+    env = dict(os.environ, SKH_LIB=lib, SKH_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OVERFLOW-REPORTED" in out.stdout, out.stdout + out.stderr
+    sc = small_kitchen()
+    gpu.set_scene(sc.arrays())
+    gpu.reset_stats()
+    gpu.trace(camera_rays(sc, 64, 64, 20000, 31), 0)
+    assert gpu.stats()["stack_overflows"] == 0
+
+
+def test_bad_scene_indices_are_refused(gpu):
+    """The C ABI validates what the kernels index with (ADVICE r1): a vertex index past its mesh, an instance that names a
+    missing mesh / light, a curve set that reads past the control points -> SKH_INVALID_ARGUMENT with a message, no GPU fault."""
+    from strelka_amd import capi
+
+    sc = small_kitchen()
+    good = sc.arrays()
+
+    def refused(base, mut, needle):
+        arr = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in base.items()}
+        mut(arr)
+        with pytest.raises(capi.SkhError) as e:
+            gpu.set_scene(arr)
+        assert needle in str(e.value), str(e.value)
+
+    def bad_index(arr):
+        m = arr["meshes"][0]
+        arr["indices"][m["index_offset"] + 1] = m["vertex_count"]
+
+    def bad_geom(arr):
+        arr["instances"]["geom_id"][0] = len(arr["meshes"])
+
+    def bad_light(arr):
+        k = int(np.nonzero(arr["instances"]["type"] == 1)[0][0])
+        arr["instances"]["light_id"][k] = len(arr["lights"])
+
+    def bad_curve(arr):
+        arr["curves"]["points_count"][0] -= 1
+
+    refused(good, bad_index, "vertex_count")
+    refused(good, bad_geom, "geom_id")
+    refused(good, bad_light, "light_id")
+    refused(small_hair().arrays(), bad_curve, "curve set")
+    gpu.set_scene(good)  # the context is still usable
+    assert (gpu.trace(camera_rays(sc, 32, 32, 500, 1), 0)["instance_id"] != 0xFFFFFFFF).any()
+
+
 def test_subframe_batching_is_exact(gpu):
     """Tracing several single-sample sub-frames in one wavefront pass (more rays per launch, used when a rank's tile
     share is small) must give exactly the image of one-at-a-time rendering: accumulation is applied in sub-frame order."""
@@ -449,7 +585,7 @@ def test_gltf_scene_through_the_dump_format_matches_oracle(gpu, tmp_path):
     cam = loaded.getCamera()
     cam.lookAt = None  # (a dumped camera is fixed)
     o, want, got = _render_both(gpu, loaded, 80, 60, 6, 4)
-    _image_close(got, want, frac_tol=1e-2)
+    _image_close(got, want)
     assert want[..., :3].max() > 0.0 and gpu.stats()["rays_radiance"] == o.stats()["rays_radiance"]
 
 
@@ -482,7 +618,7 @@ def test_textured_materials_match_oracle(gpu):
     assert hit.mean() > 0.3 and np.allclose(got[..., :3], want[..., :3], atol=2e-6)
     assert np.ptp(want[..., 0][hit]) > 0.05  # the normal map really varies across the floor
     o, want, got = _render_both(gpu, sc, 96, 72, 6, 4)
-    _image_close(got, want, frac_tol=1e-2)
+    _image_close(got, want)
     assert gpu.stats()["rays_radiance"] == o.stats()["rays_radiance"]
     plain = textured_scene()
     _, want_plain, _ = _render_both(gpu, plain, 96, 72, 6, 4)
@@ -522,7 +658,7 @@ def test_odd_resolutions_and_tile_sizes(w, h, tile):
     p0 = S.frame_params(sc.getCamera(), w, h, subframe_index=0, spp_total=spp, max_depth=3)
     ctx.render_subframes(p0, spp, None)
     got = ctx.read_accum()
-    _image_close(got, want, frac_tol=2e-2)
+    _image_close(got, want)
     assert ctx.stats()["rays_radiance"] == o.stats()["rays_radiance"]
     ctx.set_option("subframe_batch", 1)
     ctx.resize(w, h)
@@ -606,9 +742,9 @@ def test_multi_sample_launches_match_oracle(gpu):
         p = S.frame_params(sc.getCamera(), 64, 40, subframe_index=start, samples_this_launch=3, spp_total=6, max_depth=4)
         o.render_subframe(p)
         gpu.render_subframe(p)
-    _image_close(gpu.read_accum(), o.read_accum(), frac_tol=1e-2)
+    _image_close(gpu.read_accum(), o.read_accum())
     for which in (0, 1):
-        _image_close(gpu.read_aov(which), o.read_aov(which), frac_tol=2e-2)
+        _image_close(gpu.read_aov(which), o.read_aov(which))
     assert gpu.stats()["rays_radiance"] == o.stats()["rays_radiance"]
     # and it is NOT the same image as six single-sample launches (the accumulator is order dependent)
     gpu.resize(64, 40)
@@ -639,9 +775,9 @@ def test_frame_parameters_match_oracle(gpu, kw):
         p = S.frame_params(sc.getCamera(), 72, 48, subframe_index=i, spp_total=4, max_depth=4, **kw)
         o.render_subframe(p)
         gpu.render_subframe(p, img.data_ptr())
-    _image_close(img.cpu().numpy(), o.read_image(), frac_tol=1.5e-2)
+    _image_close(img.cpu().numpy(), o.read_image())
     if kw.get("enable_accumulation", 1):
-        _image_close(gpu.read_accum(), o.read_accum(), frac_tol=1.5e-2)
+        _image_close(gpu.read_accum(), o.read_accum())
 
 
 def test_randomised_scenes_transforms_and_rays_bit_exact():
