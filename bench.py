@@ -129,7 +129,7 @@ def live_pmc(argv, spp, keep_dir=None):
         else:
             child.append(a)
     child += ["--pmc-child", "--steps", "1", "--warmup", "0", "--spp", str(min(spp, 32)), "--no-cpu-baseline", "--no-pmc", "--no-drop-in"]
-    root = keep_dir or tempfile.mkdtemp(prefix="skh_pmc_", dir="/tmp")
+    root = os.path.abspath(keep_dir) if keep_dir else tempfile.mkdtemp(prefix="skh_pmc_", dir="/tmp")  # (absolute: the children run in /tmp)
     os.makedirs(root, exist_ok=True)
     counters, rays = {}, None
     t0 = time.time()

@@ -151,12 +151,13 @@ def _render_both(gpu, sc, w, h, spp, depth, **kw):
 PARITY_LOG = []  # (test id, relative L2, fraction of pixels off) of every image comparison: tests/conftest.py writes it to gpurun_out/
 
 
-def _image_close(got, want, frac_tol=5e-4, rel=2e-3, l2_tol=1e-4):
-    """Image bar (set to what is measured, not 100x looser).  Default: relative L2 <= 1e-4 over the image and <= 0.05 %
-    of the pixels off by more than 2e-3 relative.  GPU and oracle run the same fp32 operation order; they differ only where libm
-    and the ROCm device library round sin/cos/acos differently (a few ulp), and a 1-ulp change of a direction can move ONE path
-    across a triangle edge -- that pixel is then off by a whole sample.  Tests whose scenes make that likelier (specular chains,
-    hair, few samples) state their own, measured, bar."""
+def _image_close(got, want, frac_tol=1e-4, rel=2e-3, l2_tol=2e-5):
+    """Image bar, set to what is measured on MI355X (gpurun_out/image_parity.json): every scene of this
+    suite up to 200 x 136 pixels comes out at a relative L2 of 2e-8 ... 5e-6 with NO pixel off by more than 2e-3 relative, so
+    the default is relative L2 <= 2e-5 and <= 0.01 % of the pixels off.  GPU and oracle run the same fp32 operation order; they
+    differ only where libm and the ROCm device library round sin/cos/acos/exp/log differently (a few ulp), and a 1-ulp change of a
+    direction can move ONE path across a triangle edge -- that pixel is then off by a whole sample.  The two full-resolution
+    1-spp kitchen frames (2 M and 8 M pixels) do contain such paths; they state their own measured bar."""
     g, w = got[..., :3].astype(np.float64), want[..., :3].astype(np.float64)
     assert np.isfinite(g).all()
     l2 = np.sqrt(((g - w) ** 2).sum()) / max(np.sqrt((w ** 2).sum()), 1e-12)
