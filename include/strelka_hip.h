@@ -111,10 +111,20 @@ enum
 {
     SKH_MAT_DIFFUSE = 0, /* default.mdl::default_material(diffuse_color)  (OptixRender.cpp:1090-1097) */
     SKH_MAT_PBR = 1, /* OmniPBR: diffuse_color_constant, reflection_roughness_constant, metallic_constant */
-    SKH_MAT_GLASS = 2, /* OmniGlass: glass_color, glass_ior (thin_walled = false) */
-    SKH_MAT_HAIR = 3 /* hair sub-expression (mdlPtxCodeGen.cpp:143-155) */
+    SKH_MAT_GLASS = 2, /* OmniGlass: glass_color, glass_ior, frosting_roughness (thin_walled = false; gltfloader.cpp:354-406) */
+    SKH_MAT_HAIR = 3 /* hair sub-expression (mdlPtxCodeGen.cpp:143-155): df::chiang_hair_bsdf */
 };
 
+/* Field use per type:
+ *   DIFFUSE  base_color = diffuse_color
+ *   PBR      base_color = diffuse_color_constant, roughness = reflection_roughness_constant, metallic = metallic_constant,
+ *            specular = specular_level
+ *   GLASS    base_color = glass_color, ior = glass_ior, roughness = frosting_roughness (< 1e-3: clear glass, specular events;
+ *            else a rough dielectric, Walter et al. 2007 / GGX with alpha = roughness^2, glossy events)
+ *   HAIR     the arguments of df::chiang_hair_bsdf (Chiang et al. 2016): base_color = diffuse_reflection_tint,
+ *            roughness = roughness_R.x, metallic = roughness_TT.x and specular = roughness_TRT.x (<= 0: derived from R as in the
+ *            paper, v_TT = v_R / 4, v_TRT = 4 v_R), ior = ior, reserved[0..2] = absorption_coefficient, reserved[3] = azimuthal
+ *            roughness (roughness_*.y), reserved[4] = cuticle_angle (radians), reserved[5] = diffuse_reflection_weight */
 typedef struct skh_material
 {
     uint32_t type; /* SKH_MAT_* */
@@ -281,6 +291,27 @@ skh_status skh_trace(skh_context* ctx, const skh_ray* rays, uint32_t n_rays, uin
 /* same on caller-owned DEVICE arrays, asynchronous on the context stream, repeated `repeat` times */
 skh_status skh_trace_device(skh_context* ctx, const void* d_rays, uint32_t n_rays, uint32_t mode, void* d_hits,
                             uint32_t repeat);
+
+/* ---- BSDF probes for tests: mdlcode_sample and mdlcode_evaluate (the call protocol of closest_hit.cu:563-605) run on the
+ *      device for n independent inputs against the context's material list; host arrays.  One query = one MDL state
+ *      (normal, geom_normal, tangent_u[0]) + k1 + the four xi of sample() + the k2 handed to evaluate(). ---- */
+typedef struct skh_bsdf_query
+{
+    float normal[3], geom_normal[3], tangent_u[3];
+    float k1[3]; /* outgoing direction (= -ray direction) */
+    float k2[3]; /* incoming direction for evaluate() */
+    float xi[4];
+    uint32_t material; /* index into the list set by skh_set_materials */
+    uint32_t inside; /* selects ior1 / ior2 as closest_hit.cu:496-498 */
+} skh_bsdf_query;
+typedef struct skh_bsdf_result
+{
+    float k2[3], bsdf_over_pdf[3], pdf; /* Bsdf_sample_data */
+    int32_t event_type; /* mi::neuraylib::Bsdf_event_type bits */
+    float bsdf_diffuse[3], bsdf_glossy[3], eval_pdf; /* Bsdf_evaluate_data: both include the cosine */
+    uint32_t reserved0;
+} skh_bsdf_result;
+skh_status skh_bsdf_probe(skh_context* ctx, const skh_bsdf_query* queries, uint32_t n, skh_bsdf_result* results);
 
 /* ---- options / stats ----
  * None of the options changes a result: hit records and images are bit-identical for every setting

@@ -25,7 +25,13 @@ SYMBOLS = ["skh_create", "skh_destroy", "skh_last_error", "skh_abi_version", "sk
            "skh_set_instances", "skh_set_lights", "skh_set_textures", "skh_set_materials", "skh_build_accel", "skh_resize", "skh_set_tiles",
            "skh_render_subframe", "skh_render_subframes", "skh_tonemap", "skh_read_accum", "skh_read_aov",
            "skh_buffer_alloc", "skh_buffer_free", "skh_buffer_download", "skh_copy_accum", "skh_copy_accum_tiles", "skh_scatter_tiles", "skh_trace", "skh_trace_device",
-           "skh_set_option", "skh_get_stats", "skh_reset_stats", "skh_synchronize", "skh_get_stream"]
+           "skh_set_option", "skh_get_stats", "skh_reset_stats", "skh_synchronize", "skh_get_stream", "skh_bsdf_probe"]
+
+BSDF_QUERY = np.dtype([("normal", np.float32, 3), ("geom_normal", np.float32, 3), ("tangent_u", np.float32, 3), ("k1", np.float32, 3),
+                       ("k2", np.float32, 3), ("xi", np.float32, 4), ("material", np.uint32), ("inside", np.uint32)])
+BSDF_RESULT = np.dtype([("k2", np.float32, 3), ("bsdf_over_pdf", np.float32, 3), ("pdf", np.float32), ("event_type", np.int32),
+                        ("bsdf_diffuse", np.float32, 3), ("bsdf_glossy", np.float32, 3), ("eval_pdf", np.float32), ("reserved0", np.uint32)])
+assert BSDF_QUERY.itemsize == 84 and BSDF_RESULT.itemsize == 64
 
 
 class SkhError(RuntimeError):
@@ -74,6 +80,7 @@ def load():
     lib.skh_scatter_tiles.argtypes = [vp, vp, vp, u32, u32, vp, u32, u32]
     lib.skh_trace.argtypes = [vp, vp, u32, u32, vp]
     lib.skh_trace_device.argtypes = [vp, vp, u32, u32, vp, u32]
+    lib.skh_bsdf_probe.argtypes = [vp, vp, u32, vp]
     lib.skh_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.skh_get_stats.argtypes = [vp, vp]
     lib.skh_reset_stats.argtypes = [vp]
@@ -212,6 +219,17 @@ class Context:
 
     def trace_device(self, d_rays, n, mode, d_hits, repeat=1):
         self._ck(self.lib.skh_trace_device(self.h, d_rays, n, mode, d_hits, repeat), "skh_trace_device")
+
+    def set_materials(self, materials):
+        m = np.ascontiguousarray(materials, S.MATERIAL).reshape(-1)
+        self._ck(self.lib.skh_set_materials(self.h, _p(m), len(m)), "skh_set_materials")
+
+    def bsdf_probe(self, queries):
+        """mdlcode_sample + mdlcode_evaluate on the device for each BSDF_QUERY record -> BSDF_RESULT records"""
+        q = np.ascontiguousarray(queries, BSDF_QUERY)
+        out = np.zeros(len(q), BSDF_RESULT)
+        self._ck(self.lib.skh_bsdf_probe(self.h, _p(q), len(q), _p(out)), "skh_bsdf_probe")
+        return out
 
     def set_option(self, name, value):
         self._ck(self.lib.skh_set_option(self.h, name.encode(), int(value)), f"skh_set_option({name})")

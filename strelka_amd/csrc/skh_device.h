@@ -1004,9 +1004,341 @@ SKH_DI float fresnel_dielectric(float cosi, float eta, float& cost)
     const float rp = (cosi - eta * cost) / (cosi + eta * cost);
     return 0.5f * (rs * rs + rp * rp);
 }
-// mdlcode_sample equivalent; `inside` selects ior1/ior2 as closest_hit.cu:496-498
-SKH_DI void bsdf_sample(const Material& m, const v3& stN, const v3& stNg, const v3& k1, float xi0, float xi1, float xi2,
-                        bool inside, BsdfSample& out)
+// ------------------------------------------------------------------------------------------------------------
+// Rough dielectric: OmniGlass with frosting_roughness > 0 (gltfloader.cpp:354-406).  Walter et al. 2007 with the GGX
+// distribution, alpha = frosting_roughness^2, visible-normal sampling; same definitions, operation for operation, as
+// the CPU checker's twin (rough_glass_*).  Local frame: z = N on k1's side; eta = n1 / n2.
+// ------------------------------------------------------------------------------------------------------------
+#define SKH_GLASS_SMOOTH_BELOW 1e-3f
+SKH_DI void rough_glass_eval_local(float alpha, float eta, const v3& tint, const v3& wo, const v3& wi, v3& f_cos, float& pdf)
+{
+    f_cos = mk3(0.0f);
+    pdf = 0.0f;
+    if (wo.z <= 0.0f || wi.z == 0.0f)
+        return;
+    const bool reflect = wi.z > 0.0f;
+    v3 h = reflect ? wo + wi : (wo * eta + wi);
+    const float hl = sqrtf(dot(h, h));
+    if (!(hl > 0.0f))
+        return;
+    h = h * (1.0f / hl);
+    if (h.z < 0.0f)
+        h = -h;
+    const float oh = dot(wo, h), ih = dot(wi, h);
+    if (oh <= 0.0f || (reflect ? ih <= 0.0f : ih >= 0.0f))
+        return;
+    float cost;
+    const float F = fresnel_dielectric(fminf(oh, 1.0f), eta, cost);
+    const float D = ggx_D(alpha, h.z);
+    const float lo = ggx_lambda(alpha, wo.z), li = ggx_lambda(alpha, fabsf(wi.z));
+    const float G1o = 1.0f / (1.0f + lo);
+    const float G2 = 1.0f / (1.0f + lo + li);
+    const float pdf_h = G1o * D * oh / wo.z;
+    if (reflect)
+    {
+        const float jac = 1.0f / (4.0f * oh);
+        pdf = F * pdf_h * jac;
+        f_cos = mk3(F * D * G2 / (4.0f * wo.z));
+    }
+    else
+    {
+        const float denom = eta * oh + ih;
+        const float jac = fabsf(ih) / (denom * denom);
+        pdf = (1.0f - F) * pdf_h * jac;
+        f_cos = tint * ((1.0f - F) * D * G2 * oh * jac / wo.z);
+    }
+}
+SKH_DI bool rough_glass_sample_local(float alpha, float eta, const v3& tint, const v3& wo, float u0, float u1, float u2, v3& wi, v3& weight,
+                                     float& pdf, bool& transmitted)
+{
+    const v3 h = ggx_sample_vndf(wo, alpha, u0, u1);
+    const float oh = dot(wo, h);
+    if (oh <= 0.0f)
+        return false;
+    float cost;
+    const float F = fresnel_dielectric(fminf(oh, 1.0f), eta, cost);
+    transmitted = !(u2 < F);
+    if (!transmitted)
+        wi = h * (2.0f * oh) - wo;
+    else
+        wi = normalize(h * (eta * oh - cost) - wo * eta);
+    if (transmitted ? wi.z >= 0.0f : wi.z <= 0.0f)
+        return false;
+    v3 f_cos;
+    rough_glass_eval_local(alpha, eta, tint, wo, wi, f_cos, pdf);
+    if (!(pdf > 0.0f))
+        return false;
+    weight = f_cos / pdf;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Hair: df::chiang_hair_bsdf (the `hair` sub-expression the reference compiles for hair materials, mdlPtxCodeGen.cpp:143-155).
+// Chiang et al. 2016 in the pbrt-v3 formulation; parameter layout (include/strelka_hip.h) and every definition as the CPU checker's twin (hair_*), same
+// operation order.  h = 2 * text_coords[0].y - 1 with the reference's constant text_coords = 0.5 (closest_hit.cu:445).
+// ------------------------------------------------------------------------------------------------------------
+#define SKH_HAIR_TEXCOORD_Y 0.5f
+SKH_DI float lum3(const v3& c)
+{
+    return 0.299f * c.x + 0.587f * c.y + 0.114f * c.z;
+}
+SKH_DI float sqrf_(float x)
+{
+    return x * x;
+}
+SKH_DI float safe_sqrtf_(float x)
+{
+    return sqrtf(fmaxf(0.0f, x));
+}
+SKH_DI float safe_asinf_(float x)
+{
+    return asinf(clampf(x, -1.0f, 1.0f));
+}
+SKH_DI float hair_pow20(float x)
+{
+    const float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8;
+    return x16 * x4;
+}
+SKH_DI float hair_pow22(float x)
+{
+    const float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8;
+    return (x16 * x4) * x2;
+}
+SKH_DI float hair_I0(float x)
+{
+    const float y = x * x;
+    float v = 1.0f / 34519618525593600.0f;
+    v = v * y + 1.0f / 106542032486400.0f;
+    v = v * y + 1.0f / 416179814400.0f;
+    v = v * y + 1.0f / 2123366400.0f;
+    v = v * y + 1.0f / 14745600.0f;
+    v = v * y + 1.0f / 147456.0f;
+    v = v * y + 1.0f / 2304.0f;
+    v = v * y + 1.0f / 64.0f;
+    v = v * y + 0.25f;
+    v = v * y + 1.0f;
+    return v;
+}
+SKH_DI float hair_logI0(float x)
+{
+    if (x > 12.0f)
+        return x + 0.5f * ((-logf(2.0f * SKH_PI) + logf(1.0f / x)) + 1.0f / (8.0f * x));
+    return logf(hair_I0(x));
+}
+SKH_DI float hair_Mp(float cosThetaI, float cosThetaO, float sinThetaI, float sinThetaO, float v)
+{
+    const float a = cosThetaI * cosThetaO / v;
+    const float b = sinThetaI * sinThetaO / v;
+    return v <= 0.1f ? expf((((hair_logI0(a) - b) - 1.0f / v) + 0.6931f) + logf(1.0f / (2.0f * v))) :
+                       (expf(-b) * hair_I0(a)) / (sinhf(1.0f / v) * 2.0f * v);
+}
+SKH_DI float hair_logistic(float x, float s)
+{
+    x = fabsf(x);
+    const float e = expf(-x / s);
+    return e / (s * sqrf_(1.0f + e));
+}
+SKH_DI float hair_logistic_cdf(float x, float s)
+{
+    return 1.0f / (1.0f + expf(-x / s));
+}
+SKH_DI float hair_trimmed_logistic(float x, float s, float a, float b)
+{
+    return hair_logistic(x, s) / (hair_logistic_cdf(b, s) - hair_logistic_cdf(a, s));
+}
+SKH_DI float hair_sample_trimmed_logistic(float u, float s, float a, float b)
+{
+    const float k = hair_logistic_cdf(b, s) - hair_logistic_cdf(a, s);
+    const float x = -s * logf(1.0f / (u * k + hair_logistic_cdf(a, s)) - 1.0f);
+    return clampf(x, a, b);
+}
+SKH_DI float hair_Phi(int p, float gammaO, float gammaT)
+{
+    return (2.0f * (float)p * gammaT - 2.0f * gammaO) + (float)p * SKH_PI;
+}
+SKH_DI float hair_Np(float phi, int p, float s, float gammaO, float gammaT)
+{
+    float dphi = phi - hair_Phi(p, gammaO, gammaT);
+    while (dphi > SKH_PI)
+        dphi -= 2.0f * SKH_PI;
+    while (dphi < -SKH_PI)
+        dphi += 2.0f * SKH_PI;
+    return hair_trimmed_logistic(dphi, s, -SKH_PI, SKH_PI);
+}
+SKH_DI float hair_variance(float roughness)
+{
+    const float r = fmaxf(roughness, 0.02f);
+    return sqrf_((0.726f * r + 0.812f * (r * r)) + 3.7f * hair_pow20(r));
+}
+struct HairTerms
+{
+    float h, eta, s, diffuse_w;
+    v3 sigma_a, tint;
+    float v[4];
+    float sin2k[3], cos2k[3];
+};
+SKH_DI HairTerms hair_terms(const Material& m)
+{
+    HairTerms t;
+    t.h = 2.0f * SKH_HAIR_TEXCOORD_Y - 1.0f;
+    t.eta = m.ior > 1.0f ? m.ior : 1.55f;
+    t.sigma_a = mk3(fmaxf(m.reserved[0], 0.0f), fmaxf(m.reserved[1], 0.0f), fmaxf(m.reserved[2], 0.0f));
+    t.tint = mk3(m.base_color[0], m.base_color[1], m.base_color[2]);
+    t.diffuse_w = clampf(m.reserved[5], 0.0f, 1.0f);
+    t.v[0] = hair_variance(m.roughness);
+    t.v[1] = m.metallic > 0.0f ? hair_variance(m.metallic) : 0.25f * t.v[0];
+    t.v[2] = m.specular > 0.0f ? hair_variance(m.specular) : 4.0f * t.v[0];
+    t.v[3] = t.v[2];
+    const float bn = fmaxf(m.reserved[3] > 0.0f ? m.reserved[3] : m.roughness, 0.02f);
+    t.s = 0.626657069f * ((0.265f * bn + 1.194f * (bn * bn)) + 5.372f * hair_pow22(bn));
+    t.sin2k[0] = sinf(m.reserved[4]);
+    t.cos2k[0] = safe_sqrtf_(1.0f - sqrf_(t.sin2k[0]));
+#pragma unroll
+    for (int i = 1; i < 3; ++i)
+    {
+        t.sin2k[i] = 2.0f * t.cos2k[i - 1] * t.sin2k[i - 1];
+        t.cos2k[i] = sqrf_(t.cos2k[i - 1]) - sqrf_(t.sin2k[i - 1]);
+    }
+    return t;
+}
+SKH_DI void hair_Ap(const HairTerms& t, float cosThetaO, const v3& T, v3 ap[4], float apPdf[4])
+{
+    const float cosGammaO = safe_sqrtf_(1.0f - t.h * t.h);
+    const float cosTheta = cosThetaO * cosGammaO;
+    float cost;
+    const float f = fresnel_dielectric(clampf(cosTheta, 0.0f, 1.0f), 1.0f / t.eta, cost);
+    ap[0] = mk3(f);
+    ap[1] = T * sqrf_(1.0f - f);
+    ap[2] = ap[1] * T * f;
+    ap[3] = (ap[2] * f) * T / (mk3(1.0f) - T * f);
+    float y[4], sum = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+    {
+        y[p] = lum3(ap[p]);
+        sum += y[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        apPdf[p] = sum > 0.0f ? y[p] / sum : 0.25f;
+}
+struct HairGeom
+{
+    float sinThetaO, cosThetaO, phiO, gammaO, gammaT;
+    v3 T;
+};
+SKH_DI HairGeom hair_geom(const HairTerms& t, const v3& wo)
+{
+    HairGeom g;
+    g.sinThetaO = clampf(wo.x, -1.0f, 1.0f);
+    g.cosThetaO = safe_sqrtf_(1.0f - sqrf_(g.sinThetaO));
+    g.phiO = atan2f(wo.z, wo.y);
+    const float sinThetaT = g.sinThetaO / t.eta;
+    const float cosThetaT = safe_sqrtf_(1.0f - sqrf_(sinThetaT));
+    const float etap = sqrtf(t.eta * t.eta - sqrf_(g.sinThetaO)) / fmaxf(g.cosThetaO, 1e-6f);
+    const float sinGammaT = t.h / etap;
+    const float cosGammaT = safe_sqrtf_(1.0f - sqrf_(sinGammaT));
+    g.gammaT = safe_asinf_(sinGammaT);
+    g.gammaO = safe_asinf_(t.h);
+    const float l = 2.0f * cosGammaT / fmaxf(cosThetaT, 1e-6f);
+    g.T = mk3(expf(-t.sigma_a.x * l), expf(-t.sigma_a.y * l), expf(-t.sigma_a.z * l));
+    return g;
+}
+SKH_DI void hair_tilt(const HairTerms& t, const HairGeom& g, int p, float& sinThetaOp, float& cosThetaOp)
+{
+    if (p == 0)
+    {
+        sinThetaOp = g.sinThetaO * t.cos2k[1] - g.cosThetaO * t.sin2k[1];
+        cosThetaOp = g.cosThetaO * t.cos2k[1] + g.sinThetaO * t.sin2k[1];
+    }
+    else if (p == 1)
+    {
+        sinThetaOp = g.sinThetaO * t.cos2k[0] + g.cosThetaO * t.sin2k[0];
+        cosThetaOp = g.cosThetaO * t.cos2k[0] - g.sinThetaO * t.sin2k[0];
+    }
+    else if (p == 2)
+    {
+        sinThetaOp = g.sinThetaO * t.cos2k[2] + g.cosThetaO * t.sin2k[2];
+        cosThetaOp = g.cosThetaO * t.cos2k[2] - g.sinThetaO * t.sin2k[2];
+    }
+    else
+    {
+        sinThetaOp = g.sinThetaO;
+        cosThetaOp = g.cosThetaO;
+    }
+    cosThetaOp = fabsf(cosThetaOp);
+}
+SKH_DI void hair_eval_local(const HairTerms& t, const v3& wo, const v3& wi, v3& f_cos, float& pdf)
+{
+    const HairGeom g = hair_geom(t, wo);
+    const float sinThetaI = clampf(wi.x, -1.0f, 1.0f);
+    const float cosThetaI = safe_sqrtf_(1.0f - sqrf_(sinThetaI));
+    const float phi = atan2f(wi.z, wi.y) - g.phiO;
+    v3 ap[4];
+    float apPdf[4];
+    hair_Ap(t, g.cosThetaO, g.T, ap, apPdf);
+    f_cos = mk3(0.0f);
+    pdf = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+    {
+        float so, co;
+        hair_tilt(t, g, p, so, co);
+        const float mn = hair_Mp(cosThetaI, co, sinThetaI, so, t.v[p]) * hair_Np(phi, p, t.s, g.gammaO, g.gammaT);
+        f_cos = f_cos + ap[p] * mn;
+        pdf += apPdf[p] * mn;
+    }
+    const float mr = hair_Mp(cosThetaI, g.cosThetaO, sinThetaI, g.sinThetaO, t.v[3]) * (1.0f / (2.0f * SKH_PI));
+    f_cos = f_cos + ap[3] * mr;
+    pdf += apPdf[3] * mr;
+}
+SKH_DI v3 hair_sample_local(const HairTerms& t, const v3& wo, float u0, float u1, float u2, float u3)
+{
+    const HairGeom g = hair_geom(t, wo);
+    v3 ap[4];
+    float apPdf[4];
+    hair_Ap(t, g.cosThetaO, g.T, ap, apPdf);
+    int p = 0;
+    float u = u2;
+    for (; p < 3; ++p)
+    {
+        if (u < apPdf[p])
+            break;
+        u -= apPdf[p];
+    }
+    float so, co;
+    hair_tilt(t, g, p, so, co);
+    const float vp = p == 0 ? t.v[0] : (p == 1 ? t.v[1] : t.v[2]); // (v[3] == v[2])
+    const float ua = fmaxf(u0, 1e-5f);
+    const float cosTheta = 1.0f + vp * logf(ua + (1.0f - ua) * expf(-2.0f / vp));
+    const float sinTheta = safe_sqrtf_(1.0f - sqrf_(cosTheta));
+    const float cosPhi = cosf(2.0f * SKH_PI * u1);
+    const float sinThetaI = -cosTheta * so + sinTheta * cosPhi * co;
+    const float cosThetaI = safe_sqrtf_(1.0f - sqrf_(sinThetaI));
+    const float dphi = p < 3 ? hair_Phi(p, g.gammaO, g.gammaT) + hair_sample_trimmed_logistic(u3, t.s, -SKH_PI, SKH_PI) : 2.0f * SKH_PI * u3;
+    const float phiI = g.phiO + dphi;
+    return mk3(sinThetaI, cosThetaI * cosf(phiI), cosThetaI * sinf(phiI));
+}
+SKH_DI bool hair_frame(const v3& normal, const v3& tangent_u, v3& X, v3& Y, v3& Z)
+{
+    const float tl = dot(tangent_u, tangent_u);
+    if (!(tl > 0.0f))
+        return false;
+    X = tangent_u * (1.0f / sqrtf(tl));
+    const v3 z = normal - X * dot(normal, X);
+    const float zl = dot(z, z);
+    if (!(zl > 1e-12f))
+        return false;
+    Z = z * (1.0f / sqrtf(zl));
+    Y = cross(Z, X);
+    return true;
+}
+
+// mdlcode_sample equivalent; `inside` selects ior1/ior2 as closest_hit.cu:496-498.  HAIR: the build that carries the hair
+// distribution function (scenes without a hair material run the build without it: fewer registers).
+template <bool HAIR>
+SKH_DI void bsdf_sample(const Material& m, const v3& stN, const v3& stNg, const v3& stT, const v3& k1, float xi0, float xi1, float xi2,
+                        float xi3, bool inside, BsdfSample& out)
 {
     v3 N = stN, Ng = stNg;
     if (dot(Ng, k1) < 0.0f)
@@ -1035,7 +1367,51 @@ SKH_DI void bsdf_sample(const Material& m, const v3& stN, const v3& stNg, const 
         out.event_type = EV_DIFFUSE | EV_REFLECTION;
         return;
     }
-    if (m.type == 1 || m.type == 3)
+    if (HAIR && m.type == 3)
+    {
+        v3 X, Y, Z;
+        if (!hair_frame(stN, stT, X, Y, Z))
+            return;
+        const HairTerms t = hair_terms(m);
+        const v3 ho = mk3(dot(k1, X), dot(k1, Y), dot(k1, Z));
+        float u2 = xi2;
+        if (u2 < t.diffuse_w)
+        {
+            float cosT;
+            const v3 w = cosine_hemisphere(xi0, xi1, cosT);
+            const v3 k2 = normalize(w.x * b1 + w.y * b2 + w.z * N);
+            if (cosT <= 0.0f)
+                return;
+            const v3 hi = mk3(dot(k2, X), dot(k2, Y), dot(k2, Z));
+            v3 fh;
+            float ph;
+            hair_eval_local(t, ho, hi, fh, ph);
+            const float pd = cosT / SKH_PI;
+            const float pdf = t.diffuse_w * pd + (1.0f - t.diffuse_w) * ph;
+            out.k2 = k2;
+            out.pdf = pdf;
+            out.bsdf_over_pdf = (t.tint * (t.diffuse_w * pd) + fh * (1.0f - t.diffuse_w)) / pdf;
+            out.event_type = EV_DIFFUSE | EV_REFLECTION;
+            return;
+        }
+        u2 = (u2 - t.diffuse_w) / (1.0f - t.diffuse_w);
+        const v3 hi = hair_sample_local(t, ho, xi0, xi1, u2, xi3);
+        v3 fh;
+        float ph;
+        hair_eval_local(t, ho, hi, fh, ph);
+        const v3 k2 = normalize(hi.x * X + hi.y * Y + hi.z * Z);
+        const float cosN = dot(k2, N);
+        const float pd = cosN > 0.0f ? cosN / SKH_PI : 0.0f;
+        const float pdf = t.diffuse_w * pd + (1.0f - t.diffuse_w) * ph;
+        if (!(pdf > 0.0f) || !(ph > 0.0f))
+            return;
+        out.k2 = k2;
+        out.pdf = pdf;
+        out.bsdf_over_pdf = (t.tint * (t.diffuse_w * pd) + fh * (1.0f - t.diffuse_w)) / pdf;
+        out.event_type = EV_GLOSSY | EV_REFLECTION;
+        return;
+    }
+    if (m.type == 1)
     {
         if (wo.z <= 0.0f)
             return;
@@ -1075,6 +1451,22 @@ SKH_DI void bsdf_sample(const Material& m, const v3& stN, const v3& stNg, const 
         const float n1 = inside ? m.ior : 1.0f;
         const float n2 = inside ? 1.0f : m.ior;
         const float eta = n1 / n2;
+        if (m.roughness >= SKH_GLASS_SMOOTH_BELOW)
+        {
+            if (wo.z <= 0.0f)
+                return;
+            const float alpha = fmaxf(m.roughness * m.roughness, 1e-4f);
+            v3 wi, weight;
+            float pdf;
+            bool transmitted;
+            if (!rough_glass_sample_local(alpha, eta, base, wo, xi0, xi1, xi2, wi, weight, pdf, transmitted))
+                return;
+            out.k2 = normalize(wi.x * b1 + wi.y * b2 + wi.z * N);
+            out.pdf = pdf;
+            out.bsdf_over_pdf = weight;
+            out.event_type = EV_GLOSSY | (transmitted ? EV_TRANSMISSION : EV_REFLECTION);
+            return;
+        }
         const float cosi = fminf(fmaxf(wo.z, 0.0f), 1.0f);
         float cost;
         const float F = fresnel_dielectric(cosi, eta, cost);
@@ -1095,7 +1487,8 @@ SKH_DI void bsdf_sample(const Material& m, const v3& stN, const v3& stNg, const 
     }
 }
 // mdlcode_evaluate equivalent
-SKH_DI void bsdf_evaluate(const Material& m, const v3& stN, const v3& stNg, const v3& k1, const v3& k2, BsdfEval& out)
+template <bool HAIR>
+SKH_DI void bsdf_evaluate(const Material& m, const v3& stN, const v3& stNg, const v3& stT, const v3& k1, const v3& k2, bool inside, BsdfEval& out)
 {
     v3 N = stN, Ng = stNg;
     if (dot(Ng, k1) < 0.0f)
@@ -1116,7 +1509,25 @@ SKH_DI void bsdf_evaluate(const Material& m, const v3& stN, const v3& stNg, cons
         out.pdf = nk2 / SKH_PI;
         return;
     }
-    if (m.type == 1 || m.type == 3)
+    if (HAIR && m.type == 3)
+    {
+        v3 X, Y, Z;
+        if (!hair_frame(stN, stT, X, Y, Z))
+            return;
+        const HairTerms t = hair_terms(m);
+        const v3 ho = mk3(dot(k1, X), dot(k1, Y), dot(k1, Z));
+        const v3 hi = mk3(dot(k2, X), dot(k2, Y), dot(k2, Z));
+        v3 fh;
+        float ph;
+        hair_eval_local(t, ho, hi, fh, ph);
+        const float cosN = dot(k2, N);
+        const float pd = cosN > 0.0f ? cosN / SKH_PI : 0.0f;
+        out.bsdf_glossy = fh * (1.0f - t.diffuse_w);
+        out.bsdf_diffuse = t.tint * (t.diffuse_w * pd);
+        out.pdf = t.diffuse_w * pd + (1.0f - t.diffuse_w) * ph;
+        return;
+    }
+    if (m.type == 1)
     {
         v3 b1, b2;
         onb_from_z(N, b1, b2);
@@ -1126,6 +1537,17 @@ SKH_DI void bsdf_evaluate(const Material& m, const v3& stN, const v3& stNg, cons
             return;
         const PbrTerms t = pbr_terms(m);
         pbr_eval_local(t, wo, wi, out.bsdf_diffuse, out.bsdf_glossy, out.pdf);
+        return;
+    }
+    if (m.type == 2 && m.roughness >= SKH_GLASS_SMOOTH_BELOW)
+    {
+        v3 b1, b2;
+        onb_from_z(N, b1, b2);
+        const v3 wo = mk3(dot(k1, b1), dot(k1, b2), dot(k1, N));
+        const v3 wi = mk3(dot(k2, b1), dot(k2, b2), dot(k2, N));
+        const float n1 = inside ? m.ior : 1.0f;
+        const float n2 = inside ? 1.0f : m.ior;
+        rough_glass_eval_local(fmaxf(m.roughness * m.roughness, 1e-4f), n1 / n2, base, wo, wi, out.bsdf_glossy, out.pdf);
     }
 }
 

@@ -1250,7 +1250,7 @@ SKH_DI SurfaceHit fill_triangle(const HostInstance& hi, const float* w2o, const 
 }
 // fillCurveGeomData: closest_hit.cu:423-454
 SKH_DI SurfaceHit fill_curve(const DevScene& sc, const HostInstance& hi, const float* w2o, uint32_t prim, float u, float t,
-                             const v3& rayO, const v3& rayD, bool inside)
+                             const v3& rayO, const v3& rayD, bool inside, v3* tangent_u /*state.tangent_u[0], hair build only*/)
 {
     const uint32_t s0 = sc.segStartAll[sc.curveSegBase[hi.geom] + prim];
     v4 q[4];
@@ -1266,6 +1266,8 @@ SKH_DI SurfaceHit fill_curve(const DevScene& sc, const HostInstance& hi, const f
     hitPoint = xform_point(w2o, hitPoint);
     v3 worldNormal = normalize(xform_normal(w2o, curve_surface_normal(ip, u, hitPoint)));
     worldNormal = worldNormal * (inside ? -1.0f : 1.0f);
+    if (tangent_u) // curveTangent through the normal transform: closest_hit.cu:436-437, curve.h:412-417
+        *tangent_u = normalize(xform_normal(w2o, normalize(mk3(cubic_velocity(ip, u)))));
     SurfaceHit s;
     s.position = xform_point(hi.o2w, hitPoint);
     s.normal = worldNormal;
@@ -1283,6 +1285,7 @@ SKH_DI SurfaceHit fill_curve(const DevScene& sc, const HostInstance& hi, const f
 #ifndef SKH_SHADE_BLOCK
 #define SKH_SHADE_BLOCK 256 // 132 VGPRs = 3 waves/SIMD: 256-thread blocks (1 wave per SIMD) fill all three, 512-thread blocks only two
 #endif
+template <bool HAIR> // HAIR: the build with df::chiang_hair_bsdf in it (launched when the material list holds a hair material)
 __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
     k_shade(DevScene sc, FrameP fp, uint32_t sampleOffset, uint32_t depth, const uint32_t* __restrict__ tileXY, RayQ rq,
             const uint32_t* __restrict__ countPtr, HitQ hq, PathS ps, RayQ nextQ, uint32_t* __restrict__ nextCount, RayQ shadowQ,
@@ -1404,7 +1407,8 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
                 const bool useNormal = mat.normal_texture != 0u && mat.normal_texture <= sc.numTextures;
                 const bool textured = hi.type != 2 && (useBase || useNormal);
                 SurfaceTex st;
-                SurfaceHit sh = hi.type == 2 ? fill_curve(sc, hi, w2o, hprim, hu, ht, rayO, rayD, inside) :
+                v3 stT = mk3(0.0f);
+                SurfaceHit sh = hi.type == 2 ? fill_curve(sc, hi, w2o, hprim, hu, ht, rayO, rayD, inside, HAIR ? &stT : nullptr) :
                                                fill_triangle(hi, w2o, tv, hu, hv, inside, textured ? &st : nullptr);
                 if (textured)
                 {
@@ -1426,10 +1430,11 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
                 {
                     const float xi0 = sampler_random_lut(smp, DIM_BSDF0, s_sobol), xi1 = sampler_random_lut(smp, DIM_BSDF1, s_sobol),
                                 xi2 = sampler_random_lut(smp, DIM_BSDF2, s_sobol);
+                    const float xi3 = HAIR ? sampler_random_lut(smp, DIM_BSDF3, s_sobol) : 0.0f; // (only the hair BSDF consumes xi.w)
                     const v3 k1 = -rayD;
                     BsdfSample bs;
                     SKH_SP(1) // hit reconstruction, material, textures, bsdf randoms
-                    bsdf_sample(mat, sh.normal, sh.geom_normal, k1, xi0, xi1, xi2, inside, bs);
+                    bsdf_sample<HAIR>(mat, sh.normal, sh.geom_normal, stT, k1, xi0, xi1, xi2, xi3, inside, bs);
                     SKH_SP(2) // bsdf_sample
                     if (bs.event_type == EV_ABSORB)
                     {
@@ -1513,7 +1518,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
                                 {
                                     BsdfEval ev;
                                     SKH_SP(3) // light sampling
-                                    bsdf_evaluate(mat, sh.normal, sh.geom_normal, k1, toLight, ev);
+                                    bsdf_evaluate<HAIR>(mat, sh.normal, sh.geom_normal, stT, k1, toLight, inside, ev);
                                     SKH_SP(4) // bsdf_evaluate
                                     if (isnan3(ev.bsdf_diffuse) || isnan3(ev.bsdf_glossy))
                                     {

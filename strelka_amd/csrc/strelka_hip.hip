@@ -74,6 +74,7 @@ struct skh_context
     DevBuf dTexels, dTexDesc, dSegBound, dScatterXY, dRaygenBase;
     uint32_t raygenBlocksPerSub = 0, raygenValidPerSub = 0;
     uint32_t nTextures = 0;
+    bool hasHairMaterial = false; // selects the k_shade build that carries df::chiang_hair_bsdf
     DevBuf dTriNodes, dTris, dSegNodes, dSegs, dSegPrim, dTlasNodes, dTlasInst, dDevInst, dTravInst;
     int tlasRoot = SKH_REF_INVALID;
     bool accelBuilt = false;
@@ -899,6 +900,9 @@ skh_status skh_set_materials(skh_context* c, const skh_material* materials, uint
         return SKH_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
     c->nMaterials = n;
+    c->hasHairMaterial = false;
+    for (uint32_t k = 0; k < n; ++k)
+        c->hasHairMaterial = c->hasHairMaterial || materials[k].type == SKH_MAT_HAIR;
     return dev_upload(c, c->dMaterials, materials, sizeof(skh_material) * (size_t)n);
 }
 
@@ -1842,8 +1846,13 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                 (void)hipStreamWaitEvent(st, c->evShadow, 0); // shade[b] reads the radiance shadow[b-1] adds to and reuses its queue
             {
                 SpanGuard g(c, KC_SHADE);
-                k_shade<<<(NP + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b * SKH_COUNT_STRIDE, hq, ps, rq[(b + 1) & 1],
-                                                   counts + 2 * (b + 1) * SKH_COUNT_STRIDE, shq, c->dContrib.as<float>(), counts + (2 * b + 1) * SKH_COUNT_STRIDE);
+                const dim3 sg((NP + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK);
+                if (c->hasHairMaterial)
+                    k_shade<true><<<sg, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b * SKH_COUNT_STRIDE, hq, ps, rq[(b + 1) & 1],
+                                                                  counts + 2 * (b + 1) * SKH_COUNT_STRIDE, shq, c->dContrib.as<float>(), counts + (2 * b + 1) * SKH_COUNT_STRIDE);
+                else
+                    k_shade<false><<<sg, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b * SKH_COUNT_STRIDE, hq, ps, rq[(b + 1) & 1],
+                                                                   counts + 2 * (b + 1) * SKH_COUNT_STRIDE, shq, c->dContrib.as<float>(), counts + (2 * b + 1) * SKH_COUNT_STRIDE);
             }
             const uint32_t* permS = nullptr;
             if (c->sortBitsShadow)
@@ -2190,6 +2199,69 @@ skh_status skh_trace(skh_context* c, const skh_ray* rays, uint32_t n_rays, uint3
     dev_free(dr);
     dev_free(dh);
     return s;
+}
+
+// ---- BSDF probes (tests) ----
+static_assert(sizeof(skh_bsdf_query) == 84 && sizeof(skh_bsdf_result) == 64, "ABI layout");
+__global__ void k_bsdf_probe(const skh_bsdf_query* __restrict__ q, uint32_t n, const Material* __restrict__ mats, uint32_t numMaterials,
+                             skh_bsdf_result* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const skh_bsdf_query in = q[i];
+    const Material m = mats[in.material < numMaterials ? in.material : 0u];
+    const v3 N = mk3(in.normal[0], in.normal[1], in.normal[2]), Ng = mk3(in.geom_normal[0], in.geom_normal[1], in.geom_normal[2]);
+    const v3 T = mk3(in.tangent_u[0], in.tangent_u[1], in.tangent_u[2]);
+    const v3 k1 = mk3(in.k1[0], in.k1[1], in.k1[2]), k2 = mk3(in.k2[0], in.k2[1], in.k2[2]);
+    BsdfSample bs;
+    bsdf_sample<true>(m, N, Ng, T, k1, in.xi[0], in.xi[1], in.xi[2], in.xi[3], in.inside != 0u, bs);
+    BsdfEval ev;
+    bsdf_evaluate<true>(m, N, Ng, T, k1, k2, in.inside != 0u, ev);
+    skh_bsdf_result r;
+    r.k2[0] = bs.k2.x, r.k2[1] = bs.k2.y, r.k2[2] = bs.k2.z;
+    r.bsdf_over_pdf[0] = bs.bsdf_over_pdf.x, r.bsdf_over_pdf[1] = bs.bsdf_over_pdf.y, r.bsdf_over_pdf[2] = bs.bsdf_over_pdf.z;
+    r.pdf = bs.pdf;
+    r.event_type = bs.event_type;
+    r.bsdf_diffuse[0] = ev.bsdf_diffuse.x, r.bsdf_diffuse[1] = ev.bsdf_diffuse.y, r.bsdf_diffuse[2] = ev.bsdf_diffuse.z;
+    r.bsdf_glossy[0] = ev.bsdf_glossy.x, r.bsdf_glossy[1] = ev.bsdf_glossy.y, r.bsdf_glossy[2] = ev.bsdf_glossy.z;
+    r.eval_pdf = ev.pdf;
+    r.reserved0 = 0u;
+    out[i] = r;
+}
+
+skh_status skh_bsdf_probe(skh_context* c, const skh_bsdf_query* queries, uint32_t n, skh_bsdf_result* results)
+{
+    if (!c || (n && (!queries || !results)))
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    if (n == 0)
+        return SKH_OK;
+    if (c->nMaterials == 0)
+    {
+        c->err = "skh_bsdf_probe: call skh_set_materials first";
+        return SKH_INVALID_ARGUMENT;
+    }
+    DevBuf dq, dr;
+    skh_status s;
+    if ((s = dev_upload(c, dq, queries, sizeof(skh_bsdf_query) * (size_t)n)) != SKH_OK || (s = dev_alloc(c, dr, sizeof(skh_bsdf_result) * (size_t)n)) != SKH_OK)
+    {
+        dev_free(dq);
+        dev_free(dr);
+        return s;
+    }
+    k_bsdf_probe<<<(n + 127) / 128, 128, 0, c->stream>>>(dq.as<skh_bsdf_query>(), n, c->dMaterials.as<Material>(), c->nMaterials, dr.as<skh_bsdf_result>());
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess)
+        e = hipMemcpy(results, dr.p, sizeof(skh_bsdf_result) * (size_t)n, hipMemcpyDeviceToHost);
+    dev_free(dq);
+    dev_free(dr);
+    if (e != hipSuccess)
+    {
+        c->err = std::string("skh_bsdf_probe: ") + hipGetErrorString(e);
+        return SKH_FAIL;
+    }
+    return SKH_OK;
 }
 
 skh_status skh_set_option(skh_context* c, const char* name, int64_t value)

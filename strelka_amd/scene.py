@@ -188,9 +188,21 @@ class Scene:
 
     # -- scene.cpp:89-95.  `material` is a dict of the fixed-layout argument block (skh_material)
     def addMaterial(self, type=MAT_DIFFUSE, base_color=(0.8, 0.8, 0.8), roughness=0.5, metallic=0.0, specular=0.5, ior=1.5,
-                    base_color_texture=0, normal_texture=0):
-        self.mMaterials.append((type, tuple(base_color), roughness, metallic, specular, ior, base_color_texture, normal_texture))
+                    base_color_texture=0, normal_texture=0, reserved=(0.0,) * 6):
+        """MAT_GLASS: `roughness` is OmniGlass' frosting_roughness (0 = clear).  MAT_HAIR: use addHairMaterial."""
+        self.mMaterials.append((type, tuple(base_color), roughness, metallic, specular, ior, base_color_texture, normal_texture,
+                                tuple(reserved)))
         return len(self.mMaterials) - 1
+
+    def addHairMaterial(self, color=(0.35, 0.2, 0.1), roughness_r=0.3, roughness_n=0.3, roughness_tt=0.0, roughness_trt=0.0,
+                        cuticle_angle=math.radians(2.0), ior=1.55, absorption=None, diffuse_weight=0.0, diffuse_tint=(1.0, 1.0, 1.0)):
+        """The arguments of df::chiang_hair_bsdf in the fixed-layout block (include/strelka_hip.h, SKH_MAT_HAIR).  `color` is the
+        fibre's multiple-scattering albedo; the absorption coefficient follows from it by Chiang et al. 2016, eq. 9 -- what a hair
+        material's MDL code does in front of the distribution function -- unless `absorption` gives sigma_a directly."""
+        if absorption is None:
+            absorption = hair_sigma_a_from_color(color, roughness_n)
+        return self.addMaterial(MAT_HAIR, diffuse_tint, roughness=roughness_r, metallic=roughness_tt, specular=roughness_trt, ior=ior,
+                                reserved=(absorption[0], absorption[1], absorption[2], roughness_n, cuticle_angle, diffuse_weight))
 
     def addTexture(self, rgba8):
         """RGBA8 image, rows top to bottom as stbi_load returns them (OptixRender.cpp:1191-1264).  Returns the texture ID
@@ -354,10 +366,11 @@ class Scene:
         mats = np.zeros(max(1, len(self.mMaterials)), MATERIAL)
         if not self.mMaterials:  # material 0 = default.mdl::default_material (OptixRender.cpp:1090-1097)
             mats[0]["base_color"] = 0.8
-        for i, (ty, bc, r, me, sp, ior, bt, nt) in enumerate(self.mMaterials):
+        for i, (ty, bc, r, me, sp, ior, bt, nt, rsv) in enumerate(self.mMaterials):
             mats[i]["type"], mats[i]["base_color"], mats[i]["roughness"] = ty, bc, r
             mats[i]["metallic"], mats[i]["specular"], mats[i]["ior"] = me, sp, ior
             mats[i]["base_color_texture"], mats[i]["normal_texture"] = bt, nt
+            mats[i]["reserved"] = rsv
         return {
             "vertices": cat(self.mVertices, VERTEX),
             "indices": cat(self.mIndices, np.uint32),
@@ -371,6 +384,15 @@ class Scene:
             "materials": mats,
             "textures": list(self.mTextures),
         }
+
+
+def hair_sigma_a_from_color(color, roughness_n=0.3):
+    """Absorption coefficient that gives a fibre the multiple-scattering albedo `color` at azimuthal roughness beta_n:
+    Chiang et al. 2016, eq. 9 (pbrt-v3 HairBSDF::SigmaAFromReflectance)."""
+    b = float(roughness_n)
+    d = 5.969 - 0.215 * b + 2.532 * b ** 2 - 10.73 * b ** 3 + 5.574 * b ** 4 + 0.245 * b ** 5
+    c = np.clip(np.asarray(color, np.float64), 1e-4, 1.0)
+    return tuple(float(x) for x in (np.log(c) / d) ** 2)
 
 
 def pack_textures(textures):

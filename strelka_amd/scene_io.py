@@ -238,9 +238,20 @@ def material_from_description(desc):
         m["roughness"] = float(_param(desc, "reflection_roughness_constant", 0.5))
         m["metallic"] = float(_param(desc, "metallic_constant", 0.0))
     elif "hair" in low:
+        # a hair material = df::chiang_hair_bsdf behind the `hair` slot (mdlPtxCodeGen.cpp:143-155); parameter names as in the
+        # MDL specification of that distribution function, colour -> absorption by Chiang et al. 2016 eq. 9 when no
+        # absorption_coefficient is given
         m["type"] = S.MAT_HAIR
-        m["base_color"] = _param(desc, "diffuse_color", _param(desc, "color", (0.8, 0.8, 0.8)))
-        m["roughness"] = float(_param(desc, "roughness", 0.3))
+        rn = float(_param(desc, "roughness_azimuthal", _param(desc, "roughness", 0.3)))
+        sig = _param(desc, "absorption_coefficient", None)
+        if sig is None:
+            sig = S.hair_sigma_a_from_color(_param(desc, "diffuse_color", _param(desc, "color", (0.35, 0.2, 0.1))), rn)
+        m["base_color"] = _param(desc, "diffuse_reflection_tint", (1.0, 1.0, 1.0))
+        m["roughness"] = float(_param(desc, "roughness_R", _param(desc, "roughness", 0.3)))
+        m["metallic"] = float(_param(desc, "roughness_TT", 0.0))
+        m["specular"] = float(_param(desc, "roughness_TRT", 0.0))
+        m["ior"] = float(_param(desc, "ior", 1.55))
+        m["reserved"] = (sig[0], sig[1], sig[2], rn, float(_param(desc, "cuticle_angle", 0.035)), float(_param(desc, "diffuse_reflection_weight", 0.0)))
     else:
         m["type"] = S.MAT_DIFFUSE
         m["base_color"] = _param(desc, "diffuse_color", (0.8, 0.8, 0.8))

@@ -245,7 +245,7 @@ def hair_standin(seed=77, n_strands=100000, n_cp=16):
     rs = np.random.RandomState(seed)
     sc = S.Scene()
     sc.addMaterial(S.MAT_DIFFUSE, (0.6, 0.5, 0.45))
-    hair = sc.addMaterial(S.MAT_HAIR, (0.35, 0.2, 0.1), roughness=0.3, metallic=0.0, specular=1.0)
+    hair = sc.addHairMaterial((0.35, 0.2, 0.1), roughness_r=0.3, roughness_n=0.3)
     scalp_pos, scalp_tris = _grid_mesh(_sphere_fn(rs, 0.0), 64, 40)
     p = scalp_pos.astype(np.float64)
     if np.einsum("ij,ij->i", p[scalp_tris[:, 0]], np.cross(p[scalp_tris[:, 1]], p[scalp_tris[:, 2]])).sum() < 0:

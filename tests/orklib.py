@@ -160,6 +160,8 @@ def load():
         lib.ork_tonemap_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_float]
         lib.ork_bsdf_sample.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
         lib.ork_bsdf_evaluate.argtypes = [C.c_void_p] * 6
+        lib.ork_bsdf_evaluate_side.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
+        lib.ork_bsdf_set_tangent.argtypes = [C.c_void_p]
         lib.ork_intersect_triangle.restype = C.c_int
         lib.ork_intersect_triangle.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         lib.ork_intersect_curve.restype = C.c_int

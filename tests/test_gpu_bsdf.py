@@ -1,0 +1,117 @@
+"""A9 per call: mdlcode_sample / mdlcode_evaluate of every BSDF on the GPU (skh_bsdf_probe through the C ABI) against the oracle's
+bsdf_sample / bsdf_evaluate on the same inputs, value by value (image tolerances alone could hide a wrong branch).
+The two sides share one operation order; they differ by the few ulp between glibc's and the ROCm device library's
+sin/cos/exp/log/atan2/asin/sinh, which peaky lobes amplify -- hence a relative 2e-3 on densities and weights, absolute 2e-5 on
+directions, and a bit-equal event type except for a few inputs in a thousand that sit on a branch (lobe choice, Fresnel)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from strelka_amd import scene as S
+
+pytestmark = pytest.mark.gpu
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def materials():
+    sc = S.Scene()
+    sc.addMaterial(S.MAT_DIFFUSE, (0.7, 0.5, 0.3))
+    sc.addMaterial(S.MAT_PBR, (0.3, 0.6, 0.8), roughness=0.3, metallic=0.0)
+    sc.addMaterial(S.MAT_PBR, (0.9, 0.7, 0.4), roughness=0.12, metallic=1.0)
+    sc.addMaterial(S.MAT_GLASS, (0.9, 0.95, 1.0), roughness=0.0, ior=1.5)
+    sc.addMaterial(S.MAT_GLASS, (0.9, 0.95, 1.0), roughness=0.4, ior=1.45)
+    sc.addMaterial(S.MAT_GLASS, (1.0, 0.9, 0.8), roughness=1.0, ior=1.6)  # a glTF material without roughnessFactor
+    sc.addHairMaterial((0.35, 0.2, 0.1), roughness_r=0.3, roughness_n=0.3)
+    sc.addHairMaterial((0.8, 0.7, 0.5), roughness_r=0.15, roughness_n=0.2, roughness_tt=0.1, roughness_trt=0.3, cuticle_angle=0.05,
+                       diffuse_weight=0.25, diffuse_tint=(0.6, 0.5, 0.4))
+    sc.addHairMaterial(absorption=(0.0, 0.0, 0.0), roughness_r=0.5, roughness_n=0.6, cuticle_angle=0.0)
+    m = sc.arrays()["materials"]
+    return m, ["diffuse", "glossy", "metal", "glass", "frosted", "frosted-1.0", "hair", "hair-lobes+diffuse", "hair-white"]
+
+
+def unit(rs, n):
+    d = rs.normal(size=(n, 3))
+    return (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+
+
+def queries(n, seed, n_mats):
+    from strelka_amd import capi
+
+    rs = np.random.RandomState(seed)
+    q = np.zeros(n, capi.BSDF_QUERY)
+    N = unit(rs, n)
+    q["normal"] = N
+    # geometric normal: the shading normal bent a little; tangent: any direction, not parallel to the normal
+    g = N + 0.15 * unit(rs, n)
+    q["geom_normal"] = g / np.linalg.norm(g, axis=1, keepdims=True)
+    t = np.cross(N, unit(rs, n)) + 0.1 * N
+    q["tangent_u"] = t / np.linalg.norm(t, axis=1, keepdims=True)
+    q["k1"] = unit(rs, n)  # either side of the surface
+    q["k2"] = unit(rs, n)
+    q["xi"] = rs.rand(n, 4)
+    q["material"] = rs.randint(0, n_mats, n)
+    q["inside"] = rs.randint(0, 2, n)
+    return q
+
+
+def oracle_results(ork, mats, q):
+    from strelka_amd import capi
+
+    out = np.zeros(len(q), capi.BSDF_RESULT)
+    s8, e7 = np.zeros(8, np.float32), np.zeros(7, np.float32)
+    for i, r in enumerate(q):
+        m = mats[r["material"]:r["material"] + 1]
+        n, ng, t, k1, k2, xi = (np.ascontiguousarray(r[k]) for k in ("normal", "geom_normal", "tangent_u", "k1", "k2", "xi"))
+        ork.ork_bsdf_set_tangent(p(t))
+        ork.ork_bsdf_sample(p(m), p(n), p(ng), p(k1), p(xi), int(r["inside"]), p(s8))
+        ork.ork_bsdf_evaluate_side(p(m), p(n), p(ng), p(k1), p(k2), int(r["inside"]), p(e7))
+        out[i]["k2"], out[i]["bsdf_over_pdf"], out[i]["pdf"], out[i]["event_type"] = s8[:3], s8[3:6], s8[6], int(s8[7])
+        out[i]["bsdf_diffuse"], out[i]["bsdf_glossy"], out[i]["eval_pdf"] = e7[:3], e7[3:6], e7[6]
+    return out
+
+
+def test_every_bsdf_sample_and_evaluate_matches_the_oracle_per_call(ork):
+    from strelka_amd import build, capi
+
+    build.build()
+    mats, names = materials()
+    ctx = capi.Context(0)
+    ctx.set_materials(mats)
+    q = queries(24000, 17, len(mats))
+    got = ctx.bsdf_probe(q)
+    want = oracle_results(ork, mats, q)
+    ctx.close()
+    report = {}
+    for mi, name in enumerate(names):
+        sel = q["material"] == mi
+        g, w = got[sel], want[sel]
+        same_event = g["event_type"] == w["event_type"]
+        assert same_event.mean() > 0.995, (name, same_event.mean())
+        assert (w["event_type"] != 0).mean() > 0.3, name  # the inputs do exercise the BSDF, not just its rejections
+        g, w = g[same_event], w[same_event]
+        assert np.abs(g["k2"] - w["k2"]).max() < 2e-5, (name, np.abs(g["k2"] - w["k2"]).max())
+        for f in ("bsdf_over_pdf", "pdf", "bsdf_diffuse", "bsdf_glossy", "eval_pdf"):
+            a, b = g[f].astype(np.float64), w[f].astype(np.float64)
+            err = np.abs(a - b) / (np.abs(b) + 1e-4)
+            report[(name, f)] = float(err.max())
+            assert np.isfinite(a).all() and err.max() < 2e-3, (name, f, err.max())
+    # arithmetic made of + - * / sqrt only is bit-equal: the Lambert lobe's evaluate()
+    sel = q["material"] == 0
+    assert np.array_equal(got[sel]["bsdf_diffuse"].view(np.uint32), want[sel]["bsdf_diffuse"].view(np.uint32))
+    assert np.array_equal(got[sel]["eval_pdf"].view(np.uint32), want[sel]["eval_pdf"].view(np.uint32))
+    print({k: "%.1e" % v for k, v in report.items() if v > 1e-5})
+
+
+def test_probe_rejects_bad_input():
+    from strelka_amd import capi
+
+    ctx = capi.Context(0)
+    with pytest.raises(capi.SkhError, match="skh_set_materials"):
+        ctx.bsdf_probe(np.zeros(3, capi.BSDF_QUERY))
+    ctx.set_materials(materials()[0])
+    assert len(ctx.bsdf_probe(np.zeros(0, capi.BSDF_QUERY))) == 0
+    ctx.close()

@@ -302,7 +302,7 @@ def thick_curves(seed=3, n_strands=60, n_cp=9):
     BLAS's parameter sub-ranges (a hit point can be a whole radius away from C(u))"""
     rs = np.random.RandomState(seed)
     sc = S.Scene()
-    mat = sc.addMaterial(S.MAT_HAIR, (0.5, 0.4, 0.3))
+    mat = sc.addHairMaterial((0.5, 0.4, 0.3), diffuse_weight=0.15, diffuse_tint=(0.5, 0.4, 0.3))
     pts, rad = [], []
     for _ in range(n_strands):
         p = rs.uniform(-1.0, 1.0, 3)

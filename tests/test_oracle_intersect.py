@@ -167,7 +167,7 @@ def _mat(typ, color=(0.8, 0.6, 0.4), rough=0.3, metallic=0.0, spec=0.5, ior=1.5)
     return m
 
 
-@pytest.mark.parametrize("typ,metallic", [(0, 0.0), (1, 0.0), (1, 1.0), (3, 0.0)])
+@pytest.mark.parametrize("typ,metallic", [(0, 0.0), (1, 0.0), (1, 1.0)])  # (hair, type 3: tests/test_oracle_bsdf.py)
 def test_bsdf_energy_and_pdf_consistency(ork, typ, metallic):
     """White-furnace style checks: E[bsdf_over_pdf] <= 1 per channel, sample.pdf == evaluate.pdf for the sampled
     direction, evaluate == pdf * bsdf_over_pdf, and the pdf integrates to <= 1 over the hemisphere."""
@@ -209,7 +209,7 @@ def test_bsdf_energy_and_pdf_consistency(ork, typ, metallic):
 def test_glass_protocol(ork):
     """Specular events report pdf 0 (MDL convention the renderer relies on: closest_hit.cu:603); transmission flips
     sides; inside/outside selects ior1/ior2 (closest_hit.cu:496-498); total internal reflection."""
-    mat = _mat(2, color=(0.9, 0.95, 1.0), ior=1.5)
+    mat = _mat(2, color=(0.9, 0.95, 1.0), rough=0.0, ior=1.5)  # clear glass (frosting_roughness 0); frosted: tests/test_oracle_bsdf.py
     n = f32(0, 0, 1)
     k1 = f32(0.0, 0.6, 0.8)
     refl = _sample(ork, mat, n, k1, f32(0.1, 0.2, 0.0, 0))  # xi.z = 0 < F -> reflection
