@@ -325,13 +325,45 @@ def main():
             all_xy[r, :len(t)] = t
         all_xy = np.ascontiguousarray(all_xy.reshape(-1, 2))
 
+    # The frame's one collective runs BELOW the C ABI (skh_gather_tiles: grouped RCCL sends into the root on the renderer's own
+    # stream); torch.distributed only carries the 128-byte communicator id, the barrier and the timing reduction.  If RCCL cannot
+    # build the communicator (e.g. several ranks sharing one GPU in the 1-GPU tests) every rank agrees to fall back to
+    # torch.distributed's gather, and the JSON line says which one ran.
     gather_kind = "torch.distributed gather"
+    if world > 1 and os.environ.get("SKH_GATHER", "rccl" if dist.get_backend() == "nccl" else "torch") == "rccl":
+        idt = torch.zeros(128, dtype=torch.uint8)
+        ok = 1
+        if rank == 0:
+            try:
+                idt = torch.from_numpy(capi.Context.comm_unique_id().copy())
+            except capi.SkhError:
+                ok = 0
+        cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        idt = idt.to(cdev)
+        dist.broadcast(idt, src=0)
+        try:
+            if not int(idt.any()):
+                raise capi.SkhError("no communicator id")
+            ctx.comm_init(idt.cpu().numpy(), world, rank)
+        except capi.SkhError as e:
+            ok = 0
+            sys.stderr.write(f"[bench] rank {rank}: {e}\n")
+        okt = torch.tensor([ok], dtype=torch.int32, device=cdev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 1:
+            gather_kind = "skh_gather_tiles: RCCL send/recv below the C ABI"
+        else:
+            ctx.comm_destroy()
+    use_skh_gather = gather_kind.startswith("skh_gather_tiles")
 
     def frame():
         ctx.render_subframes(params, args.spp, None)  # all sub-frames of the frame, one device sync at the end
         if world > 1:
-            ctx.copy_accum_tiles(tile_buf.data_ptr())
-            tiles.gather_tiles(tile_buf, world, rank, dist, out=all_tiles)
+            if use_skh_gather:
+                ctx.gather_tiles(max_tiles, all_tiles.data_ptr() if rank == 0 else None, 0)
+            else:
+                ctx.copy_accum_tiles(tile_buf.data_ptr())
+                tiles.gather_tiles(tile_buf, world, rank, dist, out=all_tiles)
             if rank == 0:
                 ctx.scatter_tiles(all_tiles.data_ptr(), all_xy, args.tile, image.data_ptr(), W, H)
 
@@ -399,9 +431,9 @@ def main():
             frac = achieved / HBM_PEAK_GBS
         if pmc and pmc.get("valu_per_launch") and avg_ms > 0:
             scale = rpl / pmc["rays_per_launch"] if pmc.get("rays_per_launch") else 1.0
-            props = torch.cuda.get_device_properties(dev)
-            clock_ghz = props.clock_rate / 1e6  # kHz -> GHz (device maximum engine clock, read on this box)
-            simds = props.multi_processor_count * 4
+            info = ctx.device_info()
+            clock_ghz = info["clock_khz"] / 1e6  # device maximum engine clock as this box's hipDeviceProp_t reports it
+            simds = info["compute_units"] * info["simds_per_cu"]
             peak_issue = simds * clock_ghz / 2.0  # G wave-instructions / s
             rate = pmc["valu_per_launch"] * scale / (avg_ms * 1e-3) / 1e9
             lanes = pmc.get("lanes_per_valu_inst")

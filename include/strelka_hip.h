@@ -285,6 +285,20 @@ skh_status skh_copy_accum_tiles(skh_context* ctx, void* d_dst);
 skh_status skh_scatter_tiles(skh_context* ctx, const void* d_src_tiles, const uint32_t* tile_xy, uint32_t n_tiles,
                              uint32_t tile_size, void* d_dst_rgba, uint32_t width, uint32_t height);
 
+/* ---- multi-GPU: the one collective of a tile-sharded frame, below the C ABI (RCCL over xGMI; the reference is single-GPU,
+ *      include/render/render.h:19-56 has no counterpart).  One communicator per context, bootstrapped the NCCL way: rank 0
+ *      calls skh_comm_unique_id, the host distributes the 128 bytes (pipe, file, MPI, torch.distributed ...), every rank
+ *      calls skh_comm_init (collective).  skh_gather_tiles: every rank's compact tile accumulators (the layout of
+ *      skh_copy_accum_tiles, zero-padded to max_tiles tiles) -> the root's d_recv = [world][max_tiles][tile_size^2] float4, as
+ *      ONE group of point-to-point sends into the root on the context's stream -- each sender uses its own xGMI link, no ring.
+ *      Synchronous like render().  world_size 1 needs no communicator (a device-to-device copy).  librccl is loaded on first
+ *      use; a box without it gets SKH_FAIL from skh_comm_*, nothing else depends on it. ---- */
+#define SKH_COMM_ID_BYTES 128
+skh_status skh_comm_unique_id(void* out_id /* SKH_COMM_ID_BYTES */);
+skh_status skh_comm_init(skh_context* ctx, const void* id, int world_size, int rank);
+skh_status skh_comm_destroy(skh_context* ctx);
+skh_status skh_gather_tiles(skh_context* ctx, uint32_t max_tiles, void* d_recv /* root only, else NULL */, int root);
+
 /* ---- ray queries against the built accel (the optixTrace call sites), for tests and micro-benchmarks.
  *      rays/hits are HOST arrays. ---- */
 skh_status skh_trace(skh_context* ctx, const skh_ray* rays, uint32_t n_rays, uint32_t mode, skh_hit* hits);
@@ -329,6 +343,19 @@ skh_status skh_bsdf_probe(skh_context* ctx, const skh_bsdf_query* queries, uint3
  *                 world-space tree)
  * Unknown names and out-of-range values return SKH_INVALID_ARGUMENT. */
 skh_status skh_set_option(skh_context* ctx, const char* name, int64_t value);
+/* what the context's device reports (hipDeviceProp_t): the measurement code prices instruction rates against these */
+typedef struct skh_device_info
+{
+    uint32_t compute_units; /* 256 on MI355X */
+    uint32_t simds_per_cu; /* 4 */
+    uint32_t clock_khz; /* maximum engine clock */
+    uint32_t memory_clock_khz;
+    uint32_t memory_bus_bits;
+    uint32_t wavefront_size;
+    uint64_t total_memory_bytes;
+    char name[64];
+} skh_device_info;
+skh_status skh_get_device_info(skh_context* ctx, skh_device_info* out);
 skh_status skh_get_stats(skh_context* ctx, skh_stats* out);
 skh_status skh_reset_stats(skh_context* ctx);
 skh_status skh_synchronize(skh_context* ctx);

@@ -25,7 +25,11 @@ SYMBOLS = ["skh_create", "skh_destroy", "skh_last_error", "skh_abi_version", "sk
            "skh_set_instances", "skh_set_lights", "skh_set_textures", "skh_set_materials", "skh_build_accel", "skh_resize", "skh_set_tiles",
            "skh_render_subframe", "skh_render_subframes", "skh_tonemap", "skh_read_accum", "skh_read_aov",
            "skh_buffer_alloc", "skh_buffer_free", "skh_buffer_download", "skh_copy_accum", "skh_copy_accum_tiles", "skh_scatter_tiles", "skh_trace", "skh_trace_device",
-           "skh_set_option", "skh_get_stats", "skh_reset_stats", "skh_synchronize", "skh_get_stream", "skh_bsdf_probe"]
+           "skh_set_option", "skh_get_stats", "skh_reset_stats", "skh_synchronize", "skh_get_stream", "skh_bsdf_probe", "skh_get_device_info", "skh_comm_unique_id", "skh_comm_init",
+           "skh_comm_destroy", "skh_gather_tiles"]
+
+DEVICE_INFO = np.dtype([("compute_units", np.uint32), ("simds_per_cu", np.uint32), ("clock_khz", np.uint32), ("memory_clock_khz", np.uint32),
+                        ("memory_bus_bits", np.uint32), ("wavefront_size", np.uint32), ("total_memory_bytes", np.uint64), ("name", "S64")])
 
 BSDF_QUERY = np.dtype([("normal", np.float32, 3), ("geom_normal", np.float32, 3), ("tangent_u", np.float32, 3), ("k1", np.float32, 3),
                        ("k2", np.float32, 3), ("xi", np.float32, 4), ("material", np.uint32), ("inside", np.uint32)])
@@ -81,6 +85,11 @@ def load():
     lib.skh_trace.argtypes = [vp, vp, u32, u32, vp]
     lib.skh_trace_device.argtypes = [vp, vp, u32, u32, vp, u32]
     lib.skh_bsdf_probe.argtypes = [vp, vp, u32, vp]
+    lib.skh_get_device_info.argtypes = [vp, vp]
+    lib.skh_comm_unique_id.argtypes = [vp]
+    lib.skh_comm_init.argtypes = [vp, vp, i32, i32]
+    lib.skh_comm_destroy.argtypes = [vp]
+    lib.skh_gather_tiles.argtypes = [vp, u32, vp, i32]
     lib.skh_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.skh_get_stats.argtypes = [vp, vp]
     lib.skh_reset_stats.argtypes = [vp]
@@ -230,6 +239,32 @@ class Context:
         out = np.zeros(len(q), BSDF_RESULT)
         self._ck(self.lib.skh_bsdf_probe(self.h, _p(q), len(q), _p(out)), "skh_bsdf_probe")
         return out
+
+    @staticmethod
+    def comm_unique_id():
+        """rank 0: the 128 bytes every rank hands to comm_init (distribute them with whatever the host has)"""
+        buf = np.zeros(128, np.uint8)
+        st = load().skh_comm_unique_id(_p(buf))
+        if st != 0:
+            raise SkhError(f"skh_comm_unique_id failed ({st}): RCCL (librccl.so.1) is not available")
+        return buf
+
+    def comm_init(self, unique_id, world_size, rank):
+        u = np.ascontiguousarray(unique_id, np.uint8)
+        assert u.nbytes == 128
+        self._ck(self.lib.skh_comm_init(self.h, _p(u), world_size, rank), "skh_comm_init")
+
+    def comm_destroy(self):
+        self._ck(self.lib.skh_comm_destroy(self.h), "skh_comm_destroy")
+
+    def gather_tiles(self, max_tiles, d_recv=None, root=0):
+        """one RCCL gather of this context's tile accumulators into the root's [world][max_tiles][T*T] float4 buffer"""
+        self._ck(self.lib.skh_gather_tiles(self.h, max_tiles, d_recv, root), "skh_gather_tiles")
+
+    def device_info(self):
+        d = np.zeros((), DEVICE_INFO)
+        self._ck(self.lib.skh_get_device_info(self.h, _p(d)), "skh_get_device_info")
+        return {k: (d[k].item().decode() if k == "name" else int(d[k])) for k in DEVICE_INFO.names}
 
     def set_option(self, name, value):
         self._ck(self.lib.skh_set_option(self.h, name.encode(), int(value)), f"skh_set_option({name})")

@@ -3,6 +3,9 @@
 #include "../../include/strelka_hip.h"
 #include "skh_kernels.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types only: the library itself is dlopen()ed on first use (skh_comm_*)
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -55,6 +58,9 @@ struct skh_context
     hipStream_t stream2 = nullptr; // any-hit launches when `overlap` is on: shadow[b] runs beside closest[b+1] and fills its tail
     int overlap = 1; // 0 off, 1 for small passes only (<= 8 M paths: the interactive one-sub-frame-per-call mode, +7 %), 2 always
     hipEvent_t evShade = nullptr, evShadow = nullptr;
+    ncclComm_t comm = nullptr; // multi-GPU tile gather (skh_comm_init)
+    int commWorld = 1, commRank = 0;
+    DevBuf dTileSend;
     uint32_t* hOverflow = nullptr; // pinned, device-visible: traversal-stack overflow flag (DevScene::overflowFlag)
     uint32_t stackOverflows = 0; // calls that failed with it since the last skh_reset_stats
     std::string err;
@@ -742,6 +748,8 @@ void skh_destroy(skh_context* c)
         return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm)
+        (void)skh_comm_destroy(c);
     for (DevBuf* b : { &c->dShadeTris, &c->dShadeInst, &c->dVerts, &c->dIndices, &c->dMeshes, &c->dPoints, &c->dRadii, &c->dInstances, &c->dLights, &c->dMaterials,
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
                        &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
@@ -760,6 +768,7 @@ void skh_destroy(skh_context* c)
         (void)hipEventDestroy(c->evShadow);
     if (c->hOverflow)
         (void)hipHostFree(c->hOverflow);
+    dev_free(c->dTileSend);
     delete c;
 }
 
@@ -2065,6 +2074,165 @@ skh_status skh_scatter_tiles(skh_context* c, const void* d_src_tiles, const uint
     return SKH_OK;
 }
 
+// ---- multi-GPU tile gather (RCCL, loaded on first use) ----
+namespace
+{
+struct RcclApi
+{
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+RcclApi* rccl()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (tried)
+        return api.lib ? &api : nullptr;
+    tried = true;
+    // (a process that uses PyTorch has its librccl.so.1 loaded already: the same soname resolves to that copy)
+    for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" })
+        if ((api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
+            break;
+    if (!api.lib)
+    {
+        api.why = "librccl.so.1 not found";
+        return nullptr;
+    }
+#define SKH_SYM(field, sym) (*(void**)(&api.field) = dlsym(api.lib, sym))
+    SKH_SYM(GetUniqueId, "ncclGetUniqueId");
+    SKH_SYM(CommInitRank, "ncclCommInitRank");
+    SKH_SYM(CommDestroy, "ncclCommDestroy");
+    SKH_SYM(Send, "ncclSend");
+    SKH_SYM(Recv, "ncclRecv");
+    SKH_SYM(GroupStart, "ncclGroupStart");
+    SKH_SYM(GroupEnd, "ncclGroupEnd");
+    SKH_SYM(GetErrorString, "ncclGetErrorString");
+#undef SKH_SYM
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd)
+    {
+        api.why = "librccl.so.1 lacks the point-to-point API";
+        api.lib = nullptr;
+        return nullptr;
+    }
+    return &api;
+}
+} // namespace
+
+skh_status skh_comm_unique_id(void* out_id)
+{
+    static_assert(sizeof(ncclUniqueId) == SKH_COMM_ID_BYTES, "id size");
+    RcclApi* r = rccl();
+    if (!out_id || !r)
+        return out_id ? SKH_FAIL : SKH_INVALID_ARGUMENT;
+    ncclUniqueId id;
+    if (r->GetUniqueId(&id) != ncclSuccess)
+        return SKH_FAIL;
+    memcpy(out_id, &id, sizeof(id));
+    return SKH_OK;
+}
+
+skh_status skh_comm_init(skh_context* c, const void* id, int world_size, int rank)
+{
+    if (!c || !id || world_size < 1 || rank < 0 || rank >= world_size)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    RcclApi* r = rccl();
+    if (!r)
+    {
+        c->err = "skh_comm_init: RCCL is not available (librccl.so.1)";
+        return SKH_FAIL;
+    }
+    if (c->comm)
+        (void)skh_comm_destroy(c);
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    const ncclResult_t e = r->CommInitRank(&c->comm, world_size, uid, rank);
+    if (e != ncclSuccess)
+    {
+        c->comm = nullptr;
+        c->err = std::string("skh_comm_init: ncclCommInitRank: ") + (r->GetErrorString ? r->GetErrorString(e) : "error");
+        return SKH_FAIL;
+    }
+    c->commWorld = world_size;
+    c->commRank = rank;
+    return SKH_OK;
+}
+
+skh_status skh_comm_destroy(skh_context* c)
+{
+    if (!c)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    if (c->comm)
+    {
+        (void)hipStreamSynchronize(c->stream);
+        RcclApi* r = rccl();
+        if (r)
+            (void)r->CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    c->commWorld = 1;
+    c->commRank = 0;
+    return SKH_OK;
+}
+
+skh_status skh_gather_tiles(skh_context* c, uint32_t max_tiles, void* d_recv, int root)
+{
+    if (!c || root < 0 || root >= c->commWorld || max_tiles < c->numTiles || (c->commRank == root && !d_recv))
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    if (c->commWorld > 1 && !c->comm)
+    {
+        c->err = "skh_gather_tiles: call skh_comm_init first";
+        return SKH_INVALID_ARGUMENT;
+    }
+    const size_t tilePixels = (size_t)c->tileSize * c->tileSize;
+    const size_t chunk = (size_t)max_tiles * tilePixels; // float4 per rank
+    const size_t mine = (size_t)c->numTiles * tilePixels;
+    const bool isRoot = c->commRank == root;
+    // the root's own share goes straight into its slot of the receive buffer; a sender stages its tiles (zero-padded) once
+    float4* dst = isRoot ? reinterpret_cast<float4*>(d_recv) + (size_t)root * chunk : nullptr;
+    if (!isRoot)
+    {
+        skh_status s = dev_alloc(c, c->dTileSend, sizeof(float4) * chunk);
+        if (s != SKH_OK)
+            return s;
+        dst = c->dTileSend.as<float4>();
+    }
+    SKH_TRY(c, hipMemcpyAsync(dst, c->dAccum.p, sizeof(float4) * mine, hipMemcpyDeviceToDevice, c->stream));
+    if (chunk > mine)
+        SKH_TRY(c, hipMemsetAsync(dst + mine, 0, sizeof(float4) * (chunk - mine), c->stream));
+    if (c->commWorld > 1)
+    {
+        RcclApi* r = rccl();
+        ncclResult_t e = r->GroupStart();
+        if (isRoot)
+        {
+            for (int k = 0; k < c->commWorld && e == ncclSuccess; ++k)
+                if (k != root)
+                    e = r->Recv(reinterpret_cast<float4*>(d_recv) + (size_t)k * chunk, chunk * 4, ncclFloat, k, c->comm, c->stream);
+        }
+        else if (e == ncclSuccess)
+            e = r->Send(dst, chunk * 4, ncclFloat, root, c->comm, c->stream);
+        const ncclResult_t e2 = r->GroupEnd();
+        if (e != ncclSuccess || e2 != ncclSuccess)
+        {
+            c->err = std::string("skh_gather_tiles: ") + (r->GetErrorString ? r->GetErrorString(e != ncclSuccess ? e : e2) : "RCCL error");
+            return SKH_FAIL;
+        }
+    }
+    SKH_TRY(c, hipStreamSynchronize(c->stream));
+    return SKH_OK;
+}
+
 // ---- raw ray queries ----
 __global__ void k_rays_aos_to_soa(const skh_ray* __restrict__ rays, uint32_t n, RayQ rq)
 {
@@ -2377,6 +2545,24 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         c->err = "skh_set_option: unknown option " + n;
         return SKH_INVALID_ARGUMENT;
     }
+    return SKH_OK;
+}
+
+skh_status skh_get_device_info(skh_context* c, skh_device_info* out)
+{
+    if (!c || !out)
+        return SKH_INVALID_ARGUMENT;
+    hipDeviceProp_t prop;
+    SKH_TRY(c, hipGetDeviceProperties(&prop, c->device));
+    memset(out, 0, sizeof(*out));
+    out->compute_units = (uint32_t)prop.multiProcessorCount;
+    out->simds_per_cu = 4;
+    out->clock_khz = (uint32_t)prop.clockRate;
+    out->memory_clock_khz = (uint32_t)prop.memoryClockRate;
+    out->memory_bus_bits = (uint32_t)prop.memoryBusWidth;
+    out->wavefront_size = (uint32_t)prop.warpSize;
+    out->total_memory_bytes = (uint64_t)prop.totalGlobalMem;
+    strncpy(out->name, prop.name, sizeof(out->name) - 1);
     return SKH_OK;
 }
 

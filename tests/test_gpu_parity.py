@@ -271,6 +271,38 @@ def test_tiles_reproduce_full_frame_bit_for_bit(gpu):
     assert np.array_equal(out, full)
 
 
+def test_gather_tiles_below_the_c_abi(gpu):
+    """skh_gather_tiles (RCCL send/recv on the renderer's stream) with the communicator a 1-GPU box can form: world size 1, with
+    and without skh_comm_init.  The root's slot of the receive buffer must hold exactly the tile accumulators, zero-padded to
+    max_tiles; a scatter of it reproduces skh_read_accum.  (N > 1: tests/test_tiles_gloo.py on CPU, bench.py --gpus N on the
+    driver's 8-GPU node; the per-rank payload logic is the same code.)"""
+    import torch
+
+    from strelka_amd import capi
+
+    sc = scenes.cornell_box()
+    gpu.set_scene(sc.arrays())
+    w, h, T = 80, 48, 16
+    mine = tiles.assign_tiles(w, h, T, 2, 1)  # rank 1's share of a 2-rank split
+    gpu.set_tiles(T, mine)
+    gpu.resize(w, h)
+    for i in range(2):
+        gpu.render_subframe(S.frame_params(sc.getCamera(), w, h, subframe_index=i, spp_total=2))
+    want = torch.zeros((len(mine), T * T, 4), dtype=torch.float32, device="cuda")
+    gpu.copy_accum_tiles(want.data_ptr())
+    max_tiles = len(mine) + 3
+    for with_comm in (False, True):
+        if with_comm:
+            gpu.comm_init(capi.Context.comm_unique_id(), 1, 0)
+        recv = torch.full((1, max_tiles, T * T, 4), -1.0, dtype=torch.float32, device="cuda")
+        gpu.gather_tiles(max_tiles, recv.data_ptr(), 0)
+        assert torch.equal(recv[0, :len(mine)], want) and not recv[0, len(mine):].any()
+    gpu.comm_destroy()
+    with pytest.raises(capi.SkhError):
+        gpu.gather_tiles(len(mine) - 1, recv.data_ptr(), 0)  # fewer slots than tiles
+    gpu.set_tiles(32, None)
+
+
 def small_hair():
     return scenes.hair_standin(seed=5, n_strands=1500, n_cp=8)
 
