@@ -204,6 +204,13 @@ static inline f3 xform_point(const float* m, const f3& p)
     return f3{ ((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3], ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7],
                ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11] };
 }
+// world -> object for points, better conditioned than w2o * p: R^-1 (p - T) with R^-1 = the 3x3 of w2o and T = the translation of
+// the object-to-world transform (same definition, same order as the product's xform_point_rel)
+static inline f3 xform_point_rel(const float* w2o, const float* o2w, const f3& p)
+{
+    const float x = p.x - o2w[3], y = p.y - o2w[7], z = p.z - o2w[11];
+    return f3{ (w2o[0] * x + w2o[1] * y) + w2o[2] * z, (w2o[4] * x + w2o[5] * y) + w2o[6] * z, (w2o[8] * x + w2o[9] * y) + w2o[10] * z };
+}
 static inline f3 xform_vector(const float* m, const f3& v)
 {
     return f3{ (m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[4] * v.x + m[5] * v.y) + m[6] * v.z,

@@ -161,6 +161,23 @@ SKH_DI v3 xform_point(const float* m, const v3& p)
     return mk3(((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3], ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7],
                ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11]);
 }
+// world -> object for POINTS: o' = R^-1 (p - T), R^-1 = the 3x3 of the instance's world-to-object record, T = the translation of
+// its object-to-world transform, kept in the record's fourth column (m[3], m[7], m[11]).  R^-1 p + t' with t' = -R^-1 T -- the
+// usual 3x4 inverse, OptiX's too -- cancels two large terms when the instance sits far from the origin: the rounding of p is
+// amplified by |R^-1| and a squashed instance a few float spacings thick gets an object-space origin that is noise.  Subtracting
+// first is exact for p near T (Sterbenz) and moves that limit out by orders of magnitude.
+#ifndef SKH_ENTRY_REL
+#define SKH_ENTRY_REL 1 // (0: the R^-1 p + t' form, kept for A/B timing only -- the parity tests need 1)
+#endif
+SKH_DI v3 xform_point_rel(const float* m, const v3& p)
+{
+#if !SKH_ENTRY_REL
+    return mk3(((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3], ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7],
+               ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11]);
+#endif
+    const float x = p.x - m[3], y = p.y - m[7], z = p.z - m[11];
+    return mk3((m[0] * x + m[1] * y) + m[2] * z, (m[4] * x + m[5] * y) + m[6] * z, (m[8] * x + m[9] * y) + m[10] * z);
+}
 SKH_DI v3 xform_vector(const float* m, const v3& v)
 {
     return mk3((m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[4] * v.x + m[5] * v.y) + m[6] * v.z,
@@ -729,7 +746,7 @@ SKH_DI RayShear make_shear(const v3& d)
 }
 // watertight edge-function test (Woop, Benthin, Wald 2013); accepts tmin < t <= tmax
 SKH_DI bool intersect_triangle(const v3& o, const RayShear& s, float tmin, float tmax, const v3& p0, const v3& p1,
-                               const v3& p2, float& t_out, float& u_out, float& v_out)
+                               const v3& p2, float& t_out, float& u_out, float& v_out, uint32_t* prof = nullptr /*lane-profile build*/)
 {
     const v3 A = shear_permute(p0 - o, s.perm), B = shear_permute(p1 - o, s.perm), C = shear_permute(p2 - o, s.perm);
     const float Akz = A.z, Bkz = B.z, Ckz = C.z;
@@ -750,6 +767,8 @@ SKH_DI bool intersect_triangle(const v3& o, const RayShear& s, float tmin, float
         // floats are exact and the sign of their difference is therefore exact.  Without it a triangle seen exactly edge-on
         // (projected vertices collinear with the ray) passes the sign test on rounding noise and reports a "hit" far outside
         // its own bounding box -- which conservative box tests cull, i.e. the result would depend on the hierarchy.
+        if (prof)
+            *prof |= 1u;
         const double Ud = (double)Cx * (double)By - (double)Cy * (double)Bx;
         const double Vd = (double)Ax * (double)Cy - (double)Ay * (double)Cx;
         const double Wd = (double)Bx * (double)Ay - (double)By * (double)Ax;
@@ -761,6 +780,8 @@ SKH_DI bool intersect_triangle(const v3& o, const RayShear& s, float tmin, float
     }
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f))
         return false;
+    if (prof)
+        *prof |= 2u;
     const float det = (U + V) + W;
     if (det == 0.0f)
         return false;
@@ -775,6 +796,8 @@ SKH_DI bool intersect_triangle(const v3& o, const RayShear& s, float tmin, float
     const float q = T - tmin * det;
     if (!((det > 0.0f ? q : -q) > noise))
         return false;
+    if (prof)
+        *prof |= 4u;
     const float rcpDet = 1.0f / det;
     const float t = T * rcpDet;
     if (!(t > tmin && t <= tmax))

@@ -22,7 +22,7 @@ namespace skh
 
 struct DevInstance // 64 B: what traversal needs when it enters an instance
 {
-    float w2o[12];
+    float w2o[12]; // rows of R^-1 (world -> object, 3x3) with the OBJECT-TO-WORLD translation in the fourth column: xform_point_rel
     int rootRef;
     uint32_t mask; // GEOMETRY_MASK_* (OptixRenderParams.h:9-17); 0 = disabled (degenerate transform / empty geometry)
     uint32_t type; // 0 mesh, 1 light, 2 curve
@@ -132,9 +132,19 @@ struct FrameP // skh_frame_params + launch geometry
 // acceptance slack below covers the extra ulp: per plane the computed t carries a relative error <= 2^-23 (rcp) + 3 * 2^-24
 // (difference, product, fma), entry and exit of different axes can err in opposite directions, so tnear <= tfar * (1 + 2^-19)
 // keeps every box the exact arithmetic would accept (plus the 2^-20 relative inflation of the stored boxes).
+// A direction component that is exactly (or nearly) zero must not become an infinite reciprocal: the node test evaluates plane
+// distances as q * (cell * inv) + (origin - o) * inv, and inf - inf = NaN there makes min/max drop the whole axis -- the box is
+// accepted whatever the ray's position on that axis.  Still conservative, but one axis-parallel ray (a mirror bounce off a
+// vertical face: d.y == 0) then walks thousands of nodes on its own and the persistent launch waits for it: one such ray in
+// 64 M cost a launch 7.7 ms (found with the lane-profile build).  Clamped to +-2^-60 the products stay finite (cell sizes and
+// scene extents are far below 2^60) and the slab test decides the parallel axis by the ray's position, as it should.
+SKH_DI float rcp_safe(float x)
+{
+    return __builtin_amdgcn_rcpf(copysignf(fmaxf(fabsf(x), 0x1p-60f), x)); // v_max_f32 |x|, v_bfi_b32, v_rcp_f32
+}
 SKH_DI v3 rcp3(const v3& d)
 {
-    return mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    return mk3(rcp_safe(d.x), rcp_safe(d.y), rcp_safe(d.z));
 }
 #define SKH_SLAB_SLACK 1.0000019073486328125f // 1 + 2^-19
 
@@ -168,8 +178,10 @@ struct StatsDev
 #ifdef SKH_LANE_PROFILE
     // wave-level event counts of k_trace (profile build only): [0] node-loop iterations, [1] triangle-loop iterations,
     // [2] instance-entry blocks, [3] outer iterations, [4] refills, [5] lanes refilled, [6] leaf blocks, [7] pop blocks
-    unsigned long long wave[2][8];
+    unsigned long long wave[2][10]; // ... [6] triangle passes with an fp64 fallback, [7] with a division, [8] with a passed sign test
     unsigned long long shade[8]; // k_shade cycle split (SKH_SP marks)
+    unsigned int slowCount, slowPad; // rays that took more than SKH_SLOW_RAY node steps: the first 16 are recorded
+    float slow[16][12]; // steps, tris, insts, kernel, o xyz, d xyz, tmin, tmax
     unsigned long long cyc[2][8]; // summed over waves: [0] refill [1] node loop [2] leaf [3] pop [4] result write [5] whole kernel
 #endif
 };
@@ -247,9 +259,11 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
     const uint32_t rayMask = CURVES ? (ANY_HIT ? 3u : 255u) : (ANY_HIT ? 1u : 253u);
     TraceCounters tc = { 0, 0, 0, 0 };
 #ifdef SKH_LANE_PROFILE
-    uint32_t wv[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    uint32_t wv[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    uint32_t rayNodes = 0, rayTris = 0, rayInsts = 0;
     unsigned long long cy[6] = { 0, 0, 0, 0, 0, 0 };
     const unsigned long long cyStart = __builtin_readcyclecounter();
+    const unsigned long long rtStart = __builtin_amdgcn_s_memrealtime(); // constant 100 MHz counter: cycles / realtime = the clock this launch really ran at
 #define SKH_LP(...) __VA_ARGS__
 #else
 #define SKH_LP(...)
@@ -395,7 +409,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
             // ---- descend through internal nodes ----
             while (cur >= 0 && cur != SKH_REF_INVALID)
             {
-                SKH_LP(itN++;)
+                SKH_LP(itN++; rayNodes++;)
                 // one 64-byte fetch = four quantised child boxes
                 const float4* np = reinterpret_cast<const float4*>(nodes + cur);
                 const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
@@ -579,8 +593,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                     {
                         if (COUNT)
                             tc.insts++;
+                        SKH_LP(rayInsts++;)
                         const float m[12] = { i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w };
-                        o = xform_point(m, ow);
+                        o = xform_point_rel(m, ow);
                         d = xform_vector(m, dw);
                         inv = rcp3(d);
                         sh = make_shear(d);
@@ -619,9 +634,18 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                         const float4 a = tp[0], b = tp[1], c = tp[2];
                         if (COUNT)
                             tc.prims++;
-                        SKH_LP(itT++;)
+                        SKH_LP(itT++; rayTris++;)
                         float t, u, v;
+#ifdef SKH_LANE_PROFILE
+                        uint32_t pf = 0;
+                        const bool ih = intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), t, u, v, &pf);
+                        wv[6] += __any(pf & 1u) ? 1u : 0u; // triangle passes in which some lane took the fp64 edge-function fallback
+                        wv[7] += __any(pf & 4u) ? 1u : 0u; // ... in which some lane got as far as the division
+                        wv[8] += __any(pf & 2u) ? 1u : 0u; // ... passed the sign test
+                        if (ih && (best.found || t < best.t))
+#else
                         if (intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), t, u, v) && (best.found || t < best.t))
+#endif
                         {
                             const uint32_t prim = __float_as_uint(a.w);
                             if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
@@ -679,6 +703,19 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
         {
             hasRay = false;
             pending = true; // the result stays in registers until the next refill: one write block per refill, not per termination
+#ifdef SKH_LANE_PROFILE
+            if (rayNodes > 700u)
+            {
+                const uint32_t k = atomicAdd(&stats->slowCount, 1u);
+                if (k < 16u)
+                {
+                    float* r = stats->slow[k];
+                    r[0] = (float)rayNodes, r[1] = (float)rayTris, r[2] = (float)rayInsts, r[3] = ANY_HIT ? 1.0f : 0.0f;
+                    r[4] = ow.x, r[5] = ow.y, r[6] = ow.z, r[7] = dw.x, r[8] = dw.y, r[9] = dw.z, r[10] = tmin, r[11] = rq.plane(7)[ridx];
+                }
+            }
+            rayNodes = rayTris = rayInsts = 0;
+#endif
         }
         SKH_LP(cy[4] += __builtin_readcyclecounter() - cyA;)
     }
@@ -689,6 +726,11 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
         const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.prims), c2 = wave_sum(tc.segs), d2 = wave_sum(tc.insts);
 #ifdef SKH_LANE_PROFILE
         cy[5] = __builtin_readcyclecounter() - cyStart;
+        if (lane == 0)
+        {
+            atomicAdd(&stats->cyc[ANY_HIT ? 1 : 0][6], cy[5]);
+            atomicAdd(&stats->cyc[ANY_HIT ? 1 : 0][7], __builtin_amdgcn_s_memrealtime() - rtStart);
+        }
         for (int k = 0; k < 6; ++k)
         {
             // cycle sums are wave-uniform increments taken by the lanes that were active: the busiest lane has (nearly) all of them
@@ -704,7 +746,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
             atomicAdd(&stats->segs[ANY_HIT ? 1 : 0], (unsigned long long)c2);
             atomicAdd(&stats->insts[ANY_HIT ? 1 : 0], (unsigned long long)d2);
 #ifdef SKH_LANE_PROFILE
-            for (int k = 0; k < 8; ++k)
+            for (int k = 0; k < 10; ++k)
                 atomicAdd(&stats->wave[ANY_HIT ? 1 : 0][k], (unsigned long long)wv[k]);
 #endif
         }
@@ -781,7 +823,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
         if (COUNT)                                                                                                      \
             tc.insts++;                                                                                                 \
         const float m[12] = { i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w };                 \
-        oo = xform_point(m, o);                                                                                         \
+        oo = xform_point_rel(m, o);                                                                                         \
         od = xform_vector(m, d);                                                                                        \
         sh = make_shear(od);                                                                                            \
         curInst = (id);                                                                                                 \
@@ -1263,7 +1305,7 @@ SKH_DI SurfaceHit fill_curve(const DevScene& sc, const HostInstance& hi, const f
     CubicPoly ip;
     cubic_from_bspline(ip, q);
     v3 hitPoint = rayO + t * rayD;
-    hitPoint = xform_point(w2o, hitPoint);
+    hitPoint = xform_point_rel(w2o, hitPoint);
     v3 worldNormal = normalize(xform_normal(w2o, curve_surface_normal(ip, u, hitPoint)));
     worldNormal = worldNormal * (inside ? -1.0f : 1.0f);
     if (tangent_u) // curveTangent through the normal transform: closest_hit.cu:436-437, curve.h:412-417

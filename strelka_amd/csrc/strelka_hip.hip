@@ -204,7 +204,8 @@ static void init_sobol_table(uint32_t tab[5][32])
     }
 }
 
-// world->object of an affine 3x4, fp64 adjugate, one rounding to fp32 (DESIGN.md "instance transforms")
+// world->object of an affine 3x4: the 3x3 by the fp64 adjugate, one rounding to fp32; the fourth column carries the object-to-world
+// TRANSLATION itself (points go through xform_point_rel: R^-1 (p - T); DESIGN.md "instance transforms")
 static bool invert_affine(const float* m, float* out)
 {
     const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
@@ -215,9 +216,15 @@ static bool invert_affine(const float* m, float* out)
     const double det = a * A + b * D + c * G;
     const double r = 1.0 / det;
     const double i00 = A * r, i01 = B * r, i02 = C * r, i10 = D * r, i11 = E * r, i12 = F * r, i20 = G * r, i21 = H * r, i22 = I * r;
+#if SKH_ENTRY_REL
+    out[0] = (float)i00, out[1] = (float)i01, out[2] = (float)i02, out[3] = (float)tx;
+    out[4] = (float)i10, out[5] = (float)i11, out[6] = (float)i12, out[7] = (float)ty;
+    out[8] = (float)i20, out[9] = (float)i21, out[10] = (float)i22, out[11] = (float)tz;
+#else
     out[0] = (float)i00, out[1] = (float)i01, out[2] = (float)i02, out[3] = (float)(-(i00 * tx + i01 * ty + i02 * tz));
     out[4] = (float)i10, out[5] = (float)i11, out[6] = (float)i12, out[7] = (float)(-(i10 * tx + i11 * ty + i12 * tz));
     out[8] = (float)i20, out[9] = (float)i21, out[10] = (float)i22, out[11] = (float)(-(i20 * tx + i21 * ty + i22 * tz));
+#endif
     bool finite = true;
     for (int k = 0; k < 12; ++k)
         finite = finite && std::isfinite(out[k]);
@@ -1630,7 +1637,11 @@ static void harvest_spans(skh_context* c)
     {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess)
+        {
             c->msClass[s.cls] += ms;
+            if (getenv("SKH_DEBUG_SPANS"))
+                fprintf(stderr, "[span] class %d %.3f ms\n", s.cls, ms);
+        }
     }
     c->spans.clear();
     c->eventsUsed = 0;
@@ -2586,9 +2597,9 @@ skh_status skh_get_stats(skh_context* c, skh_stats* out)
     }
 #ifdef SKH_LANE_PROFILE
     for (int k = 0; k < 2; ++k)
-        fprintf(stderr, "[lane-profile] %s: rays %llu nodes %llu (TLAS %llu) tris %llu insts %llu | wave: nodeIt %llu triIt %llu instBlk %llu outer %llu refills %llu refilled %llu\n",
+        fprintf(stderr, "[lane-profile] %s: rays %llu nodes %llu (TLAS %llu) tris %llu insts %llu | wave: nodeIt %llu triIt %llu instBlk %llu outer %llu refills %llu refilled %llu | tri passes with: fp64 fallback %llu, sign test passed %llu, division %llu\n",
                 k ? "shadow" : "closest", k ? sd.raysShadow : sd.raysRadiance, sd.nodes[k], sd.segs[k], sd.prims[k], sd.insts[k], sd.wave[k][0], sd.wave[k][1],
-                sd.wave[k][2], sd.wave[k][3], sd.wave[k][4], sd.wave[k][5]);
+                sd.wave[k][2], sd.wave[k][3], sd.wave[k][4], sd.wave[k][5], sd.wave[k][6], sd.wave[k][8], sd.wave[k][7]);
     {
         double tot = 0;
         for (int k = 0; k < 8; ++k)
@@ -2597,9 +2608,14 @@ skh_status skh_get_stats(skh_context* c, skh_stats* out)
                 100 * sd.shade[0] / tot, 100 * sd.shade[1] / tot, 100 * sd.shade[2] / tot, 100 * sd.shade[3] / tot, 100 * sd.shade[4] / tot, 100 * sd.shade[5] / tot,
                 100 * sd.shade[6] / tot, 100 * sd.shade[7] / tot);
     }
+    fprintf(stderr, "[slow-rays] %u rays took more than 1500 node steps\n", sd.slowCount);
+    for (uint32_t k = 0; k < std::min(sd.slowCount, 16u); ++k)
+        fprintf(stderr, "[slow-ray] steps %.0f tris %.0f insts %.0f %s o %.9g %.9g %.9g d %.9g %.9g %.9g tmin %g tmax %g\n", sd.slow[k][0], sd.slow[k][1], sd.slow[k][2],
+                sd.slow[k][3] != 0.0f ? "shadow" : "closest", sd.slow[k][4], sd.slow[k][5], sd.slow[k][6], sd.slow[k][7], sd.slow[k][8], sd.slow[k][9], sd.slow[k][10], sd.slow[k][11]);
     for (int k = 0; k < 2; ++k)
-        fprintf(stderr, "[lane-cycles] %s: refill %.3g node %.3g leaf %.3g pop %.3g write %.3g total %.3g\n", k ? "shadow" : "closest", (double)sd.cyc[k][0],
-                (double)sd.cyc[k][1], (double)sd.cyc[k][2], (double)sd.cyc[k][3], (double)sd.cyc[k][4], (double)sd.cyc[k][5]);
+        fprintf(stderr, "[lane-cycles] %s: refill %.3g node %.3g leaf %.3g pop %.3g write %.3g total %.3g | shader clock while the waves ran: %.1f MHz (wave-seconds %.4g)\n", k ? "shadow" : "closest", (double)sd.cyc[k][0],
+                (double)sd.cyc[k][1], (double)sd.cyc[k][2], (double)sd.cyc[k][3], (double)sd.cyc[k][4], (double)sd.cyc[k][5],
+                sd.cyc[k][7] ? (double)sd.cyc[k][6] / (double)sd.cyc[k][7] * 100.0 : 0.0, (double)sd.cyc[k][7] / 1e8);
 #endif
     out->ms_trace_closest = c->msClass[KC_TRACE_CLOSEST];
     out->ms_trace_shadow = c->msClass[KC_TRACE_SHADOW];

@@ -79,10 +79,10 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         rays = np.concatenate([rays, on, seg])
     if seed % 3 == 0:
         # precision stress: the whole scene far from the origin and / or at an odd scale (rays follow)
-        sc_f, off = float(rs.choice([1e-3, 1.0, 250.0])), rs.uniform(-1, 1, 3) * float(rs.choice([0.0, 30.0, 300.0]))
-        off = off * sc_f # relative to the scene's size.  The world -> object transform amplifies the float spacing of the ray origin by
-        # |W2O|: a squashed instance (the generator makes them down to 1e-3 of the scene) 3000 scene sizes from the origin is a few
-        # spacings thick, its object-space ray is noise on both sides and differently culled (seed 31380) -- outside the contract
+        sc_f, off = float(rs.choice([1e-3, 1.0, 250.0])), rs.uniform(-1, 1, 3) * float(rs.choice([0.0, 30.0, 300.0, 3000.0]))
+        off = off * sc_f # relative to the scene's size.  With the instance entry o' = R^-1 (o - T) (round 2) a squashed instance (the
+        # generator makes them down to 1e-3 of the scene) thousands of scene sizes from the origin is still resolved: seed 31380, which
+        # the R^-1 o + t' form could not decide the same way in two hierarchies, is clean
         G = S.translate(off) @ S.scale((sc_f, sc_f, sc_f))
         inst2 = inst.copy()
         for k in range(len(inst2)):

@@ -16,8 +16,12 @@ bad = 0
 t0 = time.time()
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     rs = np.random.RandomState(seed)
-    kind = seed % 5
-    if kind == 0:
+    kind = seed % 7
+    if kind == 5:
+        sc = scenes.light_zoo(seed=seed, with_rect=bool(seed % 2))  # sphere + disk lights (+ rect + distant)
+    elif kind == 6:
+        sc = scenes.material_probe(["diffuse", "glossy", "metal", "glass", "frosted"][(seed // 7) % 5], seed=seed)
+    elif kind == 0:
         sc = scenes.kitchen_standin(seed=seed, n_meshes=8 + seed % 7, n_instances=30 + 11 * (seed % 5), tri_lo=50, tri_hi=2000)
     elif kind == 1:
         sc = scenes.hair_standin(seed=seed, n_strands=300 + 40 * (seed % 9), n_cp=6 + seed % 5)
@@ -52,7 +56,9 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     ctx.close()
     l2 = np.sqrt(((got - want) ** 2).sum()) / max(np.sqrt((want ** 2).sum()), 1e-12)
     frac = (np.abs(got - want).max(-1) > 2e-3 * (np.abs(want).max(-1) + 1e-3)).mean()
-    ok = np.isfinite(got).all() and l2 < 2e-2 and frac < 2e-2 and abs(int(ro) - int(rg)) <= max(2, ro // 2000)
+    # the bar of tests/test_gpu_parity.py::_image_close, with room for TWO flipped paths in these tiny frames (a few hundred to a few
+    # thousand pixels at 1-5 spp: one pixel off is already 0.01-0.5 % of the image)
+    ok = np.isfinite(got).all() and l2 < 2e-3 and frac <= max(1e-4, 2.5 / (w * h)) and abs(int(ro) - int(rg)) <= max(2, ro // 2000)
     if not ok:
         bad += 1
         print("seed", seed, "kind", kind, w, h, spp, depth, "L2 %.3g frac %.3g rays %d vs %d" % (l2, frac, ro, rg), flush=True)
