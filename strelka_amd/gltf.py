@@ -23,11 +23,13 @@ from external files, data: URIs or the GLB binary chunk.  What the reference doe
 Animations (:453-546) are outside the render() hot path and are not loaded.
 """
 import base64
+import binascii
 import json
 import math
 import os
 import struct
 import sys
+import zlib
 
 import numpy as np
 
@@ -227,7 +229,8 @@ def _load_textures(path, sc, doc=None, buffers=None):
                 else:
                     with open(os.path.join(base, uri), "rb") as f:
                         img = decode(f.read(), uri)
-            except (OSError, ValueError, KeyError, IndexError) as e:
+            except (OSError, ValueError, KeyError, IndexError, struct.error, zlib.error, binascii.Error) as e:
+                # (ValueError covers PngError / JpegError; the rest: truncated headers, corrupt deflate data, bad base64)
                 print(f"[gltf] unable to load texture {uri[:60]}: {e}", file=sys.stderr)
                 continue
             sc.texture_ids[uri] = sc.addTexture(img)

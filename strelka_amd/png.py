@@ -30,7 +30,15 @@ def load_png(path):
 
 
 def decode_png(blob, path="<memory>"):
-    """PNG file content (bytes) -> HxWx4 uint8"""
+    """PNG file content (bytes) -> HxWx4 uint8.  Every malformed input ends in PngError (a ValueError): truncated chunks
+    (struct.error) and corrupt deflate streams (zlib.error) included, so that one bad texture cannot abort a scene load."""
+    try:
+        return _decode_png(blob, path)
+    except (struct.error, zlib.error, IndexError) as e:
+        raise PngError(f"{path}: corrupt PNG ({e})") from e
+
+
+def _decode_png(blob, path):
     if blob[:8] != _SIG:
         raise PngError(f"{path}: not a PNG file")
     off, idat, palette, trns, hdr = 8, [], None, None, None
@@ -67,7 +75,11 @@ def decode_png(blob, path="<memory>"):
             pass
         elif ft == 2:
             line = (line + prev).astype(np.uint8)
-        elif ft in (1, 3, 4):  # need the left neighbour: per-pixel scan (vectorised over channels)
+        elif ft == 1:  # Sub: cur[x] = raw[x] + cur[x-1] (mod 256) = a running sum per channel
+            line = (np.cumsum(line.reshape(w, ch).astype(np.uint32), axis=0) & 0xFF).astype(np.uint8).reshape(-1)
+        elif ft in (3, 4):  # Average / Paeth: the predictor needs the DECODED left neighbour (floor / select: no closed form), so
+            # these rows are a per-pixel scan, vectorised over channels only: ~3 us per pixel, i.e. fine for the 256^2 ... 1 K
+            # textures of glTF samples, minutes for a 4 K one whose encoder picked these filters for every row
             px, pv = line.reshape(w, ch), prev.reshape(w, ch)
             cur = np.zeros((w, ch), np.uint8)
             left = np.zeros(ch, np.uint8)

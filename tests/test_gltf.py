@@ -196,3 +196,35 @@ def test_glb_container_and_rejections(tmp_path):
     json.dump(doc, open(bad, "w"))
     with pytest.raises(gltf.GltfError):
         gltf.load_gltf(bad)
+
+
+def test_corrupt_textures_are_reported_not_fatal(tmp_path, capsys):
+    """a corrupt PNG (bad deflate stream, truncated chunk) raised zlib.error / struct.error through the loader and
+    aborted the whole scene; now every decoder failure is a PngError and the material keeps its constant colour."""
+    import base64
+    import zlib
+
+    from strelka_amd import png
+
+    good = tmp_path / "ok.png"
+    img = (np.arange(16 * 16 * 4) % 251).astype(np.uint8).reshape(16, 16, 4)
+    png.save_png(str(good), img)
+    blob = good.read_bytes()
+    assert np.array_equal(png.decode_png(blob), img)
+    bad_deflate = blob[:60] + bytes(b ^ 0x5A for b in blob[60:80]) + blob[80:]
+    truncated = blob[:30]
+    for b in (bad_deflate, truncated, blob[:8] + b"\x00\x00"):
+        with pytest.raises(png.PngError):
+            png.decode_png(b)
+    # Sub-filtered rows (the vectorised path) decode to the same pixels as the writer's filter-0 rows
+    raw = np.zeros((16, 1 + 64), np.uint8)
+    raw[:, 0] = 1
+    px = img.reshape(16, 16, 4).astype(np.int32)
+    raw[:, 1:] = np.concatenate([px[:, :1], (px[:, 1:] - px[:, :-1]) % 256], 1).reshape(16, 64)
+    import struct
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    sub = blob[:8] + chunk(b"IHDR", struct.pack(">IIBBBBB", 16, 16, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw.tobytes())) + chunk(b"IEND", b"")
+    assert np.array_equal(png.decode_png(sub), img)

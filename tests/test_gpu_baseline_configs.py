@@ -85,31 +85,31 @@ def test_c4_kitchen_4k_depth6_roulette_and_eight_rank_tiles():
 
     sc = scenes.kitchen_standin()
     arr = sc.arrays()
-    W, H, DEPTH = 3840, 2160, 6
-    base, st = _gpu_frame(arr, sc.getCamera(), W, H, 2, DEPTH, total=256)
+    W, H, DEPTH, SPP = 3840, 2160, 6, 16  # 16 of the configuration's 256 spp (was 2)
+    base, st = _gpu_frame(arr, sc.getCamera(), W, H, SPP, DEPTH, total=256)
     assert np.isfinite(base).all() and base[..., :3].max() > 0
     # depth 6 goes past the Russian-roulette threshold (OptixRender.cu:131-146): some paths are longer than 4 segments
-    _, st4 = _gpu_frame(arr, sc.getCamera(), W, H, 2, 4, total=256)
+    _, st4 = _gpu_frame(arr, sc.getCamera(), W, H, SPP, 4, total=256)
     assert st["rays_radiance"] > st4["rays_radiance"]
     # the 8-rank tile split of C4: ranks 0, 3 and 7 reproduce their pixels of the full frame bit for bit
     for rank in (0, 3, 7):
         t = tiles.assign_tiles(W, H, 32, 8, rank)
-        tacc, _ = _gpu_frame(arr, sc.getCamera(), W, H, 2, DEPTH, tile_xy=t, total=256)
+        tacc, _ = _gpu_frame(arr, sc.getCamera(), W, H, SPP, DEPTH, tile_xy=t, total=256)
         part = detile_numpy(tacc, t, 32, W, H)
         mask = detile_numpy(np.ones_like(tacc), t, 32, W, H)[..., 0] > 0
         assert mask.mean() == pytest.approx(1 / 8, abs=0.01)
         assert part[mask].tobytes() == base[mask].tobytes()
-    # a band of the 4K frame against the oracle (32 rows of both sub-frames on the host cores)
+    # a band of the 4K frame against the oracle (32 rows of all 16 sub-frames on the host cores)
     from tests import orklib
 
     o = orklib.new_context()
     o.set_scene(arr)
     o.resize(W, H)
     r0, r1 = 1024, 1056
-    for i in range(2):
+    for i in range(SPP):
         o.render_subframe(S.frame_params(sc.getCamera(), W, H, subframe_index=i, samples_this_launch=1, spp_total=256, max_depth=DEPTH), rows=(r0, r1))
-    # measured: relative L2 2.1e-4, 0.0033 % of the band's 123 k pixels (4 of them) off after 2 spp at depth 6: flipped paths as in
-    # tests/test_gpu_fullsize.py, each worth a whole sample
+    # measured at 2 spp: relative L2 2.1e-4, 0.0033 % of the band's 123 k pixels (4 of them) off at depth 6: flipped paths as in
+    # tests/test_gpu_fullsize.py, each worth a whole sample (their weight in the LDR-space average shrinks with more sub-frames)
     _image_close(base[r0:r1], o.read_accum()[r0:r1], l2_tol=2e-3)
 
 
@@ -127,3 +127,34 @@ def test_c5_hair_1080p_depth3_properties():
     part = detile_numpy(tacc, t, 32, W, H)
     mask = detile_numpy(np.ones_like(tacc), t, 32, W, H)[..., 0] > 0
     assert part[mask].tobytes() == a[mask].tobytes()
+
+
+def test_c5_hair_full_1024_spp_frame_properties():
+    """The whole C5 configuration once (the suite ran 4 of its 1024 spp): 1920x1080, depth 3, 1024 sub-frames of 1 spp
+    = 2.1 G paths with the Chiang hair BSDF.  Properties: every pixel finite and non-negative, ray counts inside their bounds and
+    exactly 256x those of a 4-spp run's per-sample average within 1 %, the converged image's mean near the 4-spp image's, the
+    uint16 AOV counters intact (diffuse + specular first events <= 1024 per pixel), no traversal-stack overflow."""
+    from strelka_amd import capi
+
+    sc = scenes.hair_standin()
+    arr = sc.arrays()
+    W, H, SPP = 1920, 1080, 1024
+    few, stf = _gpu_frame(arr, sc.getCamera(), W, H, 4, 3, total=SPP)
+    ctx = capi.Context(0)
+    ctx.set_scene(arr)
+    ctx.resize(W, H)
+    ctx.render_subframes(S.frame_params(sc.getCamera(), W, H, subframe_index=0, samples_this_launch=1, spp_total=SPP, max_depth=3), SPP, None)
+    st = ctx.stats()
+    full, dif, spec = ctx.read_accum(), ctx.read_aov(0), ctx.read_aov(1)
+    ctx.close()
+    assert st["stack_overflows"] == 0
+    for img in (full, dif, spec):
+        assert np.isfinite(img).all() and img[..., :3].min() >= 0.0
+    assert W * H * SPP <= st["rays_radiance"] <= W * H * SPP * 3 and st["rays_shadow"] <= st["rays_radiance"]
+    assert abs(st["rays_radiance"] / SPP - stf["rays_radiance"] / 4) < 0.01 * stf["rays_radiance"] / 4
+    assert abs(full[..., :3].mean() - few[..., :3].mean()) < 0.1 * few[..., :3].mean()
+    # converged: the 1024-spp image is far smoother than the 4-spp one (mean absolute Laplacian over the hair region)
+    def rough(img):
+        g = img[..., 1]
+        return np.abs(4 * g[1:-1, 1:-1] - g[:-2, 1:-1] - g[2:, 1:-1] - g[1:-1, :-2] - g[1:-1, 2:]).mean()
+    assert rough(full) < 0.5 * rough(few)
