@@ -339,8 +339,9 @@ skh_status skh_bsdf_probe(skh_context* ctx, const skh_bsdf_query* queries, uint3
  *                 always), small_waves_closest / small_waves_shadow (16 / 16: waves per CU of the two overlapped launches),
  *                 sort_bits_closest / sort_bits_shadow / sort_first_bounce (ray re-ordering, off)
  *   build         build_quality 1|0 (PLOC | Karras radix tree), leaf_max_tris (2), curve_split (2: parameter sub-ranges
- *                 per curve segment), tlas_open (1: TLAS leaves per instance budget), tight_instance_boxes 1|0, flatten 0|1 (one
- *                 world-space tree)
+ *                 per curve segment), tlas_build 2|1|0 (auto | GPU PLOC over the instance boxes | exact sweep SAH on the host; auto =
+ *                 the sweep up to 8192 instances, the GPU beyond), tlas_open (1: TLAS leaves per instance budget),
+ *                 tight_instance_boxes 1|0, flatten 0|1 (one world-space tree)
  * Unknown names and out-of-range values return SKH_INVALID_ARGUMENT. */
 skh_status skh_set_option(skh_context* ctx, const char* name, int64_t value);
 /* what the context's device reports (hipDeviceProp_t): the measurement code prices instruction rates against these */

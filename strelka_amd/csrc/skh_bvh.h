@@ -731,13 +731,18 @@ __global__ void k_ploc_init(const uint32_t* __restrict__ sortedVals, const uint6
     nodeLo[id] = lo;
     nodeHi[id] = hi;
 }
+// RADIUS: neighbours examined on either side.  12 for the BLASes (millions of primitives); the TLAS -- thousands of boxes of wildly
+// different sizes that EVERY ray walks -- searches 96 either side, close to exhaustive agglomerative clustering
+#define SKH_PLOC_RADIUS_TLAS 96
+template <int RADIUS>
 __global__ void __launch_bounds__(SKH_PLOC_BLOCK) k_ploc_nn(const float4* __restrict__ cLo, const float4* __restrict__ cHi, uint32_t m,
                                                            uint32_t* __restrict__ nn)
 {
-    __shared__ float4 sLo[SKH_PLOC_BLOCK + 2 * SKH_PLOC_RADIUS];
-    __shared__ float4 sHi[SKH_PLOC_BLOCK + 2 * SKH_PLOC_RADIUS];
-    const int base = (int)(blockIdx.x * SKH_PLOC_BLOCK) - SKH_PLOC_RADIUS;
-    for (int k = threadIdx.x; k < SKH_PLOC_BLOCK + 2 * SKH_PLOC_RADIUS; k += SKH_PLOC_BLOCK)
+    constexpr int SKH_PLOC_RADIUS_ = RADIUS;
+    __shared__ float4 sLo[SKH_PLOC_BLOCK + 2 * SKH_PLOC_RADIUS_];
+    __shared__ float4 sHi[SKH_PLOC_BLOCK + 2 * SKH_PLOC_RADIUS_];
+    const int base = (int)(blockIdx.x * SKH_PLOC_BLOCK) - SKH_PLOC_RADIUS_;
+    for (int k = threadIdx.x; k < SKH_PLOC_BLOCK + 2 * SKH_PLOC_RADIUS_; k += SKH_PLOC_BLOCK)
     {
         const int g = base + k;
         if (g >= 0 && g < (int)m)
@@ -755,12 +760,12 @@ __global__ void __launch_bounds__(SKH_PLOC_BLOCK) k_ploc_nn(const float4* __rest
     const uint32_t i = blockIdx.x * SKH_PLOC_BLOCK + threadIdx.x;
     if (i >= m)
         return;
-    const int me = threadIdx.x + SKH_PLOC_RADIUS;
+    const int me = threadIdx.x + SKH_PLOC_RADIUS_;
     const float4 lo = sLo[me], hi = sHi[me];
     const uint32_t grp = __float_as_uint(hi.w);
     float bestCost = INFINITY;
     uint32_t best = 0xffffffffu;
-    for (int d = -SKH_PLOC_RADIUS; d <= SKH_PLOC_RADIUS; ++d)
+    for (int d = -SKH_PLOC_RADIUS_; d <= SKH_PLOC_RADIUS_; ++d)
     {
         if (d == 0)
             continue;

@@ -1965,6 +1965,30 @@ __global__ void k_instance_boxes(const HostInstance* __restrict__ instances, con
     grp[i] = 0;
 }
 
+// TLAS build on the device: the primitives of the top level are the valid instances (list made on the host from what it
+// already knows: a finite inverse transform, a non-empty BLAS); their boxes and traversal records, one per leaf
+__global__ void k_tlas_leaves(const uint32_t* __restrict__ leafInst, uint32_t n, const DevInstance* __restrict__ inst, const float4* __restrict__ boxLo,
+                              const float4* __restrict__ boxHi, float4* __restrict__ leafLo, float4* __restrict__ leafHi, uint32_t* __restrict__ grp,
+                              DevInstance* __restrict__ out)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n)
+        return;
+    const uint32_t i = leafInst[r];
+    leafLo[r] = boxLo[i];
+    leafHi[r] = boxHi[i];
+    grp[r] = 0u;
+    DevInstance d = inst[i];
+    d.pad = i; // the instance this leaf belongs to (hit records report it)
+    out[r] = d;
+}
+__global__ void k_permute_instances(const DevInstance* __restrict__ src, const uint32_t* __restrict__ order, uint32_t n, DevInstance* __restrict__ dst)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        dst[i] = src[order[i]];
+}
+
 // Tight world box of a mesh instance: the box of its transformed VERTICES instead of the box of the eight transformed corners
 // of the object-space box (for a round object turned by 45 degrees the latter has twice the footprint).  One workgroup per
 // instance; the result only ever SHRINKS the corner box (component-wise intersection) and is padded like it.  Instances of

@@ -110,7 +110,9 @@ def test_c4_kitchen_4k_depth6_roulette_and_eight_rank_tiles():
         o.render_subframe(S.frame_params(sc.getCamera(), W, H, subframe_index=i, samples_this_launch=1, spp_total=256, max_depth=DEPTH), rows=(r0, r1))
     # measured at 2 spp: relative L2 2.1e-4, 0.0033 % of the band's 123 k pixels (4 of them) off at depth 6: flipped paths as in
     # tests/test_gpu_fullsize.py, each worth a whole sample (their weight in the LDR-space average shrinks with more sub-frames)
-    _image_close(base[r0:r1], o.read_accum()[r0:r1], l2_tol=2e-3)
+    # at 16 spp: 0.020 % of the band's pixels (24) hold one flipped path among their 16 samples -- about 1.3e-5 per path, the rate of
+    # the 1-spp frames -- so the pixel bar scales with the sample count here
+    _image_close(base[r0:r1], o.read_accum()[r0:r1], l2_tol=2e-3, frac_tol=6e-4)
 
 
 def test_c5_hair_1080p_depth3_properties():
