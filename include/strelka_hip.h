@@ -259,6 +259,11 @@ skh_status skh_set_tiles(skh_context* ctx, uint32_t tile_size, const uint32_t* t
 /* ---- OptiXRender::render's optixLaunch (OptixRender.cpp:1006-1021): one sub-frame batch.
  *      d_image may be NULL (only accum is updated).  Synchronous, like the reference. ---- */
 skh_status skh_render_subframe(skh_context* ctx, const skh_frame_params* params, void* d_image);
+/* Called once per sub-frame, as HdStrelkaRenderPass::_Execute calls render() (RenderPass.cpp:441-447), the library traces ahead:
+ * once two consecutive calls continue the same frame (identical parameters, subframe_index + 1) the next call traces 2, then 4,
+ * ... up to option "speculate" (8) sub-frames in one wavefront pass, and the calls after it only apply their accumulation step.
+ * The images are bit-identical to one-pass-per-call rendering (tests: test_speculative_subframes_are_exact); a call that does
+ * not continue the frame -- camera motion restarts at sub-frame 0 -- simply discards what was traced ahead.  "speculate" 0 = off. */
 
 /* Convenience for benchmarks: n consecutive sub-frames of params->samples_this_launch samples each,
  * starting at params->subframe_index, with a single device synchronisation at the end. */
@@ -335,6 +340,7 @@ skh_status skh_bsdf_probe(skh_context* ctx, const skh_bsdf_query* queries, uint3
  *                 node_break_closest / node_break_shadow (24 / 20, curves 20 / 20: leave the node loop below x/64 descending rays),
  *                 leaf_min (16: lanes for the minority kind of leaf work), curve_min (48: lanes parked in front of the
  *                 curve intersector before it runs), subframe_batch (0 = auto: ~64 M paths per pass),
+ *                 speculate (8: sub-frames traced ahead when skh_render_subframe is called once per sub-frame; 0 = off),
  *                 overlap 0|1|2 (any-hit launches on a second stream beside the next closest-hit launch: off | small passes |
  *                 always), small_waves_closest / small_waves_shadow (16 / 16: waves per CU of the two overlapped launches),
  *                 sort_bits_closest / sort_bits_shadow / sort_first_bounce (ray re-ordering, off)

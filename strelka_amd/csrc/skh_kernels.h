@@ -117,6 +117,7 @@ struct FrameP // skh_frame_params + launch geometry
     float shadowTmin, materialTmin;
     uint32_t width, height, tileSize, tileShift, numTiles, numSlots;
     uint32_t batch; // sub-frames in flight in this wavefront (>= 1): path p = sub * numSlots + slot
+    uint32_t finalFirst, finalCount; // k_finalize_batch applies the accumulation steps of sub-frames [finalFirst, finalFirst + finalCount) of the pass
 };
 
 #ifndef SKH_STACK_LDS
@@ -1815,7 +1816,7 @@ __global__ void __launch_bounds__(256)
         return;
     const size_t S = ps.stride;
     float4 out = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-    for (uint32_t sub = 0; sub < fp.batch; ++sub)
+    for (uint32_t sub = fp.finalFirst; sub < fp.finalFirst + fp.finalCount; ++sub)
     {
         const size_t p = (size_t)sub * fp.numSlots + slot;
         const v3 rad = mk3(ps.base[p + 3 * S], ps.base[p + 4 * S], ps.base[p + 5 * S]);

@@ -80,7 +80,20 @@ struct skh_context
     DevBuf dTexels, dTexDesc, dSegBound, dScatterXY, dRaygenBase;
     uint32_t raygenBlocksPerSub = 0, raygenValidPerSub = 0;
     uint32_t nTextures = 0;
-    bool hasHairMaterial = false; // selects the k_shade build that carries df::chiang_hair_bsdf
+    bool hasHairMaterial = false;
+    // Speculative sub-frame batching for the reference's call pattern (one render() per sub-frame, RenderPass.cpp:441-447): once two
+    // consecutive calls continue the same frame (same parameters, subframe_index + 1), the next call traces several sub-frames
+    // ahead in ONE wavefront pass and the calls after it only apply their accumulation step to the radiances already in the path
+    // state.  Exact (sub-frame batching is exact); a call that does not continue the frame discards what is left.
+    struct Speculation
+    {
+        bool valid = false;
+        skh_frame_params params; // of the pass (subframe_index = its first sub-frame)
+        uint32_t count = 0, consumed = 0, lastBatch = 1, streak = 0;
+        skh_frame_params last; // the previous call's parameters
+        bool haveLast = false;
+    } spec;
+    uint32_t speculateMax = 8; // option "speculate": most sub-frames traced ahead in one pass (0 / 1 = off).  8: a pass stays below ~25 ms at 1080p // selects the k_shade build that carries df::chiang_hair_bsdf
     DevBuf dTriNodes, dTris, dSegNodes, dSegs, dSegPrim, dTlasNodes, dTlasInst, dDevInst, dTravInst;
     int tlasRoot = SKH_REF_INVALID;
     bool accelBuilt = false;
@@ -799,6 +812,7 @@ skh_status skh_set_geometry(skh_context* c, const skh_vertex* verts, uint32_t n_
 {
     if (!c || (n_verts && !verts) || (n_indices && !indices) || (n_meshes && !meshes))
         return SKH_INVALID_ARGUMENT;
+    c->spec.valid = c->spec.haveLast = false;
     (void)hipSetDevice(c->device);
     for (uint32_t m = 0; m < n_meshes; ++m)
     {
@@ -838,6 +852,7 @@ skh_status skh_set_curves(skh_context* c, const float* points_xyz, uint32_t n_po
 {
     if (!c || (n_points && !points_xyz) || (n_radii && !radii) || (n_vertex_counts && !vertex_counts) || (n_curves && !curves))
         return SKH_INVALID_ARGUMENT;
+    c->spec.valid = c->spec.haveLast = false;
     if (n_radii != n_points)
     {
         c->err = "skh_set_curves: one radius per control point is required";
@@ -873,6 +888,7 @@ skh_status skh_set_instances(skh_context* c, const skh_instance* instances, uint
 {
     if (!c || (n && !instances))
         return SKH_INVALID_ARGUMENT;
+    c->spec.valid = c->spec.haveLast = false;
     (void)hipSetDevice(c->device);
     c->instances.assign(instances, instances + n);
     c->nInstances = n;
@@ -884,6 +900,7 @@ skh_status skh_set_lights(skh_context* c, const skh_light* lights, uint32_t n)
 {
     if (!c || (n && !lights))
         return SKH_INVALID_ARGUMENT;
+    c->spec.valid = c->spec.haveLast = false;
     (void)hipSetDevice(c->device);
     c->nLights = n;
     return dev_upload(c, c->dLights, lights, sizeof(skh_light) * (size_t)n);
@@ -893,6 +910,7 @@ skh_status skh_set_textures(skh_context* c, const skh_texture* textures, uint32_
 {
     if (!c || (n && !textures))
         return SKH_INVALID_ARGUMENT;
+    c->spec.valid = c->spec.haveLast = false;
     (void)hipSetDevice(c->device);
     std::vector<uint4> desc(n);
     uint64_t total = 0;
@@ -924,6 +942,7 @@ skh_status skh_set_materials(skh_context* c, const skh_material* materials, uint
 {
     if (!c || (n && !materials))
         return SKH_INVALID_ARGUMENT;
+    c->spec.valid = c->spec.haveLast = false;
     (void)hipSetDevice(c->device);
     c->nMaterials = n;
     c->hasHairMaterial = false;
@@ -1155,6 +1174,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
 {
     if (!c)
         return SKH_INVALID_ARGUMENT;
+    c->spec.valid = c->spec.haveLast = false;
     (void)hipSetDevice(c->device);
     {
         const skh_status ss = build_shading_tables(c);
@@ -1658,6 +1678,7 @@ skh_status skh_resize(skh_context* c, uint32_t width, uint32_t height)
 {
     if (!c || width == 0 || height == 0)
         return SKH_INVALID_ARGUMENT;
+    c->spec.valid = c->spec.haveLast = false;
     (void)hipSetDevice(c->device);
     c->width = width;
     c->height = height;
@@ -1668,6 +1689,7 @@ skh_status skh_set_tiles(skh_context* c, uint32_t tile_size, const uint32_t* til
 {
     if (!c || tile_size < 8 || tile_size > 256 || (tile_size & (tile_size - 1)))
         return SKH_INVALID_ARGUMENT;
+    c->spec.valid = c->spec.haveLast = false;
     (void)hipSetDevice(c->device);
     c->tileSize = tile_size;
     c->tileShift = 0;
@@ -1877,7 +1899,8 @@ static skh_status check_stack_overflow(skh_context* c, const char* where)
 
 // One wavefront pass: either one launch of p->samples_this_launch samples (batch = 1), or `batch` consecutive sub-frames
 // of one sample each traced together (more rays per launch; results identical, see k_finalize_batch).
-static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t batch, void* d_image)
+static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t batch, void* d_image, bool trace = true, uint32_t finalFirst = 0,
+                             uint32_t finalCount = 0xffffffffu)
 {
     if (p->max_depth > 128 || p->samples_this_launch == 0)
     {
@@ -1905,6 +1928,8 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     fp.numTiles = c->numTiles;
     fp.numSlots = c->numSlots;
     fp.batch = batch;
+    fp.finalFirst = std::min(finalFirst, batch);
+    fp.finalCount = std::min(finalCount, batch - fp.finalFirst);
     const DevScene sc = make_dev_scene(c);
     const uint32_t N = c->numSlots * c->batchCapacity; // plane stride of every queue / path-state buffer
     const uint32_t NP = c->numSlots * batch; // paths in this pass
@@ -1924,7 +1949,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     // shadow[b] on a second stream: it depends on shade[b] only, and so does closest[b+1]; each fills the other's tail.  Ray
     // sorting shares scratch buffers between the two and keeps everything on one stream.
     const bool useOverlap = (c->overlap == 2 || (c->overlap == 1 && NP <= (1u << 23))) && !c->sortBitsClosest && !c->sortBitsShadow && fp.debug != 1;
-    for (uint32_t s = 0; s < fp.samplesThisLaunch; ++s)
+    for (uint32_t s = 0; trace && s < fp.samplesThisLaunch; ++s)
     {
         SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (SKH_COUNT_STRIDE * 2 * 130 + 16 * SKH_FETCH_STRIDE * (fp.maxDepth + 1)), st));
         {
@@ -2032,6 +2057,10 @@ skh_status skh_render_subframes(skh_context* c, const skh_frame_params* params, 
     skh_status s = ensure_ready(c);
     if (s != SKH_OK)
         return s;
+    if (n_subframes != 1)
+        c->spec.valid = c->spec.haveLast = false; // (the path state is about to be reused)
+    else
+        c->spec.valid = false;
     skh_frame_params p = *params;
     // single-sample sub-frames are traced `batchCapacity` at a time when that gives the GPU more rays per launch
     const uint32_t cap = (p.samples_this_launch == 1 && p.debug != 1) ? c->batchCapacity : 1u;
@@ -2049,9 +2078,73 @@ skh_status skh_render_subframes(skh_context* c, const skh_frame_params* params, 
     return check_stack_overflow(c, "skh_render_subframes");
 }
 
+// true when b continues the frame a belongs to: everything equal except the sub-frame index, which advances by `step`
+static bool same_frame(const skh_frame_params& a, const skh_frame_params& b, uint32_t step)
+{
+    skh_frame_params x = a, y = b;
+    if (y.subframe_index != x.subframe_index + step)
+        return false;
+    x.subframe_index = y.subframe_index = 0;
+    return memcmp(&x, &y, sizeof(x)) == 0;
+}
+
 skh_status skh_render_subframe(skh_context* c, const skh_frame_params* params, void* d_image)
 {
-    return skh_render_subframes(c, params, 1, d_image);
+    if (!c || !params)
+        return SKH_INVALID_ARGUMENT;
+    skh_context::Speculation& sp = c->spec;
+    const bool eligible = c->speculateMax > 1 && params->samples_this_launch == 1 && params->debug == 0 && c->width != 0 && c->batchCapacity > 1;
+    if (!eligible)
+    {
+        sp.valid = sp.haveLast = false;
+        return skh_render_subframes(c, params, 1, d_image);
+    }
+    (void)hipSetDevice(c->device);
+    skh_status s;
+    if (sp.valid && sp.consumed < sp.count && same_frame(sp.params, *params, sp.consumed))
+    {
+        // this sub-frame was traced ahead: its radiances wait in the path state, only its accumulation step is left
+        if ((s = render_one(c, &sp.params, sp.count, d_image, false, sp.consumed, 1)) != SKH_OK)
+            return s;
+        sp.consumed++;
+        sp.last = *params;
+        sp.haveLast = true;
+        sp.streak++;
+        SKH_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->timing)
+            harvest_spans(c);
+        return SKH_OK;
+    }
+    // a fresh pass.  How far ahead: nothing on the first call of a frame or after any change (interactive camera motion restarts at
+    // sub-frame 0 every call and must not pay for samples it will throw away); doubling while the caller keeps continuing the frame
+    const bool continues = sp.haveLast && same_frame(sp.last, *params, 1);
+    sp.streak = continues ? sp.streak + 1 : 0;
+    uint32_t ahead = 1;
+    if (continues && params->spp_total > params->subframe_index)
+        ahead = std::min(std::min(std::max(2u, sp.lastBatch * 2u), std::min(c->speculateMax, c->batchCapacity)), params->spp_total - params->subframe_index);
+    sp.valid = false;
+    if ((s = ensure_ready(c)) != SKH_OK)
+        return s;
+    if (ahead <= 1)
+    {
+        sp.lastBatch = 1;
+        sp.last = *params;
+        sp.haveLast = true;
+        return skh_render_subframes(c, params, 1, d_image);
+    }
+    if ((s = render_one(c, params, ahead, d_image, true, 0, 1)) != SKH_OK)
+        return s;
+    sp.valid = true;
+    sp.params = *params;
+    sp.count = ahead;
+    sp.consumed = 1;
+    sp.lastBatch = ahead;
+    sp.last = *params;
+    sp.haveLast = true;
+    SKH_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->timing)
+        harvest_spans(c);
+    return check_stack_overflow(c, "skh_render_subframe");
 }
 
 skh_status skh_tonemap(skh_context* c, void* d_image, uint32_t width, uint32_t height, uint32_t type, const float exposure[3], float gamma)
@@ -2534,6 +2627,8 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
     if (!c || !name)
         return SKH_INVALID_ARGUMENT;
     const std::string n(name);
+    if (n != "timing" && n != "count_traversal")
+        c->spec.valid = c->spec.haveLast = false;
     if (n == "count_traversal")
         c->countTraversal = value != 0;
     else if (n == "timing")
@@ -2574,6 +2669,12 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
             return SKH_INVALID_ARGUMENT;
         c->curveSplit = (uint32_t)value;
         c->accelBuilt = false;
+    }
+    else if (n == "speculate")
+    {
+        if (value < 0 || value > 64)
+            return SKH_INVALID_ARGUMENT;
+        c->speculateMax = (uint32_t)value;
     }
     else if (n == "tlas_build")
     {

@@ -602,6 +602,42 @@ def test_subframe_batching_is_exact(gpu):
             assert np.array_equal(a, b)
 
 
+def test_speculative_subframes_are_exact(gpu):
+    """The reference's call pattern is one render() per sub-frame (RenderPass.cpp:441-447).  skh_render_subframe traces ahead once
+    the caller keeps continuing a frame; every call must still hand back exactly the image one-pass-per-call rendering gives --
+    through a camera change in the middle of a speculative pass, a skipped sub-frame index, and the end of the frame (spp_total)."""
+    import torch
+
+    sc = small_kitchen()
+    gpu.set_scene(sc.arrays())
+    w, h, spp = 96, 64, 21
+    cam = sc.getCamera()
+    cam2 = S.Camera(fov=50.0)
+    cam2.lookAt((-3.0, 2.0, 2.5), (0.5, 0.6, -0.8))
+    # (camera, sub-frame index) per call: a frame, a camera move at call 9, a jump in the index at call 15, then to the frame's end
+    calls = [(cam, i) for i in range(9)] + [(cam2, i) for i in range(6)] + [(cam2, i) for i in range(8, spp)]
+    img = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    out = {}
+    for spec in (0, 8, 64):
+        gpu.set_option("speculate", spec)
+        gpu.resize(w, h)
+        gpu.reset_stats()
+        frames = []
+        for c_, i in calls:
+            gpu.render_subframe(S.frame_params(c_, w, h, subframe_index=i, spp_total=spp, max_depth=4), img.data_ptr())
+            frames.append((img.cpu().numpy().copy(), gpu.read_accum(), gpu.read_aov(0), gpu.read_aov(1)))
+        out[spec] = (frames, gpu.stats()["launches_trace_closest"])
+    gpu.set_option("speculate", 8)
+    base, launches0 = out[0]
+    for spec in (8, 64):
+        frames, launches = out[spec]
+        for k, (a, b) in enumerate(zip(base, frames)):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), (spec, k)
+        assert launches < launches0  # it did trace ahead: fewer, larger wavefront passes
+    assert not np.array_equal(base[8][0], base[9][0])
+
+
 def test_gltf_scene_through_the_dump_format_matches_oracle(gpu, tmp_path):
     """N2 end to end: glTF -> oka::Scene arrays -> .skscene -> renderer, image against the oracle on the same file
     (default distant light of the loader, OmniPBR + OmniGlass conversion, instanced primitives, the file's camera)."""
