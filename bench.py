@@ -199,6 +199,7 @@ def drop_in_leg(ctx, params, W, H, spp, torch, dev):
     skh_buffer_download of W*H float4).  Same scene, same rays; the result is the same image (sub-frame batching is exact)."""
     image = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     host = np.empty((H, W, 4), np.float32)
+    ctx.host_register(host)  # as oka::HipBuffer::map does with its host mirror
     p = np.array(params, copy=True)
     ctx.set_option("timing", 0)
     res = {}
@@ -217,8 +218,10 @@ def drop_in_leg(ctx, params, W, H, spp, torch, dev):
         rays = st["rays_radiance"] + st["rays_shadow"]
         res["with_map" if with_map else "without_map"] = {"value": round(rays / dt / 1e6, 1), "ms_per_frame": round(dt * 1e3, 2),
                                                           "ms_per_subframe": round(dt * 1e3 / spp, 3)}
+    ctx.host_unregister(host)
     return {"unit": "Mray/s", "pattern": f"{spp} x (skh_render_subframe of 1 spp + map() = D2H of the {W}x{H} float4 image), the reference "
-            "caller's loop (RenderPass.cpp:441-447)", **res}
+            "caller's loop (RenderPass.cpp:441-447); the library traces up to 8 sub-frames ahead once the caller keeps continuing the "
+            "frame (option speculate), images bit-identical", **res}
 
 
 def main():

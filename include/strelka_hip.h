@@ -279,6 +279,10 @@ skh_status skh_tonemap(skh_context* ctx, void* d_image, uint32_t width, uint32_t
 skh_status skh_buffer_alloc(skh_context* ctx, size_t bytes, void** out_device_ptr);
 skh_status skh_buffer_free(skh_context* ctx, void* device_ptr);
 skh_status skh_buffer_download(skh_context* ctx, const void* device_ptr, void* host, size_t bytes);
+/* Page-locks / releases a caller-owned host range so that skh_buffer_download into it runs at PCIe rate (the host mirror of
+ * Buffer::map, OptixBuffer.cpp:37-43, is a pageable std::vector in the reference; the caller maps after EVERY sub-frame). */
+skh_status skh_host_register(skh_context* ctx, void* host, size_t bytes);
+skh_status skh_host_unregister(skh_context* ctx, void* host);
 
 /* ---- read-back: Buffer::map (OptixBuffer.cpp:37-43) ---- */
 skh_status skh_read_accum(skh_context* ctx, float* host_rgba); /* W*H float4, row-major, row 0 = launch y 0 */

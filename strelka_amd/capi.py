@@ -26,7 +26,7 @@ SYMBOLS = ["skh_create", "skh_destroy", "skh_last_error", "skh_abi_version", "sk
            "skh_render_subframe", "skh_render_subframes", "skh_tonemap", "skh_read_accum", "skh_read_aov",
            "skh_buffer_alloc", "skh_buffer_free", "skh_buffer_download", "skh_copy_accum", "skh_copy_accum_tiles", "skh_scatter_tiles", "skh_trace", "skh_trace_device",
            "skh_set_option", "skh_get_stats", "skh_reset_stats", "skh_synchronize", "skh_get_stream", "skh_bsdf_probe", "skh_get_device_info", "skh_comm_unique_id", "skh_comm_init",
-           "skh_comm_destroy", "skh_gather_tiles"]
+           "skh_comm_destroy", "skh_gather_tiles", "skh_host_register", "skh_host_unregister"]
 
 DEVICE_INFO = np.dtype([("compute_units", np.uint32), ("simds_per_cu", np.uint32), ("clock_khz", np.uint32), ("memory_clock_khz", np.uint32),
                         ("memory_bus_bits", np.uint32), ("wavefront_size", np.uint32), ("total_memory_bytes", np.uint64), ("name", "S64")])
@@ -86,6 +86,8 @@ def load():
     lib.skh_trace_device.argtypes = [vp, vp, u32, u32, vp, u32]
     lib.skh_bsdf_probe.argtypes = [vp, vp, u32, vp]
     lib.skh_get_device_info.argtypes = [vp, vp]
+    lib.skh_host_register.argtypes = [vp, vp, C.c_size_t]
+    lib.skh_host_unregister.argtypes = [vp, vp]
     lib.skh_comm_unique_id.argtypes = [vp]
     lib.skh_comm_init.argtypes = [vp, vp, i32, i32]
     lib.skh_comm_destroy.argtypes = [vp]
@@ -215,6 +217,13 @@ class Context:
     def buffer_download(self, d_src, host):
         """Buffer::map(): device -> host copy of a caller-owned device buffer into the numpy array `host`."""
         self._ck(self.lib.skh_buffer_download(self.h, d_src, _p(host), host.nbytes), "skh_buffer_download")
+
+    def host_register(self, host):
+        """page-lock a numpy array that buffer_download will fill (Buffer::map's host mirror)"""
+        self._ck(self.lib.skh_host_register(self.h, _p(host), host.nbytes), "skh_host_register")
+
+    def host_unregister(self, host):
+        self._ck(self.lib.skh_host_unregister(self.h, _p(host)), "skh_host_unregister")
 
     def tonemap(self, d_image, width, height, type_, exposure, gamma):
         e = np.ascontiguousarray(exposure, np.float32)

@@ -2188,6 +2188,23 @@ skh_status skh_buffer_download(skh_context* c, const void* d, void* host, size_t
     return SKH_OK;
 }
 
+skh_status skh_host_register(skh_context* c, void* host, size_t bytes)
+{
+    if (!c || !host || !bytes)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    SKH_TRY(c, hipHostRegister(host, bytes, hipHostRegisterDefault));
+    return SKH_OK;
+}
+skh_status skh_host_unregister(skh_context* c, void* host)
+{
+    if (!c || !host)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    SKH_TRY(c, hipHostUnregister(host));
+    return SKH_OK;
+}
+
 static skh_status detile_to(skh_context* c, const DevBuf& src, void* d_dst)
 {
     k_detile<<<(c->numSlots + 255) / 256, 256, 0, c->stream>>>(src.as<float4>(), c->dTileXY.as<uint32_t>(), c->numSlots, c->tileShift,

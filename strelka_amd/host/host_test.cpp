@@ -191,6 +191,16 @@ int main(int argc, char** argv)
         fprintf(stderr, "init failed: %s\n", hr->lastError().c_str());
         return 5;
     }
+    if (mode == "gpu-tiles")
+    {
+        // the multi-GPU path with the communicator a 1-GPU box can form (world size 1): tile set, gather below the C ABI, scatter
+        unsigned char id[SKH_COMM_ID_BYTES];
+        if (skh_comm_unique_id(id) != SKH_OK || !hr->enableTileSharing(id, 1, 0, 16))
+        {
+            fprintf(stderr, "enableTileSharing failed: %s\n", hr->lastError().c_str());
+            return 9;
+        }
+    }
     Buffer* out = render->createBuffer(BufferDesc{ W, H, BufferFormat::FLOAT4 });
     for (int f = 0; f < frames; ++f)
     {

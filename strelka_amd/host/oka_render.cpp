@@ -809,6 +809,8 @@ HipBuffer::HipBuffer(skh_context* ctx, void* devicePtr, BufferFormat format, uin
 }
 HipBuffer::~HipBuffer()
 {
+    if (mRegistered)
+        skh_host_unregister(mCtx, mRegistered);
     if (mDeviceData)
         skh_buffer_free(mCtx, mDeviceData);
 }
@@ -824,15 +826,72 @@ void HipBuffer::resize(uint32_t width, uint32_t height)
 void* HipBuffer::map()
 {
     const size_t bytes = (size_t)mWidth * mHeight * getElementSize();
-    mHostData.resize(bytes);
+    if (mHostData.size() != bytes || mRegistered != mHostData.data())
+    {
+        // the host mirror is the reference's std::vector (buffer.h:60-88); page-locked once per size so that the copy the caller
+        // asks for after EVERY sub-frame (RenderPass.cpp:441-447) runs at PCIe rate instead of through a staging buffer
+        if (mRegistered)
+            skh_host_unregister(mCtx, mRegistered);
+        mRegistered = nullptr;
+        mHostData.resize(bytes);
+        if (bytes && skh_host_register(mCtx, mHostData.data(), bytes) == SKH_OK)
+            mRegistered = mHostData.data();
+    }
     skh_buffer_download(mCtx, mDeviceData, mHostData.data(), bytes);
     return nullptr;
 }
 
 HipRender::~HipRender()
 {
+    if (mCtx && mGatherBuf)
+        skh_buffer_free(mCtx, mGatherBuf);
     if (mCtx)
         skh_destroy(mCtx);
+}
+
+bool HipRender::enableTileSharing(const void* commId, int worldSize, int rank, uint32_t tileSize)
+{
+    if (!mCtx || worldSize < 1 || rank < 0 || rank >= worldSize)
+        return false;
+    if (worldSize > 1 && !check(skh_comm_init(mCtx, commId, worldSize, rank), "skh_comm_init"))
+        return false;
+    mSharing = true; // (world size 1 keeps the whole path -- tile set, gather, scatter -- minus the sends: what a 1-GPU box can test)
+    mWorld = worldSize;
+    mRank = rank;
+    mTileSize = tileSize;
+    mWidth = mHeight = 0; // the next render() re-derives the tile share
+    return true;
+}
+
+// tiles t = rank (mod world) of the row-major tile list: interleaving spreads expensive image regions over the GPUs
+bool HipRender::applyTiles(uint32_t width, uint32_t height)
+{
+    if (!mSharing)
+        return true;
+    std::vector<std::vector<uint32_t>> perRank(mWorld);
+    uint32_t t = 0;
+    for (uint32_t y = 0; y < height; y += mTileSize)
+        for (uint32_t x = 0; x < width; x += mTileSize, ++t)
+        {
+            perRank[t % mWorld].push_back(x);
+            perRank[t % mWorld].push_back(y);
+        }
+    mMaxTiles = (t + mWorld - 1) / mWorld;
+    const std::vector<uint32_t>& mine = perRank[mRank];
+    if (!check(skh_set_tiles(mCtx, mTileSize, mine.data(), (uint32_t)(mine.size() / 2)), "skh_set_tiles"))
+        return false;
+    if (mRank == 0)
+    {
+        // padding tiles get an origin outside the image: skh_scatter_tiles drops them
+        mAllTileXY.assign((size_t)mWorld * mMaxTiles * 2, std::max(width, height));
+        for (int r = 0; r < mWorld; ++r)
+            std::copy(perRank[r].begin(), perRank[r].end(), mAllTileXY.begin() + (size_t)r * mMaxTiles * 2);
+        if (mGatherBuf)
+            skh_buffer_free(mCtx, mGatherBuf);
+        mGatherBuf = nullptr;
+        return check(skh_buffer_alloc(mCtx, (size_t)mWorld * mMaxTiles * mTileSize * mTileSize * 16, &mGatherBuf), "skh_buffer_alloc");
+    }
+    return true;
 }
 bool HipRender::check(skh_status s, const char* what)
 {
@@ -920,6 +979,7 @@ void HipRender::render(Buffer* output)
     {
         sh.mSubframeIndex = 0;
         sh.mSettingsManager->setAs<bool>("render/pt/isResized", true);
+        applyTiles(width, height);
         check(skh_resize(mCtx, width, height), "skh_resize");
         mWidth = width;
         mHeight = height;
@@ -998,6 +1058,14 @@ void HipRender::render(Buffer* output)
     }
     else if (p.debug == 0)
         check(skh_copy_accum(mCtx, dImage), "skh_copy_accum"); // all spp done: accum -> image (OptixRender.cpp:1022-1043)
+    if (mSharing && p.debug == 0 && enableAccumulation)
+    {
+        // the frame's one collective: every rank's tile accumulators -> rank 0, whose output then holds the whole image
+        check(skh_gather_tiles(mCtx, mMaxTiles, mRank == 0 ? mGatherBuf : nullptr, 0), "skh_gather_tiles");
+        if (mRank == 0)
+            check(skh_scatter_tiles(mCtx, mGatherBuf, mAllTileXY.data(), (uint32_t)(mAllTileXY.size() / 2), mTileSize, dImage, width, height),
+                  "skh_scatter_tiles");
+    }
     if (p.debug != 1)
         check(skh_tonemap(mCtx, dImage, width, height, tonemapperType, p.exposure, gamma), "skh_tonemap");
     output->unmap();

@@ -391,6 +391,7 @@ public:
 private:
     skh_context* mCtx;
     void* mDeviceData = nullptr;
+    void* mRegistered = nullptr; // mHostData's storage while it is page-locked (skh_host_register)
 };
 
 class HipRender : public Render
@@ -413,6 +414,13 @@ public:
     {
         return mCtx;
     }
+    // Multi-GPU (new: the reference is one process on one GPU).  One HipRender per process per GPU; this one renders the pixel
+    // tiles t = rank (mod worldSize) of every frame -- the split is by tile because the accumulator is an order-dependent LDR-space
+    // lerp per pixel (OptixRender.cu:60-78): sharding by samples would change the image -- and after every render() the tile
+    // accumulators of all ranks are gathered to rank 0 below the C ABI (skh_gather_tiles: RCCL sends over xGMI), whose output
+    // buffer then holds the whole frame (the other ranks' buffers hold their own tiles).  commId: 128 bytes from
+    // skh_comm_unique_id on rank 0, handed to every rank by whatever launched the processes.  Call after init(), before render().
+    bool enableTileSharing(const void* commId, int worldSize, int rank, uint32_t tileSize = 32);
 
 private:
     skh_context* mCtx = nullptr;
@@ -424,6 +432,12 @@ private:
     uint32_t mRectLightSamplingMethodPrev = 0, mSppTotalPrev = 0;
     bool mEnableAccumulationPrev = false;
     bool check(skh_status s, const char* what);
+    bool applyTiles(uint32_t width, uint32_t height); // this rank's share of the frame -> skh_set_tiles (multi-GPU)
+    bool mSharing = false;
+    int mWorld = 1, mRank = 0;
+    uint32_t mTileSize = 32, mMaxTiles = 0;
+    std::vector<uint32_t> mAllTileXY; // root: (x0, y0) of every rank's tiles, rank-major, padded to mMaxTiles per rank
+    void* mGatherBuf = nullptr; // root: [world][mMaxTiles][tile^2] float4
     void uploadScene(); // mFrameNumber == 0 block: OptixRender.cpp:876-888
 };
 

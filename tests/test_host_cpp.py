@@ -117,3 +117,17 @@ def test_hiprender_frame_loop_matches_ctypes_path_and_oracle(tmp_path):
     ref = (r / (lum[..., None] + 1)) ** (1 / 2.4)
     assert np.allclose(image[..., :3], ref, rtol=1e-4, atol=1e-6)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_hiprender_tile_sharing_path_reproduces_the_plain_frame_loop(tmp_path):
+    """oka::HipRender::enableTileSharing (INTEGRATION.md section 1): tile share -> skh_set_tiles, skh_gather_tiles below the C ABI
+    after every render(), skh_scatter_tiles into the output on the root.  With the world size a 1-GPU box allows (1) the mapped
+    image and the accumulator must equal the plain frame loop's bit for bit."""
+    a, b = tmp_path / "plain", tmp_path / "tiles"
+    a.mkdir()
+    b.mkdir()
+    run_host(a, "gpu", 5)
+    run_host(b, "gpu-tiles", 5)
+    for f in ("image.bin", "accum.bin"):
+        assert (a / f).read_bytes() == (b / f).read_bytes(), f
