@@ -1,19 +1,19 @@
 #!/bin/bash
-# rocprofv3 passes for one round; run on the GPU box via gpurun.  Usage: tools/profile.sh <tag> [bench args...]
-# Pass 1: --kernel-trace --stats (per-kernel time).  Passes 2/3: --pmc FETCH_SIZE / WRITE_SIZE in their own runs; passes 4/5: SQ counters
-# The PMC passes render 32 spp = one full default batch per launch, so their per-launch bytes match the timed run's launches.
-# (TCC slots do not fit both; never combined with other trace domains).
+# The rocprofv3 evidence of one round; run on the GPU box via gpurun.  Usage: tools/profile.sh <tag> [bench args...]
+#  pass 1  rocprofv3 --kernel-trace --stats around one frame of bench.py               -> per-kernel time
+#  pass 2  bench.py itself (the driver's command), which runs its own rocprofv3 --pmc child passes (FETCH_SIZE | WRITE_SIZE | SQ
+#          counters, each group its own run, never combined with a trace domain) and keeps their output   -> counters + the bench line
+# tools/summarize_profile.py <tag> then turns gpurun_out/prof_<tag>/ into the tracked files under profiles/.
 set -u
-TAG=${1:-r01}; shift || true
+TAG=${1:-r02}; shift || true
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/bench_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --spp 32 "$@" > $OUT/bench_pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --spp 32 "$@" > $OUT/bench_pmc_write.log 2>&1
-# Passes 4/5 (SQ instruction counts and utilisation; each its own --pmc run)
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS --output-format csv -d $OUT/pmc_inst -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --spp 32 "$@" > $OUT/bench_pmc_inst.log 2>&1
-rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_util -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --spp 32 "$@" > $OUT/bench_pmc_util.log 2>&1
-find $OUT -name "*.csv" | head -40
-tail -2 $OUT/bench_trace.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pmc --no-drop-in "$@" > $OUT/bench_trace.log 2>&1
+cd $REPO
+python3 bench.py --steps 3 --warmup 1 --pmc-keep $OUT/pmc --pmc-save $TAG "$@" > $OUT/bench.json 2> $OUT/bench.err
+cp profiles/pmc_k_trace_closest.json $OUT/ 2>/dev/null
+find $OUT -name "*.csv" | head -20
+tail -2 $OUT/bench_trace.log | cut -c1-400
+cat $OUT/bench.json

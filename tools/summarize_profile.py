@@ -2,7 +2,9 @@
 """Turns gpurun_out/prof_<tag>/ (written by tools/profile.sh) into the tracked artefacts under profiles/:
   profiles/<tag>_kernel_stats.csv          rocprofv3 --kernel-trace --stats summary (per-kernel time)
   profiles/<tag>_pmc_hbm.csv               per-kernel FETCH_SIZE / WRITE_SIZE averages from the two --pmc passes
-  profiles/traffic_k_trace_closest.json    HBM bytes per launch of the dominant kernel, read by bench.py
+  profiles/<tag>_pmc_instructions.csv / _pmc_sq_utilisation.csv   SQ counters of the same passes
+  profiles/<tag>_bench.json, profiles/pmc_k_trace_closest.json     the bench line of that run and the counter figures bench.py replays
+                                                                     (tagged as replayed) when it cannot run rocprofv3 itself
 Units/corrections follow /opt/skills/guides (MI355X_MICROARCH.md "HBM", cdna_hip_programming.md section 7):
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) reads, so
 hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  The 2x is calibrated for coalesced streams; a BVH walk issues
@@ -36,7 +38,7 @@ def pmc(dirpath, counter):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -48,8 +50,12 @@ def main():
         lines = [l for l in open(logs) if l.startswith("{")]
         if lines:
             open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w").write(lines[-1])
-    fetch = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
-    write = pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+    for name, out in (("bench.json", f"{tag}_bench.json"), ("pmc_k_trace_closest.json", "pmc_k_trace_closest.json")):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, out))
+    # the counter passes bench.py ran itself (--pmc-keep): pass0 FETCH_SIZE, pass1 WRITE_SIZE, pass2 SQ counters
+    fetch = pmc(os.path.join(src, "pmc", "pass0"), "FETCH_SIZE")
+    write = pmc(os.path.join(src, "pmc", "pass1"), "WRITE_SIZE")
     rows = []
     for k in sorted(set(fetch) | set(write)):
         f = fetch[k][0] / max(1, fetch[k][1]) if k in fetch else 0.0
@@ -59,21 +65,6 @@ def main():
         fo.write("kernel,launches,avg_FETCH_SIZE_KiB,avg_WRITE_SIZE_KiB,hbm_bytes_per_launch=(2*FETCH+WRITE)*1024\n")
         for r in rows:
             fo.write("%s,%d,%.3f,%.3f,%.0f\n" % r)
-    meta = {}
-    plog = os.path.join(src, "bench_pmc_fetch.log")
-    if os.path.exists(plog):
-        lines = [l for l in open(plog) if l.startswith("{")]
-        if lines:
-            b = json.loads(lines[-1])
-            meta = {"workload": b["config"]["workload"], "resolution": b["config"]["resolution"],
-                    "rays_per_launch": b["roofline"].get("rays_per_launch")}
-    for r in rows:
-        if r[0].startswith("k_trace<false, false") or r[0].startswith("k_trace_flat<false, false"):
-            json.dump({"kernel": r[0], "tag": tag, "avg_FETCH_SIZE_KiB": r[2], "avg_WRITE_SIZE_KiB": r[3],
-                       "hbm_bytes_per_launch": int(r[4]), **meta,
-                       "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes, gfx950 FETCH_SIZE x2 correction"},
-                      open(os.path.join(dst, "traffic_k_trace_closest.json"), "w"), indent=1)
-            print("traffic", r)
     print(open(os.path.join(dst, f"{tag}_pmc_hbm.csv")).read())
     sq_summaries(src, dst, tag)
 
@@ -92,25 +83,26 @@ def sq_summaries(src, dst, tag):
                     cnt[k] += 1
         return acc, cnt
 
-    acc, cnt = collect("pmc_inst", "SQ_WAVES")
+    acc, cnt = collect(os.path.join("pmc", "pass2"), "SQ_WAVES")
     if acc:
         with open(os.path.join(dst, f"{tag}_pmc_instructions.csv"), "w") as fo:
-            fo.write("kernel,launches,waves_per_launch,VALU_per_wave,SALU_per_wave,VMEM_per_wave,LDS_per_wave\n")
+            fo.write("kernel,launches,waves_per_launch,VALU_per_wave,SALU_per_wave,SALU_per_VALU\n")
             for k, a in sorted(acc.items()):
                 w = a["SQ_WAVES"]
                 if w and cnt[k]:
-                    fo.write('"%s",%d,%.0f,%.0f,%.0f,%.1f,%.1f\n' % (k, cnt[k], w / cnt[k], a["SQ_INSTS_VALU"] / w, a["SQ_INSTS_SALU"] / w,
-                                                                 a["SQ_INSTS_VMEM"] / w, a["SQ_INSTS_LDS"] / w))
-    acc, cnt = collect("pmc_util", "SQ_BUSY_CYCLES")
+                    fo.write('"%s",%d,%.0f,%.0f,%.0f,%.3f\n' % (k, cnt[k], w / cnt[k], a["SQ_INSTS_VALU"] / w, a["SQ_INSTS_SALU"] / w,
+                                                              a["SQ_INSTS_SALU"] / max(1.0, a["SQ_INSTS_VALU"])))
+    acc, cnt = collect(os.path.join("pmc", "pass2"), "SQ_WAVE_CYCLES")
     if acc:
         with open(os.path.join(dst, f"{tag}_pmc_sq_utilisation.csv"), "w") as fo:
-            fo.write("kernel,launches,SQ_BUSY_CYCLES,SQ_WAVE_CYCLES,SQ_ACTIVE_INST_VALU,SQ_THREAD_CYCLES_VALU,SQ_WAIT_INST_ANY,lanes_per_valu_inst\n")
+            fo.write("kernel,launches,SQ_WAVE_CYCLES,SQ_ACTIVE_INST_VALU,SQ_THREAD_CYCLES_VALU,SQ_WAIT_INST_ANY,lanes_per_valu_inst,wait_inst_any_frac\n")
             for k, a in sorted(acc.items()):
                 n = cnt[k]
                 if n and a["SQ_ACTIVE_INST_VALU"]:
-                    fo.write('"%s",%d,%.4g,%.4g,%.4g,%.4g,%.4g,%.1f\n' % (k, n, a["SQ_BUSY_CYCLES"] / n, a["SQ_WAVE_CYCLES"] / n, a["SQ_ACTIVE_INST_VALU"] / n,
+                    fo.write('"%s",%d,%.4g,%.4g,%.4g,%.4g,%.1f,%.3f\n' % (k, n, a["SQ_WAVE_CYCLES"] / n, a["SQ_ACTIVE_INST_VALU"] / n,
                                                                         a["SQ_THREAD_CYCLES_VALU"] / n, a["SQ_WAIT_INST_ANY"] / n,
-                                                                        a["SQ_THREAD_CYCLES_VALU"] / a["SQ_ACTIVE_INST_VALU"]))
+                                                                        a["SQ_THREAD_CYCLES_VALU"] / a["SQ_ACTIVE_INST_VALU"],
+                                                                        a["SQ_WAIT_INST_ANY"] / max(1.0, a["SQ_WAVE_CYCLES"])))
 
 
 if __name__ == "__main__":
