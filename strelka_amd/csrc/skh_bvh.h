@@ -713,7 +713,9 @@ __global__ void k_permute_u32(const uint32_t* __restrict__ src, const uint32_t* 
 // left.  Tree quality is close to a top-down SAH build (agglomerative clustering minimises the same area measure
 // bottom-up), far better than the radix tree of the plain LBVH.
 // cluster record: lo = {box min, node id as int bits}, hi = {box max, group id as uint bits}
+#ifndef SKH_PLOC_RADIUS
 #define SKH_PLOC_RADIUS 12
+#endif
 #define SKH_PLOC_BLOCK 256
 __global__ void k_ploc_init(const uint32_t* __restrict__ sortedVals, const uint64_t* __restrict__ sortedKeys,
                             const float4* __restrict__ boxLo, const float4* __restrict__ boxHi, uint32_t n,
