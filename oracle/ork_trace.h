@@ -294,13 +294,24 @@ static inline void inflate(Aabb& b)
 }
 static inline bool slab(const Aabb& b, const f3& o, const f3& inv, float tmin, float tmax)
 {
-    float t0x = (b.lo.x - o.x) * inv.x, t1x = (b.hi.x - o.x) * inv.x;
-    float t0y = (b.lo.y - o.y) * inv.y, t1y = (b.hi.y - o.y) * inv.y;
-    float t0z = (b.lo.z - o.z) * inv.z, t1z = (b.hi.z - o.z) * inv.z;
+    // The subtraction (plane - o) rounds at the magnitude of the LARGER operand: with the ray origin far from a small box (object
+    // space of a strongly scaled instance: |o| = |R^-1| |o_world - T|) that absolute error exceeds the 2^-20 relative inflation of the
+    // box and a primitive the brute-force loop accepts could be culled (tools/fuzz_hits.py seed 1735, round 2: 1 ray in 10^8; the
+    // product's quantised boxes are at least one cell thick and were right).  Each plane is therefore moved outward by
+    // (|plane| + |o|) * 2^-16 before the subtraction -- which also covers the noise of the triangle test itself, whose edge
+    // functions are differences of coordinates relative to the origin (a ray aimed at a vertex from 10^4 object sizes away "hits" a
+    // triangle it passes 10^-3 sizes beside: the brute-force loop reports that hit, so the boxes must let the ray through);
+    // tFar keeps its 1 + 2^-20 for the rounding of inv and of the products.
+    const float px = (fmaxf(fabsf(b.lo.x), fabsf(b.hi.x)) + fabsf(o.x)) * 0x1p-16f;
+    const float py = (fmaxf(fabsf(b.lo.y), fabsf(b.hi.y)) + fabsf(o.y)) * 0x1p-16f;
+    const float pz = (fmaxf(fabsf(b.lo.z), fabsf(b.hi.z)) + fabsf(o.z)) * 0x1p-16f;
+    float t0x = ((b.lo.x - px) - o.x) * inv.x, t1x = ((b.hi.x + px) - o.x) * inv.x;
+    float t0y = ((b.lo.y - py) - o.y) * inv.y, t1y = ((b.hi.y + py) - o.y) * inv.y;
+    float t0z = ((b.lo.z - pz) - o.z) * inv.z, t1z = ((b.hi.z + pz) - o.z) * inv.z;
     // NaN-safe ordering (0 * inf): fminf/fmaxf drop NaNs
     const float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
     const float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
-    return tn <= tf * 1.0000002384185791015625f;
+    return tn <= tf * 1.00000095367431640625f; // 1 + 2^-20
 }
 
 struct BvhNode

@@ -54,8 +54,13 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     want, got = o.read_accum()[..., :3].astype(np.float64), ctx.read_accum()[..., :3].astype(np.float64)
     ro, rg = o.stats()["rays_radiance"], ctx.stats()["rays_radiance"]
     ctx.close()
-    l2 = np.sqrt(((got - want) ** 2).sum()) / max(np.sqrt((want ** 2).sum()), 1e-12)
-    frac = (np.abs(got - want).max(-1) > 2e-3 * (np.abs(want).max(-1) + 1e-3)).mean()
+    dev = np.abs(got - want).max(-1)
+    frac = (dev > 2e-3 * (np.abs(want).max(-1) + 1e-3)).mean()
+    # L2 without the two worst pixels: ONE flipped path in a frame this small is allowed, and with the hair BSDF's weights it can be
+    # worth many times the image mean
+    keep = np.ones(dev.shape, bool)
+    keep.reshape(-1)[np.argsort(dev.reshape(-1))[-2:]] = False
+    l2 = np.sqrt((((got - want) ** 2) * keep[..., None]).sum()) / max(np.sqrt((want ** 2).sum()), 1e-12)
     # the bar of tests/test_gpu_parity.py::_image_close, with room for TWO flipped paths in these tiny frames (a few hundred to a few
     # thousand pixels at 1-5 spp: one pixel off is already 0.01-0.5 % of the image)
     ok = np.isfinite(got).all() and l2 < 2e-3 and frac <= max(1e-4, 2.5 / (w * h)) and abs(int(ro) - int(rg)) <= max(2, ro // 2000)
