@@ -31,7 +31,7 @@ def algorithmic_bytes(rays, shadow, nodes, prims, segs, insts):
 
 def cpu_baseline(arr, cam, width, height, spp_total, depth, budget_s=12.0):
     """The CPU oracle (kind "port": the reference has no CPU path, include/render/render.h:9-14 + render.cpp:10-35)
-    timed on this box's host cores over a bounded sample: sub-frame 0, rows added until ~budget_s of work."""
+    timed on this box's host cores over a bounded sample: sub-frames 0, 1, ... in row bands until ~budget_s of work."""
     from strelka_amd import scene as S
     from tests import orklib
 
@@ -50,20 +50,23 @@ def cpu_baseline(arr, cam, width, height, spp_total, depth, budget_s=12.0):
     o.set_scene(arr)
     build_s = time.time() - t0
     o.resize(width, height)
-    p = S.frame_params(cam, width, height, subframe_index=0, spp_total=spp_total, max_depth=depth)
-    rows, y, t_used = 8, 0, 0.0
-    while y < height and t_used < budget_s:
-        y1 = min(height, y + rows)
-        t0 = time.time()
-        o.render_subframe(p, rows=(y, y1))
-        t_used += time.time() - t0
-        y = y1
-        rows = min(rows * 2, 128)
+    rows, t_used, sub, y = 8, 0.0, 0, 0
+    while t_used < budget_s and sub < spp_total:
+        p = S.frame_params(cam, width, height, subframe_index=sub, spp_total=spp_total, max_depth=depth)
+        y = 0
+        while y < height and t_used < budget_s:
+            y1 = min(height, y + rows)
+            t0 = time.time()
+            o.render_subframe(p, rows=(y, y1))
+            t_used += time.time() - t0
+            y = y1
+            rows = min(rows * 2, 128)
+        sub += 1
     st = o.stats()
     rays = st["rays_radiance"] + st["rays_shadow"]
     return {"value": round(rays / t_used / 1e6, 4), "unit": "Mray/s", "cores": int(orklib.load().ork_num_threads()),
             "kind": "port",
-            "sample": f"sub-frame 0 (1 spp), image rows 0..{y} of {height} at {width}x{height}, depth {depth}: "
+            "sample": f"sub-frames 0..{sub - 1} of {spp_total} (1 spp each; the last one up to row {y} of {height}) at {width}x{height}, depth {depth}: "
                       f"{rays} rays in {t_used:.2f} s; oracle BVH build {build_s:.2f} s not included"}
 
 
