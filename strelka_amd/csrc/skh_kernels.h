@@ -1451,8 +1451,12 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
                 const bool textured = hi.type != 2 && (useBase || useNormal);
                 SurfaceTex st;
                 v3 stT = mk3(0.0f);
+                // (a hair material on a triangle mesh reads state.tangent_u too: the vertex tangent, closest_hit.cu:399-400)
+                const bool hairOnMesh = HAIR && mat.type == 3u && hi.type != 2;
                 SurfaceHit sh = hi.type == 2 ? fill_curve(sc, hi, w2o, hprim, hu, ht, rayO, rayD, inside, HAIR ? &stT : nullptr) :
-                                               fill_triangle(hi, w2o, tv, hu, hv, inside, textured ? &st : nullptr);
+                                               fill_triangle(hi, w2o, tv, hu, hv, inside, (textured || hairOnMesh) ? &st : nullptr);
+                if (hairOnMesh)
+                    stT = st.tangent_u;
                 if (textured)
                 {
                     if (useBase)

@@ -227,6 +227,33 @@ def test_single_material_scenes_match_oracle(gpu, kind):
     assert gpu.stats()["rays_radiance"] == o.stats()["rays_radiance"]
 
 
+def test_hair_material_on_a_triangle_mesh_matches_oracle(gpu):
+    """df::chiang_hair_bsdf reads state.tangent_u; on a mesh that is the interpolated vertex tangent sent through the normal
+    transform (closest_hit.cu:399-400), not the curve tangent.  A scene whose meshes all carry a hair material."""
+    rs = np.random.RandomState(4)
+    sc = S.Scene()
+    sc.addMaterial(S.MAT_DIFFUSE, (0.7, 0.7, 0.7))
+    hair = sc.addHairMaterial((0.6, 0.35, 0.15), roughness_r=0.25, roughness_n=0.3, diffuse_weight=0.1, diffuse_tint=(0.5, 0.4, 0.3))
+    room = scenes._add_mesh(sc, *scenes._box_mesh((-1.5, 0, -1.5), (1.5, 2.2, 1.5), inward=True))
+    sc.createInstance(S.INSTANCE_MESH, room, 0, np.eye(4))
+    pos, tris = scenes._grid_mesh(scenes._sphere_fn(rs, 0.05), 24, 16)
+    p = pos.astype(np.float64)
+    if np.einsum("ij,ij->i", p[tris[:, 0]], np.cross(p[tris[:, 1]], p[tris[:, 2]])).sum() < 0:
+        tris = tris[:, ::-1]  # outward winding (the geometric normal decides which side shadow rays start on)
+    m = scenes._add_mesh(sc, pos, tris)
+    sc.createInstance(S.INSTANCE_MESH, m, hair, S.translate((0.0, 0.7, 0.0)) @ S.rotate((0, 0, 1), 0.4) @ S.scale((0.5, 0.6, 0.5)))
+    xf = S.translate((0.0, 2.18, 0.3)) @ S.rotate((1, 0, 0), np.radians(-90))
+    sc.createLight({"type": 0, "xform": xf, "useXform": True, "width": 0.9, "height": 0.6, "color": (1, 1, 1), "intensity": 20.0})
+    cam = S.Camera(fov=50.0)
+    cam.lookAt((0.0, 1.1, 1.45), (0.0, 0.6, 0.0))
+    sc.addCamera(cam)
+    o, want, got = _render_both(gpu, sc, 96, 72, 6, 3)
+    _image_close(got, want)
+    assert gpu.stats()["rays_radiance"] == o.stats()["rays_radiance"]
+    centre = want[30:42, 40:56, :3]
+    assert centre.mean() > 0.01  # the hair-shaded sphere is lit, not absorbed
+
+
 def test_accumulation_is_order_dependent_and_resets(gpu):
     sc = scenes.cornell_box()
     arr = sc.arrays()
