@@ -1948,7 +1948,13 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     uint32_t* fetch = counts + SKH_COUNT_STRIDE * 2 * 130;
     // shadow[b] on a second stream: it depends on shade[b] only, and so does closest[b+1]; each fills the other's tail.  Ray
     // sorting shares scratch buffers between the two and keeps everything on one stream.
-    const bool useOverlap = (c->overlap == 2 || (c->overlap == 1 && NP <= (1u << 23))) && !c->sortBitsClosest && !c->sortBitsShadow && fp.debug != 1;
+    // overlap 1 (default): passes up to 32 M paths -- a rank's share of an N-GPU frame, the one-sub-frame-per-call pattern and its
+    // speculative passes.  Up to 8 M paths both kernels run on reduced grids (16 + 16 waves per CU: +7 % at 2 M paths); above that on
+    // full grids, where the second kernel's blocks simply take the slots the first one's finishing waves leave (1/8 share of a 1080p
+    // frame: 24.26 -> 23.87 ms, 93.3 -> 94.9 % of 1/8 of the full frame; 1/4: 97.0 -> 97.8 %).  The full single-GPU frame (64 M paths
+    // per pass) gains 0.5 % and stays on one stream so that its per-kernel hipEvent spans do not overlap.  overlap 2: always, reduced grids.
+    const bool smallPass = NP <= (1u << 23) || c->overlap == 2;
+    const bool useOverlap = (c->overlap == 2 || (c->overlap == 1 && NP <= (1u << 25))) && !c->sortBitsClosest && !c->sortBitsShadow && fp.debug != 1;
     for (uint32_t s = 0; trace && s < fp.samplesThisLaunch; ++s)
     {
         SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (SKH_COUNT_STRIDE * 2 * 130 + 16 * SKH_FETCH_STRIDE * (fp.maxDepth + 1)), st));
@@ -1967,7 +1973,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
             }
             {
                 SpanGuard g(c, KC_TRACE_CLOSEST);
-                c->gridOverride = useOverlap ? c->smallWavesClosest * (uint32_t)c->numCUs : 0u;
+                c->gridOverride = (useOverlap && smallPass) ? c->smallWavesClosest * (uint32_t)c->numCUs : 0u;
                 if (c->countTraversal)
                     launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b * SKH_COUNT_STRIDE, fetch + 16 * b * SKH_FETCH_STRIDE, permC, hq, ps, nullptr, 0);
                 else
@@ -2000,7 +2006,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                 }
                 {
                     SpanGuard g(c, KC_TRACE_SHADOW, sst);
-                    c->gridOverride = useOverlap ? c->smallWavesShadow * (uint32_t)c->numCUs : 0u;
+                    c->gridOverride = (useOverlap && smallPass) ? c->smallWavesShadow * (uint32_t)c->numCUs : 0u;
                     if (c->countTraversal)
                         launch_trace<true, true>(c, sc, shq, counts + (2 * b + 1) * SKH_COUNT_STRIDE, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, permS, nohq, ps, c->dContrib.as<float>(), N, sst);
                     else
