@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -2303,13 +2304,18 @@ struct RcclApi
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
 };
+static bool rccl_load(RcclApi& api);
 RcclApi* rccl()
 {
+    // (contexts on different GPUs may be driven from different threads: load once)
     static RcclApi api;
-    static bool tried = false;
-    if (tried)
-        return api.lib ? &api : nullptr;
-    tried = true;
+    static std::once_flag once;
+    static bool ok = false;
+    std::call_once(once, [] { ok = rccl_load(api); });
+    return ok ? &api : nullptr;
+}
+static bool rccl_load(RcclApi& api)
+{
     // (a process that uses PyTorch has its librccl.so.1 loaded already: the same soname resolves to that copy)
     for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" })
         if ((api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
@@ -2317,7 +2323,7 @@ RcclApi* rccl()
     if (!api.lib)
     {
         api.why = "librccl.so.1 not found";
-        return nullptr;
+        return false;
     }
 #define SKH_SYM(field, sym) (*(void**)(&api.field) = dlsym(api.lib, sym))
     SKH_SYM(GetUniqueId, "ncclGetUniqueId");
@@ -2333,9 +2339,9 @@ RcclApi* rccl()
     {
         api.why = "librccl.so.1 lacks the point-to-point API";
         api.lib = nullptr;
-        return nullptr;
+        return false;
     }
-    return &api;
+    return true;
 }
 } // namespace
 
