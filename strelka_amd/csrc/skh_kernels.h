@@ -12,7 +12,7 @@
 //   k_collect / k_finalize   per-pixel sample sums, AOVs, LDR-space accumulation (OptixRender.cu:60-78,169-247)
 //
 // Queue layout: SoA, one float/uint plane per field, so that a wave's 64 lanes read 256 contiguous bytes per
-// field.  Traversal stack: per-lane, 24 entries in LDS laid out [entry][lane] (conflict-free), spilling to a
+// field.  Traversal stack: per-lane, 20 entries in LDS laid out [entry][lane] (conflict-free), spilling to a
 // per-thread global overflow area only for pathological depths.
 #pragma once
 #include "skh_bvh.h"
