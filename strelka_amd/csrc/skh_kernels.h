@@ -868,7 +868,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                 d = mk3(rq.plane(3)[ridx], rq.plane(4)[ridx], rq.plane(5)[ridx]);
                 tmin = rq.plane(6)[ridx];
                 tmax = rq.plane(7)[ridx];
-                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                inv = rcp3(d);
                 curInst = 0xffffffffu;
                 sp = 0;
                 cur = sc.wRoot;
