@@ -311,7 +311,8 @@ skh_status skh_gather_tiles(skh_context* ctx, uint32_t max_tiles, void* d_recv /
 /* ---- ray queries against the built accel (the optixTrace call sites), for tests and micro-benchmarks.
  *      rays/hits are HOST arrays. ---- */
 skh_status skh_trace(skh_context* ctx, const skh_ray* rays, uint32_t n_rays, uint32_t mode, skh_hit* hits);
-/* same on caller-owned DEVICE arrays, asynchronous on the context stream, repeated `repeat` times */
+/* same on caller-owned DEVICE arrays (skh_ray / skh_hit records), the traversal repeated `repeat` times (micro-benchmarks);
+ * returns once the hits are in d_hits */
 skh_status skh_trace_device(skh_context* ctx, const void* d_rays, uint32_t n_rays, uint32_t mode, void* d_hits,
                             uint32_t repeat);
 
