@@ -352,7 +352,8 @@ skh_status skh_bsdf_probe(skh_context* ctx, const skh_bsdf_query* queries, uint3
  *   build         build_quality 1|0 (PLOC | Karras radix tree), leaf_max_tris (2), curve_split (2: parameter sub-ranges
  *                 per curve segment), tlas_build 2|1|0 (auto | GPU PLOC over the instance boxes | exact sweep SAH on the host; auto =
  *                 the sweep up to 8192 instances, the GPU beyond), tlas_open (1: TLAS leaves per instance budget),
- *                 tight_instance_boxes 1|0, flatten 0|1 (one world-space tree)
+ *                 tight_instance_boxes 1|0, flatten 0|1 (one world-space tree), wide 4|8 (node width: 64-byte 4-wide nodes | 96-byte
+ *                 8-wide nodes with octant-ordered slots; two-level hierarchy only, measured slower: DESIGN.md section 9)
  * Unknown names and out-of-range values return SKH_INVALID_ARGUMENT. */
 skh_status skh_set_option(skh_context* ctx, const char* name, int64_t value);
 /* what the context's device reports (hipDeviceProp_t): the measurement code prices instruction rates against these */

@@ -237,7 +237,7 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 // Closest hit = smallest t, ties broken by the smaller (instance, primitive) key, ray interval open at both ends:
 // the result does not depend on the BVH or on the traversal order (DESIGN.md "determinism").
 // ------------------------------------------------------------------------------------------------------------
-template <bool ANY_HIT, bool COUNT, bool CURVES>
+template <bool ANY_HIT, bool COUNT, bool CURVES, bool W8 = false>
 __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES)) SKH_TRACE_ATTR
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
             uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, const uint32_t* __restrict__ perm /*optional: sorted order -> queue index*/,
@@ -411,6 +411,85 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
             while (cur >= 0 && cur != SKH_REF_INVALID)
             {
                 SKH_LP(itN++; rayNodes++;)
+                if constexpr (W8)
+                {
+                    // one 96-byte fetch = eight quantised child boxes; slot order is traversal order (Node8, skh_bvh.h): no sorting network
+                    const float4* np = reinterpret_cast<const float4*>(nodes) + 6 * (size_t)cur;
+                    const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3], w4 = np[4], w5 = np[5];
+                    if (COUNT)
+                        tc.nodes++;
+                    SKH_LP(if (!inBlas) tc.segs++;)
+                    const uint32_t ex = __float_as_uint(w0.w);
+                    const float ax = __uint_as_float((ex & 0xffu) << 23) * inv.x, bx = (w0.x - o.x) * inv.x;
+                    const float ay = __uint_as_float((ex & 0xff00u) << 15) * inv.y, by = (w0.y - o.y) * inv.y;
+                    const float az = __uint_as_float((ex & 0xff0000u) << 7) * inv.z, bz = (w0.z - o.z) * inv.z;
+                    const bool px = inv.x >= 0.0f, py = inv.y >= 0.0f, pz = inv.z >= 0.0f;
+                    uint32_t nxw[2], fxw[2], nyw[2], fyw[2], nzw[2], fzw[2];
+                    nxw[0] = __float_as_uint(px ? w1.x : w1.z), nxw[1] = __float_as_uint(px ? w1.y : w1.w);
+                    fxw[0] = __float_as_uint(px ? w1.z : w1.x), fxw[1] = __float_as_uint(px ? w1.w : w1.y);
+                    nyw[0] = __float_as_uint(py ? w2.x : w2.z), nyw[1] = __float_as_uint(py ? w2.y : w2.w);
+                    fyw[0] = __float_as_uint(py ? w2.z : w2.x), fyw[1] = __float_as_uint(py ? w2.w : w2.y);
+                    nzw[0] = __float_as_uint(pz ? w3.x : w3.z), nzw[1] = __float_as_uint(pz ? w3.y : w3.w);
+                    fzw[0] = __float_as_uint(pz ? w3.z : w3.x), fzw[1] = __float_as_uint(pz ? w3.w : w3.y);
+                    int r[8];
+                    r[0] = __float_as_int(w4.x), r[1] = __float_as_int(w4.y), r[2] = __float_as_int(w4.z), r[3] = __float_as_int(w4.w);
+                    r[4] = __float_as_int(w5.x), r[5] = __float_as_int(w5.y), r[6] = __float_as_int(w5.z), r[7] = __float_as_int(w5.w);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                    {
+                        const int h = k >> 2, sft = 8 * (k & 3);
+                        const float nx = fmaf((float)((nxw[h] >> sft) & 0xffu), ax, bx), fx = fmaf((float)((fxw[h] >> sft) & 0xffu), ax, bx);
+                        const float ny = fmaf((float)((nyw[h] >> sft) & 0xffu), ay, by), fy = fmaf((float)((fyw[h] >> sft) & 0xffu), ay, by);
+                        const float nz = fmaf((float)((nzw[h] >> sft) & 0xffu), az, bz), fz = fmaf((float)((fzw[h] >> sft) & 0xffu), az, bz);
+                        const float tnear = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
+                        const float tfar = fminf(fminf(fx, fy), fminf(fz, best.t));
+                        r[k] = tnear <= tfar * SKH_SLAB_SLACK ? r[k] : SKH_REF_INVALID;
+                    }
+                    if (!ANY_HIT)
+                    {
+                        // visit order k <-> slot k ^ oct, oct = signs of the direction: three conditional butterfly stages
+#define SKH_BFLY(a, b, keep)                  \
+    {                                         \
+        const int ta = keep ? r[a] : r[b];    \
+        const int tb = keep ? r[b] : r[a];    \
+        r[a] = ta, r[b] = tb;                 \
+    }
+                        SKH_BFLY(0, 1, px) SKH_BFLY(2, 3, px) SKH_BFLY(4, 5, px) SKH_BFLY(6, 7, px)
+                        SKH_BFLY(0, 2, py) SKH_BFLY(1, 3, py) SKH_BFLY(4, 6, py) SKH_BFLY(5, 7, py)
+                        SKH_BFLY(0, 4, pz) SKH_BFLY(1, 5, pz) SKH_BFLY(2, 6, pz) SKH_BFLY(3, 7, pz)
+#undef SKH_BFLY
+                    }
+                    // the hit children go on the stack last-to-visit first; the first-to-visit one (the last written) is taken back as `cur`
+                    int top = SKH_REF_INVALID;
+                    if (sp + 8 <= SKH_STACK_LDS)
+                    {
+                        int* p = lds + sp * SKH_TRACE_BLOCK;
+#pragma unroll
+                        for (int k = 7; k >= 0; --k)
+                        {
+                            const bool v = r[k] != SKH_REF_INVALID;
+                            *p = r[k]; // (unconditional: what lands above the top is never read)
+                            top = v ? r[k] : top;
+                            p += v ? SKH_TRACE_BLOCK : 0;
+                            sp += v ? 1 : 0;
+                        }
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int k = 7; k >= 0; --k)
+                            if (r[k] != SKH_REF_INVALID)
+                            {
+                                SKH_PUSH(r[k]);
+                                top = r[k];
+                            }
+                    }
+                    if (top != SKH_REF_INVALID)
+                        --sp;
+                    cur = top;
+                }
+                else
+                {
                 // one 64-byte fetch = four quantised child boxes
                 const float4* np = reinterpret_cast<const float4*>(nodes + cur);
                 const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
@@ -495,6 +574,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                         }
                 }
 #undef SKH_CSWAP
+                }
                 // a lane whose node had no hit child takes its next stack entry right here instead of idling until
                 // the whole wave leaves the node loop
                 if (cur == SKH_REF_INVALID && sp > 0)

@@ -138,6 +138,8 @@ struct skh_context
     // nodes 20.69 vs 20.60) and the closest-hit kernel runs 2.9 % faster on it, so 2 = auto (default): the sweep up to 8192 TLAS leaves
     // (<= ~15 ms of host time), the GPU builder beyond
     uint32_t tlasBuild = 2;
+    uint32_t wide = 4; // node width: 4 = Node4 (64 B, children sorted by entry distance in the traversal), 8 = Node8 (96 B, slot order = traversal order;
+                       // two-level hierarchy only, TLAS by the GPU builder, no TLAS opening)
     uint32_t tlasOpen = 1; // TLAS opening: up to tlasOpen x numInstances leaves; 1 = one leaf per instance (default: on the kitchen stand-in 2..16 were 4-9 % slower, more instance entries for no fewer nodes)
     uint32_t leafMaxTris = 2; // measured on MI355X: 2 beats 1, 3, 4, 6, 8 (the kernel is ALU bound, wasted triangle tests cost more than extra nodes)
     uint32_t buildQuality = 1; // 0: Karras radix tree (fastest build), 1: PLOC clustering (SAH-class quality)
@@ -271,7 +273,7 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
         return s;
     if ((s = dev_alloc(c, out.groupRoot, sizeof(int) * (size_t)std::max(1u, nGroups))) != SKH_OK)
         return s;
-    if ((s = dev_alloc(c, out.nodes, sizeof(Node4) * ((size_t)std::max(1u, n) + 1))) != SKH_OK)
+    if ((s = dev_alloc(c, out.nodes, (c->wide == 8 ? sizeof(Node8) : sizeof(Node4)) * ((size_t)std::max(1u, n) + 1))) != SKH_OK)
         return s;
     if ((s = dev_alloc(c, out.sortedVals, sizeof(uint32_t) * (size_t)std::max(1u, n))) != SKH_OK)
         return s;
@@ -470,10 +472,14 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
         int cur = 0;
         while (he == hipSuccess && cnt > 0)
         {
-            k_collapse4<<<(cnt + B - 1) / B, B, 0, st>>>(q[cur].as<CollapseItem>(), cnt, childL.as<int>(), childR.as<int>(), nodeSize.as<int>(),
-                                                        nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n, leafMax, out.nodes.as<Node4>(),
-                                                        ctr.as<uint32_t>(), q[cur ^ 1].as<CollapseItem>(), ctr.as<uint32_t>() + 1,
-                                                        leafOrder.as<uint32_t>());
+            if (c->wide == 8)
+                k_collapse<8><<<(cnt + B - 1) / B, B, 0, st>>>(q[cur].as<CollapseItem>(), cnt, childL.as<int>(), childR.as<int>(), nodeSize.as<int>(),
+                                                               nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n, leafMax, out.nodes.p, ctr.as<uint32_t>(),
+                                                               q[cur ^ 1].as<CollapseItem>(), ctr.as<uint32_t>() + 1, leafOrder.as<uint32_t>());
+            else
+                k_collapse<4><<<(cnt + B - 1) / B, B, 0, st>>>(q[cur].as<CollapseItem>(), cnt, childL.as<int>(), childR.as<int>(), nodeSize.as<int>(),
+                                                               nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n, leafMax, out.nodes.p, ctr.as<uint32_t>(),
+                                                               q[cur ^ 1].as<CollapseItem>(), ctr.as<uint32_t>() + 1, leafOrder.as<uint32_t>());
             he = hipMemcpyAsync(hctr, ctr.p, sizeof(hctr), hipMemcpyDeviceToHost, st);
             if (he == hipSuccess)
                 he = hipStreamSynchronize(st);
@@ -660,7 +666,7 @@ static int tlas_sah_build(const std::vector<HostBox>& boxes, const std::vector<u
         else
             bin[t.parent].right = ref;
     }
-    // collapse the binary tree into 4-wide nodes (same greedy rule as k_collapse4)
+    // collapse the binary tree into 4-wide nodes (same greedy rule as k_collapse<4>)
     struct Item
     {
         int bin, out;
@@ -1201,6 +1207,11 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     }
     const bool usePloc = (flags & SKH_BUILD_SAH) != 0 || c->buildQuality != 0;
     const auto t0 = std::chrono::steady_clock::now();
+    if (c->flatten && c->wide == 8)
+    {
+        c->err = "skh_build_accel: wide = 8 is implemented for the two-level hierarchy only (flatten = 0)";
+        return SKH_INVALID_ARGUMENT;
+    }
     if (c->flatten)
     {
         const skh_status fs = build_world(c, usePloc);
@@ -1343,8 +1354,8 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     uint32_t nValidHost = 0;
     for (uint32_t i = 0; i < nInst; ++i)
         nValidHost += valid[i] ? 1u : 0u;
-    const bool tlasOnGpu = c->tlasBuild == 1 || (c->tlasBuild == 2 && nValidHost > 8192u);
-    if (nInst > 0 && tlasOnGpu && c->tlasOpen <= 1)
+    const bool tlasOnGpu = c->tlasBuild == 1 || (c->tlasBuild == 2 && nValidHost > 8192u) || c->wide == 8;
+    if (nInst > 0 && tlasOnGpu && (c->tlasOpen <= 1 || c->wide == 8))
     {
         // ---- TLAS on the GPU: the same PLOC + 4-wide collapse that builds the BLASes, over the instance boxes.  Which instances
         //      take part is known on the host without reading anything back: a finite inverse and a non-empty BLAS. ----
@@ -1877,6 +1888,13 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
         else
             k_trace_flat<ANY, COUNT, false><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib,
                                                                                                 contribStride, ovf, sd);
+    }
+    else if (c->wide == 8)
+    {
+        if (c->nSegs)
+            k_trace<ANY, COUNT, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride, ovf, sd);
+        else
+            k_trace<ANY, COUNT, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride, ovf, sd);
     }
     else if (c->nSegs)
         k_trace<ANY, COUNT, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride,
@@ -2740,6 +2758,13 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         c->subframeBatch = (uint32_t)value;
         if (c->width)
             return alloc_frame(c);
+    }
+    else if (n == "wide")
+    {
+        if (value != 4 && value != 8)
+            return SKH_INVALID_ARGUMENT;
+        c->wide = (uint32_t)value;
+        c->accelBuilt = false;
     }
     else if (n == "flatten")
     {
