@@ -81,7 +81,7 @@ struct skh_context
     DevBuf dTexels, dTexDesc, dSegBound, dScatterXY, dRaygenBase;
     uint32_t raygenBlocksPerSub = 0, raygenValidPerSub = 0;
     uint32_t nTextures = 0;
-    bool hasHairMaterial = false;
+    bool hasHairMaterial = false; // selects the k_shade build that carries df::chiang_hair_bsdf
     // Speculative sub-frame batching for the reference's call pattern (one render() per sub-frame, RenderPass.cpp:441-447): once two
     // consecutive calls continue the same frame (same parameters, subframe_index + 1), the next call traces several sub-frames
     // ahead in ONE wavefront pass and the calls after it only apply their accumulation step to the radiances already in the path
@@ -94,7 +94,7 @@ struct skh_context
         skh_frame_params last; // the previous call's parameters
         bool haveLast = false;
     } spec;
-    uint32_t speculateMax = 8; // option "speculate": most sub-frames traced ahead in one pass (0 / 1 = off).  8: a pass stays below ~25 ms at 1080p // selects the k_shade build that carries df::chiang_hair_bsdf
+    uint32_t speculateMax = 8; // option "speculate": most sub-frames traced ahead in one pass (0 / 1 = off).  8: a pass stays below ~25 ms at 1080p
     DevBuf dTriNodes, dTris, dSegNodes, dSegs, dSegPrim, dTlasNodes, dTlasInst, dDevInst, dTravInst;
     int tlasRoot = SKH_REF_INVALID;
     bool accelBuilt = false;
