@@ -35,15 +35,7 @@ def cpu_baseline(arr, cam, width, height, spp_total, depth, budget_s=12.0):
     from strelka_amd import scene as S
     from tests import orklib
 
-    # threads = the CPUs this process may really use: affinity mask AND the cgroup CPU quota (a container that sees 256
-    # hardware threads but is throttled to 16 CPUs runs 128 OpenMP threads slower than 16)
-    usable = len(os.sched_getaffinity(0))
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            usable = max(1, min(usable, -(-int(quota) // int(period))))
-    except (OSError, ValueError):
-        pass
+    usable = orklib.usable_cpus()  # affinity mask AND cgroup CPU quota
     orklib.load().ork_set_num_threads(usable)
     o = orklib.new_context()
     t0 = time.time()

@@ -106,11 +106,26 @@ HIT_DTYPE = np.dtype([("t", np.float32), ("instance_id", np.uint32), ("prim_id",
                       ("v", np.float32)])
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask AND the cgroup CPU quota (a GPU box shows 256 hardware threads to a
+    container throttled to 16 CPUs: 256 OpenMP threads there run several times slower than 16)."""
+    usable = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            usable = max(1, min(usable, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return usable
+
+
 def load():
     global _lib
     if _lib is None:
         build()
         lib = C.CDLL(LIB)
+        if not os.environ.get("OMP_NUM_THREADS"):
+            lib.ork_set_num_threads(usable_cpus())
         lib.ork_create.restype = C.c_void_p
         lib.ork_destroy.argtypes = [C.c_void_p]
         lib.ork_mis_weight.restype = C.c_float
