@@ -1,6 +1,7 @@
 """Randomised render parity: small procedural scenes (all stand-in kinds, random extra instance transforms, optional textures),
 random resolution / spp / depth / frame parameters; the GPU image must match the oracle's within the render tolerance and the
 two sides must trace (almost) the same number of rays.  usage: python tools/fuzz_render.py <first seed> <last seed>  (GPU box)."""
+import os
 import sys
 import time
 
@@ -17,6 +18,8 @@ t0 = time.time()
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     rs = np.random.RandomState(seed)
     kind = seed % 7
+    if os.environ.get("SKH_FUZZ_KIND") and kind != int(os.environ["SKH_FUZZ_KIND"]):
+        continue  # (one family only: chasing an event)
     if kind == 5:
         sc = scenes.light_zoo(seed=seed, with_rect=bool(seed % 2))  # sphere + disk lights (+ rect + distant)
     elif kind == 6:
