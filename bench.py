@@ -66,7 +66,9 @@ PMC_RESULT = None  # filled by live_pmc() before this process touches the GPU
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),  # TCC: the two do not fit one pass (MI355X_MICROARCH.md "rocprofv3 PMC slots")
               ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES",
                "SQ_WAIT_INST_ANY"))
-CLOSEST = "void skh::k_trace<false, false"  # the timed build of the closest-hit kernel (the counting pass runs <false, true, ..>)
+# the three hot kernels of a frame (timed builds; the counting pass runs k_trace<.., true, ..>)
+KERNELS = {"closest": "void skh::k_trace<false, false", "shadow": "void skh::k_trace<true, false", "shade": "void skh::k_shade<"}
+CLOSEST = KERNELS["closest"]
 
 
 def _pmc_per_launch(outdir, kernel_prefix):
@@ -83,11 +85,11 @@ def _pmc_per_launch(outdir, kernel_prefix):
     return {c: sum(d.values()) / len(d) for c, d in per.items() if d}
 
 
-def pmc_figures(c, rays_per_launch, source):
-    """Counter averages of one launch -> the figures the roofline block quotes.  hbm bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB:
+def pmc_figures(c, units_per_launch):
+    """Counter averages of one launch -> the figures a roofline block quotes.  hbm bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB:
     gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md "HBM"); calibrated on coalesced 16-byte
     per lane streams, which is what a node / triangle fetch is per lane -- but lanes scatter, so read the absolute as +-2x."""
-    out = {"source": source, "rays_per_launch": rays_per_launch}
+    out = {"rays_per_launch": units_per_launch}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         out["hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
         out["FETCH_SIZE_KiB"], out["WRITE_SIZE_KiB"] = c["FETCH_SIZE"], c["WRITE_SIZE"]
@@ -101,18 +103,28 @@ def pmc_figures(c, rays_per_launch, source):
     return out
 
 
+def under_profiler():
+    """True when this process itself runs under rocprofv3 (its tool library is preloaded): nesting profilers is refused."""
+    return any(k.startswith(("ROCP_", "ROCPROFILER_", "ROCPROF_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
 def live_pmc(argv, spp, keep_dir=None):
-    """The HBM-side and SQ counters of k_trace<closest>, measured NOW: this process (which has not touched the GPU yet) runs
+    """The HBM-side and SQ counters of the three hot kernels, measured NOW: this process (which has not touched the GPU yet) runs
     `rocprofv3 --pmc <counters> -- python3 bench.py --pmc-child ...` once per counter group as child processes -- one frame of
-    one full batch each, so a launch there is a launch of the timed run -- and averages the kernel's dispatches.  Only --pmc,
-    never combined with a trace domain.  Returns None when rocprofv3 is missing or a pass fails (the committed profile is
-    quoted instead, with its tag as the source)."""
+    one full batch each, so a launch there is a launch of the timed run -- and averages each kernel's dispatches.  Only --pmc,
+    never combined with a trace domain; the children load the scene the parent cached and inherit no profiler variables.
+    Returns None (and says why on stderr, keeping the logs) when rocprofv3 is missing, this process is itself profiled, or a
+    pass fails: the committed profile is quoted instead and the record says "roofline_replayed"."""
     import shutil
     import subprocess
     import tempfile
 
     rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not rocprof:
+        sys.stderr.write("[bench] live counters: rocprofv3 not found\n")
+        return None
+    if under_profiler():
+        sys.stderr.write("[bench] live counters: this process already runs under a profiler -- not nesting\n")
         return None
     skip = {"--steps", "--warmup", "--spp", "--cpu-budget", "--gpus", "--pmc-keep", "--pmc-save"}
     child, it = [], iter(argv)
@@ -126,23 +138,38 @@ def live_pmc(argv, spp, keep_dir=None):
     child += ["--pmc-child", "--steps", "1", "--warmup", "0", "--spp", str(min(spp, 32)), "--no-cpu-baseline", "--no-pmc", "--no-drop-in"]
     root = os.path.abspath(keep_dir) if keep_dir else tempfile.mkdtemp(prefix="skh_pmc_", dir="/tmp")  # (absolute: the children run in /tmp)
     os.makedirs(root, exist_ok=True)
-    counters, rays = {}, None
-    t0 = time.time()
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "LD_PRELOAD"))}
+    env["TMPDIR"] = "/tmp"
+    counters = {k: {} for k in KERNELS}
+    units, seconds = {}, []
+
+    def fail(why):
+        sys.stderr.write("[bench] live counters failed (%s); logs kept in %s\n" % (why, root))
+        return None
+
+    t_all = time.time()
     for k, group in enumerate(PMC_PASSES):
         outdir = os.path.join(root, "pass%d" % k)
         cmd = [rocprof, "--pmc", *group, "--output-format", "csv", "-d", outdir, "--", sys.executable, os.path.abspath(__file__)] + child
+        t0 = time.time()
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
-        except (OSError, subprocess.TimeoutExpired):
-            return None
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+        except (OSError, subprocess.TimeoutExpired) as e:
+            return fail("pass %d: %s" % (k, type(e).__name__))
+        seconds.append(round(time.time() - t0, 1))
         open(os.path.join(root, "pass%d.log" % k), "w").write(r.stdout[-4000:] + r.stderr[-4000:])
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        got = _pmc_per_launch(outdir, CLOSEST)
-        if r.returncode != 0 or not lines or not all(g in got for g in group):
-            return None
-        rays = json.loads(lines[-1])["roofline"]["rays_per_launch"]
-        counters.update(got)
-    fig = pmc_figures(counters, rays, "live: rocprofv3 --pmc child passes of this run (%s), %.0f s" % (" | ".join(" ".join(g) for g in PMC_PASSES), time.time() - t0))
+        if r.returncode != 0 or not lines:
+            return fail("pass %d: exit code %d" % (k, r.returncode))
+        line = json.loads(lines[-1])
+        for name, prefix in KERNELS.items():
+            got = _pmc_per_launch(outdir, prefix)
+            if not all(g in got for g in group):
+                return fail("pass %d: no %s counters for %s" % (k, "/".join(group), name))
+            counters[name].update(got)
+            units[name] = line["roofline"]["kernels"][name]["units_per_launch"]
+    source = "live: rocprofv3 --pmc child passes of this run (%s): %s s" % (" | ".join(" ".join(g) for g in PMC_PASSES), " + ".join(str(x) for x in seconds))
+    fig = {"source": source, "seconds": round(time.time() - t_all, 1), "kernels": {k: pmc_figures(counters[k], units[k]) for k in KERNELS}}
     if not keep_dir:
         shutil.rmtree(root, ignore_errors=True)
     return fig
@@ -150,14 +177,15 @@ def live_pmc(argv, spp, keep_dir=None):
 
 def committed_pmc(workload, resolution):
     """Fallback when the counters cannot be collected in this run: the last committed profile of the same workload."""
-    path = os.path.join(ROOT, "profiles", "pmc_k_trace_closest.json")
+    path = os.path.join(ROOT, "profiles", "pmc_kernels.json")
     try:
         j = json.load(open(path))
     except (OSError, ValueError):
         return None
     if j.get("workload") != workload or j.get("resolution") != resolution:
         return None
-    j["source"] = "replayed from profiles/pmc_k_trace_closest.json (tag %s), not measured in this run" % j.get("tag")
+    j["source"] = "replayed from profiles/pmc_kernels.json (tag %s), not measured in this run" % j.get("tag")
+    j["replayed"] = True
     return j
 
 
@@ -180,6 +208,7 @@ def maybe_self_launch(args, argv):
         import subprocess
 
         env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's peer buffers need it on this driver
         return subprocess.run(launch_command(args.gpus, argv), env=env).returncode
     if int(ws) != args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws}: launch with --nproc-per-node {args.gpus} or pass --gpus {ws}\n")
@@ -219,6 +248,68 @@ def drop_in_leg(ctx, params, W, H, spp, torch, dev):
             "frame (option speculate), images bit-identical", **res}
 
 
+SCENE_RECIPES = {
+    # name: (generator call, workload line)
+    "kitchen": (lambda scenes: scenes.kitchen_standin(),
+                "kitchen stand-in (SURVEY 8d C3): %d unique triangles, %d instances of %d meshes, "
+                "4 rect + 1 distant light, 60/25/10/5 %% diffuse/glossy/metal/glass"),
+    # the shape HdStrelka's bake hands over: one mesh per instance (createMesh per instance, RenderPass.cpp:126-129,252-257):
+    # the same room, layout, lights, materials and triangle budget, 2000 unique meshes instead of 150 shared ones
+    "kitchen_unshared": (lambda scenes: scenes.kitchen_standin(n_meshes=2000, n_instances=2000, tri_lo=200, tri_hi=5000, target_tris=1.72e6),
+                         "kitchen stand-in WITHOUT mesh sharing (HdStrelka's per-instance meshes): %d unique triangles, %d instances of %d meshes, "
+                         "4 rect + 1 distant light, 60/25/10/5 %% diffuse/glossy/metal/glass"),
+    "hair": (lambda scenes: scenes.hair_standin(), "hair stand-in (SURVEY 8d C5): %d scalp triangles, %d instances of %d meshes + 100 k strands"),
+    "cornell": (lambda scenes: scenes.cornell_box(), "cornell box (C2): %d triangles, %d instances of %d meshes"),
+}
+
+
+def scene_cache_path(name):
+    """/tmp/skh_bench_<name>_<hash of the generator's source>.skscene: the procedural scenes take tens of seconds of numpy to
+    generate; the counter child passes and the ranks of an N-GPU run load the dump one process wrote (strelka_amd/scene_io.py)."""
+    import hashlib
+
+    h = hashlib.sha1()
+    for f in ("strelka_amd/scenes.py", "strelka_amd/scene.py", "strelka_amd/scene_io.py"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return os.path.join("/tmp", "skh_bench_%s_%s_%d.skscene" % (name, h.hexdigest()[:12], os.getuid()))
+
+
+def load_workload(name, make=True):
+    """(scene, workload line).  Procedural scenes go through the /tmp cache (make=False: wait for another process to write it)."""
+    from strelka_amd import scene_io, scenes
+
+    if name in SCENE_RECIPES:
+        gen, line = SCENE_RECIPES[name]
+        path = scene_cache_path(name)
+        if not os.path.exists(path):
+            if make:
+                sc = gen(scenes)
+                tmp = "%s.tmp.%d" % (path, os.getpid())
+                scene_io.save_scene(tmp, sc.arrays(), sc.getCamera())
+                os.replace(tmp, path)
+            else:
+                t0 = time.time()
+                while not os.path.exists(path):
+                    if time.time() - t0 > 600:
+                        raise RuntimeError("scene cache %s did not appear" % path)
+                    time.sleep(0.2)
+        sc = scene_io.load_scene(path)
+    elif name.endswith((".gltf", ".glb")):
+        from strelka_amd import gltf
+
+        sc, line = gltf.load_gltf(name), os.path.basename(name) + ": %d triangles, %d instances of %d meshes"
+    else:  # a flat dump of a real bake (strelka_amd/scene_io.py, INTEGRATION.md section 4)
+        sc, line = scene_io.load_scene(name), os.path.basename(name) + ": %d triangles, %d instances of %d meshes"
+    arr = sc.arrays()
+    return sc, arr, line % (len(arr["indices"]) // 3, len(arr["instances"]), len(arr["meshes"]))
+
+
+def shade_bytes(rays, next_rays, shadow_rays):
+    """k_shade, algorithmic: ray 36 r + hit record 32 r + path state 32 r + 32 w per ray; per surface hit (every ray counted as
+    one: upper bound) instance 64 + 64, shading triangle 96, material 64; 36 w per continuation ray, 36 + 12 w per shadow ray."""
+    return rays * (36 + 32 + 64) + rays * (128 + 96 + 64) + next_rays * 36 + shadow_rays * 48
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,7 +320,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--tile", type=int, default=32)
-    ap.add_argument("--scene", default="kitchen", help="kitchen | cornell | hair | path to a .skscene dump or a .gltf file")
+    ap.add_argument("--scene", default="kitchen", help="kitchen | kitchen_unshared | cornell | hair | path to a .skscene dump or a .gltf file")
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to skh_set_option")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -237,19 +328,24 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc child passes (roofline quotes the committed profile)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-keep", default=None, help="keep the rocprofv3 output of the child passes in this directory")
-    ap.add_argument("--pmc-save", default=None, metavar="TAG", help="write the live counter figures to profiles/pmc_k_trace_closest.json under this tag")
+    ap.add_argument("--pmc-save", default=None, metavar="TAG", help="write the live counter figures to profiles/pmc_kernels.json under this tag")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the one-render()+map()-per-sub-frame leg")
     args = ap.parse_args()
 
     rc = maybe_self_launch(args, sys.argv[1:])
     if rc is not None:
         sys.exit(rc)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before anything touches the GPU (RCCL peer buffers)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # the scene: generated (or loaded from the /tmp cache) before the GPU is touched; one process of a job writes the cache
+    t_scene = time.time()
+    sc, arr, workload = load_workload(args.scene, make=(rank == 0))
+    t_scene = time.time() - t_scene
     global PMC_RESULT
     if world == 1 and not args.no_pmc and not args.pmc_child:
         PMC_RESULT = live_pmc(sys.argv[1:], args.spp, args.pmc_keep)  # child processes; nothing here has touched the GPU yet
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
 
     dist = None
@@ -267,32 +363,9 @@ def main():
             dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
 
-    from strelka_amd import build, capi, scene as S, scenes, tiles
+    from strelka_amd import build, capi, scene as S, tiles
 
     build.build()
-    if args.scene == "kitchen":
-        sc = scenes.kitchen_standin()
-        workload = ("kitchen stand-in (SURVEY 8d C3): %d unique triangles, %d instances of %d meshes, "
-                    "4 rect + 1 distant light, 60/25/10/5 %% diffuse/glossy/metal/glass")
-    elif args.scene == "hair":
-        sc = scenes.hair_standin()
-        workload = "hair stand-in (SURVEY 8d C5): %d scalp triangles, %d instances of %d meshes + 100 k strands"
-    elif args.scene == "cornell":
-        sc = scenes.cornell_box()
-        workload = "cornell box (C2): %d triangles, %d instances of %d meshes"
-    else:
-        # a flat dump of a real bake (strelka_amd/scene_io.py) or a glTF file
-        from strelka_amd import scene_io
-
-        if args.scene.endswith((".gltf", ".glb")):
-            from strelka_amd import gltf
-
-            sc = gltf.load_gltf(args.scene)
-        else:
-            sc = scene_io.load_scene(args.scene)
-        workload = os.path.basename(args.scene) + ": %d triangles, %d instances of %d meshes"
-    arr = sc.arrays()
-    workload = workload % (len(arr["indices"]) // 3, len(arr["instances"]), len(arr["meshes"]))
     cam = sc.getCamera()
     W, H = args.width, args.height
 
@@ -307,6 +380,7 @@ def main():
     ctx.set_tiles(args.tile, my_tiles if world > 1 else None)
     ctx.resize(W, H)
     build_ms = ctx.stats()["ms_build"]
+    baked = ctx.baked(len(arr["instances"]))
     params = S.frame_params(cam, W, H, subframe_index=0, samples_this_launch=1, spp_total=args.spp, max_depth=args.depth)
 
     max_tiles = tiles.max_tiles_per_rank(W, H, args.tile, world)
@@ -325,17 +399,19 @@ def main():
 
     # The frame's one collective runs BELOW the C ABI (skh_gather_tiles: grouped RCCL sends into the root on the renderer's own
     # stream); torch.distributed only carries the 128-byte communicator id, the barrier and the timing reduction.  If RCCL cannot
-    # build the communicator (e.g. several ranks sharing one GPU in the 1-GPU tests) every rank agrees to fall back to
-    # torch.distributed's gather, and the JSON line says which one ran.
-    gather_kind = "torch.distributed gather"
-    if world > 1 and os.environ.get("SKH_GATHER", "rccl" if dist.get_backend() == "nccl" else "torch") == "rccl":
+    # build the communicator (several ranks sharing one GPU in the 1-GPU tests) every rank agrees to fall back to
+    # torch.distributed's gather and the record says so; with the nccl backend (one rank per GPU: the real thing) that
+    # fall-back is an ERROR -- the run ends with a non-zero exit code instead of timing a different collective.
+    gather_kind, rccl_nranks, gather_error = ("none" if world == 1 else "torch.distributed gather"), 0, None
+    want_rccl = world > 1 and os.environ.get("SKH_GATHER", "rccl" if dist.get_backend() == "nccl" else "torch") == "rccl"
+    if want_rccl:
         idt = torch.zeros(128, dtype=torch.uint8)
         ok = 1
         if rank == 0:
             try:
                 idt = torch.from_numpy(capi.Context.comm_unique_id().copy())
-            except capi.SkhError:
-                ok = 0
+            except capi.SkhError as e:
+                ok, gather_error = 0, str(e)
         cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
         idt = idt.to(cdev)
         dist.broadcast(idt, src=0)
@@ -344,14 +420,23 @@ def main():
                 raise capi.SkhError("no communicator id")
             ctx.comm_init(idt.cpu().numpy(), world, rank)
         except capi.SkhError as e:
-            ok = 0
+            ok, gather_error = 0, str(e)
             sys.stderr.write(f"[bench] rank {rank}: {e}\n")
         okt = torch.tensor([ok], dtype=torch.int32, device=cdev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         if int(okt.item()) == 1:
             gather_kind = "skh_gather_tiles: RCCL send/recv below the C ABI"
+            rccl_nranks = ctx.comm_info()[2]  # what RCCL itself reports (ncclCommCount)
         else:
             ctx.comm_destroy()
+            if dist.get_backend() == "nccl" and not os.environ.get("SKH_ALLOW_GATHER_FALLBACK"):
+                if rank == 0:
+                    sys.stderr.write("[bench] --gpus %d on the nccl backend, but the RCCL communicator below the C ABI could not be formed (%s): "
+                                     "refusing to time torch.distributed's gather instead (SKH_ALLOW_GATHER_FALLBACK=1 overrides)\n" % (world, gather_error))
+                dist.barrier()
+                dist.destroy_process_group()
+                ctx.close()
+                sys.exit(3)
     use_skh_gather = gather_kind.startswith("skh_gather_tiles")
 
     def frame():
@@ -370,13 +455,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- untimed counting pass: exact traversal counters for the algorithmic-bytes figure (identical every frame,
-    #      the renderer is deterministic) ----
-    ctx.set_option("count_traversal", 1)
-    ctx.reset_stats()
-    ctx.render_subframes(params, args.spp, None)
-    cst = ctx.stats()
-    ctx.set_option("count_traversal", 0)
+    # ---- untimed counting pass: exact traversal counters for the algorithmic-bytes figures (identical every frame, the
+    #      renderer is deterministic); rank 0 only -- they describe rank 0's kernels ----
+    cst = None
+    if rank == 0:
+        ctx.set_option("count_traversal", 1)
+        ctx.reset_stats()
+        ctx.render_subframes(params, args.spp, None)
+        cst = ctx.stats()
+        ctx.set_option("count_traversal", 0)
     for _ in range(args.warmup):
         frame()
     ctx.set_option("timing", 1)
@@ -385,18 +472,29 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame()
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0  # this rank alone: render + its part of the gather
     barrier()
     dt = time.perf_counter() - t0
     st = ctx.stats()
     rays_local = st["rays_radiance"] + st["rays_shadow"]
+    per_rank = None
     if world > 1:
         rdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
         tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        rr = torch.tensor([float(rays_local)], dtype=torch.float64, device=rdev)
-        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
-        rays_total = float(rr.item())
+        mine = torch.tensor([dt_own, float(rays_local), float(len(my_tiles))], dtype=torch.float64, device=rdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = np.array([t.cpu().numpy() for t in allr])
+        rays_total = float(allr[:, 1].sum())
+        K_ = max(1, args.steps)
+        ms = allr[:, 0] / K_ * 1e3
+        per_rank = {"ms_per_step": {"min": round(float(ms.min()), 3), "mean": round(float(ms.mean()), 3), "max": round(float(ms.max()), 3),
+                                    "all": [round(float(x), 3) for x in ms]},
+                    "rays_imbalance_max_over_mean": round(float(allr[:, 1].max() / max(1.0, allr[:, 1].mean())), 4),
+                    "tiles": [int(x) for x in allr[:, 2]]}
     else:
         rays_total = float(rays_local)
 
@@ -405,45 +503,77 @@ def main():
         drop_in = drop_in_leg(ctx, params, W, H, args.spp, torch, dev)
     if rank == 0:
         K = max(1, args.steps)
-        # ---- roofline of the dominant kernel, k_trace<closest> ----
-        # Three figures, none of which can exceed 1:
+        # ---- rooflines of the three hot kernels.  Per kernel, from this run's counters and hipEvent times:
         #   frac (= frac_hbm)   HBM-side bytes per launch from the TCC counters / live launch time / 8 TB/s.  FETCH_SIZE counts
         #                       Infinity-Cache hits too (MI355X_MICROARCH.md "HBM"), so this is an UPPER bound on HBM use.
         #   frac_valu_issue     VALU wave-instructions per second / (SIMDs x clock / 2): a wave64 VALU op issues over 2 cycles.
         #   cached_bw           SURVEY 8(d)'s algorithmic bytes / time: what L2 + Infinity Cache + HBM deliver together; it is
-        #                       NOT divided by the HBM peak (two thirds of those bytes never reach HBM).
-        bytes_closest = algorithmic_bytes(cst["rays_radiance"], False, cst["nodes_visited"][0], cst["prims_tested"][0],
-                                          cst["segs_tested"][0], cst["instances_entered"][0])
-        launches = max(1, st["launches_trace_closest"])
-        avg_ms = st["ms_trace_closest"] / launches
-        bytes_per_launch = bytes_closest * K / launches
-        cached = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        rpl = cst["rays_radiance"] * K / launches
+        #                       NOT divided by the HBM peak (most of those bytes never reach HBM).
         pmc = PMC_RESULT if PMC_RESULT else committed_pmc(workload, f"{W}x{H}")
-        traffic = achieved = frac = None
-        valu = None
-        if pmc and pmc.get("hbm_bytes_per_launch") and avg_ms > 0:
-            scale = rpl / pmc["rays_per_launch"] if pmc.get("rays_per_launch") else 1.0
-            traffic = int(pmc["hbm_bytes_per_launch"] * scale)
-            achieved = traffic / (avg_ms * 1e-3) / 1e9
-            frac = achieved / HBM_PEAK_GBS
-        if pmc and pmc.get("valu_per_launch") and avg_ms > 0:
-            scale = rpl / pmc["rays_per_launch"] if pmc.get("rays_per_launch") else 1.0
-            info = ctx.device_info()
-            clock_ghz = info["clock_khz"] / 1e6  # device maximum engine clock as this box's hipDeviceProp_t reports it
-            simds = info["compute_units"] * info["simds_per_cu"]
-            peak_issue = simds * clock_ghz / 2.0  # G wave-instructions / s
-            rate = pmc["valu_per_launch"] * scale / (avg_ms * 1e-3) / 1e9
-            lanes = pmc.get("lanes_per_valu_inst")
-            valu = {"valu_wave_insts_per_launch": int(pmc["valu_per_launch"] * scale), "rate_G_per_s": round(rate, 1),
-                    "peak_G_per_s": round(peak_issue, 1), "clock_ghz": round(clock_ghz, 3), "simds": simds,
-                    "frac_valu_issue": round(rate / peak_issue, 4), "lanes_per_valu_inst": lanes,
-                    "frac_lane_throughput": round(rate / peak_issue * lanes / 64.0, 4) if lanes else None,
-                    "valu_per_ray": round(pmc["valu_per_launch"] / max(1, pmc.get("rays_per_launch") or rpl), 1),
-                    "salu_per_valu": pmc.get("salu_per_valu"), "wait_inst_any_frac": pmc.get("wait_inst_any_frac")}
-        for f in (frac, valu and valu["frac_valu_issue"]):
-            assert f is None or f <= 1.0, f"roofline fraction {f} > 1: the model or the counters are wrong"
+        info = ctx.device_info()
+        clock_ghz = info["clock_khz"] / 1e6  # device maximum engine clock as this box's hipDeviceProp_t reports it
+        simds = info["compute_units"] * info["simds_per_cu"]
+        peak_issue = simds * clock_ghz / 2.0  # G wave-instructions / s
+        flags = []
+        # rays entering k_shade = radiance rays; what it emits = the radiance rays of the later bounces + the shadow rays
+        first = W * H * args.spp if world == 1 else None
+        next_rays = max(0, cst["rays_radiance"] - (first or 0)) if first else 0
+        alg = {"closest": algorithmic_bytes(cst["rays_radiance"], False, cst["nodes_visited"][0], cst["prims_tested"][0], cst["segs_tested"][0], cst["instances_entered"][0]),
+               "shadow": algorithmic_bytes(cst["rays_shadow"], True, cst["nodes_visited"][1], cst["prims_tested"][1], cst["segs_tested"][1], cst["instances_entered"][1]),
+               "shade": shade_bytes(cst["rays_radiance"], next_rays, cst["rays_shadow"])}
+        units = {"closest": cst["rays_radiance"], "shadow": cst["rays_shadow"], "shade": cst["rays_radiance"]}
+        stat_key = {"closest": "trace_closest", "shadow": "trace_shadow", "shade": "shade"}
+        kern = {}
+        for name in ("closest", "shadow", "shade"):
+            launches = max(1, st["launches_" + stat_key[name]])
+            avg_ms = st["ms_" + stat_key[name]] / launches
+            upl = units[name] * K / launches  # rays (paths for k_shade) per launch
+            blk = {"kernel": {"closest": "k_trace<closest>", "shadow": "k_trace<shadow>", "shade": "k_shade"}[name], "bound": "hbm",
+                   "avg_launch_ms": round(avg_ms, 4), "launches_per_frame": launches // K, "units_per_launch": int(upl),
+                   "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+            pk = (pmc or {}).get("kernels", {}).get(name)
+            if pk and pk.get("hbm_bytes_per_launch") and avg_ms > 0:
+                scale = upl / pk["rays_per_launch"] if pk.get("rays_per_launch") else 1.0
+                blk["traffic"] = int(pk["hbm_bytes_per_launch"] * scale)
+                blk["achieved"] = round(blk["traffic"] / (avg_ms * 1e-3) / 1e9, 2)
+                blk["frac"] = round(blk["achieved"] / HBM_PEAK_GBS, 5)
+                blk["write_bytes_per_unit"] = round(pk["WRITE_SIZE_KiB"] * 1024.0 / max(1, pk["rays_per_launch"]), 1)
+                blk["fetch_bytes_per_unit"] = round(2.0 * pk["FETCH_SIZE_KiB"] * 1024.0 / max(1, pk["rays_per_launch"]), 1)
+                if blk["frac"] > 1.0:
+                    flags.append("%s: counter bytes / time exceed the HBM peak (FETCH_SIZE counts Infinity-Cache hits)" % name)
+            if pk and pk.get("valu_per_launch") and avg_ms > 0:
+                scale = upl / pk["rays_per_launch"] if pk.get("rays_per_launch") else 1.0
+                rate = pk["valu_per_launch"] * scale / (avg_ms * 1e-3) / 1e9
+                lanes = pk.get("lanes_per_valu_inst")
+                blk["valu"] = {"valu_wave_insts_per_launch": int(pk["valu_per_launch"] * scale), "rate_G_per_s": round(rate, 1),
+                               "peak_G_per_s": round(peak_issue, 1), "frac_valu_issue": round(rate / peak_issue, 4), "lanes_per_valu_inst": lanes,
+                               "frac_lane_throughput": round(rate / peak_issue * lanes / 64.0, 4) if lanes else None,
+                               "valu_per_unit": round(pk["valu_per_launch"] / max(1, pk.get("rays_per_launch") or upl), 1),
+                               "salu_per_valu": pk.get("salu_per_valu"), "wait_inst_any_frac": pk.get("wait_inst_any_frac")}
+                if rate / peak_issue > 1.0:
+                    flags.append("%s: VALU issue rate above the roof: the clock or the counters are off" % name)
+            bpl = alg[name] * K / launches
+            blk["cached_bw"] = {"GB/s": round(bpl / (avg_ms * 1e-3) / 1e9, 2) if avg_ms > 0 else 0.0, "algorithmic_bytes_per_launch": int(bpl),
+                                "algorithmic_bytes_per_unit": round(alg[name] / max(1, units[name]), 1)}
+            kern[name] = blk
         nrs = max(1, cst["rays_shadow"])
+        c0 = kern["closest"]
+        roofline = {"kernel": "k_trace<closest>", "bound": "hbm", "achieved": c0["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": c0["frac"],
+                    "frac_is": "upper bound on HBM use: FETCH_SIZE counts Infinity-Cache hits",
+                    "traffic": c0["traffic"], "traffic_source": pmc.get("source") if pmc else None,
+                    "limiter": "valu_issue (divergence): see valu", "valu": c0.get("valu"),
+                    "cached_bw": dict(c0["cached_bw"], note="SURVEY 8(d) bytes / time; served by L2 + Infinity Cache + HBM together, not an HBM fraction"),
+                    "avg_launch_ms": c0["avg_launch_ms"], "rays_per_launch": c0["units_per_launch"],
+                    "clock_ghz": round(clock_ghz, 3), "simds": simds,
+                    "per_ray": {"nodes": round(cst["nodes_visited"][0] / max(1, cst["rays_radiance"]), 2),
+                                "tris": round(cst["prims_tested"][0] / max(1, cst["rays_radiance"]), 2),
+                                "instances": round(cst["instances_entered"][0] / max(1, cst["rays_radiance"]), 2)},
+                    "per_shadow_ray": {"nodes": round(cst["nodes_visited"][1] / nrs, 2), "tris": round(cst["prims_tested"][1] / nrs, 2),
+                                       "instances": round(cst["instances_entered"][1] / nrs, 2)},
+                    "kernels": kern}
+        if flags:
+            roofline["flags"] = flags
+            sys.stderr.write("[bench] roofline flags: %s\n" % "; ".join(flags))
         out = {
             "metric": "Mray/s", "value": round(rays_total / dt / 1e6, 3), "unit": "Mray/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3),
@@ -451,28 +581,23 @@ def main():
             "config": {"workload": workload, "resolution": f"{W}x{H}", "bounces": args.depth, "spp": args.spp,
                        "step": f"one frame = {args.spp} sub-frames of 1 spp", "tile": args.tile, "world_size": world,
                        "parallelism": f"pixel tiles round-robin over {world} GPU(s), 1 gather/frame ({gather_kind})" if world > 1
-                       else "single GPU", "rays_per_frame": int(rays_total / K), "bvh_build_ms": round(build_ms, 2)},
+                       else "single GPU", "rays_per_frame": int(rays_total / K), "bvh_build_ms": round(build_ms, 2),
+                       "bake_world": {"baked_instances": baked[1], "baked_triangles": baked[2]}, "scene_load_s": round(t_scene, 1)},
+            "gather": gather_kind, "rccl_nranks": rccl_nranks,
+            "roofline_replayed": bool(pmc and pmc.get("replayed")) or pmc is None,
             "kernel_ms_per_frame": {k: round(st[k] / K, 3) for k in ("ms_trace_closest", "ms_trace_shadow", "ms_shade",
                                                                      "ms_raygen", "ms_accumulate", "ms_sort")},
-            "roofline": {"kernel": "k_trace<closest>", "bound": "hbm", "achieved": None if achieved is None else round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if frac is None else round(frac, 5),
-                         "frac_is": "upper bound on HBM use: FETCH_SIZE counts Infinity-Cache hits",
-                         "traffic": traffic, "traffic_source": pmc.get("source") if pmc else None,
-                         "limiter": "valu_issue (divergence): see valu", "valu": valu,
-                         "cached_bw": {"GB/s": round(cached, 2), "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                                       "note": "SURVEY 8(d) bytes / time; served by L2 + Infinity Cache + HBM together, not an HBM fraction"},
-                         "avg_launch_ms": round(avg_ms, 4), "rays_per_launch": int(rpl),
-                         "per_ray": {"nodes": round(cst["nodes_visited"][0] / max(1, cst["rays_radiance"]), 2),
-                                     "tris": round(cst["prims_tested"][0] / max(1, cst["rays_radiance"]), 2),
-                                     "instances": round(cst["instances_entered"][0] / max(1, cst["rays_radiance"]), 2)},
-                         "per_shadow_ray": {"nodes": round(cst["nodes_visited"][1] / nrs, 2), "tris": round(cst["prims_tested"][1] / nrs, 2),
-                                            "instances": round(cst["instances_entered"][1] / nrs, 2)}},
+            "roofline": roofline,
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+        if gather_error:
+            out["gather_error"] = gather_error
         if drop_in is not None:
             out["drop_in"] = drop_in
         if args.pmc_save and PMC_RESULT:
-            json.dump({**PMC_RESULT, "tag": args.pmc_save, "workload": workload, "resolution": f"{W}x{H}", "kernel": "k_trace<closest>"},
-                      open(os.path.join(ROOT, "profiles", "pmc_k_trace_closest.json"), "w"), indent=1)
+            json.dump({**PMC_RESULT, "tag": args.pmc_save, "workload": workload, "resolution": f"{W}x{H}"},
+                      open(os.path.join(ROOT, "profiles", "pmc_kernels.json"), "w"), indent=1)
         if os.environ.get("SKH_BENCH_CHECKSUM"):
             # CRC of the final accumulation image (tests: a tile-sharded N-rank run must reproduce the 1-rank image exactly)
             import zlib

@@ -249,6 +249,12 @@ skh_status skh_set_materials(skh_context* ctx, const skh_material* materials, ui
 /* ---- createAccelerationStructure (OptixRender.cpp:388-496): per-mesh / per-curve BLAS + one TLAS ---- */
 skh_status skh_build_accel(skh_context* ctx, uint32_t flags);
 
+/* Which instances skh_build_accel baked to world space (option bake_world; `flags` receives one byte per instance, 1 = baked;
+ * either pointer may be NULL).  A baked mesh instance has no IAS entry (OptixRender.cpp:412-441 creates one per instance): its
+ * triangles are transformed once and intersected in world space.  Hit records name the same instance and primitive. */
+skh_status skh_get_baked(skh_context* ctx, uint8_t* flags, uint32_t n_instances, uint32_t* out_baked_instances,
+                         uint32_t* out_baked_triangles);
+
 /* ---- updatePathtracerParams (OptixRender.cpp:827-872): (re)allocates accum/AOV buffers, resets history ---- */
 skh_status skh_resize(skh_context* ctx, uint32_t width, uint32_t height);
 
@@ -306,6 +312,8 @@ skh_status skh_scatter_tiles(skh_context* ctx, const void* d_src_tiles, const ui
 skh_status skh_comm_unique_id(void* out_id /* SKH_COMM_ID_BYTES */);
 skh_status skh_comm_init(skh_context* ctx, const void* id, int world_size, int rank);
 skh_status skh_comm_destroy(skh_context* ctx);
+/* world size / rank of the context's communicator and the rank count RCCL itself reports for it (ncclCommCount; 0 = none) */
+skh_status skh_comm_info(skh_context* ctx, int* out_world_size, int* out_rank, int* out_rccl_ranks);
 skh_status skh_gather_tiles(skh_context* ctx, uint32_t max_tiles, void* d_recv /* root only, else NULL */, int root);
 
 /* ---- ray queries against the built accel (the optixTrace call sites), for tests and micro-benchmarks.
@@ -339,7 +347,10 @@ skh_status skh_bsdf_probe(skh_context* ctx, const skh_bsdf_query* queries, uint3
 
 /* ---- options / stats ----
  * None of the options changes a result: hit records and images are bit-identical for every setting
- * (tests/test_gpu_parity.py::test_results_do_not_depend_on_the_acceleration_structure_or_scheduling).
+ * (tests/test_gpu_parity.py::test_results_do_not_depend_on_the_acceleration_structure_or_scheduling) -- with ONE exception,
+ * bake_world, which is part of the intersection's definition: a baked instance's triangles are tested in world space, so the
+ * t, u, v of hits on it differ in the last bits from the object-space test (same instance, same primitive; the CPU oracle
+ * takes the same setting and the bit-exact contract holds per setting).
  *   measurement   count_traversal 0|1 (counter build of the trace kernels), timing 0|1 (per-kernel hipEvent spans)
  *   scheduling    waves_per_cu (28) / waves_per_cu_shadow (28) (7 waves per SIMD), fetch_min_closest / fetch_min_shadow (24 / 32, scenes with curves 16 / 24: idle lanes before a wave refills),
  *                 node_break_closest / node_break_shadow (24 / 20, curves 20 / 20: leave the node loop below x/64 descending rays),
@@ -349,10 +360,13 @@ skh_status skh_bsdf_probe(skh_context* ctx, const skh_bsdf_query* queries, uint3
  *                 overlap 0|1|2 (any-hit launches on a second stream beside the next closest-hit launch: off | small passes |
  *                 always), small_waves_closest / small_waves_shadow (16 / 16: waves per CU of the two overlapped launches),
  *                 sort_bits_closest / sort_bits_shadow / sort_first_bounce (ray re-ordering, off)
+ *   definition    bake_world 2|1|0 (mesh instances intersected in world space, no instance entry: 1 = instances whose mesh has one
+ *                 user -- what HdStrelka's per-instance meshes are --, 2 = also instances of meshes with <= bake_small_tris (64)
+ *                 triangles; 0 = every instance keeps its TLAS leaf)
  *   build         build_quality 1|0 (PLOC | Karras radix tree), leaf_max_tris (2), curve_split (2: parameter sub-ranges
  *                 per curve segment), tlas_build 2|1|0 (auto | GPU PLOC over the instance boxes | exact sweep SAH on the host; auto =
  *                 the sweep up to 8192 instances, the GPU beyond), tlas_open (1: TLAS leaves per instance budget),
- *                 tight_instance_boxes 1|0, flatten 0|1 (one world-space tree), wide 4|8 (node width: 64-byte 4-wide nodes | 96-byte
+ *                 tight_instance_boxes 1|0, wide 4|8 (node width: 64-byte 4-wide nodes | 96-byte
  *                 8-wide nodes with octant-ordered slots; two-level hierarchy only, measured slower: DESIGN.md section 9)
  * Unknown names and out-of-range values return SKH_INVALID_ARGUMENT. */
 skh_status skh_set_option(skh_context* ctx, const char* name, int64_t value);

@@ -26,7 +26,7 @@ SYMBOLS = ["skh_create", "skh_destroy", "skh_last_error", "skh_abi_version", "sk
            "skh_render_subframe", "skh_render_subframes", "skh_tonemap", "skh_read_accum", "skh_read_aov",
            "skh_buffer_alloc", "skh_buffer_free", "skh_buffer_download", "skh_copy_accum", "skh_copy_accum_tiles", "skh_scatter_tiles", "skh_trace", "skh_trace_device",
            "skh_set_option", "skh_get_stats", "skh_reset_stats", "skh_synchronize", "skh_get_stream", "skh_bsdf_probe", "skh_get_device_info", "skh_comm_unique_id", "skh_comm_init",
-           "skh_comm_destroy", "skh_gather_tiles", "skh_host_register", "skh_host_unregister"]
+           "skh_comm_destroy", "skh_gather_tiles", "skh_host_register", "skh_host_unregister", "skh_get_baked", "skh_comm_info"]
 
 DEVICE_INFO = np.dtype([("compute_units", np.uint32), ("simds_per_cu", np.uint32), ("clock_khz", np.uint32), ("memory_clock_khz", np.uint32),
                         ("memory_bus_bits", np.uint32), ("wavefront_size", np.uint32), ("total_memory_bytes", np.uint64), ("name", "S64")])
@@ -91,8 +91,10 @@ def load():
     lib.skh_comm_unique_id.argtypes = [vp]
     lib.skh_comm_init.argtypes = [vp, vp, i32, i32]
     lib.skh_comm_destroy.argtypes = [vp]
+    lib.skh_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.skh_gather_tiles.argtypes = [vp, u32, vp, i32]
     lib.skh_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    lib.skh_get_baked.argtypes = [vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]
     lib.skh_get_stats.argtypes = [vp, vp]
     lib.skh_reset_stats.argtypes = [vp]
     lib.skh_synchronize.argtypes = [vp]
@@ -263,6 +265,12 @@ class Context:
         assert u.nbytes == 128
         self._ck(self.lib.skh_comm_init(self.h, _p(u), world_size, rank), "skh_comm_init")
 
+    def comm_info(self):
+        """(world size, rank, ranks RCCL itself reports for the communicator -- ncclCommCount; 0 = no communicator)"""
+        w, r, n = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._ck(self.lib.skh_comm_info(self.h, C.byref(w), C.byref(r), C.byref(n)), "skh_comm_info")
+        return w.value, r.value, n.value
+
     def comm_destroy(self):
         self._ck(self.lib.skh_comm_destroy(self.h), "skh_comm_destroy")
 
@@ -274,6 +282,13 @@ class Context:
         d = np.zeros((), DEVICE_INFO)
         self._ck(self.lib.skh_get_device_info(self.h, _p(d)), "skh_get_device_info")
         return {k: (d[k].item().decode() if k == "name" else int(d[k])) for k in DEVICE_INFO.names}
+
+    def baked(self, n_instances):
+        """(per-instance flags, baked instances, baked triangles) of option bake_world after the build"""
+        flags = np.zeros(max(1, n_instances), np.uint8)
+        ni, nt = C.c_uint32(0), C.c_uint32(0)
+        self._ck(self.lib.skh_get_baked(self.h, _p(flags), n_instances, C.byref(ni), C.byref(nt)), "skh_get_baked")
+        return flags[:n_instances], ni.value, nt.value
 
     def set_option(self, name, value):
         self._ck(self.lib.skh_set_option(self.h, name.encode(), int(value)), f"skh_set_option({name})")

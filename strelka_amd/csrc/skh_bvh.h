@@ -986,11 +986,6 @@ __global__ void __launch_bounds__(SKH_SCAN_BLOCK) k_scan_add(uint32_t* __restric
             data[base + k] += add;
 }
 
-// ---- world-space primitive enumeration (flattened instancing) ------------------------------------------------------
-// The hierarchy is built over ALL instanced primitives in world space (one tree, no TLAS/BLAS switch during
-// traversal); the leaf records keep OBJECT-space vertices + the instance id, so the intersection arithmetic -- and
-// therefore every hit record -- is identical to the two-level formulation (ray transformed into the instance).
-// 288 GB of HBM make the duplication affordable: 48 B per instanced triangle.
 SKH_DI uint32_t find_segment(const uint32_t* __restrict__ first, uint32_t count, uint32_t k) // largest j with first[j] <= k
 {
     uint32_t lo = 0, hi = count;
@@ -1004,11 +999,15 @@ SKH_DI uint32_t find_segment(const uint32_t* __restrict__ first, uint32_t count,
     }
     return lo;
 }
-// wInst[j]: instance id of the j-th triangle-carrying (valid) instance, wFirst[j]: its first world primitive (wFirst[nW] = W)
-__global__ void k_world_tri_boxes(const uint8_t* __restrict__ instances /*64 B*/, const uint32_t* __restrict__ wInst,
+// ---- baked instances ("bake_world") -------------------------------------------------------------------
+// A baked mesh instance has no TLAS leaf: its triangles are carried to WORLD space once (xform_point, the arithmetic the CPU
+// oracle restates) and join one extra primitive group of the triangle build, whose tree every ray walks first, in world space,
+// with no instance entry.  Baked primitive k (0 <= k < W) = triangle k - wFirst[j] of instance wInst[j].
+// boxes: exactly the box of the three world-space vertices that the leaf record will hold (the node encoding adds the margins)
+__global__ void k_baked_tri_boxes(const uint8_t* __restrict__ instances /*64 B*/, const uint32_t* __restrict__ wInst,
                                   const uint32_t* __restrict__ wFirst, uint32_t nW, const uint8_t* __restrict__ verts,
-                                  const uint32_t* __restrict__ indices, const uint4* __restrict__ meshes, uint32_t W,
-                                  float4* __restrict__ boxLo, float4* __restrict__ boxHi, uint32_t* __restrict__ grp)
+                                  const uint32_t* __restrict__ indices, const uint4* __restrict__ meshes, uint32_t W, uint32_t offset,
+                                  uint32_t group, uint32_t split /* primitives >= split: group + 1 (light proxies) */, float4* __restrict__ boxLo, float4* __restrict__ boxHi, uint32_t* __restrict__ grp)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= W)
@@ -1028,128 +1027,58 @@ __global__ void k_world_tri_boxes(const uint8_t* __restrict__ instances /*64 B*/
         lo = mk3(fminf(lo.x, w.x), fminf(lo.y, w.y), fminf(lo.z, w.z));
         hi = mk3(fmaxf(hi.x, w.x), fmaxf(hi.y, w.y), fmaxf(hi.z, w.z));
     }
-    float4 blo = make_float4(lo.x, lo.y, lo.z, 0.0f), bhi = make_float4(hi.x, hi.y, hi.z, 0.0f);
-    inflate_box(blo, bhi); // covers the rounding of the object->world transform
-    boxLo[k] = blo;
-    boxHi[k] = bhi;
-    grp[k] = 0;
-}
-__global__ void k_world_seg_boxes(const uint8_t* __restrict__ instances, const uint32_t* __restrict__ wInst,
-                                  const uint32_t* __restrict__ wFirst, uint32_t nW, const float* __restrict__ points,
-                                  const float* __restrict__ radii, const uint32_t* __restrict__ curveSegBase,
-                                  const uint32_t* __restrict__ segStartAll, uint32_t W, uint32_t offset, float4* __restrict__ boxLo,
-                                  float4* __restrict__ boxHi, uint32_t* __restrict__ grp)
-{
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= W)
-        return;
-    const uint32_t j = find_segment(wFirst, nW, k);
-    const uint32_t inst = wInst[j], sidx = k - wFirst[j];
-    const float* m = reinterpret_cast<const float*>(instances + (size_t)inst * 64);
-    const uint32_t geom = reinterpret_cast<const uint32_t*>(instances + (size_t)inst * 64)[13];
-    const uint32_t s0 = segStartAll[curveSegBase[geom] + sidx];
-    v3 lo = mk3(INFINITY), hi = mk3(-INFINITY);
-    float rmax = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-    {
-        const float* p = points + 3 * (size_t)(s0 + c);
-        lo = mk3(fminf(lo.x, p[0]), fminf(lo.y, p[1]), fminf(lo.z, p[2]));
-        hi = mk3(fmaxf(hi.x, p[0]), fmaxf(hi.y, p[1]), fmaxf(hi.z, p[2]));
-        rmax = fmaxf(rmax, radii[s0 + c]);
-    }
-    lo = lo - mk3(rmax);
-    hi = hi + mk3(rmax);
-    v3 wlo = mk3(INFINITY), whi = mk3(-INFINITY);
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-    {
-        const v3 w = xform_point(m, mk3((c & 1) ? hi.x : lo.x, (c & 2) ? hi.y : lo.y, (c & 4) ? hi.z : lo.z));
-        wlo = mk3(fminf(wlo.x, w.x), fminf(wlo.y, w.y), fminf(wlo.z, w.z));
-        whi = mk3(fmaxf(whi.x, w.x), fmaxf(whi.y, w.y), fmaxf(whi.z, w.z));
-    }
-    float4 blo = make_float4(wlo.x, wlo.y, wlo.z, 0.0f), bhi = make_float4(whi.x, whi.y, whi.z, 0.0f);
-    inflate_box(blo, bhi);
-    boxLo[offset + k] = blo;
-    boxHi[offset + k] = bhi;
-    grp[offset + k] = 1;
-}
-// leaf records, leaf order.  triangle: {v0.xyz, primId | v1.xyz, instId | v2.xyz, visibility mask} (object space)
-__global__ void k_gather_world_tris(const uint8_t* __restrict__ instances, const uint32_t* __restrict__ wInst,
-                                    const uint32_t* __restrict__ wFirst, uint32_t nW, const uint8_t* __restrict__ verts,
-                                    const uint32_t* __restrict__ indices, const uint4* __restrict__ meshes,
-                                    const uint32_t* __restrict__ sortedVals, uint32_t Wt, float4* __restrict__ out)
-{
-    const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= Wt)
-        return;
-    const uint32_t k = sortedVals[pos];
-    const uint32_t j = find_segment(wFirst, nW, k);
-    const uint32_t inst = wInst[j], t = k - wFirst[j];
-    const uint32_t* iw = reinterpret_cast<const uint32_t*>(instances + (size_t)inst * 64);
-    const uint32_t type = iw[12], geom = iw[13];
-    const uint32_t mask = type == 0 ? 1u : 4u; // GEOMETRY_MASK_TRIANGLE / GEOMETRY_MASK_LIGHT
-    const uint4 me = meshes[geom];
-    float4 r[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-    {
-        const uint32_t vi = me.z + indices[me.x + 3 * t + c];
-        const float* p = reinterpret_cast<const float*>(verts + (size_t)vi * 32);
-        r[c] = make_float4(p[0], p[1], p[2], __uint_as_float(c == 0 ? t : (c == 1 ? inst : mask)));
-    }
-    out[3 * (size_t)pos + 0] = r[0];
-    out[3 * (size_t)pos + 1] = r[1];
-    out[3 * (size_t)pos + 2] = r[2];
-}
-// segment: 4 x {xyz, radius} + meta {primId, instId}
-__global__ void k_gather_world_segs(const uint8_t* __restrict__ instances, const uint32_t* __restrict__ wInst,
-                                    const uint32_t* __restrict__ wFirst, uint32_t nW, const float* __restrict__ points,
-                                    const float* __restrict__ radii, const uint32_t* __restrict__ curveSegBase,
-                                    const uint32_t* __restrict__ segStartAll, const uint32_t* __restrict__ sortedVals, uint32_t Wt,
-                                    uint32_t Ws, float4* __restrict__ out, uint2* __restrict__ meta)
-{
-    const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= Ws)
-        return;
-    const uint32_t k = sortedVals[Wt + pos] - Wt;
-    const uint32_t j = find_segment(wFirst, nW, k);
-    const uint32_t inst = wInst[j], sidx = k - wFirst[j];
-    const uint32_t geom = reinterpret_cast<const uint32_t*>(instances + (size_t)inst * 64)[13];
-    const uint32_t s0 = segStartAll[curveSegBase[geom] + sidx];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-    {
-        const float* p = points + 3 * (size_t)(s0 + c);
-        out[4 * (size_t)pos + c] = make_float4(p[0], p[1], p[2], radii[s0 + c]);
-    }
-    meta[pos] = make_uint2(sidx, inst);
+    boxLo[offset + k] = make_float4(lo.x, lo.y, lo.z, 0.0f);
+    boxHi[offset + k] = make_float4(hi.x, hi.y, hi.z, 0.0f);
+    grp[offset + k] = k < split ? group : group + 1u;
 }
 
-// gather triangles into leaf order: 48 B records {v0.xyz, primId | v1.xyz, 0 | v2.xyz, 0}
+// gather triangles into leaf order: 48 B records {v0.xyz, primId | v1.xyz, 0 | v2.xyz, 0}; primitives >= nMeshTris are baked
+// ones: WORLD-space vertices, {v0, primId | v1, instance id | v2, 0}
 __global__ void k_gather_tris(const uint8_t* __restrict__ verts, const uint32_t* __restrict__ indices,
-                              const uint4* __restrict__ meshes, const uint32_t* __restrict__ triMesh,
-                              const uint32_t* __restrict__ triLocal, const uint32_t* __restrict__ sortedVals, uint32_t n,
-                              float4* __restrict__ out)
+                                    const uint4* __restrict__ meshes, const uint32_t* __restrict__ triMesh,
+                                    const uint32_t* __restrict__ triLocal, const uint32_t* __restrict__ sortedVals, uint32_t n,
+                                    uint32_t nMeshTris, const uint8_t* __restrict__ instances, const uint32_t* __restrict__ wInst,
+                                    const uint32_t* __restrict__ wFirst, uint32_t nW, float4* __restrict__ out)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n)
         return;
     const uint32_t i = sortedVals[j];
-    const uint32_t m = triMesh[i], t = triLocal[i];
-    const uint4 me = meshes[m];
     float4 r[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
+    if (i < nMeshTris)
     {
-        const uint32_t vi = me.z + indices[me.x + 3 * t + k];
-        const float* p = reinterpret_cast<const float*>(verts + (size_t)vi * 32);
-        r[k] = make_float4(p[0], p[1], p[2], k == 0 ? __uint_as_float(t) : 0.0f);
+        const uint32_t m = triMesh[i], t = triLocal[i];
+        const uint4 me = meshes[m];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+        {
+            const uint32_t vi = me.z + indices[me.x + 3 * t + k];
+            const float* p = reinterpret_cast<const float*>(verts + (size_t)vi * 32);
+            r[k] = make_float4(p[0], p[1], p[2], k == 0 ? __uint_as_float(t) : 0.0f);
+        }
+    }
+    else
+    {
+        const uint32_t kk = i - nMeshTris;
+        const uint32_t w = find_segment(wFirst, nW, kk);
+        const uint32_t inst = wInst[w], t = kk - wFirst[w];
+        const float* m = reinterpret_cast<const float*>(instances + (size_t)inst * 64);
+        const uint32_t geom = reinterpret_cast<const uint32_t*>(instances + (size_t)inst * 64)[13];
+        const uint4 me = meshes[geom];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+        {
+            const uint32_t vi = me.z + indices[me.x + 3 * t + k];
+            const float* p = reinterpret_cast<const float*>(verts + (size_t)vi * 32);
+            const v3 q = xform_point(m, mk3(p[0], p[1], p[2]));
+            r[k] = make_float4(q.x, q.y, q.z, k == 0 ? __uint_as_float(t) : (k == 1 ? __uint_as_float(inst) : 0.0f));
+        }
     }
     out[3 * (size_t)j + 0] = r[0];
     out[3 * (size_t)j + 1] = r[1];
     out[3 * (size_t)j + 2] = r[2];
 }
+
 // gather curve segments into leaf order: 64 B records (4 x {xyz, radius}) + the segment's primitive index
 // leaf order -> leaf records.  out: the segment's four control points (duplicated per sub-range: one 64-byte fetch per test);
 // outPrim: segment index inside its curve set | sub-range << 28; outBound: conservative bounding cylinder of the (padded)

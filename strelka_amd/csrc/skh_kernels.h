@@ -40,22 +40,18 @@ struct DevScene
     const uint32_t* tlasInst; // leaf order -> instance id
     int tlasRoot;
     uint32_t numInstances;
-    const DevInstance* inst; // per instance (shading side, flattening)
+    const DevInstance* inst; // per instance (shading side: w2o)
     const DevInstance* tinst; // per TLAS leaf: (instance, BLAS subtree) after opening; pad = instance id
     const Node4* triNodes;
     const float4* tris; // 3 x float4 per triangle, leaf order
+    int worldRoot; // root (inside triNodes) of the group of BAKED mesh instances: world-space triangles {v0, prim | v1, instance | v2, 0} that every
+                   // ray walks first, in world space, with no instance entry; SKH_REF_INVALID = nothing baked
+    int lightRoot; // the same for baked light proxies: radiance rays only (shadow rays do not see lights)
     const Node4* segNodes;
     const float4* segs; // 4 x float4 per segment, leaf order
     const uint32_t* segPrim; // leaf order -> segment index inside its curve set
     const float4* segBound; // 2 x float4 per leaf record: bounding cylinder {A, R}, {unit axis, 0}
     uint32_t curveSplit; // parameter sub-ranges per segment (sub-range in segPrim >> 28)
-    // flattened world-space hierarchy (default): one tree over every instanced primitive
-    const Node4* wNodes;
-    int wRoot;
-    uint32_t wTriCount; // leaf positions < wTriCount are triangles, the rest curve segments
-    const float4* wTris; // 3 x float4 per instanced triangle: object-space vertices + primId / instId / mask
-    const float4* wSegs; // 4 x float4 per instanced segment
-    const uint2* wSegMeta; // {primId, instId}
     // shading side
     const HostInstance* instances; // shading copy: for mesh instances `light` holds the mesh's first record in shadeTris
     const float4* shadeTris; // de-indexed shading vertices, 3 x 32 B per triangle, meshes back to back
@@ -90,10 +86,18 @@ struct RayQ // SoA planes of `stride` elements: ox oy oz dx dy dz tmin tmax path
         return reinterpret_cast<uint32_t*>(base + (size_t)8 * stride);
     }
 };
-struct HitQ // SoA: t inst prim u v  (20 B / hit)
+// Hit records: ONE 32-byte record per ray {t, u, v, 0 | instance, primitive, 0, 0}.  Results are written by whichever lanes finished
+// since the last refill -- scattered queue positions --, so five 4-byte planes left five partly written lines per ray (73 B of
+// write traffic per 20-byte hit, round-2 counters); a record is one aligned 32-byte sector, and k_shade reads it as two dwordx4.
+// (An any-hit launch in raw query mode uses `base` as one float plane: 1 = occluded, -1 = not.)
+struct HitQ
 {
     float* base;
-    uint32_t stride;
+    uint32_t stride; // rays the buffer holds
+    __device__ float4* rec(uint32_t i) const
+    {
+        return reinterpret_cast<float4*>(base) + 2 * (size_t)i;
+    }
 };
 struct PathS // per path slot: throughput rgb, radiance rgb, lastBsdfPdf, flags
 {
@@ -337,11 +341,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                 }
                 else
                 {
-                    hq.base[i] = best.found ? best.t : -1.0f;
-                    reinterpret_cast<uint32_t*>(hq.base)[i + hq.stride] = best.inst;
-                    reinterpret_cast<uint32_t*>(hq.base)[i + 2 * (size_t)hq.stride] = best.prim;
-                    hq.base[i + 3 * (size_t)hq.stride] = best.u;
-                    hq.base[i + 4 * (size_t)hq.stride] = best.v;
+                    float4* hr = hq.rec(i);
+                    hr[0] = make_float4(best.found ? best.t : -1.0f, best.u, best.v, 0.0f);
+                    hr[1] = make_float4(__uint_as_float(best.inst), __uint_as_float(best.prim), 0.0f, 0.0f);
                 }
             }
         }
@@ -383,10 +385,37 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                 inv = rcp3(d);
                 if (ANY_HIT)
                     invw = inv;
-                nodes = sc.tlasNodes;
-                inBlas = false;
-                sp = 0;
-                cur = sc.tlasRoot;
+                const int wr0 = sc.worldRoot, wr1 = ANY_HIT ? SKH_REF_INVALID : sc.lightRoot; // (kernel arguments: scalar branches)
+                if (wr0 != SKH_REF_INVALID || wr1 != SKH_REF_INVALID)
+                {
+                    // baked instances first: the ray starts INSIDE their world-space groups (identity entry: o = ow, d = dw), the top
+                    // level waits under a sentinel on the stack
+                    sh = make_shear(dw);
+                    nodes = sc.triNodes;
+                    inBlas = true;
+                    curInst = 0xffffffffu; // = "the instance id is in the triangle record"
+                    curType = 0;
+                    sp = 0;
+                    if (sc.tlasRoot != SKH_REF_INVALID)
+                    {
+                        lds[0] = sc.tlasRoot;
+                        lds[SKH_TRACE_BLOCK] = SKH_REF_SENTINEL;
+                        sp = 2;
+                    }
+                    if (wr0 != SKH_REF_INVALID && wr1 != SKH_REF_INVALID)
+                    {
+                        lds[sp * SKH_TRACE_BLOCK] = wr1;
+                        ++sp;
+                    }
+                    cur = wr0 != SKH_REF_INVALID ? wr0 : wr1;
+                }
+                else
+                {
+                    nodes = sc.tlasNodes;
+                    inBlas = false;
+                    sp = 0;
+                    cur = sc.tlasRoot;
+                }
                 best.t = rq.plane(7)[ridx];
                 best.inst = best.prim = 0xffffffffu;
                 best.u = best.v = 0.0f;
@@ -729,10 +758,11 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
 #endif
                         {
                             const uint32_t prim = __float_as_uint(a.w);
-                            if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
+                            const uint32_t hinst = curInst == 0xffffffffu ? __float_as_uint(b.w) : curInst; // (baked group: the record names its instance)
+                            if (!best.found || t < best.t || hinst < best.inst || (hinst == best.inst && prim < best.prim))
                             {
                                 best.t = t;
-                                best.inst = curInst;
+                                best.inst = hinst;
                                 best.prim = prim;
                                 best.u = u;
                                 best.v = v;
@@ -833,308 +863,6 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
         }
     }
 #undef SKH_LP
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// k_trace_flat: same contract as k_trace, over the FLATTENED hierarchy (one world-space tree of 4-wide nodes over all
-// instanced primitives).  No TLAS/BLAS switch, no sentinel on the stack: the node loop only ever sees world-space
-// boxes.  A leaf record carries object-space vertices and its instance id; the lane keeps the object-space ray of the
-// last instance it touched and re-derives it (one 48-byte fetch) only when the instance changes, so the
-// intersection arithmetic and hence every hit record stay identical to the two-level formulation.
-// ------------------------------------------------------------------------------------------------------------
-template <bool ANY_HIT, bool COUNT, bool CURVES>
-__global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES : SKH_TRACE_MIN_WAVES)
-    k_trace_flat(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch, uint32_t fetchMin,
-                 const uint32_t* __restrict__ perm, HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride,
-                 int* __restrict__ ovfBase, StatsDev* __restrict__ stats)
-{
-    fetchMin &= 0xffu;
-    __shared__ int s_stack[SKH_STACK_LDS * SKH_TRACE_BLOCK];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t n = *countPtr;
-    if (n == 0)
-        return;
-    const uint32_t perGroup = (((n + 7u) >> 3) + 63u) & ~63u;
-    const uint32_t group = blockIdx.x & 7u;
-    uint32_t tries = 0;
-    bool exhausted = false;
-    int* lds = s_stack + lane;
-    int* ovf = ovfBase + (blockIdx.x * SKH_TRACE_BLOCK + lane);
-    const uint32_t ovfStride = gridDim.x * SKH_TRACE_BLOCK;
-    const uint32_t rayMask = ANY_HIT ? 3u : 255u;
-    TraceCounters tc = { 0, 0, 0, 0 };
-
-    bool hasRay = false;
-    uint32_t ridx = 0;
-    v3 o = mk3(0.0f), d = mk3(0.0f), inv = mk3(0.0f), oo = mk3(0.0f), od = mk3(0.0f);
-    float tmin = 0.0f, tmax = 0.0f;
-    RayShear sh;
-    sh.perm = 0;
-    sh.Sx = sh.Sy = sh.Sz = 0.0f;
-    uint32_t curInst = 0xffffffffu;
-    int sp = 0, cur = SKH_REF_INVALID;
-    HitRec best;
-    best.t = 0.0f, best.inst = best.prim = 0xffffffffu, best.u = best.v = 0.0f, best.found = false;
-
-#define SKH_PUSH(v)                                                  \
-    {                                                                \
-        if (sp < SKH_STACK_LDS)                                      \
-            lds[sp * SKH_TRACE_BLOCK] = (v);                         \
-        else if (sp < SKH_STACK_LDS + SKH_STACK_OVF)                 \
-            ovf[(size_t)(sp - SKH_STACK_LDS) * ovfStride] = (v);     \
-        else                                                         \
-            *sc.overflowFlag = 1u; /* the entry is dropped: the call that launched this kernel returns SKH_FAIL, never silent */ \
-        ++sp;                                                        \
-    }
-#define SKH_POP(dst)                                                 \
-    {                                                                \
-        --sp;                                                        \
-        if (sp < SKH_STACK_LDS)                                      \
-            dst = lds[sp * SKH_TRACE_BLOCK];                         \
-        else if (sp < SKH_STACK_LDS + SKH_STACK_OVF)                 \
-            dst = ovf[(size_t)(sp - SKH_STACK_LDS) * ovfStride];     \
-        else                                                         \
-            dst = SKH_REF_INVALID;                                   \
-    }
-#define SKH_SWITCH_INSTANCE(id)                                                                                         \
-    if ((id) != curInst)                                                                                                \
-    {                                                                                                                   \
-        const float4* ip = reinterpret_cast<const float4*>(sc.inst + (id));                                             \
-        const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2];                                                                \
-        if (COUNT)                                                                                                      \
-            tc.insts++;                                                                                                 \
-        const float m[12] = { i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w };                 \
-        oo = xform_point_rel(m, o);                                                                                         \
-        od = xform_vector(m, d);                                                                                        \
-        sh = make_shear(od);                                                                                            \
-        curInst = (id);                                                                                                 \
-    }
-
-    for (;;)
-    {
-        // ---------------- refill idle lanes from the queue ----------------
-        const unsigned long long needMask = __ballot(!hasRay);
-        const uint32_t want = (uint32_t)__popcll(needMask);
-        if (!exhausted && (want >= fetchMin || want == 64u))
-        {
-            uint32_t base = 0, count = 0;
-            const int leader = __ffsll((long long)needMask) - 1;
-            while (tries < 8u)
-            {
-                const uint32_t g = (group + tries) & 7u;
-                uint32_t b = 0;
-                if ((int)lane == leader)
-                    b = atomicAdd(&fetch[g * SKH_FETCH_STRIDE], want);
-                b = __shfl(b, leader);
-                const uint32_t lo = g * perGroup;
-                const uint32_t hi = min(n, lo + perGroup);
-                if (lo < hi && b < hi - lo)
-                {
-                    base = lo + b;
-                    count = min(want, hi - base);
-                    if (count < want)
-                        ++tries;
-                    break;
-                }
-                ++tries;
-            }
-            if (tries >= 8u && count == 0)
-                exhausted = true;
-            const uint32_t rank = (uint32_t)__popcll(needMask & ((1ull << lane) - 1ull));
-            if (!hasRay && rank < count)
-            {
-                ridx = perm ? perm[base + rank] : base + rank;
-                o = mk3(rq.plane(0)[ridx], rq.plane(1)[ridx], rq.plane(2)[ridx]);
-                d = mk3(rq.plane(3)[ridx], rq.plane(4)[ridx], rq.plane(5)[ridx]);
-                tmin = rq.plane(6)[ridx];
-                tmax = rq.plane(7)[ridx];
-                inv = rcp3(d);
-                curInst = 0xffffffffu;
-                sp = 0;
-                cur = sc.wRoot;
-                best.t = tmax;
-                best.inst = best.prim = 0xffffffffu;
-                best.u = best.v = 0.0f;
-                best.found = false;
-                hasRay = true;
-            }
-        }
-        if (!__any(hasRay))
-        {
-            if (exhausted)
-                break;
-            continue;
-        }
-        bool terminated = false;
-        if (hasRay)
-        {
-            // ---- node loop: world-space boxes only ----
-            while (cur >= 0 && cur != SKH_REF_INVALID)
-            {
-                const float4* np = reinterpret_cast<const float4*>(sc.wNodes + cur);
-                const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-                if (COUNT)
-                    tc.nodes++;
-                const float ax = w1.w * inv.x, bx = (w0.x - o.x) * inv.x;
-                const float ay = w2.w * inv.y, by = (w0.y - o.y) * inv.y;
-                const float az = w0.w * inv.z, bz = (w0.z - o.z) * inv.z;
-                const bool px = inv.x >= 0.0f, py = inv.y >= 0.0f, pz = inv.z >= 0.0f;
-                const uint32_t nxw = __float_as_uint(px ? w1.x : w2.x), fxw = __float_as_uint(px ? w2.x : w1.x);
-                const uint32_t nyw = __float_as_uint(py ? w1.y : w2.y), fyw = __float_as_uint(py ? w2.y : w1.y);
-                const uint32_t nzw = __float_as_uint(pz ? w1.z : w2.z), fzw = __float_as_uint(pz ? w2.z : w1.z);
-                float tn[4];
-                int rf[4];
-                rf[0] = __float_as_int(w3.x), rf[1] = __float_as_int(w3.y), rf[2] = __float_as_int(w3.z), rf[3] = __float_as_int(w3.w);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                {
-                    const float nx = fmaf((float)((nxw >> (8 * k)) & 0xffu), ax, bx), fx = fmaf((float)((fxw >> (8 * k)) & 0xffu), ax, bx);
-                    const float ny = fmaf((float)((nyw >> (8 * k)) & 0xffu), ay, by), fy = fmaf((float)((fyw >> (8 * k)) & 0xffu), ay, by);
-                    const float nz = fmaf((float)((nzw >> (8 * k)) & 0xffu), az, bz), fz = fmaf((float)((fzw >> (8 * k)) & 0xffu), az, bz);
-                    const float tnear = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
-                    const float tfar = fminf(fminf(fx, fy), fminf(fz, best.t));
-                    const bool hit = rf[k] != SKH_REF_INVALID && tnear <= tfar * 1.0000002384185791015625f;
-                    tn[k] = hit ? tnear : INFINITY;
-                }
-#define SKH_CSWAP(a, b)                      \
-    {                                        \
-        const bool sw = tn[b] < tn[a];       \
-        const float ta = sw ? tn[b] : tn[a]; \
-        const float tb = sw ? tn[a] : tn[b]; \
-        const int ra = sw ? rf[b] : rf[a];   \
-        const int rb = sw ? rf[a] : rf[b];   \
-        tn[a] = ta, tn[b] = tb;              \
-        rf[a] = ra, rf[b] = rb;              \
-    }
-                SKH_CSWAP(0, 1)
-                SKH_CSWAP(2, 3)
-                SKH_CSWAP(0, 2)
-                SKH_CSWAP(1, 3)
-                SKH_CSWAP(1, 2)
-#undef SKH_CSWAP
-                if (tn[3] < INFINITY)
-                    SKH_PUSH(rf[3]);
-                if (tn[2] < INFINITY)
-                    SKH_PUSH(rf[2]);
-                if (tn[1] < INFINITY)
-                    SKH_PUSH(rf[1]);
-                cur = tn[0] < INFINITY ? rf[0] : SKH_REF_INVALID;
-            }
-            // ---- leaf ----
-            if (cur < 0)
-            {
-                const uint32_t enc = (uint32_t)~cur;
-                const uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
-                if (CURVES && first >= sc.wTriCount)
-                {
-                    for (uint32_t k = 0; k < count; ++k)
-                    {
-                        const uint32_t sidx = first - sc.wTriCount + k;
-                        const uint2 meta = sc.wSegMeta[sidx];
-                        const float4* cp = sc.wSegs + 4 * (size_t)sidx;
-                        const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
-                        if (COUNT)
-                            tc.segs++;
-                        SKH_SWITCH_INSTANCE(meta.y)
-                        v4 q[4];
-                        q[0] = mk4(c0.x, c0.y, c0.z, c0.w);
-                        q[1] = mk4(c1.x, c1.y, c1.z, c1.w);
-                        q[2] = mk4(c2.x, c2.y, c2.z, c2.w);
-                        q[3] = mk4(c3.x, c3.y, c3.z, c3.w);
-                        float t, u;
-                        if (intersect_curve_segment(oo, od, tmin, best.t, q, t, u) && t < tmax)
-                        {
-                            const uint32_t prim = meta.x;
-                            if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
-                            {
-                                best.t = t;
-                                best.inst = curInst;
-                                best.prim = prim;
-                                best.u = u;
-                                best.v = 0.0f;
-                                best.found = true;
-                            }
-                        }
-                    }
-                }
-                else
-                {
-                    for (uint32_t k = 0; k < count; ++k)
-                    {
-                        const float4* tp = sc.wTris + 3 * (size_t)(first + k);
-                        const float4 a = tp[0], b = tp[1], c = tp[2];
-                        if (!(__float_as_uint(c.w) & rayMask))
-                            continue; // light proxies are invisible to shadow rays (RAY_MASK_SHADOW)
-                        if (COUNT)
-                            tc.prims++;
-                        const uint32_t inst = __float_as_uint(b.w);
-                        SKH_SWITCH_INSTANCE(inst)
-                        float t, u, v;
-                        if (intersect_triangle(oo, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), t, u, v) && t < tmax)
-                        {
-                            const uint32_t prim = __float_as_uint(a.w);
-                            if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
-                            {
-                                best.t = t;
-                                best.inst = curInst;
-                                best.prim = prim;
-                                best.u = u;
-                                best.v = v;
-                                best.found = true;
-                            }
-                        }
-                    }
-                }
-            }
-            // ---- pop ----
-            if (ANY_HIT && best.found)
-                terminated = true;
-            else if (sp == 0)
-                terminated = true;
-            else
-                SKH_POP(cur);
-        }
-        if (terminated)
-        {
-            hasRay = false;
-            const uint32_t i = ridx;
-            if (ANY_HIT)
-            {
-                if (hq.base)
-                    hq.base[i] = best.found ? 1.0f : -1.0f;
-                else if (!best.found)
-                {
-                    const uint32_t pid = rq.ids()[i];
-                    float* rad = ps.base + (size_t)3 * ps.stride;
-                    rad[pid] += contrib[i];
-                    rad[pid + ps.stride] += contrib[i + contribStride];
-                    rad[pid + 2 * (size_t)ps.stride] += contrib[i + 2 * (size_t)contribStride];
-                }
-            }
-            else
-            {
-                hq.base[i] = best.found ? best.t : -1.0f;
-                reinterpret_cast<uint32_t*>(hq.base)[i + hq.stride] = best.inst;
-                reinterpret_cast<uint32_t*>(hq.base)[i + 2 * (size_t)hq.stride] = best.prim;
-                hq.base[i + 3 * (size_t)hq.stride] = best.u;
-                hq.base[i + 4 * (size_t)hq.stride] = best.v;
-            }
-        }
-    }
-#undef SKH_PUSH
-#undef SKH_POP
-#undef SKH_SWITCH_INSTANCE
-    if (COUNT)
-    {
-        const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.prims), c2 = wave_sum(tc.segs), d2 = wave_sum(tc.insts);
-        if (lane == 0)
-        {
-            atomicAdd(&stats->nodes[ANY_HIT ? 1 : 0], (unsigned long long)a);
-            atomicAdd(&stats->prims[ANY_HIT ? 1 : 0], (unsigned long long)b);
-            atomicAdd(&stats->segs[ANY_HIT ? 1 : 0], (unsigned long long)c2);
-            atomicAdd(&stats->insts[ANY_HIT ? 1 : 0], (unsigned long long)d2);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1454,10 +1182,9 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
         pid = rq.ids()[i];
         const v3 rayO = mk3(rq.plane(0)[i], rq.plane(1)[i], rq.plane(2)[i]);
         const v3 rayD = mk3(rq.plane(3)[i], rq.plane(4)[i], rq.plane(5)[i]);
-        const float ht = hq.base[i];
-        const uint32_t hinst = reinterpret_cast<const uint32_t*>(hq.base)[i + hq.stride];
-        const uint32_t hprim = reinterpret_cast<const uint32_t*>(hq.base)[i + 2 * (size_t)hq.stride];
-        const float hu = hq.base[i + 3 * (size_t)hq.stride], hv = hq.base[i + 4 * (size_t)hq.stride];
+        const float4 hr0 = hq.rec(i)[0], hr1 = hq.rec(i)[1];
+        const float ht = hr0.x, hu = hr0.y, hv = hr0.z;
+        const uint32_t hinst = __float_as_uint(hr1.x), hprim = __float_as_uint(hr1.y);
         float* P = ps.base;
         const size_t S = ps.stride;
         v3 throughput = mk3(P[pid], P[pid + S], P[pid + 2 * S]);

@@ -4,7 +4,21 @@
 #include "skh_kernels.h"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h> // types only: the library itself is dlopen()ed on first use (skh_comm_*)
+// RCCL is dlopen()ed on first use (skh_comm_*); the handful of types its point-to-point API needs are declared here, so that a
+// box without the RCCL development headers still builds the renderer (nccl.h 2.x: the layouts below are part of its stable ABI)
+typedef struct ncclComm* ncclComm_t;
+typedef struct
+{
+    char internal[128];
+} ncclUniqueId;
+typedef enum
+{
+    ncclSuccess = 0
+} ncclResult_t;
+typedef enum
+{
+    ncclFloat = 7 // ncclFloat32
+} ncclDataType_t;
 
 #include <algorithm>
 #include <chrono>
@@ -122,13 +136,6 @@ struct skh_context
     uint32_t leafMin = 16; // postpone the minority kind of leaf work unless it has this many lanes (0 = never postpone; measured +1.5 % at 16)
     // ray re-ordering (per bounce): 0 = off, else Morton bits per axis of the origin cell (key = octant : morton)
     uint32_t sortBitsClosest = 0, sortBitsShadow = 0, sortFirstBounce = 1;
-    // flatten = true: one world-space tree over all instanced primitives instead of TLAS + per-mesh BLAS.  Measured
-    // slower on MI355X for the kitchen scene (928 vs 1104 Mray/s): 1.1 GB of duplicated leaf records fall out of the
-    // 256 MB Infinity Cache, while the shared BLAS data (83 MB) stays resident.  Kept as an option, default off.
-    bool flatten = false;
-    DevBuf dWNodes, dWTris, dWSegs, dWSegMeta;
-    int wRoot = SKH_REF_INVALID;
-    uint32_t wTriCount = 0, wSegCount = 0;
     uint32_t subframeBatch = 0, batchCapacity = 1; // option subframe_batch: 0 = auto
     bool tightInstanceBoxes = true; // TLAS leaf boxes from the transformed vertices, not from the transformed object box
     uint32_t curveSplit = 2; // parameter sub-ranges per curve segment in the curve BLAS (1 = off; hair stand-in, ms per 1080p sub-frame: 1: 61.6, 2: 52.1, 4: 49.7, 8: 50.1 -- build time and leaf memory grow with it)
@@ -141,6 +148,15 @@ struct skh_context
     uint32_t wide = 4; // node width: 4 = Node4 (64 B, children sorted by entry distance in the traversal), 8 = Node8 (96 B, slot order = traversal order;
                        // two-level hierarchy only, TLAS by the GPU builder, no TLAS opening)
     uint32_t tlasOpen = 1; // TLAS opening: up to tlasOpen x numInstances leaves; 1 = one leaf per instance (default: on the kitchen stand-in 2..16 were 4-9 % slower, more instance entries for no fewer nodes)
+    // bake_world: mesh instances that skip the TLAS -- their triangles are carried to world space once and join ONE extra
+    // group of the triangle build that every ray walks first, with no instance entry (DESIGN.md section 2 "bake_world").
+    // 0 off; 1: instances whose mesh has a single user (what HdStrelka's per-instance meshes are, RenderPass.cpp:126-129,252-257);
+    // 2: also instances of meshes with <= bakeSmallTris triangles (room shells, boards, quads: big boxes that every ray enters
+    // for a dozen triangles), while they add at most max(unique triangles, 2^20) triangles
+    uint32_t bakeWorld = 2, bakeSmallTris = 64;
+    std::vector<uint8_t> baked; // per instance, valid after skh_build_accel
+    int worldRoot = SKH_REF_INVALID, lightRoot = SKH_REF_INVALID; // roots of the two baked groups (mesh instances, light proxies) inside dTriNodes
+    uint32_t nBakedTris = 0, nBakedInst = 0;
     uint32_t leafMaxTris = 2; // measured on MI355X: 2 beats 1, 3, 4, 6, 8 (the kernel is ALU bound, wasted triangle tests cost more than extra nodes)
     uint32_t buildQuality = 1; // 0: Karras radix tree (fastest build), 1: PLOC clustering (SAH-class quality)
     float sceneLo[3] = { 0, 0, 0 }, sceneHi[3] = { 1, 1, 1 };
@@ -792,7 +808,7 @@ void skh_destroy(skh_context* c)
                        &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
                        &c->dCounts, &c->dOvf, &c->dOvf2, &c->dStats, &c->dScratchImage, &c->dSortKeys[0], &c->dSortKeys[1], &c->dSortVals[0],
-                       &c->dSortVals[1], &c->dSortHist, &c->dWNodes, &c->dWTris, &c->dWSegs, &c->dWSegMeta })
+                       &c->dSortVals[1], &c->dSortHist })
         dev_free(*b);
     for (hipEvent_t e : c->eventPool)
         (void)hipEventDestroy(e);
@@ -958,191 +974,6 @@ skh_status skh_set_materials(skh_context* c, const skh_material* materials, uint
     return dev_upload(c, c->dMaterials, materials, sizeof(skh_material) * (size_t)n);
 }
 
-// Flattened build: enumerate every instanced primitive in world space, build ONE tree (two key groups: triangles,
-// curve segments; a host-made top node joins the two roots), gather object-space leaf records in leaf order.
-static skh_status build_world(skh_context* c, bool usePloc)
-{
-    hipStream_t st = c->stream;
-    skh_status s;
-    const uint32_t B = 256;
-    const uint32_t nMeshes = (uint32_t)c->meshes.size(), nCurves = (uint32_t)c->curves.size(), nInst = c->nInstances;
-    // curve segment tables (segment enumeration: OptixRender.cpp:226-245)
-    std::vector<uint32_t> segStart, curveSegCount(nCurves), curveSegBase(nCurves);
-    for (uint32_t ci = 0; ci < nCurves; ++ci)
-    {
-        const skh_curve& cu = c->curves[ci];
-        curveSegBase[ci] = (uint32_t)segStart.size();
-        uint32_t off = 0, local = 0;
-        for (uint32_t k = 0; k < cu.vertex_counts_count; ++k)
-        {
-            const uint32_t ncp = c->curveVertexCounts[cu.vertex_counts_start + k];
-            for (int i = 0; i < (int)ncp - 3; ++i)
-            {
-                segStart.push_back(cu.points_start + off + (uint32_t)i);
-                ++local;
-            }
-            off += ncp;
-        }
-        curveSegCount[ci] = local;
-    }
-    for (uint32_t k = 0; k < (uint32_t)segStart.size(); ++k)
-        if ((uint64_t)segStart[k] + 4 > c->nPoints)
-        {
-            c->err = "skh_build_accel: curve segment reads past the control-point buffer";
-            return SKH_INVALID_ARGUMENT;
-        }
-    c->nSegs = (uint32_t)segStart.size();
-    if ((s = dev_upload(c, c->dSegStartAll, segStart.data(), sizeof(uint32_t) * segStart.size())) != SKH_OK ||
-        (s = dev_upload(c, c->dCurveSegBase, curveSegBase.data(), sizeof(uint32_t) * curveSegBase.size())) != SKH_OK)
-        return s;
-    // instance records (w2o) + the lists of primitive-carrying instances
-    std::vector<DevInstance> dinst(std::max(1u, nInst));
-    std::vector<uint32_t> wInstT, wFirstT(1, 0u), wInstS, wFirstS(1, 0u);
-    uint64_t Wt64 = 0, Ws64 = 0;
-    for (uint32_t i = 0; i < nInst; ++i)
-    {
-        const skh_instance& in = c->instances[i];
-        DevInstance& d = dinst[i];
-        const bool inv = invert_affine(in.transform, d.w2o);
-        d.rootRef = SKH_REF_INVALID;
-        d.type = in.type;
-        d.pad = 0;
-        d.mask = 0;
-        if (!inv)
-            continue; // singular transform (the reference's distant-light proxy, scene.cpp:337-345): unhittable
-        if (in.type == SKH_INSTANCE_CURVE)
-        {
-            if (in.geom_id < nCurves && curveSegCount[in.geom_id])
-            {
-                d.mask = 2;
-                wInstS.push_back(i);
-                Ws64 += curveSegCount[in.geom_id];
-                wFirstS.push_back((uint32_t)Ws64);
-            }
-        }
-        else if (in.geom_id < nMeshes && c->meshes[in.geom_id].index_count >= 3)
-        {
-            d.mask = in.type == SKH_INSTANCE_MESH ? 1u : 4u;
-            wInstT.push_back(i);
-            Wt64 += c->meshes[in.geom_id].index_count / 3;
-            wFirstT.push_back((uint32_t)Wt64);
-        }
-    }
-    if (Wt64 + Ws64 >= (1ull << 28))
-    {
-        c->err = "skh_build_accel: more than 2^28 instanced primitives; set option flatten=0 for the two-level hierarchy";
-        return SKH_INVALID_ARGUMENT;
-    }
-    const uint32_t Wt = (uint32_t)Wt64, Ws = (uint32_t)Ws64, W = Wt + Ws;
-    c->wTriCount = Wt;
-    c->wSegCount = Ws;
-    c->nTris = Wt;
-    if ((s = dev_upload(c, c->dDevInst, dinst.data(), sizeof(DevInstance) * dinst.size())) != SKH_OK)
-        return s;
-    DevBuf dWInstT, dWFirstT, dWInstS, dWFirstS, dBoxLo, dBoxHi, dGrp;
-    LbvhOut wOut;
-    auto cleanup = [&]() {
-        for (DevBuf* b : { &dWInstT, &dWFirstT, &dWInstS, &dWFirstS, &dBoxLo, &dBoxHi, &dGrp, &wOut.sortedVals, &wOut.groupRoot, &wOut.groupBounds })
-            dev_free(*b);
-    };
-#define BW(expr)                \
-    if ((s = (expr)) != SKH_OK) \
-    {                           \
-        cleanup();              \
-        return s;               \
-    }
-    BW(dev_upload(c, dWInstT, wInstT.data(), sizeof(uint32_t) * wInstT.size()));
-    BW(dev_upload(c, dWFirstT, wFirstT.data(), sizeof(uint32_t) * wFirstT.size()));
-    BW(dev_upload(c, dWInstS, wInstS.data(), sizeof(uint32_t) * wInstS.size()));
-    BW(dev_upload(c, dWFirstS, wFirstS.data(), sizeof(uint32_t) * wFirstS.size()));
-    BW(dev_alloc(c, dBoxLo, sizeof(float4) * (size_t)std::max(1u, W)));
-    BW(dev_alloc(c, dBoxHi, sizeof(float4) * (size_t)std::max(1u, W)));
-    BW(dev_alloc(c, dGrp, sizeof(uint32_t) * (size_t)std::max(1u, W)));
-    if (Wt)
-        k_world_tri_boxes<<<(Wt + B - 1) / B, B, 0, st>>>(c->dInstances.as<uint8_t>(), dWInstT.as<uint32_t>(), dWFirstT.as<uint32_t>(),
-                                                         (uint32_t)wInstT.size(), c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(),
-                                                         c->dMeshes.as<uint4>(), Wt, dBoxLo.as<float4>(), dBoxHi.as<float4>(),
-                                                         dGrp.as<uint32_t>());
-    if (Ws)
-        k_world_seg_boxes<<<(Ws + B - 1) / B, B, 0, st>>>(c->dInstances.as<uint8_t>(), dWInstS.as<uint32_t>(), dWFirstS.as<uint32_t>(),
-                                                         (uint32_t)wInstS.size(), c->dPoints.as<float>(), c->dRadii.as<float>(),
-                                                         c->dCurveSegBase.as<uint32_t>(), c->dSegStartAll.as<uint32_t>(), Ws, Wt,
-                                                         dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>());
-    const std::vector<uint32_t> groupCount = { Wt, Ws };
-    BW(lbvh_build(c, W, 2, groupCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), (int)c->leafMaxTris, usePloc, wOut));
-    BW(dev_alloc(c, c->dWTris, sizeof(float4) * 3 * (size_t)std::max(1u, Wt)));
-    BW(dev_alloc(c, c->dWSegs, sizeof(float4) * 4 * (size_t)std::max(1u, Ws)));
-    BW(dev_alloc(c, c->dWSegMeta, sizeof(uint2) * (size_t)std::max(1u, Ws)));
-    if (Wt)
-        k_gather_world_tris<<<(Wt + B - 1) / B, B, 0, st>>>(c->dInstances.as<uint8_t>(), dWInstT.as<uint32_t>(), dWFirstT.as<uint32_t>(),
-                                                           (uint32_t)wInstT.size(), c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(),
-                                                           c->dMeshes.as<uint4>(), wOut.sortedVals.as<uint32_t>(), Wt,
-                                                           c->dWTris.as<float4>());
-    if (Ws)
-        k_gather_world_segs<<<(Ws + B - 1) / B, B, 0, st>>>(c->dInstances.as<uint8_t>(), dWInstS.as<uint32_t>(), dWFirstS.as<uint32_t>(),
-                                                           (uint32_t)wInstS.size(), c->dPoints.as<float>(), c->dRadii.as<float>(),
-                                                           c->dCurveSegBase.as<uint32_t>(), c->dSegStartAll.as<uint32_t>(),
-                                                           wOut.sortedVals.as<uint32_t>(), Wt, Ws, c->dWSegs.as<float4>(),
-                                                           c->dWSegMeta.as<uint2>());
-    // roots: one per non-empty group; a host-made top node joins them when both exist
-    float gb[12] = { 0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1 };
-    if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(gb, wOut.groupBounds.p, sizeof(gb), hipMemcpyDeviceToHost) != hipSuccess)
-    {
-        cleanup();
-        c->err = "skh_build_accel: group bounds read-back failed";
-        return SKH_FAIL;
-    }
-    const int r0 = Wt ? wOut.hostGroupRoot[0] : SKH_REF_INVALID, r1 = Ws ? wOut.hostGroupRoot[1] : SKH_REF_INVALID;
-    if (Wt && Ws)
-    {
-        Node4 top;
-        float clo[4][3] = {}, chi[4][3] = {}, nlo[3], nhi[3];
-        for (int k = 0; k < 3; ++k)
-        {
-            clo[0][k] = gb[k], chi[0][k] = gb[3 + k], clo[1][k] = gb[6 + k], chi[1][k] = gb[9 + k];
-            nlo[k] = std::min(gb[k], gb[6 + k]);
-            nhi[k] = std::max(gb[3 + k], gb[9 + k]);
-        }
-        const int refs[4] = { r0, r1, SKH_REF_INVALID, SKH_REF_INVALID };
-        encode_node4(top, nlo, nhi, clo, chi, refs, 2);
-        if (hipMemcpy(wOut.nodes.as<Node4>() + wOut.numNodes, &top, sizeof(top), hipMemcpyHostToDevice) != hipSuccess)
-        {
-            cleanup();
-            c->err = "skh_build_accel: top node upload failed";
-            return SKH_FAIL;
-        }
-        c->wRoot = (int)wOut.numNodes;
-        for (int k = 0; k < 3; ++k)
-        {
-            c->sceneLo[k] = nlo[k];
-            c->sceneHi[k] = nhi[k];
-        }
-    }
-    else
-    {
-        c->wRoot = Wt ? r0 : r1;
-        const float* g = Wt ? gb : gb + 6;
-        for (int k = 0; k < 3; ++k)
-        {
-            c->sceneLo[k] = W ? g[k] : 0.0f;
-            c->sceneHi[k] = W ? g[3 + k] : 1.0f;
-        }
-    }
-    dev_free(c->dWNodes);
-    c->dWNodes = wOut.nodes;
-    hipError_t e = hipStreamSynchronize(st);
-    cleanup();
-    if (e != hipSuccess || (e = hipGetLastError()) != hipSuccess)
-    {
-        c->err = std::string("skh_build_accel (flattened): ") + hipGetErrorString(e);
-        return SKH_FAIL;
-    }
-    return SKH_OK;
-#undef BW
-}
-
-// Shading-side tables (k_shade): one 96-byte record per triangle and a copy of the instance records whose unused light id (mesh
-// instances) holds the first record of the instance's mesh.
 static skh_status build_shading_tables(skh_context* c)
 {
     const uint32_t nMeshes = (uint32_t)c->meshes.size();
@@ -1207,29 +1038,114 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     }
     const bool usePloc = (flags & SKH_BUILD_SAH) != 0 || c->buildQuality != 0;
     const auto t0 = std::chrono::steady_clock::now();
-    if (c->flatten && c->wide == 8)
-    {
-        c->err = "skh_build_accel: wide = 8 is implemented for the two-level hierarchy only (flatten = 0)";
-        return SKH_INVALID_ARGUMENT;
-    }
-    if (c->flatten)
-    {
-        const skh_status fs = build_world(c, usePloc);
-        if (fs != SKH_OK)
-            return fs;
-        c->accelBuilt = true;
-        c->msBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        return SKH_OK;
-    }
     hipStream_t st = c->stream;
     skh_status s;
     const uint32_t B = 256;
-    // ---- triangles of all meshes ----
     const uint32_t nMeshes = (uint32_t)c->meshes.size();
-    std::vector<uint32_t> triMesh, triLocal, meshTriCount(nMeshes);
+    const uint32_t nInst = c->nInstances;
+    // ---- instance validity (finite inverse) and the baked set ----
+    std::vector<float> w2o(12 * (size_t)std::max(1u, nInst));
+    std::vector<uint8_t> valid(std::max(1u, nInst));
+    for (uint32_t i = 0; i < nInst; ++i)
+        valid[i] = invert_affine(c->instances[i].transform, &w2o[12 * (size_t)i]) ? 1 : 0;
+    std::vector<uint32_t> meshUsers(nMeshes, 0u), meshUsersLeft(nMeshes, 0u); // users: mesh + light instances; left: those that keep their TLAS leaf
+    c->baked.assign(std::max(1u, nInst), 0);
+    // two world-space groups: [0] mesh instances (every ray), [1] light proxies (radiance rays only: shadow rays do not see lights,
+    // RAY_MASK_SHADOW, closest_hit.cu:191) -- the ray mask stays a property of the group, not of the triangle
+    std::vector<uint32_t> wInst, wFirst;
+    uint32_t nBakedG[2] = { 0, 0 };
+    {
+        uint64_t uniqueTris = 0;
+        for (const skh_mesh& me : c->meshes)
+            uniqueTris += me.index_count / 3;
+        for (uint32_t i = 0; i < nInst; ++i)
+            if (c->instances[i].type != SKH_INSTANCE_CURVE && valid[i]) // (a singular instance is disabled: the reference's distant-light proxy is one, of mesh 0, scene.cpp:337-345)
+                meshUsers[c->instances[i].geom_id]++;
+        const uint64_t smallBudget = std::max<uint64_t>(uniqueTris, 1ull << 20);
+        uint64_t total = 0;
+        std::vector<uint8_t> pick(std::max(1u, nInst), 0);
+        auto trisOf = [&](uint32_t i) { return c->meshes[c->instances[i].geom_id].index_count / 3; };
+        auto eligible = [&](uint32_t i) { return c->bakeWorld >= 1 && c->instances[i].type != SKH_INSTANCE_CURVE && valid[i] && trisOf(i) > 0; };
+        for (uint32_t i = 0; i < nInst; ++i)
+            pick[i] = eligible(i) && (meshUsers[c->instances[i].geom_id] == 1 || c->bakeWorld >= 3) ? 1 : 0;
+        if (c->bakeWorld == 2)
+        {
+            // Small SHARED meshes (boards, quads) follow only when that leaves no mesh instance behind: beside a populated top level
+            // a partly baked scene measured no faster (kitchen stand-in, any-hit 41.1 -> 42.6 ms), an emptied one saves the level
+            bool all = true;
+            uint64_t sum = 0;
+            for (uint32_t i = 0; i < nInst; ++i)
+                if (c->instances[i].type == SKH_INSTANCE_MESH && eligible(i) && !pick[i])
+                {
+                    all = all && trisOf(i) <= c->bakeSmallTris;
+                    sum += trisOf(i);
+                }
+            all = all && sum <= smallBudget;
+            for (uint32_t i = 0; i < nInst; ++i)
+                if (eligible(i) && !pick[i] && trisOf(i) <= c->bakeSmallTris && (all || c->instances[i].type == SKH_INSTANCE_LIGHT))
+                    pick[i] = 1;
+        }
+        for (uint32_t i = 0; i < nInst; ++i)
+            if (pick[i])
+            {
+                if (total + trisOf(i) >= (1ull << 27)) // (leaf references address 2^28 primitives)
+                    pick[i] = 0;
+                else
+                    total += trisOf(i);
+            }
+        // Light proxies follow the meshes only when that EMPTIES the top level (then no ray ever leaves world space): beside a
+        // populated TLAS their own group costs every radiance ray a root visit that the TLAS's distance-ordered culling mostly
+        // avoided (kitchen stand-in, closest-hit 99.4 -> 102.4 ms), without a TLAS it saves the whole level (unshared variant: 89.7 -> 81.2 ms)
+        bool tlasStays = false;
+        for (uint32_t i = 0; i < nInst; ++i)
+        {
+            const skh_instance& in = c->instances[i];
+            if (in.type == SKH_INSTANCE_CURVE)
+            {
+                uint32_t segs = 0; // (a curve set without a segment has no BLAS and no leaf)
+                if (in.geom_id < c->curves.size())
+                    for (uint32_t k = 0; k < c->curves[in.geom_id].vertex_counts_count; ++k)
+                        segs += std::max(3u, c->curveVertexCounts[c->curves[in.geom_id].vertex_counts_start + k]) - 3u;
+                tlasStays = tlasStays || (valid[i] && segs > 0);
+            }
+            else if (in.type == SKH_INSTANCE_MESH)
+                tlasStays = tlasStays || (valid[i] && !pick[i] && c->meshes[in.geom_id].index_count >= 3);
+        }
+        for (uint32_t i = 0; i < nInst; ++i)
+        {
+            const skh_instance& in = c->instances[i];
+            if (in.type == SKH_INSTANCE_CURVE)
+                continue;
+            if (in.type == SKH_INSTANCE_LIGHT && tlasStays)
+                pick[i] = 0;
+            if (!pick[i])
+                meshUsersLeft[in.geom_id] += valid[i] ? 1u : 0u;
+        }
+        total = 0;
+        for (uint32_t g = 0; g < 2; ++g)
+            for (uint32_t i = 0; i < nInst; ++i)
+            {
+                const skh_instance& in = c->instances[i];
+                if (!pick[i] || (in.type == SKH_INSTANCE_LIGHT ? 1u : 0u) != g)
+                    continue;
+                c->baked[i] = 1;
+                valid[i] = 0; // no TLAS leaf
+                wInst.push_back(i);
+                wFirst.push_back((uint32_t)total);
+                const uint32_t nt = c->meshes[in.geom_id].index_count / 3;
+                total += nt;
+                nBakedG[g] += nt;
+            }
+        wFirst.push_back((uint32_t)total);
+    }
+    const uint32_t nBaked = nBakedG[0] + nBakedG[1];
+    c->nBakedTris = nBaked;
+    c->nBakedInst = (uint32_t)wInst.size();
+    // ---- triangles of all meshes (a mesh whose users were all baked needs no object-space tree) + the baked group ----
+    std::vector<uint32_t> triMesh, triLocal, meshTriCount(nMeshes + 2u);
     for (uint32_t m = 0; m < nMeshes; ++m)
     {
-        const uint32_t nt = c->meshes[m].index_count / 3;
+        const uint32_t nt = (meshUsers[m] > 0 && meshUsersLeft[m] == 0) ? 0u : c->meshes[m].index_count / 3;
         meshTriCount[m] = nt;
         for (uint32_t t = 0; t < nt; ++t)
         {
@@ -1237,12 +1153,15 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
             triLocal.push_back(t);
         }
     }
-    const uint32_t nTris = (uint32_t)triMesh.size();
+    meshTriCount[nMeshes] = nBakedG[0];
+    meshTriCount[nMeshes + 1u] = nBakedG[1];
+    const uint32_t nMeshTris = (uint32_t)triMesh.size();
+    const uint32_t nTris = nMeshTris + nBaked;
     c->nTris = nTris;
     LbvhOut triOut, segOut;
-    DevBuf dTriMesh, dTriLocal, dBoxLo, dBoxHi, dGrp, dSegStart, dSegCurve, dSegLocal, dW2o, dValid;
+    DevBuf dTriMesh, dTriLocal, dBoxLo, dBoxHi, dGrp, dSegStart, dSegCurve, dSegLocal, dW2o, dValid, dWInst, dWFirst;
     auto cleanup = [&]() {
-        for (DevBuf* b : { &dTriMesh, &dTriLocal, &dBoxLo, &dBoxHi, &dGrp, &dSegStart, &dSegCurve, &dSegLocal, &dW2o, &dValid,
+        for (DevBuf* b : { &dTriMesh, &dTriLocal, &dBoxLo, &dBoxHi, &dGrp, &dSegStart, &dSegCurve, &dSegLocal, &dW2o, &dValid, &dWInst, &dWFirst,
                            &triOut.sortedVals, &segOut.sortedVals, &triOut.groupRoot, &segOut.groupRoot, &triOut.groupBounds,
                            &segOut.groupBounds })
             dev_free(*b);
@@ -1253,23 +1172,53 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         cleanup();                  \
         return s;                   \
     }
-    BA(dev_upload(c, dTriMesh, triMesh.data(), sizeof(uint32_t) * (size_t)nTris));
-    BA(dev_upload(c, dTriLocal, triLocal.data(), sizeof(uint32_t) * (size_t)nTris));
+    BA(dev_upload(c, dTriMesh, triMesh.data(), sizeof(uint32_t) * (size_t)nMeshTris));
+    BA(dev_upload(c, dTriLocal, triLocal.data(), sizeof(uint32_t) * (size_t)nMeshTris));
+    BA(dev_upload(c, dWInst, wInst.data(), sizeof(uint32_t) * wInst.size()));
+    BA(dev_upload(c, dWFirst, wFirst.data(), sizeof(uint32_t) * wFirst.size()));
     BA(dev_alloc(c, dBoxLo, sizeof(float4) * (size_t)std::max(1u, nTris)));
     BA(dev_alloc(c, dBoxHi, sizeof(float4) * (size_t)std::max(1u, nTris)));
     BA(dev_alloc(c, dGrp, sizeof(uint32_t) * (size_t)std::max(1u, nTris)));
-    if (nTris)
-        k_tri_boxes<<<(nTris + B - 1) / B, B, 0, st>>>(c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(), c->dMeshes.as<uint4>(),
-                                                      dTriMesh.as<uint32_t>(), dTriLocal.as<uint32_t>(), nTris, dBoxLo.as<float4>(),
-                                                      dBoxHi.as<float4>(), dGrp.as<uint32_t>());
-    BA(lbvh_build(c, nTris, nMeshes, meshTriCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), (int)c->leafMaxTris, usePloc, triOut));
+    if (nMeshTris)
+        k_tri_boxes<<<(nMeshTris + B - 1) / B, B, 0, st>>>(c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(), c->dMeshes.as<uint4>(),
+                                                          dTriMesh.as<uint32_t>(), dTriLocal.as<uint32_t>(), nMeshTris, dBoxLo.as<float4>(),
+                                                          dBoxHi.as<float4>(), dGrp.as<uint32_t>());
+    if (nBaked)
+        k_baked_tri_boxes<<<(nBaked + B - 1) / B, B, 0, st>>>(c->dInstances.as<uint8_t>(), dWInst.as<uint32_t>(), dWFirst.as<uint32_t>(),
+                                                             (uint32_t)wInst.size(), c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(),
+                                                             c->dMeshes.as<uint4>(), nBaked, nMeshTris, nMeshes, nBakedG[0], dBoxLo.as<float4>(),
+                                                             dBoxHi.as<float4>(), dGrp.as<uint32_t>());
+    BA(lbvh_build(c, nTris, nMeshes + 2u, meshTriCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), (int)c->leafMaxTris, usePloc, triOut));
     BA(dev_alloc(c, c->dTris, sizeof(float4) * 3 * (size_t)std::max(1u, nTris)));
     if (nTris)
         k_gather_tris<<<(nTris + B - 1) / B, B, 0, st>>>(c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(), c->dMeshes.as<uint4>(),
-                                                        dTriMesh.as<uint32_t>(), dTriLocal.as<uint32_t>(),
-                                                        triOut.sortedVals.as<uint32_t>(), nTris, c->dTris.as<float4>());
+                                                              dTriMesh.as<uint32_t>(), dTriLocal.as<uint32_t>(),
+                                                              triOut.sortedVals.as<uint32_t>(), nTris, nMeshTris, c->dInstances.as<uint8_t>(),
+                                                              dWInst.as<uint32_t>(), dWFirst.as<uint32_t>(), (uint32_t)wInst.size(),
+                                                              c->dTris.as<float4>());
     dev_free(c->dTriNodes);
     c->dTriNodes = triOut.nodes;
+    c->worldRoot = nBakedG[0] ? triOut.hostGroupRoot[nMeshes] : SKH_REF_INVALID;
+    c->lightRoot = nBakedG[1] ? triOut.hostGroupRoot[nMeshes + 1u] : SKH_REF_INVALID;
+    float worldBounds[6] = { INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY };
+    if (nBaked)
+    {
+        float gb[12];
+        if (hipMemcpyAsync(gb, triOut.groupBounds.as<float>() + 6 * (size_t)nMeshes, sizeof(gb), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+        {
+            c->err = "skh_build_accel: bounds of the baked groups: read-back failed";
+            cleanup();
+            return SKH_FAIL;
+        }
+        for (uint32_t g = 0; g < 2; ++g)
+            if (nBakedG[g])
+                for (int k = 0; k < 3; ++k)
+                {
+                    worldBounds[k] = std::min(worldBounds[k], gb[6 * g + k]);
+                    worldBounds[3 + k] = std::max(worldBounds[3 + k], gb[6 * g + 3 + k]);
+                }
+    }
     // ---- curve segments of all curve sets (segment enumeration: OptixRender.cpp:226-245) ----
     const uint32_t nCurves = (uint32_t)c->curves.size();
     std::vector<uint32_t> segStart, segCurve, segLocal, curveSegCount(nCurves), curveSegBase(nCurves);
@@ -1333,12 +1282,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     c->curveSplitBuilt = K;
     dev_free(c->dSegNodes);
     c->dSegNodes = segOut.nodes;
-    // ---- instances -> TLAS ----
-    const uint32_t nInst = c->nInstances;
-    std::vector<float> w2o(12 * (size_t)std::max(1u, nInst));
-    std::vector<uint8_t> valid(std::max(1u, nInst));
-    for (uint32_t i = 0; i < nInst; ++i)
-        valid[i] = invert_affine(c->instances[i].transform, &w2o[12 * (size_t)i]) ? 1 : 0;
+    // ---- instances -> TLAS (baked instances were marked invalid above: they get a record for shading, no leaf) ----
     BA(dev_upload(c, dW2o, w2o.data(), sizeof(float) * w2o.size()));
     BA(dev_upload(c, dValid, valid.data(), valid.size()));
     BA(dev_alloc(c, c->dDevInst, sizeof(DevInstance) * (size_t)std::max(1u, nInst)));
@@ -1585,6 +1529,16 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         dev_free(c->dTravInst);
         c->tlasRoot = SKH_REF_INVALID;
     }
+    if (nBaked)
+        for (int k = 0; k < 3; ++k)
+        {
+            const bool none = c->tlasRoot == SKH_REF_INVALID;
+            c->sceneLo[k] = none ? worldBounds[k] : std::min(c->sceneLo[k], worldBounds[k]);
+            c->sceneHi[k] = none ? worldBounds[3 + k] : std::max(c->sceneHi[k], worldBounds[3 + k]);
+        }
+    if (getenv("SKH_DEBUG"))
+        fprintf(stderr, "[skh] bake_world %u: %u of %u instances baked, %u + %u world-space triangles, roots %d %d; %u object-space triangles; TLAS root %d\n", c->bakeWorld,
+                c->nBakedInst, nInst, nBakedG[0], nBakedG[1], c->worldRoot, c->lightRoot, nMeshTris, c->tlasRoot);
     hipError_t e = hipStreamSynchronize(st);
     cleanup();
     if (e != hipSuccess || (e = hipGetLastError()) != hipSuccess)
@@ -1596,6 +1550,27 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     c->msBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SKH_OK;
 #undef BA
+}
+
+skh_status skh_get_baked(skh_context* c, uint8_t* flags, uint32_t n_instances, uint32_t* out_baked_instances, uint32_t* out_baked_triangles)
+{
+    if (!c)
+        return SKH_INVALID_ARGUMENT;
+    if (!c->accelBuilt)
+    {
+        const skh_status s = skh_build_accel(c, SKH_BUILD_LBVH);
+        if (s != SKH_OK)
+            return s;
+    }
+    const bool on = true;
+    if (flags)
+        for (uint32_t i = 0; i < n_instances; ++i)
+            flags[i] = (on && i < c->nInstances && i < c->baked.size()) ? c->baked[i] : 0;
+    if (out_baked_instances)
+        *out_baked_instances = on ? c->nBakedInst : 0u;
+    if (out_baked_triangles)
+        *out_baked_triangles = on ? c->nBakedTris : 0u;
+    return SKH_OK;
 }
 
 static skh_status alloc_frame(skh_context* c)
@@ -1663,7 +1638,7 @@ static skh_status alloc_frame(skh_context* c)
     AF(dev_alloc(c, c->dPath, sizeof(float) * 8 * N));
     AF(dev_alloc(c, c->dRayQ[0], sizeof(float) * 9 * N));
     AF(dev_alloc(c, c->dRayQ[1], sizeof(float) * 9 * N));
-    AF(dev_alloc(c, c->dHits, sizeof(float) * 5 * N));
+    AF(dev_alloc(c, c->dHits, sizeof(float) * 8 * N));
     AF(dev_alloc(c, c->dShadowQ, sizeof(float) * 9 * N));
     AF(dev_alloc(c, c->dContrib, sizeof(float) * 3 * N));
     AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * (SKH_COUNT_STRIDE * 2 * 130 + 16 * SKH_FETCH_STRIDE * 130)));
@@ -1783,12 +1758,8 @@ static DevScene make_dev_scene(const skh_context* c)
     sc.segPrim = c->dSegPrim.as<uint32_t>();
     sc.segBound = c->dSegBound.as<float4>();
     sc.curveSplit = c->curveSplitBuilt;
-    sc.wNodes = c->dWNodes.as<Node4>();
-    sc.wRoot = c->wRoot;
-    sc.wTriCount = c->wTriCount;
-    sc.wTris = c->dWTris.as<float4>();
-    sc.wSegs = c->dWSegs.as<float4>();
-    sc.wSegMeta = c->dWSegMeta.as<uint2>();
+    sc.worldRoot = c->worldRoot;
+    sc.lightRoot = c->lightRoot;
     sc.instances = c->dShadeInst.as<HostInstance>();
     sc.shadeTris = c->dShadeTris.as<float4>();
     sc.verts = c->dVerts.as<uint8_t>();
@@ -1870,7 +1841,7 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
                          HitQ hq, PathS ps, const float* contrib, uint32_t contribStride, hipStream_t st = nullptr)
 {
     // scenes without curve instances run the build of the kernel that has no curve intersector in it (fewer VGPRs)
-    const bool curveBuild = c->nSegs != 0 || (c->flatten && c->wSegCount);
+    const bool curveBuild = c->nSegs != 0;
     const uint32_t fetchMin = ANY ? (curveBuild ? c->curveFetchMinShadow : c->fetchMinShadow) : (curveBuild ? c->curveFetchMinClosest : c->fetchMinClosest);
     const uint32_t nodeBreak = ANY ? c->nodeBreakShadow : (curveBuild ? c->curveNodeBreakClosest : c->nodeBreakClosest);
     const uint32_t fm = fetchMin | (c->curveMin << 8) | (nodeBreak << 16) | (c->leafMin << 24);
@@ -1878,18 +1849,9 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
         st = c->stream;
     int* ovf = st == c->stream ? c->dOvf.as<int>() : c->dOvf2.as<int>(); // (two trace kernels may be in flight)
     StatsDev* sd = c->dStats.as<StatsDev>();
-    const uint32_t fullGrid = (ANY && !c->nSegs && !c->flatten) ? (uint32_t)c->numCUs * c->wavesPerCUShadow : c->traceBlocks;
+    const uint32_t fullGrid = (ANY && !c->nSegs) ? (uint32_t)c->numCUs * c->wavesPerCUShadow : c->traceBlocks;
     const uint32_t blocks = c->gridOverride ? std::min(c->gridOverride, fullGrid) : fullGrid;
-    if (c->flatten)
-    {
-        if (c->wSegCount)
-            k_trace_flat<ANY, COUNT, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib,
-                                                                                               contribStride, ovf, sd);
-        else
-            k_trace_flat<ANY, COUNT, false><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib,
-                                                                                                contribStride, ovf, sd);
-    }
-    else if (c->wide == 8)
+    if (c->wide == 8)
     {
         if (c->nSegs)
             k_trace<ANY, COUNT, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride, ovf, sd);
@@ -2320,6 +2282,8 @@ struct RcclApi
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr; // optional
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr; // optional
     std::string why;
 };
 static bool rccl_load(RcclApi& api);
@@ -2352,6 +2316,8 @@ static bool rccl_load(RcclApi& api)
     SKH_SYM(GroupStart, "ncclGroupStart");
     SKH_SYM(GroupEnd, "ncclGroupEnd");
     SKH_SYM(GetErrorString, "ncclGetErrorString");
+    SKH_SYM(CommCount, "ncclCommCount");
+    SKH_SYM(CommUserRank, "ncclCommUserRank");
 #undef SKH_SYM
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd)
     {
@@ -2400,6 +2366,26 @@ skh_status skh_comm_init(skh_context* c, const void* id, int world_size, int ran
     }
     c->commWorld = world_size;
     c->commRank = rank;
+    return SKH_OK;
+}
+
+skh_status skh_comm_info(skh_context* c, int* out_world, int* out_rank, int* out_rccl_ranks)
+{
+    if (!c)
+        return SKH_INVALID_ARGUMENT;
+    if (out_world)
+        *out_world = c->commWorld;
+    if (out_rank)
+        *out_rank = c->commRank;
+    if (out_rccl_ranks)
+    {
+        // what RCCL itself says about the communicator (ncclCommCount): 0 = no communicator (world size 1, or the caller gathers another way)
+        int n = 0;
+        RcclApi* r = c->comm ? rccl() : nullptr;
+        if (r && r->CommCount && r->CommCount(c->comm, &n) != ncclSuccess)
+            n = -1;
+        *out_rccl_ranks = n;
+    }
     return SKH_OK;
 }
 
@@ -2493,18 +2479,18 @@ __global__ void k_hits_soa_to_aos(HitQ hq, uint32_t n, uint32_t mode, skh_hit* _
     if (i >= n)
         return;
     skh_hit h;
-    h.t = hq.base[i];
     if (mode == SKH_TRACE_SHADOW)
     {
+        h.t = hq.base[i];
         h.instance_id = h.prim_id = 0xffffffffu;
         h.u = h.v = 0.0f;
     }
     else
     {
-        h.instance_id = reinterpret_cast<const uint32_t*>(hq.base)[i + hq.stride];
-        h.prim_id = reinterpret_cast<const uint32_t*>(hq.base)[i + 2 * (size_t)hq.stride];
-        h.u = hq.base[i + 3 * (size_t)hq.stride];
-        h.v = hq.base[i + 4 * (size_t)hq.stride];
+        const float4 r0 = hq.rec(i)[0], r1 = hq.rec(i)[1];
+        h.t = r0.x, h.u = r0.y, h.v = r0.z;
+        h.instance_id = __float_as_uint(r1.x);
+        h.prim_id = __float_as_uint(r1.y);
     }
     hits[i] = h;
 }
@@ -2523,7 +2509,7 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
         dev_free(h);
         dev_free(cnt);
     };
-    if ((s = dev_alloc(c, q, sizeof(float) * 9 * (size_t)n_rays)) != SKH_OK || (s = dev_alloc(c, h, sizeof(float) * 5 * (size_t)n_rays)) != SKH_OK ||
+    if ((s = dev_alloc(c, q, sizeof(float) * 9 * (size_t)n_rays)) != SKH_OK || (s = dev_alloc(c, h, sizeof(float) * 8 * (size_t)n_rays)) != SKH_OK ||
         (s = dev_alloc(c, cnt, sizeof(uint32_t) * (SKH_FETCH_STRIDE + 8 * SKH_FETCH_STRIDE))) != SKH_OK)
     {
         cleanup();
@@ -2766,9 +2752,18 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         c->wide = (uint32_t)value;
         c->accelBuilt = false;
     }
-    else if (n == "flatten")
+    else if (n == "bake_world")
     {
-        c->flatten = value != 0;
+        if (value < 0 || value > 3)
+            return SKH_INVALID_ARGUMENT;
+        c->bakeWorld = (uint32_t)value;
+        c->accelBuilt = false;
+    }
+    else if (n == "bake_small_tris")
+    {
+        if (value < 0 || value > (1 << 20))
+            return SKH_INVALID_ARGUMENT;
+        c->bakeSmallTris = (uint32_t)value;
         c->accelBuilt = false;
     }
     else if (n == "leaf_max_tris")

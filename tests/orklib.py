@@ -56,6 +56,21 @@ class Oracle:
             raise ValueError("ork_set_textures: descriptor outside the texel array")
         L.ork_build_accel(self.ctx)
 
+    def set_bake(self, mode, small_tris=64):
+        """the product's bake_world / bake_small_tris options (part of the intersection's definition); call before set_scene"""
+        self.lib.ork_set_bake(self.ctx, int(mode), int(small_tris))
+
+    def baked(self, n_instances):
+        out = np.zeros(max(1, n_instances), np.uint8)
+        self.lib.ork_get_baked(self.ctx, fptr(out), n_instances)
+        return out[:n_instances]
+
+    def debug_path(self, params, px, py, sample_index, max_rays=64):
+        """(diagnosis) the rays one path traces: rows {kind 0 radiance / 1 shadow, o xyz, tmin, d xyz, tmax, hit t, inst, prim}, and its radiance"""
+        out, rad = np.zeros((max_rays, 12), np.float32), np.zeros(3, np.float32)
+        n = self.lib.ork_debug_path(self.ctx, fptr(np.ascontiguousarray(params)), px, py, sample_index, fptr(out), max_rays, fptr(rad))
+        return out[:n], rad
+
     def resize(self, w, h):
         self.width, self.height = w, h
         self.lib.ork_resize(self.ctx, w, h)
@@ -141,6 +156,10 @@ def load():
         for name in ("ork_set_instances", "ork_set_lights", "ork_set_materials"):
             getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         lib.ork_build_accel.argtypes = [C.c_void_p]
+        lib.ork_debug_path.restype = C.c_int
+        lib.ork_debug_path.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.ork_set_bake.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.ork_get_baked.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         lib.ork_resize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         lib.ork_render_subframe.argtypes = [C.c_void_p, C.c_void_p]
         lib.ork_render_subframe_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]

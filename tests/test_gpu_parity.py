@@ -458,12 +458,12 @@ def test_tonemap_kernels_match_oracle(gpu, ork):
             assert np.allclose(got, want, rtol=2e-5, atol=1e-6), (typ, gamma)
 
 
-@pytest.mark.parametrize("opts", [{"build_quality": 0}, {"flatten": 1}, {"leaf_max_tris": 4}, {"sort_bits_closest": 6, "sort_bits_shadow": 6},
+@pytest.mark.parametrize("opts", [{"build_quality": 0}, {"leaf_max_tris": 4}, {"sort_bits_closest": 6, "sort_bits_shadow": 6},
                                   {"fetch_min_closest": 1, "fetch_min_shadow": 64, "waves_per_cu": 8},
                                   {"node_break_closest": 0, "node_break_shadow": 48, "leaf_min": 0}, {"leaf_min": 40}, {"tlas_open": 8}, {"tlas_build": 0}, {"tlas_build": 1}, {"wide": 8}, {"wide": 8, "leaf_max_tris": 4, "build_quality": 0}, {"curve_split": 1}, {"curve_split": 5, "curve_min": 1}, {"curve_min": 64}, {"tight_instance_boxes": 0}, {"overlap": 2}, {"overlap": 0}])
 def test_results_do_not_depend_on_the_acceleration_structure_or_scheduling(opts):
     """Closest hit = min t with (instance, primitive) tie-break and conservative boxes, any-hit = existence: builder
-    (PLOC / radix tree), hierarchy shape (two-level / flattened / opened TLAS leaves), leaf size, ray order, refill and
+    (PLOC / radix tree), hierarchy shape (opened TLAS leaves, 8-wide nodes), leaf size, ray order, refill and
     node-loop exit policy may change
     speed only.  Hit records AND the accumulated image must be bit-identical to the default configuration."""
     from strelka_amd import capi
@@ -490,6 +490,58 @@ def test_results_do_not_depend_on_the_acceleration_structure_or_scheduling(opts)
     base, other = run({}), run(opts)
     for a, b in zip(base, other):
         assert a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("mode,small", [(0, 64), (1, 64), (2, 64), (2, 4000), (3, 64)])
+def test_bake_world_modes_match_oracle(mode, small):
+    """Option bake_world is part of the intersection's DEFINITION (a baked instance's triangles are carried to world space once
+    and tested there, no instance entry), so the oracle takes the same setting: for every mode both sides must bake the same
+    instances (integer rule) and agree bit for bit on closest hits, occlusion and -- within the image bar -- radiance.  Scenes:
+    shared meshes + a unique room + 12-triangle boards (small_kitchen), every light type's proxy (light_zoo), unique meshes only."""
+    from strelka_amd import capi
+    from tests import orklib
+
+    ctx = capi.Context(0)
+    ctx.set_option("bake_world", mode)
+    ctx.set_option("bake_small_tris", small)
+    counts = []
+    for sc in (small_kitchen(), scenes.light_zoo(), scenes.kitchen_standin(seed=3, n_meshes=40, n_instances=40, tri_lo=50, tri_hi=600)):
+        arr = sc.arrays()
+        o = orklib.new_context()
+        o.set_bake(mode, small)
+        o.set_scene(arr)
+        ctx.set_scene(arr)
+        n = len(arr["instances"])
+        flags, ni, nt = ctx.baked(n)
+        assert np.array_equal(flags, o.baked(n)) and ni == int(flags.sum())
+        counts.append(ni)
+        rays = np.concatenate([camera_rays(sc, 64, 64, 20000, 31), scenes.random_rays(20000, 32, -4.0, 4.0)])
+        want = o.trace(rays, 0)
+        assert_hits_equal(ctx.trace(rays, 0), want)
+        assert_hits_equal(o.trace(rays[:2000], 0, brute=True), want[:2000])
+        rays["tmax"] = np.random.RandomState(33).uniform(0.1, 6.0, len(rays)).astype(np.float32)
+        assert np.array_equal(ctx.trace(rays, 1)["t"], o.trace(rays, 1)["t"])
+        ctx.resize(72, 40)
+        o.resize(72, 40)
+        for i in range(2):
+            p = S.frame_params(sc.getCamera(), 72, 40, subframe_index=i, spp_total=2, max_depth=4)
+            ctx.render_subframe(p)
+            o.render_subframe(p)
+        # One path of this room re-hits the wall it starts on at t = 7.7e-6 (a grazing transmission exit; found with
+        # orklib.debug_path): whether it does hangs on the last bit of its origin, which the BSDF's transcendentals decide
+        # differently on the two sides.  At most that one pixel may be off by a sample; everything else meets the image bar.
+        got, want = ctx.read_accum(), o.read_accum()
+        off = np.abs(got[..., :3] - want[..., :3]).max(axis=-1) > 2e-3 * (np.abs(want[..., :3]).max(axis=-1) + 1e-3)
+        assert off.sum() <= 1, off.sum()
+        got[off] = want[off]
+        _image_close(got, want)
+    ctx.close()
+    if mode == 0:
+        assert counts == [0, 0, 0]
+    else:
+        assert counts[2] >= 40 and counts[0] >= 1  # every unique mesh; at least the room of the shared scene
+    if mode == 3:
+        assert counts[0] >= 60
 
 
 def test_stack_spill_path_is_exact(tmp_path):
