@@ -304,6 +304,13 @@ def load_workload(name, make=True):
     return sc, arr, line % (len(arr["indices"]) // 3, len(arr["instances"]), len(arr["meshes"]))
 
 
+def gather_fallback_allowed(backend, environ):
+    """May a multi-rank run whose RCCL communicator (skh_comm_init) could not be formed time torch.distributed's gather instead?
+    Only off the real path: the gloo backend (several ranks on one GPU in the 1-GPU tests) or an explicit override.  With one rank
+    per GPU on the nccl backend the run must fail loudly -- a record of a different collective is worse than no record."""
+    return backend != "nccl" or bool(environ.get("SKH_ALLOW_GATHER_FALLBACK"))
+
+
 def shade_bytes(rays, next_rays, shadow_rays):
     """k_shade, algorithmic: ray 36 r + hit record 32 r + path state 32 r + 32 w per ray; per surface hit (every ray counted as
     one: upper bound) instance 64 + 64, shading triangle 96, material 64; 36 w per continuation ray, 36 + 12 w per shadow ray."""
@@ -429,7 +436,7 @@ def main():
             rccl_nranks = ctx.comm_info()[2]  # what RCCL itself reports (ncclCommCount)
         else:
             ctx.comm_destroy()
-            if dist.get_backend() == "nccl" and not os.environ.get("SKH_ALLOW_GATHER_FALLBACK"):
+            if not gather_fallback_allowed(dist.get_backend(), os.environ):
                 if rank == 0:
                     sys.stderr.write("[bench] --gpus %d on the nccl backend, but the RCCL communicator below the C ABI could not be formed (%s): "
                                      "refusing to time torch.distributed's gather instead (SKH_ALLOW_GATHER_FALLBACK=1 overrides)\n" % (world, gather_error))

@@ -224,7 +224,9 @@ typedef struct skh_stats
     /* render / trace calls since the last reset that returned SKH_FAIL because a traversal stack (20 LDS + 104 global entries per
      * ray) overflowed and dropped a subtree -- a degenerate hierarchy; such a call's hits may be incomplete */
     uint32_t stack_overflows;
-    uint32_t reserved0;
+    /* sub-frames skh_render_subframe traced ahead (option speculate) and had to throw away since the last reset -- the caller moved
+     * the camera, changed the scene or resized; their rays are NOT in rays_radiance / rays_shadow */
+    uint32_t speculated_discarded;
 } skh_stats;
 
 /* ---- lifetime: RenderFactory::createRender + Render::init (render.cpp:10-35, OptixRender.cpp:1059-1105) ---- */

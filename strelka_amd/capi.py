@@ -19,7 +19,7 @@ STATS = np.dtype([("rays_radiance", np.uint64), ("rays_shadow", np.uint64), ("no
                   ("ms_raygen", np.float64), ("ms_accumulate", np.float64), ("ms_build", np.float64), ("ms_sort", np.float64),
                   ("launches_trace_closest", np.uint32), ("launches_trace_shadow", np.uint32),
                   ("launches_shade", np.uint32), ("launches_other", np.uint32), ("stack_overflows", np.uint32),
-                  ("reserved0", np.uint32)])
+                  ("speculated_discarded", np.uint32)])
 
 SYMBOLS = ["skh_create", "skh_destroy", "skh_last_error", "skh_abi_version", "skh_set_geometry", "skh_set_curves",
            "skh_set_instances", "skh_set_lights", "skh_set_textures", "skh_set_materials", "skh_build_accel", "skh_resize", "skh_set_tiles",

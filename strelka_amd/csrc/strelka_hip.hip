@@ -107,7 +107,12 @@ struct skh_context
         uint32_t count = 0, consumed = 0, lastBatch = 1, streak = 0;
         skh_frame_params last; // the previous call's parameters
         bool haveLast = false;
+        uint64_t passRadiance = 0, passShadow = 0; // rays the pass traced (all `count` sub-frames; counted when traced)
     } spec;
+    // sub-frames traced ahead and then thrown away (camera move, a setter, resize): their rays are taken out of the ray counts again,
+    // so that a Mray/s figure from skh_get_stats only counts rays whose sub-frame was delivered
+    uint64_t discardedRadiance = 0, discardedShadow = 0;
+    uint32_t discardedSubframes = 0;
     uint32_t speculateMax = 8; // option "speculate": most sub-frames traced ahead in one pass (0 / 1 = off).  8: a pass stays below ~25 ms at 1080p
     DevBuf dTriNodes, dTris, dSegNodes, dSegs, dSegPrim, dTlasNodes, dTlasInst, dDevInst, dTravInst;
     int tlasRoot = SKH_REF_INVALID;
@@ -740,6 +745,23 @@ static int tlas_sah_build(const std::vector<HostBox>& boxes, const std::vector<u
 
 // The entry points below take C linkage from their declarations in include/strelka_hip.h.
 
+// Ends the speculation.  Whatever was traced ahead and not yet delivered is dropped: its share of the pass's rays (sub-frames of a
+// pass trace the same pixels with different samples: equal shares to a fraction of a per cent) leaves the ray counts.
+static void spec_drop(skh_context* c, bool keepLast = false)
+{
+    skh_context::Speculation& sp = c->spec;
+    if (sp.valid && sp.consumed < sp.count && sp.count > 0)
+    {
+        const uint32_t left = sp.count - sp.consumed;
+        c->discardedRadiance += sp.passRadiance * left / sp.count;
+        c->discardedShadow += sp.passShadow * left / sp.count;
+        c->discardedSubframes += left;
+    }
+    sp.valid = false;
+    if (!keepLast)
+        sp.haveLast = false;
+}
+
 uint32_t skh_abi_version(void)
 {
     return SKH_ABI_VERSION;
@@ -835,7 +857,7 @@ skh_status skh_set_geometry(skh_context* c, const skh_vertex* verts, uint32_t n_
 {
     if (!c || (n_verts && !verts) || (n_indices && !indices) || (n_meshes && !meshes))
         return SKH_INVALID_ARGUMENT;
-    c->spec.valid = c->spec.haveLast = false;
+    spec_drop(c);
     (void)hipSetDevice(c->device);
     for (uint32_t m = 0; m < n_meshes; ++m)
     {
@@ -875,7 +897,7 @@ skh_status skh_set_curves(skh_context* c, const float* points_xyz, uint32_t n_po
 {
     if (!c || (n_points && !points_xyz) || (n_radii && !radii) || (n_vertex_counts && !vertex_counts) || (n_curves && !curves))
         return SKH_INVALID_ARGUMENT;
-    c->spec.valid = c->spec.haveLast = false;
+    spec_drop(c);
     if (n_radii != n_points)
     {
         c->err = "skh_set_curves: one radius per control point is required";
@@ -911,7 +933,7 @@ skh_status skh_set_instances(skh_context* c, const skh_instance* instances, uint
 {
     if (!c || (n && !instances))
         return SKH_INVALID_ARGUMENT;
-    c->spec.valid = c->spec.haveLast = false;
+    spec_drop(c);
     (void)hipSetDevice(c->device);
     c->instances.assign(instances, instances + n);
     c->nInstances = n;
@@ -923,7 +945,7 @@ skh_status skh_set_lights(skh_context* c, const skh_light* lights, uint32_t n)
 {
     if (!c || (n && !lights))
         return SKH_INVALID_ARGUMENT;
-    c->spec.valid = c->spec.haveLast = false;
+    spec_drop(c);
     (void)hipSetDevice(c->device);
     c->nLights = n;
     return dev_upload(c, c->dLights, lights, sizeof(skh_light) * (size_t)n);
@@ -933,7 +955,7 @@ skh_status skh_set_textures(skh_context* c, const skh_texture* textures, uint32_
 {
     if (!c || (n && !textures))
         return SKH_INVALID_ARGUMENT;
-    c->spec.valid = c->spec.haveLast = false;
+    spec_drop(c);
     (void)hipSetDevice(c->device);
     std::vector<uint4> desc(n);
     uint64_t total = 0;
@@ -965,7 +987,7 @@ skh_status skh_set_materials(skh_context* c, const skh_material* materials, uint
 {
     if (!c || (n && !materials))
         return SKH_INVALID_ARGUMENT;
-    c->spec.valid = c->spec.haveLast = false;
+    spec_drop(c);
     (void)hipSetDevice(c->device);
     c->nMaterials = n;
     c->hasHairMaterial = false;
@@ -1012,7 +1034,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
 {
     if (!c)
         return SKH_INVALID_ARGUMENT;
-    c->spec.valid = c->spec.haveLast = false;
+    spec_drop(c);
     (void)hipSetDevice(c->device);
     {
         const skh_status ss = build_shading_tables(c);
@@ -1665,7 +1687,7 @@ skh_status skh_resize(skh_context* c, uint32_t width, uint32_t height)
 {
     if (!c || width == 0 || height == 0)
         return SKH_INVALID_ARGUMENT;
-    c->spec.valid = c->spec.haveLast = false;
+    spec_drop(c);
     (void)hipSetDevice(c->device);
     c->width = width;
     c->height = height;
@@ -1676,7 +1698,7 @@ skh_status skh_set_tiles(skh_context* c, uint32_t tile_size, const uint32_t* til
 {
     if (!c || tile_size < 8 || tile_size > 256 || (tile_size & (tile_size - 1)))
         return SKH_INVALID_ARGUMENT;
-    c->spec.valid = c->spec.haveLast = false;
+    spec_drop(c);
     (void)hipSetDevice(c->device);
     c->tileSize = tile_size;
     c->tileShift = 0;
@@ -2045,9 +2067,9 @@ skh_status skh_render_subframes(skh_context* c, const skh_frame_params* params, 
     if (s != SKH_OK)
         return s;
     if (n_subframes != 1)
-        c->spec.valid = c->spec.haveLast = false; // (the path state is about to be reused)
+        spec_drop(c); // (the path state is about to be reused)
     else
-        c->spec.valid = false;
+        spec_drop(c, true);
     skh_frame_params p = *params;
     // single-sample sub-frames are traced `batchCapacity` at a time when that gives the GPU more rays per launch
     const uint32_t cap = (p.samples_this_launch == 1 && p.debug != 1) ? c->batchCapacity : 1u;
@@ -2083,7 +2105,7 @@ skh_status skh_render_subframe(skh_context* c, const skh_frame_params* params, v
     const bool eligible = c->speculateMax > 1 && params->samples_this_launch == 1 && params->debug == 0 && c->width != 0 && c->batchCapacity > 1;
     if (!eligible)
     {
-        sp.valid = sp.haveLast = false;
+        spec_drop(c);
         return skh_render_subframes(c, params, 1, d_image);
     }
     (void)hipSetDevice(c->device);
@@ -2109,7 +2131,7 @@ skh_status skh_render_subframe(skh_context* c, const skh_frame_params* params, v
     uint32_t ahead = 1;
     if (continues && params->spp_total > params->subframe_index)
         ahead = std::min(std::min(std::max(2u, sp.lastBatch * 2u), std::min(c->speculateMax, c->batchCapacity)), params->spp_total - params->subframe_index);
-    sp.valid = false;
+    spec_drop(c, true);
     if ((s = ensure_ready(c)) != SKH_OK)
         return s;
     if (ahead <= 1)
@@ -2119,8 +2141,14 @@ skh_status skh_render_subframe(skh_context* c, const skh_frame_params* params, v
         sp.haveLast = true;
         return skh_render_subframes(c, params, 1, d_image);
     }
+    unsigned long long before[2] = { 0, 0 }, after[2] = { 0, 0 }; // (StatsDev starts with raysRadiance, raysShadow; the stream is idle here)
+    SKH_TRY(c, hipMemcpy(before, c->dStats.p, sizeof(before), hipMemcpyDeviceToHost));
     if ((s = render_one(c, params, ahead, d_image, true, 0, 1)) != SKH_OK)
         return s;
+    SKH_TRY(c, hipStreamSynchronize(c->stream));
+    SKH_TRY(c, hipMemcpy(after, c->dStats.p, sizeof(after), hipMemcpyDeviceToHost));
+    sp.passRadiance = after[0] - before[0];
+    sp.passShadow = after[1] - before[1];
     sp.valid = true;
     sp.params = *params;
     sp.count = ahead;
@@ -2661,7 +2689,7 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         return SKH_INVALID_ARGUMENT;
     const std::string n(name);
     if (n != "timing" && n != "count_traversal")
-        c->spec.valid = c->spec.haveLast = false;
+        spec_drop(c);
     if (n == "count_traversal")
         c->countTraversal = value != 0;
     else if (n == "timing")
@@ -2829,8 +2857,10 @@ skh_status skh_get_stats(skh_context* c, skh_stats* out)
     SKH_TRY(c, hipStreamSynchronize(c->stream));
     SKH_TRY(c, hipMemcpy(&sd, c->dStats.p, sizeof(sd), hipMemcpyDeviceToHost));
     memset(out, 0, sizeof(*out));
-    out->rays_radiance = sd.raysRadiance;
-    out->rays_shadow = sd.raysShadow;
+    // rays of sub-frames that were traced ahead and never delivered do not count (spec_drop); what is still pending does
+    out->rays_radiance = sd.raysRadiance - std::min<uint64_t>(sd.raysRadiance, c->discardedRadiance);
+    out->rays_shadow = sd.raysShadow - std::min<uint64_t>(sd.raysShadow, c->discardedShadow);
+    out->speculated_discarded = c->discardedSubframes;
     for (int k = 0; k < 2; ++k)
     {
         out->nodes_visited[k] = sd.nodes[k];
@@ -2883,6 +2913,8 @@ skh_status skh_reset_stats(skh_context* c)
     SKH_TRY(c, hipStreamSynchronize(c->stream));
     SKH_TRY(c, hipMemset(c->dStats.p, 0, sizeof(StatsDev)));
     c->stackOverflows = 0;
+    c->discardedRadiance = c->discardedShadow = 0;
+    c->discardedSubframes = 0;
     for (int k = 0; k < KC_COUNT; ++k)
     {
         c->msClass[k] = 0.0;

@@ -187,9 +187,12 @@ class Scene:
         return inst_id
 
     # -- scene.cpp:89-95.  `material` is a dict of the fixed-layout argument block (skh_material)
-    def addMaterial(self, type=MAT_DIFFUSE, base_color=(0.8, 0.8, 0.8), roughness=0.5, metallic=0.0, specular=0.5, ior=1.5,
+    def addMaterial(self, type=MAT_DIFFUSE, base_color=(0.8, 0.8, 0.8), roughness=None, metallic=0.0, specular=0.5, ior=1.5,
                     base_color_texture=0, normal_texture=0, reserved=(0.0,) * 6):
-        """MAT_GLASS: `roughness` is OmniGlass' frosting_roughness (0 = clear).  MAT_HAIR: use addHairMaterial."""
+        """MAT_GLASS: `roughness` is OmniGlass' frosting_roughness (default 0 = clear glass: gltfloader.cpp:354-406 sets it from the
+        file's roughnessFactor, OmniGlass.mdl's own default is clear).  Other types: default 0.5.  MAT_HAIR: use addHairMaterial."""
+        if roughness is None:
+            roughness = 0.0 if type == MAT_GLASS else 0.5
         self.mMaterials.append((type, tuple(base_color), roughness, metallic, specular, ior, base_color_texture, normal_texture,
                                 tuple(reserved)))
         return len(self.mMaterials) - 1

@@ -26,6 +26,7 @@ def test_self_launch_builds_the_drivers_command(monkeypatch):
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3"]
     assert seen["env"]["MASTER_ADDR"] == "127.0.0.1"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"  # dmabuf IPC for RCCL's peer buffers, before any rank touches the GPU
 
 
 def test_single_gpu_and_launched_ranks_do_not_relaunch(monkeypatch):
@@ -45,3 +46,47 @@ def test_bench_does_not_touch_torch_before_the_launch_decision():
     src = open(os.path.join(ROOT, "bench.py")).read()
     head = src[: src.index("rc = maybe_self_launch")]
     assert "import torch" not in head.split("def main")[1]
+
+
+def test_scene_cache_hands_every_process_the_same_scene(tmp_path, monkeypatch):
+    """The counter child passes and the ranks of an N-GPU run load the .skscene one process wrote instead of regenerating the
+    scene: arrays and camera must come back bit for bit (the N-rank image is compared with the 1-rank image by CRC)."""
+    import numpy as np
+
+    from strelka_amd import scene as S, scenes
+
+    monkeypatch.setattr(bench, "scene_cache_path", lambda name: str(tmp_path / (name + ".skscene")))
+    sc1, arr1, line1 = bench.load_workload("cornell")  # generates + writes
+    assert os.path.exists(tmp_path / "cornell.skscene")
+    sc2, arr2, line2 = bench.load_workload("cornell", make=False)  # what a rank != 0 does
+    ref = scenes.cornell_box()
+    refarr = ref.arrays()
+    assert line1 == line2 and "cornell" in line1
+    for k in ("vertices", "indices", "meshes", "instances", "lights", "materials"):
+        assert np.array_equal(np.asarray(arr2[k]).view(np.uint8), np.asarray(refarr[k]).view(np.uint8)), k
+    a = S.frame_params(sc2.getCamera(), 200, 136, subframe_index=3, spp_total=8, max_depth=4)
+    b = S.frame_params(ref.getCamera(), 200, 136, subframe_index=3, spp_total=8, max_depth=4)
+    assert a.tobytes() == b.tobytes()
+
+
+def test_counter_arithmetic_and_profiler_detection(monkeypatch):
+    f = bench.pmc_figures({"FETCH_SIZE": 1000.0, "WRITE_SIZE": 500.0, "SQ_INSTS_VALU": 2e6, "SQ_INSTS_SALU": 5e5, "SQ_ACTIVE_INST_VALU": 1e6,
+                           "SQ_THREAD_CYCLES_VALU": 3.2e7, "SQ_WAVE_CYCLES": 4e6, "SQ_WAIT_INST_ANY": 1e6}, 1000)
+    assert f["hbm_bytes_per_launch"] == (2 * 1000.0 + 500.0) * 1024 and f["lanes_per_valu_inst"] == 32.0
+    assert f["salu_per_valu"] == 0.25 and f["wait_inst_any_frac"] == 0.25 and f["rays_per_launch"] == 1000
+    for k in list(os.environ):
+        if k.startswith(("ROCP", "LD_PRELOAD")):
+            monkeypatch.delenv(k)
+    assert not bench.under_profiler()
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "librocprofiler-sdk-tool.so")
+    assert bench.under_profiler()  # live_pmc refuses to nest profilers
+    assert bench.live_pmc([], 64) is None
+    # SURVEY 8(d): 36 + 20 + 64 nodes + 48 tris + 64 segs + 48 instances per radiance ray, 36 + 4 + ... per shadow ray
+    assert bench.algorithmic_bytes(10, False, 20, 5, 0, 2) == 10 * 56 + 64 * 20 + 48 * 5 + 48 * 2
+    assert bench.algorithmic_bytes(10, True, 0, 0, 1, 0) == 10 * 40 + 64
+
+
+def test_a_real_multi_gpu_run_never_times_the_fallback_gather():
+    assert not bench.gather_fallback_allowed("nccl", {})  # one rank per GPU: no communicator below the C ABI = exit code 3
+    assert bench.gather_fallback_allowed("nccl", {"SKH_ALLOW_GATHER_FALLBACK": "1"})
+    assert bench.gather_fallback_allowed("gloo", {})  # the 1-GPU tests: two ranks share cuda:0, RCCL refuses that by design

@@ -31,6 +31,12 @@ def test_two_ranks_reproduce_the_single_rank_image():
     assert two["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
     assert two["image_crc32"] == one["image_crc32"]
     assert two["scaling"] == "strong" and two["value"] > 0
+    # what the record says about the collective and the ranks (the 8-GPU run is read from exactly these fields)
+    assert one["gather"] == "none" and one["rccl_nranks"] == 0 and "per_rank" not in one
+    assert two["gather"] == "torch.distributed gather" and two["rccl_nranks"] == 0  # (gloo: two ranks on one GPU cannot form an RCCL communicator)
+    pr = two["per_rank"]
+    assert len(pr["ms_per_step"]["all"]) == 2 and pr["ms_per_step"]["min"] <= pr["ms_per_step"]["mean"] <= pr["ms_per_step"]["max"] <= two["ms_per_step"] * 1.05
+    assert sum(pr["tiles"]) == ((200 + 31) // 32) * ((136 + 31) // 32) and 1.0 <= pr["rays_imbalance_max_over_mean"] < 1.5
 
 
 @pytest.mark.gpu
@@ -44,3 +50,19 @@ def test_gpus_flag_alone_starts_the_ranks():
     two = _run([sys.executable, "bench.py", "--gpus", "2"] + ARGS, env)
     assert two["n_gpus"] == 2 and two["config"]["world_size"] == 2
     assert two["image_crc32"] == one["image_crc32"]
+
+
+@pytest.mark.gpu
+def test_a_failed_communicator_is_recorded_with_its_error():
+    """Two ranks on ONE GPU asking for the RCCL gather: ncclCommInitRank refuses (two ranks, one device).  Off the real path (gloo
+    backend) all ranks agree on torch.distributed's gather and the record names the error; on the nccl backend the same situation
+    ends the run with exit code 3 (bench.gather_fallback_allowed, tests/test_bench_launch.py)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SKH_DIST_BACKEND="gloo", SKH_GATHER="rccl")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29539", "bench.py", "--gpus", "2"] + ARGS
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    # (gloo carries the hand-shake here; the communicator attempt itself is the real skh_comm_init and fails the same way)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-1500:]
+    rec = json.loads(lines[0])
+    assert rec["gather"] == "torch.distributed gather" and rec["rccl_nranks"] == 0 and "gather_error" in rec

@@ -705,15 +705,20 @@ def test_speculative_subframes_are_exact(gpu):
         for c_, i in calls:
             gpu.render_subframe(S.frame_params(c_, w, h, subframe_index=i, spp_total=spp, max_depth=4), img.data_ptr())
             frames.append((img.cpu().numpy().copy(), gpu.read_accum(), gpu.read_aov(0), gpu.read_aov(1)))
-        out[spec] = (frames, gpu.stats()["launches_trace_closest"])
+        st = gpu.stats()
+        out[spec] = (frames, st["launches_trace_closest"], st["rays_radiance"] + st["rays_shadow"], st["speculated_discarded"])
     gpu.set_option("speculate", 8)
-    base, launches0 = out[0]
+    base, launches0, rays0, dropped0 = out[0]
+    assert dropped0 == 0
     for spec in (8, 64):
-        frames, launches = out[spec]
+        frames, launches, rays, dropped = out[spec]
         for k, (a, b) in enumerate(zip(base, frames)):
             for x, y in zip(a, b):
                 assert np.array_equal(x, y), (spec, k)
         assert launches < launches0  # it did trace ahead: fewer, larger wavefront passes
+        # the camera move and the index jump threw sub-frames away: they are reported, and their rays are NOT counted -- the ray
+        # count of the delivered sub-frames is the one-pass-per-call count (equal shares per sub-frame of a pass: a fraction of a per cent)
+        assert dropped > 0 and abs(rays - rays0) <= 0.005 * rays0, (spec, dropped, rays, rays0)
     assert not np.array_equal(base[8][0], base[9][0])
 
 
