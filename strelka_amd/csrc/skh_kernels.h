@@ -217,6 +217,9 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 #ifndef SKH_TRACE_MIN_WAVES
 #define SKH_TRACE_MIN_WAVES 7 // 72 VGPRs (2 dwords spilled): the launch runs 28 one-wave blocks per CU (closest 103.3 -> 100.6 ms over 6 waves at 77 VGPRs)
 #endif
+#ifndef SKH_CURVE_COOP
+#define SKH_CURVE_COOP 1 // the curve intersector as a wave-cooperative block: one (candidate, end point) run per lane (0 = every parked lane runs its own candidates)
+#endif
 #ifndef SKH_SORT_ANYHIT
 #define SKH_SORT_ANYHIT 0
 #endif
@@ -430,6 +433,192 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                 break;
             continue;
         }
+#if SKH_CURVE_COOP
+        if constexpr (CURVES)
+        {
+            // ---- the iterative curve intersector, wave-cooperative ----
+            // A lane whose leaf produced candidates (segments that passed the cylinder test) parks; each candidate needs two independent
+            // Newton runs (one from either end of the segment, up to 40 steps of ~70 instructions).  Run by their owners, the wave waited
+            // for 48 parked lanes before it started them (a block costs the same for 3 lanes as for 64) and then ran two to four runs per
+            // lane back to back: on average half of the wave sat parked (hair stand-in: 13 of 64 lanes per VALU instruction).  Here the
+            // runs of all parked lanes are dealt out one per lane -- to EVERY lane, idle and descending ones included --, so ~25 parked
+            // lanes already fill the wave and a block lasts one run.  A run sees the owner's ray (pulled with ds_bpermute) and returns
+            // (t, u) or nothing; the owner applies the interval's upper end, takes the nearer root of a candidate (the first run's on a
+            // tie) and merges candidates in slot order -- the same decisions in the same order as intersect_curve_segment, same bits.
+            __shared__ uint16_t s_runs[256]; // run -> owner lane | slot << 6 | end << 9
+            // (a block takes at most two candidates per lane -- a curve leaf holds at most two sub-segments; anything beyond waits for the next block)
+            const uint32_t take = hasRay ? ((pend & (0u - pend)) | ((pend & (pend - 1u)) & (0u - (pend & (pend - 1u))))) : 0u;
+            const uint32_t myCand = (uint32_t)__popc(take);
+            uint32_t incl = 2u * myCand; // inclusive prefix sum of the run counts
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1)
+            {
+                const uint32_t v = __shfl_up(incl, off);
+                incl += lane >= (uint32_t)off ? v : 0u;
+            }
+            const uint32_t nRuns = (uint32_t)__shfl(incl, 63);
+            const uint32_t nWalking = (uint32_t)__popcll(__ballot(hasRay && pend == 0u));
+            if (nRuns != 0u && (nRuns >= curveMin || nWalking == 0u))
+            {
+                const uint32_t P = incl - 2u * myCand;
+                {
+                    uint32_t bits = take, j = P; // (<= 64 lanes x 2 candidates x 2 ends = 256 runs)
+                    while (bits != 0u)
+                    {
+                        const uint32_t k = (uint32_t)__ffs((int)bits) - 1u;
+                        bits &= bits - 1u;
+                        s_runs[j] = (uint16_t)(lane | (k << 6));
+                        s_runs[j + 1u] = (uint16_t)(lane | (k << 6) | (1u << 9));
+                        j += 2u;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t myFirst = ((uint32_t)~cur) >> 3; // (a parked lane keeps its leaf in `cur`)
+                uint32_t bitsLeft = take, doneCand = 0;
+                for (uint32_t base = 0; base < nRuns; base += 64u)
+                {
+                    const uint32_t r = base + lane;
+                    const bool work = r < nRuns;
+                    const uint32_t desc = work ? (uint32_t)s_runs[r & 255u] : 0u;
+                    const int owner = (int)(desc & 63u);
+                    const uint32_t slot = (desc >> 6) & 7u, ep = desc >> 9;
+                    // the owner's (object-space) ray and leaf
+                    const v3 oo = mk3(__shfl(o.x, owner), __shfl(o.y, owner), __shfl(o.z, owner));
+                    const v3 od = mk3(__shfl(d.x, owner), __shfl(d.y, owner), __shfl(d.z, owner));
+                    const float otmin = __shfl(tmin, owner);
+                    const uint32_t ofirst = (uint32_t)__shfl((int)myFirst, owner);
+                    float resT = 0.0f, resU = -1.0f;
+                    if (work)
+                    {
+                        const float4* cp = sc.segs + 4 * (size_t)(ofirst + slot);
+                        const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+                        const float dlen = sqrtf(dot(od, od));
+                        const float inv_dlen = 1.0f / dlen;
+                        const v3 dn = od * inv_dlen;
+                        v3 bx, by;
+                        onb_from_z(dn, bx, by);
+                        CubicPoly poly;
+                        {
+                            v4 qc[4];
+                            const v3 p0 = mk3(c0.x, c0.y, c0.z) - oo, p1 = mk3(c1.x, c1.y, c1.z) - oo, p2 = mk3(c2.x, c2.y, c2.z) - oo, p3 = mk3(c3.x, c3.y, c3.z) - oo;
+                            qc[0] = mk4(dot(p0, bx), dot(p0, by), dot(p0, dn), c0.w);
+                            qc[1] = mk4(dot(p1, bx), dot(p1, by), dot(p1, dn), c1.w);
+                            qc[2] = mk4(dot(p2, bx), dot(p2, by), dot(p2, dn), c2.w);
+                            qc[3] = mk4(dot(p3, bx), dot(p3, by), dot(p3, dn), c3.w);
+                            cubic_from_bspline(poly, qc);
+                        }
+                        const v4 e0 = cubic_position(poly, 0.0f);
+                        const v4 e1 = cubic_position(poly, 1.0f);
+                        const float tstart = (e1.z - e0.z) > 0.0f ? 0.0f : 1.0f;
+                        float tpar = ep == 0u ? tstart : 1.0f - tstart;
+                        float told = 0.0f, dt1 = 0.0f, dt2 = 0.0f;
+                        for (int it = 0; it < 40; ++it)
+                        {
+                            // one step of the ray / tangent-cone iteration (intersect_curve_segment, loop body)
+                            const v4 c4 = cubic_position(poly, tpar);
+                            const v4 d4 = ((3.0f * poly.p[0] * tpar) + 2.0f * poly.p[1]) * tpar + poly.p[2];
+                            const v3 cc0 = mk3(c4), cd = mk3(d4);
+                            const float rr = c4.w, dr = d4.w;
+                            const float r2 = rr * rr;
+                            const float drr = rr * dr;
+                            float ddd = cd.x * cd.x + cd.y * cd.y;
+                            const float dp = cc0.x * cc0.x + cc0.y * cc0.y;
+                            const float cdd = cc0.x * cd.x + cc0.y * cd.y;
+                            const float cxd = cc0.x * cd.y - cc0.y * cd.x;
+                            const float cc = ddd;
+                            const float bb = cd.z * (drr - cdd);
+                            const float cdz2 = cd.z * cd.z;
+                            ddd += cdz2;
+                            const float aa = ((2.0f * drr * cdd + cxd * cxd) - ddd * r2) + dp * cdz2;
+                            const float det = bb * bb - aa * cc;
+                            const float ss = (bb - (det > 0.0f ? sqrtf(det) : 0.0f)) / cc;
+                            float dt = (ss * cd.z - cdd) / ddd;
+                            const bool phantom = !(det > 0.0f);
+                            if (!phantom && fabsf(dt) < 5e-5f)
+                            {
+                                const float sw = (ss + cc0.z) * inv_dlen;
+                                if (sw > otmin && tpar >= 0.0f && tpar <= 1.0f) // (the upper end of the interval is the owner's to apply)
+                                {
+                                    resT = sw;
+                                    resU = tpar;
+                                }
+                                break;
+                            }
+                            dt = fminf(dt, 0.5f);
+                            dt = fmaxf(dt, -0.5f);
+                            dt1 = dt2;
+                            dt2 = dt;
+                            if (dt1 * dt2 < 0.0f)
+                            {
+                                float tnext;
+                                if ((it & 3) == 0)
+                                    tnext = 0.5f * (told + tpar);
+                                else
+                                    tnext = (dt2 * told - dt1 * tpar) / (dt2 - dt1);
+                                told = tpar;
+                                tpar = tnext;
+                            }
+                            else
+                            {
+                                told = tpar;
+                                tpar += dt;
+                            }
+                            if (!(tpar >= 0.0f && tpar <= 1.0f))
+                                break;
+                        }
+                    }
+                    // owners collect the runs of this round: candidate c of a lane = runs P + 2c (its first end) and P + 2c + 1
+                    const uint32_t maxCand = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max(myCand));
+                    for (uint32_t c = 0; c < maxCand; ++c)
+                    {
+                        const uint32_t rr0 = P + 2u * c;
+                        const bool mine = c < myCand && c == doneCand && rr0 >= base && rr0 < base + 64u;
+                        const int src = (int)((rr0 - base) & 63u);
+                        const float t0 = __shfl(resT, src), u0 = __shfl(resU, src);
+                        const float t1 = __shfl(resT, (src + 1) & 63), u1 = __shfl(resU, (src + 1) & 63);
+                        if (mine)
+                        {
+                            const uint32_t k = (uint32_t)__ffs((int)bitsLeft) - 1u;
+                            bitsLeft &= bitsLeft - 1u;
+                            ++doneCand;
+                            if (COUNT)
+                                tc.segs++;
+                            // intersect_curve_segment's acceptance: a root counts if it is within (tmin, tmax], tmax = best.t now; the nearer
+                            // root wins, the first run's on a tie
+                            const bool f0 = u0 >= 0.0f && t0 <= best.t, f1 = u1 >= 0.0f && t1 <= best.t;
+                            const bool first = f0 && !(f1 && t1 < t0);
+                            const float t = first ? t0 : t1, u = first ? u0 : u1;
+                            if ((f0 || f1) && (best.found || t < best.t)) // (open at tmax: best.t is the ray's tmax until a hit is found)
+                            {
+                                const uint32_t spw = sc.segPrim[myFirst + k];
+                                const uint32_t prim = spw & 0x0fffffffu;
+                                // a sub-range leaf keeps the hit only if u is its own (the leaf that owns u reports the same bits)
+                                if (min((uint32_t)(u * (float)sc.curveSplit), sc.curveSplit - 1u) == (spw >> 28) &&
+                                    (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim)))
+                                {
+                                    best.t = t;
+                                    best.inst = curInst;
+                                    best.prim = prim;
+                                    best.u = u;
+                                    best.v = 0.0f;
+                                    best.found = true;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (myCand != 0u)
+                {
+                    pend &= ~take;
+                    if (pend == 0u)
+                        cur = SKH_REF_INVALID; // leaf done: the lane pops its next entry below
+                }
+                __builtin_amdgcn_wave_barrier(); // (s_runs is rewritten by the next block)
+            }
+        }
+#endif
         bool terminated = false;
         SKH_LP(uint32_t itN = 0, itT = 0; { const unsigned long long t = __builtin_readcyclecounter(); cy[0] += t - cyA; cyA = t; })
         // (lanes parked in front of the curve intersector do not count: they are not waiting for the node loop to end)
@@ -633,6 +822,13 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                 // owns the wave (measured on the hair stand-in: 89 % of the kernel time at ~3 active lanes).  Lanes whose segment
                 // passed the cheap cylinder test PARK in front of it (`pend`) and the block runs once `curveMin` lanes wait, or
                 // when no other lane of the wave can make progress.
+#if SKH_CURVE_COOP
+                if (pend != 0u)
+                {
+                    isLeaf = false;
+                    entered = true; // parked: waits for the cooperative block at the top of the loop (no pop)
+                }
+#else
                 const uint32_t nParked = (uint32_t)__popcll(__ballot(pend != 0u)), nActive = (uint32_t)__popcll(__ballot(pend == 0u));
                 if (pend != 0u)
                 {
@@ -677,6 +873,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                     else
                         entered = true; // keep waiting (no pop)
                 }
+#endif
             }
             if (leafMin > 1u)
             {

@@ -137,7 +137,7 @@ struct skh_context
     uint32_t fetchMinClosest = 24, fetchMinShadow = 32; // idle lanes before a wave pulls new rays from the queue (re-tuned at 7 waves/SIMD: was 16 / 24)
     uint32_t curveFetchMinClosest = 16, curveFetchMinShadow = 24, curveNodeBreakClosest = 20; // the same three for the curve build (6 waves/SIMD): hair 482 vs 465 Mray/s
     uint32_t nodeBreakClosest = 24, nodeBreakShadow = 20; // leave the node loop when fewer than x/64 of the wave's rays are still descending
-    uint32_t curveMin = 48; // lanes parked in front of the curve intersector before it runs (hair stand-in, Mray/s: 1: 113, 16: 225, 32: 310, 48: 334, 64: 321)
+    uint32_t curveMin = 48; // (cooperative curve block) end-point runs queued by the parked lanes before the block runs: one run per lane, so 56 fills the wave; round 2, lanes parked before their owners ran them: (hair stand-in, Mray/s: 1: 113, 16: 225, 32: 310, 48: 334, 64: 321)
     uint32_t leafMin = 16; // postpone the minority kind of leaf work unless it has this many lanes (0 = never postpone; measured +1.5 % at 16)
     // ray re-ordering (per bounce): 0 = off, else Morton bits per axis of the origin cell (key = octant : morton)
     uint32_t sortBitsClosest = 0, sortBitsShadow = 0, sortFirstBounce = 1;
