@@ -835,7 +835,9 @@ __global__ void k_ploc_init(const uint32_t* __restrict__ sortedVals, const uint6
 }
 // RADIUS: neighbours examined on either side.  12 for the BLASes (millions of primitives); the TLAS -- thousands of boxes of wildly
 // different sizes that EVERY ray walks -- searches 96 either side, close to exhaustive agglomerative clustering
+#ifndef SKH_PLOC_RADIUS_TLAS
 #define SKH_PLOC_RADIUS_TLAS 96
+#endif
 template <int RADIUS>
 __global__ void __launch_bounds__(SKH_PLOC_BLOCK) k_ploc_nn(const float4* __restrict__ cLo, const float4* __restrict__ cHi, uint32_t m,
                                                            uint32_t* __restrict__ nn)

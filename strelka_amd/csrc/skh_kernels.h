@@ -220,6 +220,9 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 #ifndef SKH_CURVE_COOP
 #define SKH_CURVE_COOP 1 // the curve intersector as a wave-cooperative block: one (candidate, end point) run per lane (0 = every parked lane runs its own candidates)
 #endif
+#ifndef SKH_WORLD_MIN_WAVES
+#define SKH_WORLD_MIN_WAVES 7
+#endif
 #ifndef SKH_SORT_ANYHIT
 #define SKH_SORT_ANYHIT 0
 #endif
@@ -244,13 +247,16 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 // Closest hit = smallest t, ties broken by the smaller (instance, primitive) key, ray interval open at both ends:
 // the result does not depend on the BVH or on the traversal order (DESIGN.md "determinism").
 // ------------------------------------------------------------------------------------------------------------
-template <bool ANY_HIT, bool COUNT, bool CURVES, bool W8 = false>
-__global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES)) SKH_TRACE_ATTR
+// WORLD: the build for scenes whose every instance is baked (no TLAS leaf, no curve set -- what a bake without mesh sharing gives,
+// HdStrelka's per-instance meshes): one world-space tree, no instance entry / exit, no object-space copy of the ray, no sentinel.
+template <bool ANY_HIT, bool COUNT, bool CURVES, bool W8 = false, bool WORLD = false>
+__global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES : (CURVES ? SKH_CURVE_MIN_WAVES : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES))) SKH_TRACE_ATTR
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
             uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, const uint32_t* __restrict__ perm /*optional: sorted order -> queue index*/,
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
             StatsDev* __restrict__ stats)
 {
+    static_assert(!WORLD || (!CURVES && !W8), "the world-only build is the 4-wide triangle kernel");
     __shared__ int s_stack[SKH_STACK_LDS * SKH_TRACE_BLOCK];
     const uint32_t fetchMin = fetchArg & 0xffu, curveMin = (fetchArg >> 8) & 0xffu, nodeBreak = (fetchArg >> 16) & 0xffu, leafMin = fetchArg >> 24;
     const uint32_t lane = threadIdx.x;
@@ -386,7 +392,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                 o = ow;
                 d = dw;
                 inv = rcp3(d);
-                if (ANY_HIT)
+                if (ANY_HIT && !WORLD)
                     invw = inv;
                 const int wr0 = sc.worldRoot, wr1 = ANY_HIT ? SKH_REF_INVALID : sc.lightRoot; // (kernel arguments: scalar branches)
                 if (wr0 != SKH_REF_INVALID || wr1 != SKH_REF_INVALID)
@@ -399,7 +405,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                     curInst = 0xffffffffu; // = "the instance id is in the triangle record"
                     curType = 0;
                     sp = 0;
-                    if (sc.tlasRoot != SKH_REF_INVALID)
+                    if (!WORLD && sc.tlasRoot != SKH_REF_INVALID)
                     {
                         lds[0] = sc.tlasRoot;
                         lds[SKH_TRACE_BLOCK] = SKH_REF_SENTINEL;
@@ -709,7 +715,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                 else
                 {
                 // one 64-byte fetch = four quantised child boxes
-                const float4* np = reinterpret_cast<const float4*>(nodes + cur);
+                const float4* np = reinterpret_cast<const float4*>((WORLD ? sc.triNodes : nodes) + cur);
                 const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
                 if (COUNT)
                     tc.nodes++;
@@ -801,7 +807,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                 if ((uint32_t)__popcll(__ballot(cur >= 0 && cur != SKH_REF_INVALID)) < breakBelow)
                     break;
             }
-            if (cur == SKH_REF_SENTINEL)
+            if (!WORLD && cur == SKH_REF_SENTINEL)
             {
                 o = ow;
                 d = dw;
@@ -875,7 +881,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                 }
 #endif
             }
-            if (leafMin > 1u)
+            if (!WORLD && leafMin > 1u)
             {
                 const uint32_t nI = (uint32_t)__popcll(__ballot(isLeaf && !inBlas)), nT = (uint32_t)__popcll(__ballot(isLeaf && inBlas));
                 const bool runI = nI >= nT || nI >= leafMin, runT = nT > nI || nT >= leafMin;
@@ -889,7 +895,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
             {
                 const uint32_t enc = (uint32_t)~cur;
                 const uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
-                if (!inBlas)
+                if (!WORLD && !inBlas)
                 {
                     // TLAS leaves hold exactly one instance
                     // the whole 64-byte record in one round trip (loading the transform only after the mask test made it two)
@@ -955,7 +961,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
 #endif
                         {
                             const uint32_t prim = __float_as_uint(a.w);
-                            const uint32_t hinst = curInst == 0xffffffffu ? __float_as_uint(b.w) : curInst; // (baked group: the record names its instance)
+                            const uint32_t hinst = (WORLD || curInst == 0xffffffffu) ? __float_as_uint(b.w) : curInst; // (baked group: the record names its instance)
                             if (!best.found || t < best.t || hinst < best.inst || (hinst == best.inst && prim < best.prim))
                             {
                                 best.t = t;
@@ -983,7 +989,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? SKH_CURVE_MIN_WAVES 
                         break;
                     }
                     SKH_POP(cur);
-                    if (cur == SKH_REF_SENTINEL)
+                    if (!WORLD && cur == SKH_REF_SENTINEL)
                     {
                         o = ow;
                         d = dw;

@@ -159,6 +159,7 @@ struct skh_context
     // 2: also instances of meshes with <= bakeSmallTris triangles (room shells, boards, quads: big boxes that every ray enters
     // for a dozen triangles), while they add at most max(unique triangles, 2^20) triangles
     uint32_t bakeWorld = 2, bakeSmallTris = 64;
+    bool worldKernel = true; // option world_kernel: scenes with an empty top level run the world-only build of k_trace (0 = the general build: A/B, tests)
     std::vector<uint8_t> baked; // per instance, valid after skh_build_accel
     int worldRoot = SKH_REF_INVALID, lightRoot = SKH_REF_INVALID; // roots of the two baked groups (mesh instances, light proxies) inside dTriNodes
     uint32_t nBakedTris = 0, nBakedInst = 0;
@@ -1873,7 +1874,10 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
     StatsDev* sd = c->dStats.as<StatsDev>();
     const uint32_t fullGrid = (ANY && !c->nSegs) ? (uint32_t)c->numCUs * c->wavesPerCUShadow : c->traceBlocks;
     const uint32_t blocks = c->gridOverride ? std::min(c->gridOverride, fullGrid) : fullGrid;
-    if (c->wide == 8)
+    if (c->wide != 8 && !c->nSegs && c->tlasRoot == SKH_REF_INVALID && (c->worldRoot != SKH_REF_INVALID || c->lightRoot != SKH_REF_INVALID) && c->worldKernel)
+        // every instance is baked: the world-only build of the kernel (no instance entry, no object-space copy of the ray)
+        k_trace<ANY, COUNT, false, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride, ovf, sd);
+    else if (c->wide == 8)
     {
         if (c->nSegs)
             k_trace<ANY, COUNT, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride, ovf, sd);
@@ -2787,6 +2791,8 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         c->bakeWorld = (uint32_t)value;
         c->accelBuilt = false;
     }
+    else if (n == "world_kernel")
+        c->worldKernel = value != 0;
     else if (n == "bake_small_tris")
     {
         if (value < 0 || value > (1 << 20))
