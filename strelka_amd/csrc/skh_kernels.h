@@ -220,6 +220,9 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 #ifndef SKH_CURVE_COOP
 #define SKH_CURVE_COOP 1 // the curve intersector as a wave-cooperative block: one (candidate, end point) run per lane (0 = every parked lane runs its own candidates)
 #endif
+#ifndef SKH_SHADOW_ATOMIC
+#define SKH_SHADOW_ATOMIC 0 // fire-and-forget float atomics for the shadow contribution instead of load / add / store: measured equal (40.87 vs 40.90 ms)
+#endif
 #ifndef SKH_WORLD_MIN_WAVES
 #define SKH_WORLD_MIN_WAVES 7
 #endif
@@ -343,9 +346,17 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                     {
                         const uint32_t pid = rq.ids()[i];
                         float* rad = ps.base + (size_t)3 * ps.stride;
+#if SKH_SHADOW_ATOMIC
+                        // a path has at most one shadow ray in a launch, so a fire-and-forget add gives the bits `+=` gives -- without the
+                        // wave sitting through the load -> add -> store round trip at every refill
+                        unsafeAtomicAdd(&rad[pid], contrib[i]);
+                        unsafeAtomicAdd(&rad[pid + ps.stride], contrib[i + contribStride]);
+                        unsafeAtomicAdd(&rad[pid + 2 * (size_t)ps.stride], contrib[i + 2 * (size_t)contribStride]);
+#else
                         rad[pid] += contrib[i];
                         rad[pid + ps.stride] += contrib[i + contribStride];
                         rad[pid + 2 * (size_t)ps.stride] += contrib[i + 2 * (size_t)contribStride];
+#endif
                     }
                 }
                 else

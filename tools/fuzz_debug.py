@@ -4,16 +4,17 @@ import sys, numpy as np
 sys.path.insert(0, ".")
 src = open("tools/fuzz_hits.py").read()
 for seed in [int(a) for a in sys.argv[1:]]:
-    pre, post = src.split("    o = orklib.new_context(); o.set_scene(arr); want = o.trace(rays, 0)")
+    pre, post = src.split("    bk = (seed // 3) % 4")
     pre = pre.replace("for seed in range(int(sys.argv[1]), int(sys.argv[2])):", "for seed in [%d]:" % seed)
     ns = {}
     exec(compile(pre + "    break\n", "fuzz", "exec"), ns)
     arr, rays, S, capi, orklib = ns["arr"], ns["rays"], ns["S"], ns["capi"], ns["orklib"]
-    o = orklib.new_context(); o.set_scene(arr)
+    bk = (seed // 3) % 4
+    o = orklib.new_context(); o.set_bake(bk); o.set_scene(arr)
     want = o.trace(rays, 0)
     res = {}
     for name, opts in (("default", {"curve_split": 1 + seed % 4, "leaf_max_tris": 1 + seed % 4}), ("karras", {"build_quality": 0}), ("leaf1", {"leaf_max_tris": 1}), ("leaf4", {"leaf_max_tris": 4, "tlas_build": 1})):
-        ctx = capi.Context(0)
+        ctx = capi.Context(0); ctx.set_option("bake_world", bk)
         for k, v in opts.items(): ctx.set_option(k, v)
         ctx.set_scene(arr); res[name] = ctx.trace(rays, 0); ctx.close()
     eq = lambda a, b: (a.view(np.uint8).reshape(len(a), -1) == b.view(np.uint8).reshape(len(b), -1)).all(1)

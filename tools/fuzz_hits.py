@@ -126,8 +126,9 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         rays = rays.copy()
         rays["origin"] = (rays["origin"].astype(np.float64) * sc_f + off).astype(np.float32)
         rays["tmax"] = np.where(rays["tmax"] < 1e15, rays["tmax"] * np.float32(sc_f), rays["tmax"]).astype(np.float32)
-    o = orklib.new_context(); o.set_scene(arr); want = o.trace(rays, 0)
-    ctx = capi.Context(0)
+    bk = (seed // 3) % 4  # bake_world is part of the intersection's definition: both sides take the same mode (0 none .. 3 everything)
+    o = orklib.new_context(); o.set_bake(bk); o.set_scene(arr); want = o.trace(rays, 0)
+    ctx = capi.Context(0); ctx.set_option("bake_world", bk)
     ctx.set_option("curve_split", 1 + seed % 4); ctx.set_option("leaf_max_tris", 1 + seed % 4)
     if (seed // 4) % 3 == 2:
         ctx.set_option("wide", 8)  # the 8-wide node layout (octant-ordered slots) must give the same records

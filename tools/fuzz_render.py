@@ -42,11 +42,17 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     w, h = int(rs.randint(17, 120)), int(rs.randint(11, 90))
     spp, depth = int(rs.randint(1, 6)), int(rs.randint(1, 7))
     kw = {"rect_light_sampling_method": int(rs.randint(0, 2)), "max_depth": depth}
+    import zlib as _z
+
+    crc = lambda: {k: _z.crc32(np.ascontiguousarray(v).tobytes()) for k, v in arr.items() if isinstance(v, np.ndarray)}
     o = orklib.new_context()
+    crc_o = crc()  # the arrays as the oracle receives them
     o.set_scene(arr)
     o.resize(w, h)
     ctx = capi.Context(0)
-    ctx.set_option("subframe_batch", int(rs.choice([0, 1, 2])))
+    gpu_opts = {"subframe_batch": int(rs.choice([0, 1, 2])), "overlap": 1, "speculate": 8}
+    ctx.set_option("subframe_batch", gpu_opts["subframe_batch"])
+    crc_g = crc()  # ... and as the GPU receives them
     ctx.set_scene(arr)
     ctx.set_tiles(int(rs.choice([8, 16, 32, 64])), None)
     ctx.resize(w, h)
@@ -55,7 +61,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         o.render_subframe(S.frame_params(sc.getCamera(), w, h, subframe_index=i, spp_total=spp, **kw))
     ctx.render_subframes(p0, spp, None)
     want, got = o.read_accum()[..., :3].astype(np.float64), ctx.read_accum()[..., :3].astype(np.float64)
-    ro, rg = o.stats()["rays_radiance"], ctx.stats()["rays_radiance"]
+    so_, sg_ = o.stats(), ctx.stats()
+    ro, rg = so_["rays_radiance"], sg_["rays_radiance"]
     ctx.close()
     dev = np.abs(got - want).max(-1)
     frac = (dev > 2e-3 * (np.abs(want).max(-1) + max(1e-3, 0.05 * want.mean()))).mean()  # (floor: 5 % of the image mean, for near-black pixels)
@@ -89,7 +96,48 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             o2.render_subframe(S.frame_params(sc.getCamera(), w, h, subframe_index=i, spp_total=spp, **kw))
         want2 = o2.read_accum()[..., :3].astype(np.float64)
         ro2 = o2.stats()["rays_radiance"]
+        # everything needed to name the cause: the scene as both sides received it, checksums of every array at the moment each side
+        # took it, both stats blocks, the stream settings, a GPU render on ONE stream, and the worst pixel's path -- the oracle's rays,
+        # one by one, re-traced through the GPU's and the oracle's raw query entry (a flipped path shows up as the first ray whose
+        # hit differs, or as none: then the two sides shaded the same hits differently)
+        import json
+        import zlib
+
+        from strelka_amd import scene_io
+
+        outdir = os.path.join("gpurun_out", "fuzz_fail_%d" % seed)
+        os.makedirs(outdir, exist_ok=True)
+        scene_io.save_scene(os.path.join(outdir, "scene.skscene"), arr, sc.getCamera())
+        crc_now = {k: zlib.crc32(np.ascontiguousarray(v).tobytes()) for k, v in arr.items() if isinstance(v, np.ndarray)}
+        ctx1 = capi.Context(0)
+        ctx1.set_option("overlap", 0)
+        ctx1.set_option("speculate", 0)
+        ctx1.set_scene(arr)
+        ctx1.resize(w, h)
+        ctx1.render_subframes(p0, spp, None)
+        one_stream = ctx1.read_accum()[..., :3].astype(np.float64)
+        wy, wx = np.unravel_index(int(np.argmax(dev)), dev.shape)
+        trail = []
+        for i in range(spp):
+            pp = S.frame_params(sc.getCamera(), w, h, subframe_index=i, spp_total=spp, **kw)
+            path, rad = o2.debug_path(pp, int(wx), int(wy), i)
+            rr = np.zeros(len(path), S.RAY)
+            rr["origin"], rr["tmin"], rr["dir"], rr["tmax"] = path[:, 1:4], path[:, 4], path[:, 5:8], path[:, 8]
+            for k_, row in enumerate(path):
+                gh, oh = ctx1.trace(rr[k_:k_ + 1], int(row[0]))[0], o2.trace(rr[k_:k_ + 1], int(row[0]))[0]
+                trail.append({"sample": i, "kind": "shadow" if row[0] else "radiance", "oracle_in_path": [float(row[9]), int(row[10]), int(row[11])],
+                              "gpu_trace": [float(gh["t"]), int(gh["instance_id"]), int(gh["prim_id"])],
+                              "oracle_trace": [float(oh["t"]), int(oh["instance_id"]), int(oh["prim_id"])]})
+        st1 = ctx1.stats()
+        ctx1.close()
+        json.dump({"seed": seed, "kind": kind, "w": w, "h": h, "spp": spp, "depth": depth, "l2": l2, "frac": frac,
+                   "crc32_at_oracle_upload": crc_o, "crc32_at_gpu_upload": crc_g, "crc32_now": crc_now,
+                   "inputs_identical": crc_o == crc_g == crc_now, "stats_oracle": so_, "stats_gpu": sg_, "stats_gpu_one_stream": st1,
+                   "gpu_options": gpu_opts, "one_stream_render_equals_first": bool(np.array_equal(one_stream, got)),
+                   "worst_pixel": [int(wx), int(wy)], "worst_pixel_gpu": got[wy, wx].tolist(), "worst_pixel_oracle": want[wy, wx].tolist(),
+                   "worst_pixel_path": trail}, open(os.path.join(outdir, "report.json"), "w"), indent=1)
         print("seed", seed, "kind", kind, w, h, spp, depth, "L2 %.3g frac %.3g rays oracle %d vs GPU %d" % (l2, frac, ro, rg),
+              "| inputs identical: %s | one-stream GPU render %s the first | report: %s" % (crc_o == crc_g == crc_now, "equals" if np.array_equal(one_stream, got) else "DIFFERS from", outdir),
               "| second GPU render: rays %d, %s the first" % (rg2, "equals" if np.array_equal(again, got) else "DIFFERS from"),
               "| second oracle render: rays %d, %s the first" % (ro2, "equals" if np.array_equal(want2, want) else "DIFFERS from"), flush=True)
 print("fuzz done: %d seeds, %d failures, %.0f s" % (int(sys.argv[2]) - int(sys.argv[1]), bad, time.time() - t0))
