@@ -362,9 +362,11 @@ skh_status skh_bsdf_probe(skh_context* ctx, const skh_bsdf_query* queries, uint3
  *                 overlap 0|1|2 (any-hit launches on a second stream beside the next closest-hit launch: off | small passes |
  *                 always), small_waves_closest / small_waves_shadow (16 / 16: waves per CU of the two overlapped launches),
  *                 sort_bits_closest / sort_bits_shadow / sort_first_bounce (ray re-ordering, off)
- *   definition    bake_world 2|1|0 (mesh instances intersected in world space, no instance entry: 1 = instances whose mesh has one
+ *   definition    bake_world 4|3|2|1|0 (mesh instances intersected in world space, no instance entry: 1 = instances whose mesh has one
  *                 user -- what HdStrelka's per-instance meshes are --, 2 = also instances of meshes with <= bake_small_tris (64)
- *                 triangles; 0 = every instance keeps its TLAS leaf)
+ *                 triangles when that empties the top level, 3 = every mesh instance, 4 (default) = 3 while the instanced triangles stay
+ *                 within bake_budget_mtris (64) million, else 2; 0 = every instance keeps its TLAS leaf), world_kernel 1|0 (scenes
+ *                 with an empty top level run the world-only build of the traversal kernel)
  *   build         build_quality 1|0 (PLOC | Karras radix tree), leaf_max_tris (2), curve_split (2: parameter sub-ranges
  *                 per curve segment), tlas_build 2|1|0 (auto | GPU PLOC over the instance boxes | exact sweep SAH on the host; auto =
  *                 the sweep up to 8192 instances, the GPU beyond), tlas_open (1: TLAS leaves per instance budget),

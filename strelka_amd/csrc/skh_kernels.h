@@ -827,6 +827,28 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                 inBlas = false;
                 cur = SKH_REF_INVALID;
             }
+#ifdef SKH_EXCHANGE_PROBE
+            // (measurement only, docs/LOG.md "re-binning": the LDS traffic of handing a ray to another lane at every phase change --
+            // SKH_EXCHANGE_PROBE dwords of state out and back through the dead part of the lane's own stack column, no result changes)
+            {
+                volatile int* xs = lds;
+                float* st[16] = { &o.x, &o.y, &o.z, &inv.x, &inv.y, &inv.z, &tmin, &best.t, &best.u, &best.v, &sh.Sx, &sh.Sy, &sh.Sz, &d.x, &d.y, &d.z };
+                const int top = sp < SKH_STACK_LDS - SKH_EXCHANGE_PROBE ? sp : 0; // (a full stack: the probe borrows the bottom, and restores it)
+                int saved[SKH_EXCHANGE_PROBE];
+#pragma unroll
+                for (int k = 0; k < SKH_EXCHANGE_PROBE; ++k)
+                {
+                    saved[k] = xs[(top + k) * SKH_TRACE_BLOCK];
+                    xs[(top + k) * SKH_TRACE_BLOCK] = __float_as_int(*st[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < SKH_EXCHANGE_PROBE; ++k)
+                {
+                    *st[k] = __int_as_float(xs[(top + k) * SKH_TRACE_BLOCK]);
+                    xs[(top + k) * SKH_TRACE_BLOCK] = saved[k];
+                }
+            }
+#endif
             // ---- leaf ----
             SKH_LP({ const unsigned long long t = __builtin_readcyclecounter(); cy[1] += t - cyA; cyA = t; })
             bool entered = false;

@@ -158,7 +158,7 @@ struct skh_context
     // 0 off; 1: instances whose mesh has a single user (what HdStrelka's per-instance meshes are, RenderPass.cpp:126-129,252-257);
     // 2: also instances of meshes with <= bakeSmallTris triangles (room shells, boards, quads: big boxes that every ray enters
     // for a dozen triangles), while they add at most max(unique triangles, 2^20) triangles
-    uint32_t bakeWorld = 2, bakeSmallTris = 64;
+    uint32_t bakeWorld = 4, bakeSmallTris = 64, bakeBudgetMTris = 64;
     bool worldKernel = true; // option world_kernel: scenes with an empty top level run the world-only build of k_trace (0 = the general build: A/B, tests)
     std::vector<uint8_t> baked; // per instance, valid after skh_build_accel
     int worldRoot = SKH_REF_INVALID, lightRoot = SKH_REF_INVALID; // roots of the two baked groups (mesh instances, light proxies) inside dTriNodes
@@ -1089,9 +1089,20 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         std::vector<uint8_t> pick(std::max(1u, nInst), 0);
         auto trisOf = [&](uint32_t i) { return c->meshes[c->instances[i].geom_id].index_count / 3; };
         auto eligible = [&](uint32_t i) { return c->bakeWorld >= 1 && c->instances[i].type != SKH_INSTANCE_CURVE && valid[i] && trisOf(i) > 0; };
+        // mode 4 (default) = everything (3) while the instanced triangles stay within bake_budget_mtris million, else 2: a scene
+        // whose instancing fits in memory many times over is fastest with no instancing at all (kitchen stand-in, 23 M instanced
+        // triangles = 1.8 GB of leaf records + nodes of 288 GB: closest-hit 98.0 -> 91.0 ms), a forest of 10^9 instanced triangles is not
+        uint32_t mode = c->bakeWorld;
+        if (mode == 4)
+        {
+            uint64_t all = 0;
+            for (uint32_t i = 0; i < nInst; ++i)
+                all += eligible(i) ? trisOf(i) : 0u;
+            mode = all <= (uint64_t)c->bakeBudgetMTris * 1000000ull ? 3u : 2u;
+        }
         for (uint32_t i = 0; i < nInst; ++i)
-            pick[i] = eligible(i) && (meshUsers[c->instances[i].geom_id] == 1 || c->bakeWorld >= 3) ? 1 : 0;
-        if (c->bakeWorld == 2)
+            pick[i] = eligible(i) && (meshUsers[c->instances[i].geom_id] == 1 || mode >= 3) ? 1 : 0;
+        if (mode == 2)
         {
             // Small SHARED meshes (boards, quads) follow only when that leaves no mesh instance behind: beside a populated top level
             // a partly baked scene measured no faster (kitchen stand-in, any-hit 41.1 -> 42.6 ms), an emptied one saves the level
@@ -2786,13 +2797,20 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
     }
     else if (n == "bake_world")
     {
-        if (value < 0 || value > 3)
+        if (value < 0 || value > 4)
             return SKH_INVALID_ARGUMENT;
         c->bakeWorld = (uint32_t)value;
         c->accelBuilt = false;
     }
     else if (n == "world_kernel")
         c->worldKernel = value != 0;
+    else if (n == "bake_budget_mtris")
+    {
+        if (value < 0 || value > 100)
+            return SKH_INVALID_ARGUMENT; // (leaf references address 2^27 baked triangles)
+        c->bakeBudgetMTris = (uint32_t)value;
+        c->accelBuilt = false;
+    }
     else if (n == "bake_small_tris")
     {
         if (value < 0 || value > (1 << 20))

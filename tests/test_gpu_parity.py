@@ -492,7 +492,7 @@ def test_results_do_not_depend_on_the_acceleration_structure_or_scheduling(opts)
         assert a.tobytes() == b.tobytes()
 
 
-@pytest.mark.parametrize("mode,small", [(0, 64), (1, 64), (2, 64), (2, 4000), (3, 64)])
+@pytest.mark.parametrize("mode,small", [(0, 64), (1, 64), (2, 64), (2, 4000), (3, 64), (4, 64)])
 def test_bake_world_modes_match_oracle(mode, small):
     """Option bake_world is part of the intersection's DEFINITION (a baked instance's triangles are carried to world space once
     and tested there, no instance entry), so the oracle takes the same setting: for every mode both sides must bake the same
@@ -540,7 +540,7 @@ def test_bake_world_modes_match_oracle(mode, small):
         assert counts == [0, 0, 0]
     else:
         assert counts[2] >= 40 and counts[0] >= 1  # every unique mesh; at least the room of the shared scene
-    if mode == 3:
+    if mode >= 3:
         assert counts[0] >= 60
 
 
@@ -570,7 +570,7 @@ def _zoomed_out_rays(arr, ratio, n, seed):
     return rays
 
 
-@pytest.mark.parametrize("bake", [0, 2])
+@pytest.mark.parametrize("bake", [0, 4])
 def test_hit_records_are_hierarchy_independent_inside_the_stated_envelope(bake):
     """The contract "hit records do not depend on the hierarchy" holds up to 10^3 THINNEST instance extents between the ray origin
     and what it is aimed at: inside it the GPU (4-wide, 8-wide, another leaf size), the oracle's BVH and brute

@@ -130,7 +130,7 @@ def test_bvh_never_changes_a_result(maker):
     assert (a["instance_id"] != 0xFFFFFFFF).mean() > 0.2
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_bake_world_definition(mode):
     """bake_world: a baked mesh / light-proxy instance is intersected in world space.  For every mode:
     the baked set follows the integer rule, the oracle's BVH still never changes a result, hits name the same (instance,
@@ -150,6 +150,9 @@ def test_bake_world_definition(mode):
     users = np.bincount(inst["geom_id"][(inst["type"] != S.INSTANCE_CURVE) & valid], minlength=len(meshes))
     tris = meshes["index_count"] // 3
     geom, typ = inst["geom_id"], inst["type"]
+    if mode == 4:  # the default: everything while the instanced triangles fit the budget (64 M), else mode 2
+        assert tris[geom[valid & (typ != S.INSTANCE_CURVE)]].sum() <= 64e6
+        mode = 3
     pick = np.array([bool(valid[i]) and (mode >= 3 or (mode >= 1 and users[geom[i]] == 1)) for i in range(n)])
     if mode == 2:  # small shared meshes only when no mesh instance stays behind; small light proxies are candidates on their own
         rest = valid & ~pick & (typ == S.INSTANCE_MESH)
