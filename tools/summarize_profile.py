@@ -3,7 +3,7 @@
   profiles/<tag>_kernel_stats.csv          rocprofv3 --kernel-trace --stats summary (per-kernel time)
   profiles/<tag>_pmc_hbm.csv               per-kernel FETCH_SIZE / WRITE_SIZE averages from the two --pmc passes
   profiles/<tag>_pmc_instructions.csv / _pmc_sq_utilisation.csv   SQ counters of the same passes
-  profiles/<tag>_bench.json, profiles/pmc_k_trace_closest.json     the bench line of that run and the counter figures bench.py replays
+  profiles/<tag>_bench.json, profiles/pmc_kernels.json     the bench line of that run and the counter figures bench.py replays
                                                                      (tagged as replayed) when it cannot run rocprofv3 itself
 Units/corrections follow /opt/skills/guides (MI355X_MICROARCH.md "HBM", cdna_hip_programming.md section 7):
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) reads, so
@@ -50,7 +50,7 @@ def main():
         lines = [l for l in open(logs) if l.startswith("{")]
         if lines:
             open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w").write(lines[-1])
-    for name, out in (("bench.json", f"{tag}_bench.json"), ("pmc_k_trace_closest.json", "pmc_k_trace_closest.json")):
+    for name, out in (("bench.json", f"{tag}_bench.json"), ("pmc_kernels.json", "pmc_kernels.json")):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, out))
     # the counter passes bench.py ran itself (--pmc-keep): pass0 FETCH_SIZE, pass1 WRITE_SIZE, pass2 SQ counters
