@@ -360,8 +360,7 @@ skh_status skh_bsdf_probe(skh_context* ctx, const skh_bsdf_query* queries, uint3
  *                 curve intersector before it runs), subframe_batch (0 = auto: ~64 M paths per pass),
  *                 speculate (8: sub-frames traced ahead when skh_render_subframe is called once per sub-frame; 0 = off),
  *                 overlap 0|1|2 (any-hit launches on a second stream beside the next closest-hit launch: off | small passes |
- *                 always), small_waves_closest / small_waves_shadow (16 / 16: waves per CU of the two overlapped launches),
- *                 sort_bits_closest / sort_bits_shadow / sort_first_bounce (ray re-ordering, off)
+ *                 always), small_waves_closest / small_waves_shadow (16 / 16: waves per CU of the two overlapped launches)
  *   definition    bake_world 4|3|2|1|0 (mesh instances intersected in world space, no instance entry: 1 = instances whose mesh has one
  *                 user -- what HdStrelka's per-instance meshes are --, 2 = also instances of meshes with <= bake_small_tris (64)
  *                 triangles when that empties the top level, 3 = every mesh instance, 4 (default) = 3 while the instanced triangles stay

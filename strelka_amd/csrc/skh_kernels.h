@@ -73,10 +73,17 @@ struct DevScene
     uint32_t* overflowFlag; // host-mapped word: set when a traversal stack had to drop an entry (checked after every render / trace call)
 };
 
+// Queues are SHARDED 8 ways (SKH_SHARDS = the XCD count): shard g owns the positions [g * region, g * region + count[g]) of every plane.
+// A k_shade workgroup b reads and compacts into shard b & 7 -- one queue-tail word per shard and queue, each in its own 128-byte
+// line -- and the k_trace waves with blockIdx & 7 == g pull from shard g first: workgroups are dealt round-robin to the 8 XCDs, so a
+// ray is written, traced and shaded under the same L2.  One tail word for the whole queue took 256 K returning atomics per launch at
+// the ~88 per microsecond one line sustains: 2.9 ms of a 4.0 ms k_shade launch (round 3).
+#define SKH_SHARDS 8u
 struct RayQ // SoA planes of `stride` elements: ox oy oz dx dy dz tmin tmax pathId  (36 B / ray)
 {
     float* base;
     uint32_t stride;
+    uint32_t region; // positions per shard (stride = SKH_SHARDS * region)
     __device__ float* plane(int k) const
     {
         return base + (size_t)k * stride;
@@ -255,7 +262,7 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 template <bool ANY_HIT, bool COUNT, bool CURVES, bool W8 = false, bool WORLD = false>
 __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES : (CURVES ? SKH_CURVE_MIN_WAVES : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES))) SKH_TRACE_ATTR
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
-            uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, const uint32_t* __restrict__ perm /*optional: sorted order -> queue index*/,
+            uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, const uint32_t* __restrict__ /*unused*/,
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
             StatsDev* __restrict__ stats)
 {
@@ -263,10 +270,13 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
     __shared__ int s_stack[SKH_STACK_LDS * SKH_TRACE_BLOCK];
     const uint32_t fetchMin = fetchArg & 0xffu, curveMin = (fetchArg >> 8) & 0xffu, nodeBreak = (fetchArg >> 16) & 0xffu, leafMin = fetchArg >> 24;
     const uint32_t lane = threadIdx.x;
-    const uint32_t n = *countPtr;
+    uint32_t n = 0; // (countPtr: SKH_SHARDS queue-length words, SKH_COUNT_STRIDE apart)
+#pragma unroll
+    for (uint32_t g = 0; g < SKH_SHARDS; ++g)
+        n += countPtr[g * SKH_COUNT_STRIDE];
     if (n == 0)
         return;
-    const uint32_t perGroup = (((n + 7u) >> 3) + 63u) & ~63u;
+    const uint32_t perGroup = rq.region;
     const uint32_t group = blockIdx.x & 7u;
     uint32_t tries = 0;
     bool exhausted = false;
@@ -380,7 +390,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                     b = atomicAdd(&fetch[g * SKH_FETCH_STRIDE], want);
                 b = __shfl(b, leader);
                 const uint32_t lo = g * perGroup;
-                const uint32_t hi = min(n, lo + perGroup);
+                const uint32_t hi = lo + countPtr[g * SKH_COUNT_STRIDE];
                 if (lo < hi && b < hi - lo)
                 {
                     base = lo + b;
@@ -396,7 +406,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
             const uint32_t rank = (uint32_t)__popcll(needMask & ((1ull << lane) - 1ull));
             if (!hasRay && rank < count)
             {
-                ridx = perm ? perm[base + rank] : base + rank;
+                ridx = base + rank;
                 ow = mk3(rq.plane(0)[ridx], rq.plane(1)[ridx], rq.plane(2)[ridx]);
                 dw = mk3(rq.plane(3)[ridx], rq.plane(4)[ridx], rq.plane(5)[ridx]);
                 tmin = rq.plane(6)[ridx];
@@ -1102,30 +1112,6 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Ray re-ordering for coherence: key = direction octant : Morton code of the origin inside the scene box.  Rays that
-// start close together and point the same way walk the same BVH nodes, which raises both the cache hit rate and the
-// fraction of active lanes per wave.  Only the (key, index) pairs are sorted; k_trace gathers rays through the
-// permutation and writes hit records at the ORIGINAL queue index, so nothing downstream changes.
-// ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ray_keys(RayQ rq, const uint32_t* __restrict__ countPtr, float lox, float loy, float loz,
-                                                 float sx, float sy, float sz, uint32_t mortonBits /*per axis, <= 10*/,
-                                                 uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= *countPtr)
-        return;
-    const float ox = rq.plane(0)[i], oy = rq.plane(1)[i], oz = rq.plane(2)[i];
-    const float dx = rq.plane(3)[i], dy = rq.plane(4)[i], dz = rq.plane(5)[i];
-    const uint32_t qx = (uint32_t)fminf(fmaxf((ox - lox) * sx, 0.0f), 1023.0f);
-    const uint32_t qy = (uint32_t)fminf(fmaxf((oy - loy) * sy, 0.0f), 1023.0f);
-    const uint32_t qz = (uint32_t)fminf(fmaxf((oz - loz) * sz, 0.0f), 1023.0f);
-    const uint32_t code = ((expand_bits10(qx) << 2) | (expand_bits10(qy) << 1) | expand_bits10(qz)) >> (3u * (10u - mortonBits));
-    const uint32_t oct = (dx < 0.0f ? 1u : 0u) | (dy < 0.0f ? 2u : 0u) | (dz < 0.0f ? 4u : 0u);
-    keys[i] = ((uint64_t)oct << (3u * mortonBits)) | code;
-    vals[i] = i;
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // slot <-> pixel: slot = tile * T^2 + morton(xl, yl): a wave's 64 lanes cover an 8x8 pixel block
 // ------------------------------------------------------------------------------------------------------------
 SKH_DI bool slot_to_pixel(const FrameP& fp, const uint32_t* __restrict__ tileXY, uint32_t slot, uint32_t& px, uint32_t& py)
@@ -1243,9 +1229,14 @@ __global__ void __launch_bounds__(512) k_raygen(FrameP fp, const uint32_t* __res
     uint32_t before = 0;
     for (uint32_t w = 0; w < wave; ++w)
         before += s_wave[w];
-    const uint32_t idx = sub * validPerSub + blockBase[bi] + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        *counter = validPerSub * fp.batch; // the queue length the next kernels read
+    // dense index in slot order -> shard: the queue is cut into SKH_SHARDS equal runs of `per` rays (the last one shorter)
+    const uint32_t dense = sub * validPerSub + blockBase[bi] + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const uint32_t total = validPerSub * fp.batch;
+    const uint32_t per = (((total + SKH_SHARDS - 1u) / SKH_SHARDS) + 63u) & ~63u;
+    const uint32_t shard = per ? dense / per : 0u;
+    const uint32_t idx = shard * rq.region + (dense - shard * per);
+    if (blockIdx.x == 0 && threadIdx.x < SKH_SHARDS) // the queue lengths the next kernels read
+        counter[threadIdx.x * SKH_COUNT_STRIDE] = min(per, total - min(total, threadIdx.x * per));
     if (active)
     {
         rq.plane(0)[idx] = o.x;
@@ -1380,10 +1371,13 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
 {
     __shared__ uint32_t s_wave[2 * (SKH_COMPACT_MAX_WAVES + 1)];
     __shared__ uint32_t s_sobol[SKH_SOBOL_LUT_WORDS];
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n = *countPtr;
-    if (blockIdx.x * blockDim.x >= n)
-        return; // whole block past the end of the queue
+    // workgroup b works on shard b & 7 (and compacts into the same shard of both output queues)
+    const uint32_t shard = blockIdx.x & (SKH_SHARDS - 1u), lb = blockIdx.x / SKH_SHARDS;
+    const uint32_t n = countPtr[shard * SKH_COUNT_STRIDE]; // rays in this shard
+    if (lb * blockDim.x >= n)
+        return; // whole block past the end of its shard
+    const uint32_t il = lb * blockDim.x + threadIdx.x;
+    const uint32_t i = shard * rq.region + il;
 #ifdef SKH_LANE_PROFILE
     unsigned long long spc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, spT = __builtin_readcyclecounter();
 #define SKH_SP(k)                                                    \
@@ -1408,7 +1402,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
             reinterpret_cast<uint4*>(s_sobol)[threadIdx.x + k * SKH_SHADE_BLOCK] = lut[k];
     }
     __syncthreads();
-    const bool valid = i < n;
+    const bool valid = il < n;
     bool emitNext = false, emitShadow = false;
     v3 nextO = mk3(0.0f), nextD = mk3(0.0f), shO = mk3(0.0f), shD = mk3(0.0f), shC = mk3(0.0f);
     float shTmax = 0.0f;
@@ -1684,7 +1678,9 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
     SKH_SP(6) // bounce tail + path-state write
     // stream compaction of live paths / shadow rays: one atomic per queue per workgroup, both in flight together
     uint32_t ni, si;
-    block_compact2(emitNext, nextCount, emitShadow, shadowCount, s_wave, ni, si);
+    block_compact2(emitNext, nextCount + shard * SKH_COUNT_STRIDE, emitShadow, shadowCount + shard * SKH_COUNT_STRIDE, s_wave, ni, si);
+    ni += shard * nextQ.region; // (a shard's output never outgrows its region: at most one ray of either kind per input ray)
+    si += shard * shadowQ.region;
     if (emitNext)
     {
         nextQ.plane(0)[ni] = nextO.x;
@@ -1898,10 +1894,11 @@ __global__ void k_add_stats(const uint32_t* __restrict__ counts, uint32_t numBou
     {
         unsigned long long r = 0, s = 0;
         for (uint32_t b = 0; b < numBounces; ++b)
-        {
-            r += counts[2 * b * SKH_COUNT_STRIDE];
-            s += counts[(2 * b + 1) * SKH_COUNT_STRIDE];
-        }
+            for (uint32_t g = 0; g < SKH_SHARDS; ++g)
+            {
+                r += counts[(2 * b * SKH_SHARDS + g) * SKH_COUNT_STRIDE];
+                s += counts[((2 * b + 1) * SKH_SHARDS + g) * SKH_COUNT_STRIDE];
+            }
         stats->raysRadiance += r;
         stats->raysShadow += s;
     }

@@ -139,9 +139,8 @@ struct skh_context
     uint32_t nodeBreakClosest = 24, nodeBreakShadow = 20; // leave the node loop when fewer than x/64 of the wave's rays are still descending
     uint32_t curveMin = 48; // (cooperative curve block) end-point runs queued by the parked lanes before the block runs: one run per lane, so 56 fills the wave; round 2, lanes parked before their owners ran them: (hair stand-in, Mray/s: 1: 113, 16: 225, 32: 310, 48: 334, 64: 321)
     uint32_t leafMin = 16; // postpone the minority kind of leaf work unless it has this many lanes (0 = never postpone; measured +1.5 % at 16)
-    // ray re-ordering (per bounce): 0 = off, else Morton bits per axis of the origin cell (key = octant : morton)
-    uint32_t sortBitsClosest = 0, sortBitsShadow = 0, sortFirstBounce = 1;
     uint32_t subframeBatch = 0, batchCapacity = 1; // option subframe_batch: 0 = auto
+    uint32_t queueRegion = 64; // positions per queue shard (RayQ::region): the queues hold SKH_SHARDS * queueRegion rays
     bool tightInstanceBoxes = true; // TLAS leaf boxes from the transformed vertices, not from the transformed object box
     uint32_t curveSplit = 2; // parameter sub-ranges per curve segment in the curve BLAS (1 = off; hair stand-in, ms per 1080p sub-frame: 1: 61.6, 2: 52.1, 4: 49.7, 8: 50.1 -- build time and leaf memory grow with it)
     // TLAS builder.  1: on the GPU -- PLOC over the instance boxes with a 96-neighbour search, the BLAS builder, no host round trip:
@@ -166,7 +165,6 @@ struct skh_context
     uint32_t leafMaxTris = 2; // measured on MI355X: 2 beats 1, 3, 4, 6, 8 (the kernel is ALU bound, wasted triangle tests cost more than extra nodes)
     uint32_t buildQuality = 1; // 0: Karras radix tree (fastest build), 1: PLOC clustering (SAH-class quality)
     float sceneLo[3] = { 0, 0, 0 }, sceneHi[3] = { 1, 1, 1 };
-    DevBuf dSortKeys[2], dSortVals[2], dSortHist;
 
     // timing
     std::vector<TimedSpan> spans;
@@ -830,8 +828,7 @@ void skh_destroy(skh_context* c)
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
                        &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
-                       &c->dCounts, &c->dOvf, &c->dOvf2, &c->dStats, &c->dScratchImage, &c->dSortKeys[0], &c->dSortKeys[1], &c->dSortVals[0],
-                       &c->dSortVals[1], &c->dSortHist })
+                       &c->dCounts, &c->dOvf, &c->dOvf2, &c->dStats, &c->dScratchImage })
         dev_free(*b);
     for (hipEvent_t e : c->eventPool)
         (void)hipEventDestroy(e);
@@ -1627,9 +1624,13 @@ static skh_status alloc_frame(skh_context* c)
     // rays walk 10x the average number of nodes); at 2 M rays per launch the tail is half of the kernel time, at 64 M it
     // is amortised (measured at 1080p, Mray/s: 1 sub-frame per pass 1104, 16: 1942, 64: 2055 before the kernel work; with
     // the final kernels 8: 3455, 16: 3579, 32: 3678).  ~270 B per path: 18 GB of 288 GB at the default.
-    c->batchCapacity = c->subframeBatch ? c->subframeBatch : std::min(64u, std::max(1u, (1u << 26) / std::max(1u, c->numSlots)));
+    c->batchCapacity = c->subframeBatch ? c->subframeBatch : std::min(64u, std::max(1u, (1u << 27) / std::max(1u, c->numSlots)));
     const size_t N1 = std::max(1u, c->numSlots);
     const size_t N = N1 * c->batchCapacity;
+    // queues are sharded SKH_SHARDS ways: a shard's region holds an eighth of the paths (rounded up to whole waves); k_raygen deals the
+    // first queue out in equal runs, and a k_shade workgroup emits into the shard it read from, so no shard outgrows its region
+    c->queueRegion = (uint32_t)((((N + SKH_SHARDS - 1) / SKH_SHARDS) + 63) & ~(size_t)63);
+    const size_t NQ = (size_t)SKH_SHARDS * c->queueRegion;
 #define AF(expr)                \
     if ((s = (expr)) != SKH_OK) \
         return s;
@@ -1670,18 +1671,12 @@ static skh_status alloc_frame(skh_context* c)
     AF(dev_alloc(c, c->dSpecCnt, sizeof(uint16_t) * N1));
     AF(dev_alloc(c, c->dSums, sizeof(float) * 11 * N1));
     AF(dev_alloc(c, c->dPath, sizeof(float) * 8 * N));
-    AF(dev_alloc(c, c->dRayQ[0], sizeof(float) * 9 * N));
-    AF(dev_alloc(c, c->dRayQ[1], sizeof(float) * 9 * N));
-    AF(dev_alloc(c, c->dHits, sizeof(float) * 8 * N));
-    AF(dev_alloc(c, c->dShadowQ, sizeof(float) * 9 * N));
-    AF(dev_alloc(c, c->dContrib, sizeof(float) * 3 * N));
-    AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * (SKH_COUNT_STRIDE * 2 * 130 + 16 * SKH_FETCH_STRIDE * 130)));
-    for (int k = 0; k < 2; ++k)
-    {
-        AF(dev_alloc(c, c->dSortKeys[k], sizeof(uint64_t) * N));
-        AF(dev_alloc(c, c->dSortVals[k], sizeof(uint32_t) * N));
-    }
-    AF(dev_alloc(c, c->dSortHist, sizeof(uint32_t) * 256 * ((N + SKH_RS_THREADS * SKH_RS_ITEMS - 1) / (SKH_RS_THREADS * SKH_RS_ITEMS))));
+    AF(dev_alloc(c, c->dRayQ[0], sizeof(float) * 9 * NQ));
+    AF(dev_alloc(c, c->dRayQ[1], sizeof(float) * 9 * NQ));
+    AF(dev_alloc(c, c->dHits, sizeof(float) * 8 * NQ));
+    AF(dev_alloc(c, c->dShadowQ, sizeof(float) * 9 * NQ));
+    AF(dev_alloc(c, c->dContrib, sizeof(float) * 3 * NQ));
+    AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * (SKH_COUNT_STRIDE * SKH_SHARDS * 2 * 130 + 16 * SKH_FETCH_STRIDE * 130)));
     c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
     AF(dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * std::max(c->traceBlocks, (uint32_t)c->numCUs * c->wavesPerCUShadow) * SKH_TRACE_BLOCK));
     AF(dev_alloc(c, c->dOvf2, sizeof(int) * (size_t)SKH_STACK_OVF * std::max(c->traceBlocks, (uint32_t)c->numCUs * c->wavesPerCUShadow) * SKH_TRACE_BLOCK));
@@ -1838,38 +1833,6 @@ static skh_status ensure_ready(skh_context* c)
 }
 
 // sorts (key, index) pairs of the rays in rq (length on the device) and returns the permutation, or nullptr when off
-static const uint32_t* sort_rays(skh_context* c, RayQ rq, const uint32_t* countPtr, uint32_t mortonBits)
-{
-    if (mortonBits == 0 || rq.stride == 0)
-        return nullptr;
-    mortonBits = std::min(mortonBits, 10u);
-    hipStream_t st = c->stream;
-    const uint32_t N = rq.stride;
-    float sc[3];
-    for (int k = 0; k < 3; ++k)
-    {
-        const float e = c->sceneHi[k] - c->sceneLo[k];
-        sc[k] = e > 0.0f ? 1024.0f / e : 0.0f;
-    }
-    uint64_t* kin = c->dSortKeys[0].as<uint64_t>();
-    uint64_t* kout = c->dSortKeys[1].as<uint64_t>();
-    uint32_t* vin = c->dSortVals[0].as<uint32_t>();
-    uint32_t* vout = c->dSortVals[1].as<uint32_t>();
-    k_ray_keys<<<(N + 255) / 256, 256, 0, st>>>(rq, countPtr, c->sceneLo[0], c->sceneLo[1], c->sceneLo[2], sc[0], sc[1], sc[2], mortonBits, kin,
-                                                vin);
-    const uint32_t bits = 3 * mortonBits + 3;
-    const uint32_t rsBlocks = (N + SKH_RS_THREADS * SKH_RS_ITEMS - 1) / (SKH_RS_THREADS * SKH_RS_ITEMS);
-    for (uint32_t shift = 0; shift < bits; shift += 8)
-    {
-        k_rs_hist<<<rsBlocks, SKH_RS_THREADS, 0, st>>>(kin, N, shift, c->dSortHist.as<uint32_t>(), rsBlocks, countPtr);
-        k_rs_scan<<<1, 1024, 0, st>>>(c->dSortHist.as<uint32_t>(), 256 * rsBlocks);
-        k_rs_scatter<<<rsBlocks, SKH_RS_THREADS, 0, st>>>(kin, vin, kout, vout, N, shift, c->dSortHist.as<uint32_t>(), rsBlocks, countPtr);
-        std::swap(kin, kout);
-        std::swap(vin, vout);
-    }
-    return vin;
-}
-
 template <bool ANY, bool COUNT>
 static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint32_t* countPtr, uint32_t* fetch, const uint32_t* perm,
                          HitQ hq, PathS ps, const float* contrib, uint32_t contribStride, hipStream_t st = nullptr)
@@ -1949,21 +1912,23 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     fp.finalFirst = std::min(finalFirst, batch);
     fp.finalCount = std::min(finalCount, batch - fp.finalFirst);
     const DevScene sc = make_dev_scene(c);
-    const uint32_t N = c->numSlots * c->batchCapacity; // plane stride of every queue / path-state buffer
+    const uint32_t N = c->numSlots * c->batchCapacity; // plane stride of the path-state buffer
+    const uint32_t NQ = SKH_SHARDS * c->queueRegion; // plane stride of every queue (rays, hits, shadow contributions)
     const uint32_t NP = c->numSlots * batch; // paths in this pass
     if (NP == 0)
         return SKH_OK;
     const uint32_t gridSlots = (c->numSlots + 255) / 256;
     const uint32_t* tiles = c->dTileXY.as<uint32_t>();
     PathS ps{ c->dPath.as<float>(), N };
-    RayQ rq[2] = { RayQ{ c->dRayQ[0].as<float>(), N }, RayQ{ c->dRayQ[1].as<float>(), N } };
-    RayQ shq{ c->dShadowQ.as<float>(), N };
-    HitQ hq{ c->dHits.as<float>(), N };
+    RayQ rq[2] = { RayQ{ c->dRayQ[0].as<float>(), NQ, c->queueRegion }, RayQ{ c->dRayQ[1].as<float>(), NQ, c->queueRegion } };
+    RayQ shq{ c->dShadowQ.as<float>(), NQ, c->queueRegion };
+    HitQ hq{ c->dHits.as<float>(), NQ };
     HitQ nohq{ nullptr, 0 };
-    // dCounts: 260 queue-length words (2 per bounce), then the ray-fetch cursors (8 per trace launch); every word that is the
-    // target of atomics has a 128-byte line of its own (returning atomics on one line serialise at ~88 per microsecond)
+    // dCounts: 260 queues (2 per bounce) x SKH_SHARDS queue-length words, then the ray-fetch cursors (8 per trace launch); every word
+    // that is the target of atomics has a 128-byte line of its own (returning atomics on one line serialise at ~88 per microsecond)
     uint32_t* counts = c->dCounts.as<uint32_t>();
-    uint32_t* fetch = counts + SKH_COUNT_STRIDE * 2 * 130;
+    const uint32_t QW = SKH_COUNT_STRIDE * SKH_SHARDS; // words per queue's lengths
+    uint32_t* fetch = counts + QW * 2 * 130;
     // shadow[b] on a second stream: it depends on shade[b] only, and so does closest[b+1]; each fills the other's tail.  Ray
     // sorting shares scratch buffers between the two and keeps everything on one stream.
     // overlap 1 (default): passes up to 32 M paths -- a rank's share of an N-GPU frame, the one-sub-frame-per-call pattern and its
@@ -1972,10 +1937,10 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     // frame: 24.26 -> 23.87 ms, 93.3 -> 94.9 % of 1/8 of the full frame; 1/4: 97.0 -> 97.8 %).  The full single-GPU frame (64 M paths
     // per pass) gains 0.5 % and stays on one stream so that its per-kernel hipEvent spans do not overlap.  overlap 2: always, reduced grids.
     const bool smallPass = NP <= (1u << 23) || c->overlap == 2;
-    const bool useOverlap = (c->overlap == 2 || (c->overlap == 1 && NP <= (1u << 25))) && !c->sortBitsClosest && !c->sortBitsShadow && fp.debug != 1;
+    const bool useOverlap = (c->overlap == 2 || (c->overlap == 1 && NP <= (1u << 25))) && fp.debug != 1;
     for (uint32_t s = 0; trace && s < fp.samplesThisLaunch; ++s)
     {
-        SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (SKH_COUNT_STRIDE * 2 * 130 + 16 * SKH_FETCH_STRIDE * (fp.maxDepth + 1)), st));
+        SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (QW * 2 * 130 + 16 * SKH_FETCH_STRIDE * (fp.maxDepth + 1)), st));
         {
             SpanGuard g(c, KC_RAYGEN);
             k_raygen<<<c->raygenBlocksPerSub * fp.batch, 512, 0, st>>>(fp, tiles, s, rq[0], counts, ps, c->dRaygenBase.as<uint32_t>(),
@@ -1983,37 +1948,28 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
         }
         for (uint32_t b = 0; b < fp.maxDepth; ++b)
         {
-            const uint32_t* permC = nullptr;
-            if (b >= c->sortFirstBounce && c->sortBitsClosest)
-            {
-                SpanGuard g(c, KC_SORT);
-                permC = sort_rays(c, rq[b & 1], counts + 2 * b * SKH_COUNT_STRIDE, c->sortBitsClosest);
-            }
             {
                 SpanGuard g(c, KC_TRACE_CLOSEST);
                 c->gridOverride = (useOverlap && smallPass) ? c->smallWavesClosest * (uint32_t)c->numCUs : 0u;
                 if (c->countTraversal)
-                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b * SKH_COUNT_STRIDE, fetch + 16 * b * SKH_FETCH_STRIDE, permC, hq, ps, nullptr, 0);
+                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, nullptr, hq, ps, nullptr, 0);
                 else
-                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b * SKH_COUNT_STRIDE, fetch + 16 * b * SKH_FETCH_STRIDE, permC, hq, ps, nullptr, 0);
+                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, nullptr, hq, ps, nullptr, 0);
             }
             if (useOverlap && b > 0)
                 (void)hipStreamWaitEvent(st, c->evShadow, 0); // shade[b] reads the radiance shadow[b-1] adds to and reuses its queue
             {
                 SpanGuard g(c, KC_SHADE);
-                const dim3 sg((NP + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK);
+                // a shard holds at most an eighth of the pass's paths (rounded up to whole waves): SKH_SHARDS x that many workgroups,
+                // workgroup b on shard b & 7; those past the end of their shard leave at once
+                const uint32_t perShard = (((NP + SKH_SHARDS - 1u) / SKH_SHARDS) + 63u) & ~63u;
+                const dim3 sg(SKH_SHARDS * ((perShard + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK));
                 if (c->hasHairMaterial)
-                    k_shade<true><<<sg, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b * SKH_COUNT_STRIDE, hq, ps, rq[(b + 1) & 1],
-                                                                  counts + 2 * (b + 1) * SKH_COUNT_STRIDE, shq, c->dContrib.as<float>(), counts + (2 * b + 1) * SKH_COUNT_STRIDE);
+                    k_shade<true><<<sg, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b * QW, hq, ps, rq[(b + 1) & 1],
+                                                                  counts + 2 * (b + 1) * QW, shq, c->dContrib.as<float>(), counts + (2 * b + 1) * QW);
                 else
-                    k_shade<false><<<sg, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b * SKH_COUNT_STRIDE, hq, ps, rq[(b + 1) & 1],
-                                                                   counts + 2 * (b + 1) * SKH_COUNT_STRIDE, shq, c->dContrib.as<float>(), counts + (2 * b + 1) * SKH_COUNT_STRIDE);
-            }
-            const uint32_t* permS = nullptr;
-            if (c->sortBitsShadow)
-            {
-                SpanGuard g(c, KC_SORT);
-                permS = sort_rays(c, shq, counts + (2 * b + 1) * SKH_COUNT_STRIDE, c->sortBitsShadow);
+                    k_shade<false><<<sg, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b * QW, hq, ps, rq[(b + 1) & 1],
+                                                                   counts + 2 * (b + 1) * QW, shq, c->dContrib.as<float>(), counts + (2 * b + 1) * QW);
             }
             {
                 hipStream_t sst = useOverlap ? c->stream2 : st;
@@ -2026,9 +1982,9 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                     SpanGuard g(c, KC_TRACE_SHADOW, sst);
                     c->gridOverride = (useOverlap && smallPass) ? c->smallWavesShadow * (uint32_t)c->numCUs : 0u;
                     if (c->countTraversal)
-                        launch_trace<true, true>(c, sc, shq, counts + (2 * b + 1) * SKH_COUNT_STRIDE, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, permS, nohq, ps, c->dContrib.as<float>(), N, sst);
+                        launch_trace<true, true>(c, sc, shq, counts + (2 * b + 1) * QW, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, nullptr, nohq, ps, c->dContrib.as<float>(), NQ, sst);
                     else
-                        launch_trace<true, false>(c, sc, shq, counts + (2 * b + 1) * SKH_COUNT_STRIDE, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, permS, nohq, ps, c->dContrib.as<float>(), N, sst);
+                        launch_trace<true, false>(c, sc, shq, counts + (2 * b + 1) * QW, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, nullptr, nohq, ps, c->dContrib.as<float>(), NQ, sst);
                 }
                 c->gridOverride = 0;
                 if (useOverlap)
@@ -2500,12 +2456,14 @@ skh_status skh_gather_tiles(skh_context* c, uint32_t max_tiles, void* d_recv, in
 }
 
 // ---- raw ray queries ----
-__global__ void k_rays_aos_to_soa(const skh_ray* __restrict__ rays, uint32_t n, RayQ rq)
+// raw queries: ray k of the caller sits in shard k / per at offset k % per (per = rays per shard, a multiple of 64)
+__global__ void k_rays_aos_to_soa(const skh_ray* __restrict__ rays, uint32_t n, uint32_t per, RayQ rq)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n)
         return;
-    const skh_ray r = rays[i];
+    const skh_ray r = rays[k];
+    const uint32_t g = k / per, i = g * rq.region + (k - g * per);
     rq.plane(0)[i] = r.origin[0];
     rq.plane(1)[i] = r.origin[1];
     rq.plane(2)[i] = r.origin[2];
@@ -2514,13 +2472,14 @@ __global__ void k_rays_aos_to_soa(const skh_ray* __restrict__ rays, uint32_t n, 
     rq.plane(5)[i] = r.dir[2];
     rq.plane(6)[i] = r.tmin;
     rq.plane(7)[i] = r.tmax;
-    rq.ids()[i] = i;
+    rq.ids()[i] = k;
 }
-__global__ void k_hits_soa_to_aos(HitQ hq, uint32_t n, uint32_t mode, skh_hit* __restrict__ hits)
+__global__ void k_hits_soa_to_aos(HitQ hq, uint32_t n, uint32_t per, uint32_t region, uint32_t mode, skh_hit* __restrict__ hits)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n)
         return;
+    const uint32_t g = k / per, i = g * region + (k - g * per);
     skh_hit h;
     if (mode == SKH_TRACE_SHADOW)
     {
@@ -2535,7 +2494,7 @@ __global__ void k_hits_soa_to_aos(HitQ hq, uint32_t n, uint32_t mode, skh_hit* _
         h.instance_id = __float_as_uint(r1.x);
         h.prim_id = __float_as_uint(r1.y);
     }
-    hits[i] = h;
+    hits[k] = h;
 }
 
 skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays, uint32_t mode, void* d_hits, uint32_t repeat)
@@ -2552,8 +2511,10 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
         dev_free(h);
         dev_free(cnt);
     };
-    if ((s = dev_alloc(c, q, sizeof(float) * 9 * (size_t)n_rays)) != SKH_OK || (s = dev_alloc(c, h, sizeof(float) * 8 * (size_t)n_rays)) != SKH_OK ||
-        (s = dev_alloc(c, cnt, sizeof(uint32_t) * (SKH_FETCH_STRIDE + 8 * SKH_FETCH_STRIDE))) != SKH_OK)
+    const uint32_t per = (((n_rays + SKH_SHARDS - 1u) / SKH_SHARDS) + 63u) & ~63u; // rays per shard = the shard's region
+    const size_t NQ = (size_t)SKH_SHARDS * per;
+    if ((s = dev_alloc(c, q, sizeof(float) * 9 * NQ)) != SKH_OK || (s = dev_alloc(c, h, sizeof(float) * 8 * NQ)) != SKH_OK ||
+        (s = dev_alloc(c, cnt, sizeof(uint32_t) * (SKH_SHARDS * SKH_COUNT_STRIDE + 8 * SKH_FETCH_STRIDE))) != SKH_OK)
     {
         cleanup();
         return s;
@@ -2565,14 +2526,18 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
         cleanup();
         return s;
     }
-    RayQ rq{ q.as<float>(), n_rays };
-    HitQ hq{ h.as<float>(), n_rays };
+    RayQ rq{ q.as<float>(), (uint32_t)NQ, per };
+    HitQ hq{ h.as<float>(), (uint32_t)NQ };
     PathS ps{ nullptr, 0 };
     uint32_t* dcount = cnt.as<uint32_t>();
-    uint32_t* dfetch = dcount + SKH_FETCH_STRIDE;
-    SKH_TRY(c, hipMemcpyAsync(dcount, &n_rays, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    uint32_t* dfetch = dcount + SKH_SHARDS * SKH_COUNT_STRIDE;
+    uint32_t hcount[SKH_SHARDS * SKH_COUNT_STRIDE] = { 0 };
+    for (uint32_t g = 0; g < SKH_SHARDS; ++g)
+        hcount[g * SKH_COUNT_STRIDE] = std::min(per, n_rays - std::min(n_rays, g * per));
+    SKH_TRY(c, hipMemcpyAsync(dcount, hcount, sizeof(hcount), hipMemcpyHostToDevice, c->stream));
+    SKH_TRY(c, hipStreamSynchronize(c->stream)); // (hcount lives on this stack frame)
     const DevScene sc = make_dev_scene(c);
-    k_rays_aos_to_soa<<<(n_rays + 255) / 256, 256, 0, c->stream>>>(reinterpret_cast<const skh_ray*>(d_rays), n_rays, rq);
+    k_rays_aos_to_soa<<<(n_rays + 255) / 256, 256, 0, c->stream>>>(reinterpret_cast<const skh_ray*>(d_rays), n_rays, per, rq);
     for (uint32_t r = 0; r < std::max(1u, repeat); ++r)
     {
         (void)hipMemsetAsync(dfetch, 0, sizeof(uint32_t) * 8 * SKH_FETCH_STRIDE, c->stream);
@@ -2592,7 +2557,7 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
                 launch_trace<false, false>(c, sc, rq, dcount, dfetch, nullptr, hq, ps, nullptr, 0);
         }
     }
-    k_hits_soa_to_aos<<<(n_rays + 255) / 256, 256, 0, c->stream>>>(hq, n_rays, mode, reinterpret_cast<skh_hit*>(d_hits));
+    k_hits_soa_to_aos<<<(n_rays + 255) / 256, 256, 0, c->stream>>>(hq, n_rays, per, per, mode, reinterpret_cast<skh_hit*>(d_hits));
     hipError_t e = hipStreamSynchronize(c->stream);
     cleanup();
     if (e != hipSuccess || (e = hipGetLastError()) != hipSuccess)
@@ -2774,12 +2739,6 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (n == "node_break_closest")
             c->curveNodeBreakClosest = (uint32_t)value;
     }
-    else if (n == "sort_bits_closest" || n == "sort_bits_shadow")
-    {
-        if (value < 0 || value > 10)
-            return SKH_INVALID_ARGUMENT;
-        (n == "sort_bits_closest" ? c->sortBitsClosest : c->sortBitsShadow) = (uint32_t)value;
-    }
     else if (n == "subframe_batch")
     {
         if (value < 0 || value > 64)
@@ -2836,8 +2795,6 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         c->buildQuality = value != 0;
         c->accelBuilt = false;
     }
-    else if (n == "sort_first_bounce")
-        c->sortFirstBounce = (uint32_t)std::max<int64_t>(0, value);
     else if (n == "waves_per_cu" || n == "waves_per_cu_shadow")
     {
         if (value < 1 || value > 32)

@@ -458,7 +458,7 @@ def test_tonemap_kernels_match_oracle(gpu, ork):
             assert np.allclose(got, want, rtol=2e-5, atol=1e-6), (typ, gamma)
 
 
-@pytest.mark.parametrize("opts", [{"build_quality": 0}, {"leaf_max_tris": 4}, {"sort_bits_closest": 6, "sort_bits_shadow": 6},
+@pytest.mark.parametrize("opts", [{"build_quality": 0}, {"leaf_max_tris": 4}, {"subframe_batch": 3},
                                   {"fetch_min_closest": 1, "fetch_min_shadow": 64, "waves_per_cu": 8},
                                   {"node_break_closest": 0, "node_break_shadow": 48, "leaf_min": 0}, {"leaf_min": 40}, {"tlas_open": 8}, {"tlas_build": 0}, {"tlas_build": 1}, {"wide": 8}, {"wide": 8, "leaf_max_tris": 4, "build_quality": 0}, {"curve_split": 1}, {"curve_split": 5, "curve_min": 1}, {"curve_min": 64}, {"tight_instance_boxes": 0}, {"overlap": 2}, {"overlap": 0}])
 def test_results_do_not_depend_on_the_acceleration_structure_or_scheduling(opts):
