@@ -367,10 +367,10 @@ skh_status skh_bsdf_probe(skh_context* ctx, const skh_bsdf_query* queries, uint3
  *                 within bake_budget_mtris (64) million, else 2; 0 = every instance keeps its TLAS leaf), world_kernel 1|0 (scenes
  *                 with an empty top level run the world-only build of the traversal kernel)
  *   build         build_quality 1|0 (PLOC | Karras radix tree), leaf_max_tris (2), curve_split (2: parameter sub-ranges
- *                 per curve segment), tlas_build 2|1|0 (auto | GPU PLOC over the instance boxes | exact sweep SAH on the host; auto =
- *                 the sweep up to 8192 instances, the GPU beyond), tlas_open (1: TLAS leaves per instance budget),
+ *                 per curve segment), tlas_build 1|0|2 (GPU PLOC over the instance boxes (default) | exact sweep SAH on the host: 5 % fewer instance
+ *                 entries, single-threaded | the sweep up to 8192 instances, the GPU beyond), tlas_open (1: TLAS leaves per instance budget),
  *                 tight_instance_boxes 1|0, wide 4|8 (node width: 64-byte 4-wide nodes | 96-byte
- *                 8-wide nodes with octant-ordered slots; two-level hierarchy only, measured slower: DESIGN.md section 9)
+ *                 8-wide nodes with octant-ordered slots; two-level hierarchy only, measured slower: docs/LOG.md)
  * Unknown names and out-of-range values return SKH_INVALID_ARGUMENT. */
 skh_status skh_set_option(skh_context* ctx, const char* name, int64_t value);
 /* what the context's device reports (hipDeviceProp_t): the measurement code prices instruction rates against these */

@@ -143,12 +143,13 @@ struct skh_context
     uint32_t queueRegion = 64; // positions per queue shard (RayQ::region): the queues hold SKH_SHARDS * queueRegion rays
     bool tightInstanceBoxes = true; // TLAS leaf boxes from the transformed vertices, not from the transformed object box
     uint32_t curveSplit = 2; // parameter sub-ranges per curve segment in the curve BLAS (1 = off; hair stand-in, ms per 1080p sub-frame: 1: 61.6, 2: 52.1, 4: 49.7, 8: 50.1 -- build time and leaf memory grow with it)
-    // TLAS builder.  1: on the GPU -- PLOC over the instance boxes with a 96-neighbour search, the BLAS builder, no host round trip:
-    // 4 / 5 / 9 ms for 2 k / 20 k / 100 k instances.  0: exact three-axis sweep SAH on the host, O(n log^2 n) single-threaded: 4 / 45 ms
-    // for 2 k / 20 k.  On the kitchen stand-in (2022 instances) the sweep's tree has fewer instance entries per ray (2.29 vs 2.35;
-    // nodes 20.69 vs 20.60) and the closest-hit kernel runs 2.9 % faster on it, so 2 = auto (default): the sweep up to 8192 TLAS leaves
-    // (<= ~15 ms of host time), the GPU builder beyond
-    uint32_t tlasBuild = 2;
+    // TLAS builder.  1 (default): on the GPU -- PLOC over the instance boxes with a 96-neighbour search, the BLAS builder, no host round
+    // trip: 4 / 5 / 9 ms for 2 k / 20 k / 100 k instances.  0: exact three-axis sweep SAH on the host, O(n log^2 n) single-threaded
+    // (4 / 45 ms for 2 k / 20 k), whose tree enters 5 % fewer instances (1.28 vs 1.35 per ray on the kitchen stand-in with only its
+    // room baked: closest-hit 97.6 vs 100.3 ms; PLOC radius 24 .. 512 makes no difference, docs/LOG.md).  With bake_world 4 a top level
+    // only exists for curve sets, for light proxies beside them, and for scenes with more than bake_budget_mtris instanced triangles:
+    // every structure the bench workloads traverse is built by GPU kernels.  2: the sweep up to 8192 TLAS leaves, the GPU beyond.
+    uint32_t tlasBuild = 1;
     uint32_t wide = 4; // node width: 4 = Node4 (64 B, children sorted by entry distance in the traversal), 8 = Node8 (96 B, slot order = traversal order;
                        // two-level hierarchy only, TLAS by the GPU builder, no TLAS opening)
     uint32_t tlasOpen = 1; // TLAS opening: up to tlasOpen x numInstances leaves; 1 = one leaf per instance (default: on the kitchen stand-in 2..16 were 4-9 % slower, more instance entries for no fewer nodes)
