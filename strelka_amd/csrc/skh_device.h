@@ -875,6 +875,8 @@ SKH_DI bool intersect_curve_segment(const v3& o, const v3& d, float tmin, float 
                 }
                 break;
             }
+            if (phantom && fabsf(dt) < 5e-5f)
+                break; // converged onto a point the ray does not touch (the closest approach of a miss): same rule as the oracle
             dt = fminf(dt, 0.5f);
             dt = fmaxf(dt, -0.5f);
             dt1 = dt2;

@@ -573,6 +573,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                                 }
                                 break;
                             }
+                            if (phantom && fabsf(dt) < 5e-5f)
+                                break; // converged onto a point the ray does not touch: a miss (intersect_curve_segment's rule)
                             dt = fminf(dt, 0.5f);
                             dt = fmaxf(dt, -0.5f);
                             dt1 = dt2;
@@ -592,6 +594,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                                 told = tpar;
                                 tpar += dt;
                             }
+#ifdef SKH_ITER_STATS
+                            if (COUNT)
+                                tc.insts++; // (one-off measurement: Newton steps, reported as "instances")
+#endif
                             if (!(tpar >= 0.0f && tpar <= 1.0f))
                                 break;
                         }
