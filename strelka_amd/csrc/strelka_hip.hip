@@ -142,7 +142,8 @@ struct skh_context
     uint32_t subframeBatch = 0, batchCapacity = 1; // option subframe_batch: 0 = auto
     uint32_t queueRegion = 64; // positions per queue shard (RayQ::region): the queues hold SKH_SHARDS * queueRegion rays
     bool tightInstanceBoxes = true; // TLAS leaf boxes from the transformed vertices, not from the transformed object box
-    uint32_t curveSplit = 2; // parameter sub-ranges per curve segment in the curve BLAS (1 = off; hair stand-in, ms per 1080p sub-frame: 1: 61.6, 2: 52.1, 4: 49.7, 8: 50.1 -- build time and leaf memory grow with it)
+    uint32_t curveLeaf = 1; // sub-segments per curve leaf (hair stand-in after the intersector's early exit, Mray/s: 1: 1456, 2: 1392, 3: 1309, 4: 1240; (option curve_leaf; the cooperative block takes two candidates per lane and block)
+    uint32_t curveSplit = 4; // parameter sub-ranges per curve segment in the curve BLAS (round 3, with one-sub-segment leaves: 2: 1460, 3: 1480, 4: 1503 Mray/s; round 2: 1 = off; hair stand-in, ms per 1080p sub-frame: 1: 61.6, 2: 52.1, 4: 49.7, 8: 50.1 -- build time and leaf memory grow with it)
     // TLAS builder.  1 (default): on the GPU -- PLOC over the instance boxes with a 96-neighbour search, the BLAS builder, no host round
     // trip: 4 / 5 / 9 ms for 2 k / 20 k / 100 k instances.  0: exact three-axis sweep SAH on the host, O(n log^2 n) single-threaded
     // (4 / 45 ms for 2 k / 20 k), whose tree enters 5 % fewer instances (1.28 vs 1.35 per ray on the kitchen stand-in with only its
@@ -1303,7 +1304,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         k_seg_boxes<<<(nSub + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), c->dSegStartAll.as<uint32_t>(),
                                                       dSegCurve.as<uint32_t>(), nSub, K, dBoxLo.as<float4>(), dBoxHi.as<float4>(),
                                                       dGrp.as<uint32_t>());
-    BA(lbvh_build(c, nSub, nCurves, curveSubCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), 2, usePloc, segOut));
+    BA(lbvh_build(c, nSub, nCurves, curveSubCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), (int)c->curveLeaf, usePloc, segOut));
     BA(dev_alloc(c, c->dSegs, sizeof(float4) * 4 * (size_t)std::max(1u, nSub)));
     BA(dev_alloc(c, c->dSegPrim, sizeof(uint32_t) * (size_t)std::max(1u, nSub)));
     BA(dev_alloc(c, c->dSegBound, sizeof(float4) * 2 * (size_t)std::max(1u, nSub)));
@@ -2703,6 +2704,13 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
     else if (n == "tight_instance_boxes")
     {
         c->tightInstanceBoxes = value != 0;
+        c->accelBuilt = false;
+    }
+    else if (n == "curve_leaf")
+    {
+        if (value < 1 || value > 4)
+            return SKH_INVALID_ARGUMENT;
+        c->curveLeaf = (uint32_t)value;
         c->accelBuilt = false;
     }
     else if (n == "curve_split")
