@@ -544,6 +544,65 @@ def test_bake_world_modes_match_oracle(mode, small):
         assert counts[0] >= 60
 
 
+def test_bake_world_edge_cases():
+    """Scenes that stress the bake selection: only light proxies (the top level empties, the light group is the whole scene), a unique
+    mesh behind a singular transform (disabled: never baked, never hit), an instance of a mesh without triangles, a unique mesh used by a
+    mesh instance AND a light proxy, no instances at all -- hit records must equal the oracle's in every bake mode."""
+    from strelka_amd import capi
+    from tests import orklib
+
+    def quad_scene(variant):
+        sc = S.Scene()
+        sc.addMaterial()
+        vb, ib = S.deindex([(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)], [(0, 1, 2), (0, 2, 3)])
+        if variant == "lights_only":
+            sc.createLight({"type": 0, "xform": S.translate((0, 0, -2)), "useXform": True, "width": 1, "height": 1, "color": (1, 1, 1), "intensity": 1})
+            sc.createLight({"type": 2, "xform": S.translate((0.5, 0.2, -3)), "useXform": True, "radius": 0.4, "color": (1, 1, 1), "intensity": 1})
+        elif variant == "singular":
+            m = sc.createMesh(vb, ib)
+            sc.createInstance(S.INSTANCE_MESH, m, 0, S.translate((0, 0, -5)) @ S.scale((2, 0, 1)))  # not invertible
+            m2 = sc.createMesh(vb, ib)
+            sc.createInstance(S.INSTANCE_MESH, m2, 0, S.translate((0, 0, -6)))
+        elif variant == "empty_mesh":
+            m = sc.createMesh(vb[:0], ib[:0])
+            sc.createInstance(S.INSTANCE_MESH, m, 0, S.translate((0, 0, -4)))
+            m2 = sc.createMesh(vb, ib)
+            sc.createInstance(S.INSTANCE_MESH, m2, 0, S.translate((0, 0, -6)))
+            sc.createInstance(S.INSTANCE_MESH, m2, 0, S.translate((0.5, 0, -7)))
+        elif variant == "none":
+            sc.createMesh(vb, ib)
+        return sc
+
+    rs = np.random.RandomState(3)
+    rays = np.zeros(4000, S.RAY)
+    rays["origin"] = rs.uniform(-1.5, 1.5, (4000, 3)) * (1, 1, 0.2)
+    d = rs.normal(size=(4000, 3)) * (0.4, 0.4, 0.1) + (0, 0, -1)
+    rays["dir"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays["tmax"] = 1e16
+    for variant in ("lights_only", "singular", "empty_mesh", "none"):
+        arr = quad_scene(variant).arrays()
+        for mode in (0, 1, 2, 3, 4):
+            o = orklib.new_context()
+            o.set_bake(mode)
+            o.set_scene(arr)
+            ctx = capi.Context(0)
+            ctx.set_option("bake_world", mode)
+            ctx.set_scene(arr)
+            n = len(arr["instances"])
+            assert np.array_equal(ctx.baked(n)[0], o.baked(n)), (variant, mode)
+            want = o.trace(rays, 0)
+            assert_hits_equal(ctx.trace(rays, 0), want)
+            assert_hits_equal(o.trace(rays, 0, brute=True), want)
+            sh = rays.copy()
+            sh["tmax"] = 6.5
+            assert np.array_equal(ctx.trace(sh, 1)["t"], o.trace(sh, 1)["t"]), (variant, mode)
+            ctx.close()
+            if variant == "none":
+                assert (want["instance_id"] == 0xFFFFFFFF).all()
+            elif variant != "none" and mode == 0:
+                assert (want["instance_id"] != 0xFFFFFFFF).any()
+
+
 def _zoomed_out_rays(arr, ratio, n, seed):
     """rays aimed at vertices / edge midpoints of random mesh instances from `ratio` THINNEST instance extents away (the smallest
     singular value of the instance's 3x3 -- the meshes are unit-sized): the distance that matters to the triangle test's noise is
