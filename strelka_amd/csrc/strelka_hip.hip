@@ -134,7 +134,7 @@ struct skh_context
     uint32_t wavesPerCUShadow = 28; // the any-hit build of the triangle kernel fits 7 per SIMD
     uint32_t smallWavesClosest = 16, smallWavesShadow = 16; // overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24
     uint32_t gridOverride = 0; // set by render_one around its launches
-    uint32_t fetchMinClosest = 24, fetchMinShadow = 32; // idle lanes before a wave pulls new rays from the queue (re-tuned at 7 waves/SIMD: was 16 / 24)
+    uint32_t fetchMinClosest = 24, fetchMinShadow = 48; // idle lanes before a wave pulls new rays from the queue (round 3, world-space hierarchy: any-hit 32 -> 48: 39.7 -> 36.2 ms, 56: 37.5, 64: 51; closest 12..40 within 1 %)
     uint32_t curveFetchMinClosest = 16, curveFetchMinShadow = 24, curveNodeBreakClosest = 20; // the same three for the curve build (6 waves/SIMD): hair 482 vs 465 Mray/s
     uint32_t nodeBreakClosest = 24, nodeBreakShadow = 20; // leave the node loop when fewer than x/64 of the wave's rays are still descending
     uint32_t curveMin = 48; // (cooperative curve block) end-point runs queued by the parked lanes before the block runs: one run per lane, so 56 fills the wave; round 2, lanes parked before their owners ran them: (hair stand-in, Mray/s: 1: 113, 16: 225, 32: 310, 48: 334, 64: 321)
