@@ -83,3 +83,41 @@ for label, order in orders.items():
         ms = (st["ms_trace_shadow"] if mode else st["ms_trace_closest"]) / 4
         print("OCTANT %-18s %-32s %-8s %8d rays  %.3f ms  %.0f Mray/s" % (name, label, kind, m, ms, m / ms / 1e3), flush=True)
 ctx.close()
+
+# ---- shadow rays as the renderer makes them: from the primary hit points to a random point on one of the scene's rect lights (or along the
+#      distant light), in queue order vs re-ordered by light INSIDE every 256-ray block (what a block-local binned compaction in k_shade would write)
+ctx = capi.Context(0)
+ctx.set_scene(arr)
+L = arr["lights"]
+nl = len(L)
+lid = rs.randint(0, nl, m)
+sh = np.zeros(m, S.RAY)
+sh["origin"] = sec["origin"]
+tgt = np.zeros((m, 3))
+far = np.zeros(m, bool)
+for k in range(nl):
+    sel = lid == k
+    pts = L["points"][k][:, :3].astype(np.float64)  # 4 corners (rect) -- good enough for every type here
+    if int(L["type"][k]) == 0:
+        u, v = rs.rand(sel.sum(), 1), rs.rand(sel.sum(), 1)
+        tgt[sel] = pts[0] + (pts[1] - pts[0]) * u + (pts[3] - pts[0]) * v
+    else:
+        tgt[sel] = sh["origin"][sel] + np.array([0.35, 0.8, 0.45]) * 1e3
+        far[sel] = True
+dv = tgt - sh["origin"]
+ln = np.linalg.norm(dv, axis=1, keepdims=True)
+sh["dir"] = dv / ln
+sh["tmax"] = np.where(far, 1e9, ln[:, 0] * 0.999)
+blk = np.arange(m) // 256
+orders = {"queue order": np.arange(m), "by light inside 256-ray blocks": np.lexsort((np.arange(m), lid, blk)), "by light inside 1024-ray blocks": np.lexsort((np.arange(m), lid, np.arange(m) // 1024))}
+for label, order in orders.items():
+    rays = np.ascontiguousarray(sh[order])
+    d_r = torch.from_numpy(rays.view(np.uint8).copy()).cuda()
+    d_h = torch.zeros(m * 20, dtype=torch.uint8, device="cuda")
+    ctx.trace_device(d_r.data_ptr(), m, 1, d_h.data_ptr(), 1)
+    ctx.set_option("timing", 1); ctx.reset_stats()
+    ctx.trace_device(d_r.data_ptr(), m, 1, d_h.data_ptr(), 4)
+    ms = ctx.stats()["ms_trace_shadow"] / 4; ctx.set_option("timing", 0)
+    occ = (torch.frombuffer(bytearray(d_h.cpu().numpy().tobytes()), dtype=torch.float32).reshape(-1, 5)[:, 0] > 0).float().mean().item()
+    print("OCTANT %-18s %-32s %-8s %8d rays  %.3f ms  %.0f Mray/s  occluded %.2f" % (name, label, "NEE", m, ms, m / ms / 1e3, occ), flush=True)
+ctx.close()
