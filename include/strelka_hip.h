@@ -216,7 +216,7 @@ typedef struct skh_stats
     double ms_raygen;
     double ms_accumulate;
     double ms_build; /* last skh_build_accel */
-    double ms_sort; /* ray re-ordering (key build + radix sort) */
+    double ms_sort; /* always 0 (ray re-ordering, a measured negative of round 1, was removed in round 3) */
     uint32_t launches_trace_closest;
     uint32_t launches_trace_shadow;
     uint32_t launches_shade;

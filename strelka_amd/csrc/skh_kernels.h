@@ -265,7 +265,7 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 template <bool ANY_HIT, bool COUNT, bool CURVES, bool W8 = false, bool WORLD = false>
 __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES : (CURVES ? SKH_CURVE_MIN_WAVES : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES))) SKH_TRACE_ATTR
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
-            uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, const uint32_t* __restrict__ /*unused*/,
+            uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, 
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
             StatsDev* __restrict__ stats)
 {

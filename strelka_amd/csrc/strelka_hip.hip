@@ -1834,9 +1834,9 @@ static skh_status ensure_ready(skh_context* c)
     return SKH_OK;
 }
 
-// sorts (key, index) pairs of the rays in rq (length on the device) and returns the permutation, or nullptr when off
+// one launch of the persistent trace kernel over a sharded queue: picks the build (world-only / general / curves / 8-wide) and the grid
 template <bool ANY, bool COUNT>
-static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint32_t* countPtr, uint32_t* fetch, const uint32_t* perm,
+static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint32_t* countPtr, uint32_t* fetch,
                          HitQ hq, PathS ps, const float* contrib, uint32_t contribStride, hipStream_t st = nullptr)
 {
     // scenes without curve instances run the build of the kernel that has no curve intersector in it (fewer VGPRs)
@@ -1852,19 +1852,19 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
     const uint32_t blocks = c->gridOverride ? std::min(c->gridOverride, fullGrid) : fullGrid;
     if (c->wide != 8 && !c->nSegs && c->tlasRoot == SKH_REF_INVALID && (c->worldRoot != SKH_REF_INVALID || c->lightRoot != SKH_REF_INVALID) && c->worldKernel)
         // every instance is baked: the world-only build of the kernel (no instance entry, no object-space copy of the ray)
-        k_trace<ANY, COUNT, false, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride, ovf, sd);
+        k_trace<ANY, COUNT, false, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
     else if (c->wide == 8)
     {
         if (c->nSegs)
-            k_trace<ANY, COUNT, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride, ovf, sd);
+            k_trace<ANY, COUNT, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
         else
-            k_trace<ANY, COUNT, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride, ovf, sd);
+            k_trace<ANY, COUNT, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
     }
     else if (c->nSegs)
-        k_trace<ANY, COUNT, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride,
+        k_trace<ANY, COUNT, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride,
                                                                                       ovf, sd);
     else
-        k_trace<ANY, COUNT, false><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, perm, hq, ps, contrib, contribStride,
+        k_trace<ANY, COUNT, false><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride,
                                                                                        ovf, sd);
 }
 
@@ -1954,9 +1954,9 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                 SpanGuard g(c, KC_TRACE_CLOSEST);
                 c->gridOverride = (useOverlap && smallPass) ? c->smallWavesClosest * (uint32_t)c->numCUs : 0u;
                 if (c->countTraversal)
-                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, nullptr, hq, ps, nullptr, 0);
+                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, hq, ps, nullptr, 0);
                 else
-                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, nullptr, hq, ps, nullptr, 0);
+                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, hq, ps, nullptr, 0);
             }
             if (useOverlap && b > 0)
                 (void)hipStreamWaitEvent(st, c->evShadow, 0); // shade[b] reads the radiance shadow[b-1] adds to and reuses its queue
@@ -1984,9 +1984,9 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                     SpanGuard g(c, KC_TRACE_SHADOW, sst);
                     c->gridOverride = (useOverlap && smallPass) ? c->smallWavesShadow * (uint32_t)c->numCUs : 0u;
                     if (c->countTraversal)
-                        launch_trace<true, true>(c, sc, shq, counts + (2 * b + 1) * QW, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, nullptr, nohq, ps, c->dContrib.as<float>(), NQ, sst);
+                        launch_trace<true, true>(c, sc, shq, counts + (2 * b + 1) * QW, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, nohq, ps, c->dContrib.as<float>(), NQ, sst);
                     else
-                        launch_trace<true, false>(c, sc, shq, counts + (2 * b + 1) * QW, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, nullptr, nohq, ps, c->dContrib.as<float>(), NQ, sst);
+                        launch_trace<true, false>(c, sc, shq, counts + (2 * b + 1) * QW, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, nohq, ps, c->dContrib.as<float>(), NQ, sst);
                 }
                 c->gridOverride = 0;
                 if (useOverlap)
@@ -2547,16 +2547,16 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
         if (mode == SKH_TRACE_SHADOW)
         {
             if (c->countTraversal)
-                launch_trace<true, true>(c, sc, rq, dcount, dfetch, nullptr, hq, ps, nullptr, 0);
+                launch_trace<true, true>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
             else
-                launch_trace<true, false>(c, sc, rq, dcount, dfetch, nullptr, hq, ps, nullptr, 0);
+                launch_trace<true, false>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
         }
         else
         {
             if (c->countTraversal)
-                launch_trace<false, true>(c, sc, rq, dcount, dfetch, nullptr, hq, ps, nullptr, 0);
+                launch_trace<false, true>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
             else
-                launch_trace<false, false>(c, sc, rq, dcount, dfetch, nullptr, hq, ps, nullptr, 0);
+                launch_trace<false, false>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
         }
     }
     k_hits_soa_to_aos<<<(n_rays + 255) / 256, 256, 0, c->stream>>>(hq, n_rays, per, per, mode, reinterpret_cast<skh_hit*>(d_hits));
