@@ -311,6 +311,35 @@ def gather_fallback_allowed(backend, environ):
     return backend != "nccl" or bool(environ.get("SKH_ALLOW_GATHER_FALLBACK"))
 
 
+def other_workload_leg(name, W, H, spp, depth, device_ordinal, steps=2):
+    """A second workload timed beside the headline (same resolution, spp, depth; its own context): `kitchen_unshared` is the shape
+    HdStrelka's bake really hands over -- one mesh per instance (RenderPass.cpp:126-129,252-257)."""
+    from strelka_amd import capi, scene as S
+
+    t0 = time.time()
+    sc, arr, workload = load_workload(name)
+    load_s = time.time() - t0
+    ctx = capi.Context(device_ordinal)
+    ctx.set_scene(arr)
+    ctx.resize(W, H)
+    params = S.frame_params(sc.getCamera(), W, H, subframe_index=0, samples_this_launch=1, spp_total=spp, max_depth=depth)
+    ctx.render_subframes(params, spp, None)  # warm-up
+    ctx.set_option("timing", 1)
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.render_subframes(params, spp, None)
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    baked = ctx.baked(len(arr["instances"]))
+    ctx.close()
+    rays = st["rays_radiance"] + st["rays_shadow"]
+    return {"workload": workload, "value": round(rays / dt / 1e6, 1), "unit": "Mray/s", "ms_per_step": round(dt / steps * 1e3, 3),
+            "kernel_ms_per_frame": {k: round(st[k] / steps, 3) for k in ("ms_trace_closest", "ms_trace_shadow", "ms_shade")},
+            "bvh_build_ms": round(st["ms_build"], 2), "bake_world": {"baked_instances": baked[1], "baked_triangles": baked[2]},
+            "scene_load_s": round(load_s, 1)}
+
+
 def shade_bytes(rays, next_rays, shadow_rays):
     """k_shade, algorithmic: ray 36 r + hit record 32 r + path state 32 r + 32 w per ray; per surface hit (every ray counted as
     one: upper bound) instance 64 + 64, shading triangle 96, material 64; 36 w per continuation ray, 36 + 12 w per shadow ray."""
@@ -337,6 +366,7 @@ def main():
     ap.add_argument("--pmc-keep", default=None, help="keep the rocprofv3 output of the child passes in this directory")
     ap.add_argument("--pmc-save", default=None, metavar="TAG", help="write the live counter figures to profiles/pmc_kernels.json under this tag")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the one-render()+map()-per-sub-frame leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the second workload (kitchen_unshared) timed beside the headline")
     args = ap.parse_args()
 
     rc = maybe_self_launch(args, sys.argv[1:])
@@ -510,6 +540,9 @@ def main():
     drop_in = None
     if rank == 0 and world == 1 and not args.no_drop_in and not args.pmc_child:
         drop_in = drop_in_leg(ctx, params, W, H, args.spp, torch, dev)
+    extra = None
+    if rank == 0 and world == 1 and args.scene == "kitchen" and not args.no_extra and not args.no_drop_in and not args.pmc_child:
+        extra = other_workload_leg("kitchen_unshared", W, H, args.spp, args.depth, local_rank)
     if rank == 0:
         K = max(1, args.steps)
         # ---- rooflines of the three hot kernels.  Per kernel, from this run's counters and hipEvent times:
@@ -604,6 +637,8 @@ def main():
             out["gather_error"] = gather_error
         if drop_in is not None:
             out["drop_in"] = drop_in
+        if extra is not None:
+            out["also"] = {"kitchen_unshared": extra}
         if args.pmc_save and PMC_RESULT:
             json.dump({**PMC_RESULT, "tag": args.pmc_save, "workload": workload, "resolution": f"{W}x{H}"},
                       open(os.path.join(ROOT, "profiles", "pmc_kernels.json"), "w"), indent=1)
