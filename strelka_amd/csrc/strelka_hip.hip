@@ -137,13 +137,16 @@ struct skh_context
     uint32_t fetchMinClosest = 24, fetchMinShadow = 48; // idle lanes before a wave pulls new rays from the queue (round 3, world-space hierarchy: any-hit 32 -> 48: 39.7 -> 36.2 ms, 56: 37.5, 64: 51; closest 12..40 within 1 %)
     uint32_t curveFetchMinClosest = 16, curveFetchMinShadow = 24, curveNodeBreakClosest = 20; // the same three for the curve build (6 waves/SIMD): hair 482 vs 465 Mray/s
     uint32_t nodeBreakClosest = 24, nodeBreakShadow = 20; // leave the node loop when fewer than x/64 of the wave's rays are still descending
-    uint32_t curveMin = 48; // (cooperative curve block) end-point runs queued by the parked lanes before the block runs: one run per lane, so 56 fills the wave; round 2, lanes parked before their owners ran them: (hair stand-in, Mray/s: 1: 113, 16: 225, 32: 310, 48: 334, 64: 321)
+    uint32_t curveMin = 48; // (cooperative curve block) end-point runs queued by the parked lanes before the block runs, one run per lane (round 3, Mray/s on the hair
+                            // stand-in: 16: 712, 32: 907, 40: 958, 48: 984, 56: 971, 64: 887; round 2 counted parked LANES whose owners ran their own runs: 48: 334)
     uint32_t leafMin = 16; // postpone the minority kind of leaf work unless it has this many lanes (0 = never postpone; measured +1.5 % at 16)
     uint32_t subframeBatch = 0, batchCapacity = 1; // option subframe_batch: 0 = auto
     uint32_t queueRegion = 64; // positions per queue shard (RayQ::region): the queues hold SKH_SHARDS * queueRegion rays
     bool tightInstanceBoxes = true; // TLAS leaf boxes from the transformed vertices, not from the transformed object box
-    uint32_t curveLeaf = 1; // sub-segments per curve leaf (hair stand-in after the intersector's early exit, Mray/s: 1: 1456, 2: 1392, 3: 1309, 4: 1240; (option curve_leaf; the cooperative block takes two candidates per lane and block)
-    uint32_t curveSplit = 4; // parameter sub-ranges per curve segment in the curve BLAS (round 3, with one-sub-segment leaves: 2: 1460, 3: 1480, 4: 1503 Mray/s; round 2: 1 = off; hair stand-in, ms per 1080p sub-frame: 1: 61.6, 2: 52.1, 4: 49.7, 8: 50.1 -- build time and leaf memory grow with it)
+    uint32_t curveLeaf = 1; // sub-segments per curve leaf (option curve_leaf; hair stand-in after the intersector's early exit, Mray/s: 1: 1456, 2: 1392, 3: 1309, 4: 1240;
+                            // the cooperative block takes two candidates per lane and block)
+    uint32_t curveSplit = 4; // parameter sub-ranges per curve segment in the curve BLAS (round 3, one-sub-segment leaves: 2: 1460, 3: 1480, 4: 1503 Mray/s; build time and leaf
+                             // memory grow with it.  Round 2, ms per 1080p sub-frame: 1: 61.6, 2: 52.1, 4: 49.7, 8: 50.1)
     // TLAS builder.  1 (default): on the GPU -- PLOC over the instance boxes with a 96-neighbour search, the BLAS builder, no host round
     // trip: 4 / 5 / 9 ms for 2 k / 20 k / 100 k instances.  0: exact three-axis sweep SAH on the host, O(n log^2 n) single-threaded
     // (4 / 45 ms for 2 k / 20 k), whose tree enters 5 % fewer instances (1.28 vs 1.35 per ray on the kitchen stand-in with only its
