@@ -136,7 +136,8 @@ struct skh_context
     uint32_t gridOverride = 0; // set by render_one around its launches
     uint32_t fetchMinClosest = 24, fetchMinShadow = 48; // idle lanes before a wave pulls new rays from the queue (round 3, world-space hierarchy: any-hit 32 -> 48: 39.7 -> 36.2 ms, 56: 37.5, 64: 51; closest 12..40 within 1 %)
     uint32_t curveFetchMinClosest = 16, curveFetchMinShadow = 24, curveNodeBreakClosest = 20; // the same three for the curve build (6 waves/SIMD): hair 482 vs 465 Mray/s
-    uint32_t nodeBreakClosest = 24, nodeBreakShadow = 20; // leave the node loop when fewer than x/64 of the wave's rays are still descending
+    uint32_t nodeBreakClosest = 32, nodeBreakShadow = 20; // (closest: 24 -> 32 in round 3 for the world-only kernel: kitchen 86.6 -> 85.9 ms, unshared 74.7 -> 73.6, three runs each)
+    // leave the node loop when fewer than x/64 of the wave's rays are still descending
     uint32_t curveMin = 48; // (cooperative curve block) end-point runs queued by the parked lanes before the block runs, one run per lane (round 3, Mray/s on the hair
                             // stand-in: 16: 712, 32: 907, 40: 958, 48: 984, 56: 971, 64: 887; round 2 counted parked LANES whose owners ran their own runs: 48: 334)
     uint32_t leafMin = 16; // postpone the minority kind of leaf work unless it has this many lanes (0 = never postpone; measured +1.5 % at 16)
