@@ -598,6 +598,30 @@ def main():
             blk["cached_bw"] = {"GB/s": round(bpl / (avg_ms * 1e-3) / 1e9, 2) if avg_ms > 0 else 0.0, "algorithmic_bytes_per_launch": int(bpl),
                                 "algorithmic_bytes_per_unit": round(alg[name] / max(1, units[name]), 1)}
             kern[name] = blk
+        # ---- measured memory ceilings of this box (skh_probe_memory; SURVEY 8(d) "report a measured STREAM-copy ceiling"): a uint4
+        #      copy, and random aligned 64- / 128-byte record fetches from one-wave workgroups on the trace kernels' grid over a buffer
+        #      the size of the kitchen hierarchy.  The fabric serves random fetches by the 128-byte LINE (32-, 64- and 128-byte records
+        #      all arrive at the same records/s; TCC_EA0_RDREQ = one per record: profiles/r03d_probe_calibration.txt), so a kernel's
+        #      L2-miss rate is compared in lines/s: FETCH_SIZE KiB x 1024 / 64 = requests = lines.
+        ceilings = None
+        try:
+            psize = 1792 << 20
+            copy = ctx.probe_memory(0, psize)[0]
+            g64, g128, c64 = ctx.probe_memory(1, psize, 64)[0], ctx.probe_memory(1, psize, 128)[0], ctx.probe_memory(2, psize, 64)[0]
+            line_rate = max(g64, c64) / 64.0  # G lines / s
+            ceilings = {"buffer_MiB": psize >> 20, "stream_copy_GBps": round(copy, 1), "gather64_GBps": round(g64, 1), "gather128_GBps": round(g128, 1),
+                        "chase64_GBps": round(c64, 1), "random_line_rate_G_per_s": round(line_rate, 2),
+                        "note": "random record fetches cost one 128-byte line each whatever their size; copy counts read + write"}
+            for name, blk in kern.items():
+                pk = (pmc or {}).get("kernels", {}).get(name)
+                if pk and pk.get("FETCH_SIZE_KiB") and blk["avg_launch_ms"] > 0:
+                    scale = blk["units_per_launch"] / pk["rays_per_launch"] if pk.get("rays_per_launch") else 1.0
+                    lines = pk["FETCH_SIZE_KiB"] * 1024.0 / 64.0 * scale
+                    rate = lines / (blk["avg_launch_ms"] * 1e-3) / 1e9
+                    blk["l2_miss_lines"] = {"per_unit": round(lines / max(1, blk["units_per_launch"]), 2), "G_per_s": round(rate, 2),
+                                            "frac_of_measured_random_line_rate": round(rate / line_rate, 4)}
+        except Exception as e:  # a ceiling is context, not the measurement: say so and go on
+            sys.stderr.write("[bench] memory ceilings not measured: %s\n" % e)
         nrs = max(1, cst["rays_shadow"])
         c0 = kern["closest"]
         roofline = {"kernel": "k_trace<closest>", "bound": "hbm", "achieved": c0["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": c0["frac"],
@@ -612,7 +636,7 @@ def main():
                                 "instances": round(cst["instances_entered"][0] / max(1, cst["rays_radiance"]), 2)},
                     "per_shadow_ray": {"nodes": round(cst["nodes_visited"][1] / nrs, 2), "tris": round(cst["prims_tested"][1] / nrs, 2),
                                        "instances": round(cst["instances_entered"][1] / nrs, 2)},
-                    "kernels": kern}
+                    "kernels": kern, "ceilings": ceilings}
         if flags:
             roofline["flags"] = flags
             sys.stderr.write("[bench] roofline flags: %s\n" % "; ".join(flags))

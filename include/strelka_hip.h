@@ -326,6 +326,18 @@ skh_status skh_trace(skh_context* ctx, const skh_ray* rays, uint32_t n_rays, uin
 skh_status skh_trace_device(skh_context* ctx, const void* d_rays, uint32_t n_rays, uint32_t mode, void* d_hits,
                             uint32_t repeat);
 
+/* ---- memory ceilings of this GPU, measured with the access shapes of the hot path ("report a measured STREAM-copy
+ *      ceiling"; the reference has no counterpart).  bench.py puts them beside the roofline fractions.  `bytes` = size of the
+ *      probed buffer (allocated and freed inside; COPY takes two).  COPY: uint4 grid-stride copy, rate counts read + write.
+ *      GATHER / CHASE: one-wave workgroups on the trace kernels' grid, every lane fetches 256 pseudo-random aligned records of
+ *      record_bytes (32, 64 = one BVH node, or 128 = one cache line) -- four independent fetches in flight, or each address taken
+ *      from the record before it (a traversal step); rate = record_bytes x fetches / time, whatever cache level served them. ---- */
+#define SKH_PROBE_COPY 0u
+#define SKH_PROBE_GATHER 1u
+#define SKH_PROBE_CHASE 2u
+skh_status skh_probe_memory(skh_context* ctx, uint32_t kind, uint64_t bytes, uint32_t record_bytes, uint32_t repeat, double* out_gbps,
+                            double* out_ms);
+
 /* ---- BSDF probes for tests: mdlcode_sample and mdlcode_evaluate (the call protocol of closest_hit.cu:563-605) run on the
  *      device for n independent inputs against the context's material list; host arrays.  One query = one MDL state
  *      (normal, geom_normal, tangent_u[0]) + k1 + the four xi of sample() + the k2 handed to evaluate(). ---- */
@@ -366,7 +378,8 @@ skh_status skh_bsdf_probe(skh_context* ctx, const skh_bsdf_query* queries, uint3
  *                 triangles when that empties the top level, 3 = every mesh instance, 4 (default) = 3 while the instanced triangles stay
  *                 within bake_budget_mtris (64) million, else 2; 0 = every instance keeps its TLAS leaf), world_kernel 1|0 (scenes
  *                 with an empty top level run the world-only build of the traversal kernel)
- *   build         build_quality 1|0 (PLOC | Karras radix tree), leaf_max_tris (2), curve_leaf (1), curve_split (4: parameter sub-ranges
+ *   build         build_quality 1|0 (PLOC | Karras radix tree), leaf_max_tris (2), leaf_lines 0|1 (triangle leaves padded so that none
+ *                 straddles a 128-byte line it need not: -11 % fetched lines, same time, more memory), curve_leaf (1), curve_split (4: parameter sub-ranges
  *                 per curve segment), tlas_build 1|0|2 (GPU PLOC over the instance boxes (default) | exact sweep SAH on the host: 5 % fewer instance
  *                 entries, single-threaded | the sweep up to 8192 instances, the GPU beyond), tlas_open (1: TLAS leaves per instance budget),
  *                 tight_instance_boxes 1|0, wide 4|8 (node width: 64-byte 4-wide nodes | 96-byte

@@ -26,7 +26,7 @@ SYMBOLS = ["skh_create", "skh_destroy", "skh_last_error", "skh_abi_version", "sk
            "skh_render_subframe", "skh_render_subframes", "skh_tonemap", "skh_read_accum", "skh_read_aov",
            "skh_buffer_alloc", "skh_buffer_free", "skh_buffer_download", "skh_copy_accum", "skh_copy_accum_tiles", "skh_scatter_tiles", "skh_trace", "skh_trace_device",
            "skh_set_option", "skh_get_stats", "skh_reset_stats", "skh_synchronize", "skh_get_stream", "skh_bsdf_probe", "skh_get_device_info", "skh_comm_unique_id", "skh_comm_init",
-           "skh_comm_destroy", "skh_gather_tiles", "skh_host_register", "skh_host_unregister", "skh_get_baked", "skh_comm_info"]
+           "skh_comm_destroy", "skh_gather_tiles", "skh_host_register", "skh_host_unregister", "skh_get_baked", "skh_comm_info", "skh_probe_memory"]
 
 DEVICE_INFO = np.dtype([("compute_units", np.uint32), ("simds_per_cu", np.uint32), ("clock_khz", np.uint32), ("memory_clock_khz", np.uint32),
                         ("memory_bus_bits", np.uint32), ("wavefront_size", np.uint32), ("total_memory_bytes", np.uint64), ("name", "S64")])
@@ -92,6 +92,7 @@ def load():
     lib.skh_comm_init.argtypes = [vp, vp, i32, i32]
     lib.skh_comm_destroy.argtypes = [vp]
     lib.skh_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.skh_probe_memory.argtypes = [vp, u32, C.c_uint64, u32, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.skh_gather_tiles.argtypes = [vp, u32, vp, i32]
     lib.skh_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.skh_get_baked.argtypes = [vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]
@@ -270,6 +271,12 @@ class Context:
         w, r, n = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         self._ck(self.lib.skh_comm_info(self.h, C.byref(w), C.byref(r), C.byref(n)), "skh_comm_info")
         return w.value, r.value, n.value
+
+    def probe_memory(self, kind, nbytes, record_bytes=64, repeat=3):
+        """measured memory ceiling: kind 0 stream copy, 1 independent random record fetches, 2 dependent ones -> (GB/s, ms)"""
+        g, ms = C.c_double(0), C.c_double(0)
+        self._ck(self.lib.skh_probe_memory(self.h, kind, int(nbytes), record_bytes, repeat, C.byref(g), C.byref(ms)), "skh_probe_memory")
+        return g.value, ms.value
 
     def comm_destroy(self):
         self._ck(self.lib.skh_comm_destroy(self.h), "skh_comm_destroy")

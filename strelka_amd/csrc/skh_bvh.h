@@ -988,6 +988,84 @@ __global__ void __launch_bounds__(SKH_SCAN_BLOCK) k_scan_add(uint32_t* __restric
             data[base + k] += add;
 }
 
+// ---- leaf records laid out by 128-byte line (triangles; Node4 trees) ------------------------------------------------------------
+// The memory system delivers random fetches by the 128-byte LINE (skh_probe_memory: 32-, 64- and 128-byte records all arrive at ~55 G
+// records/s), and 48-byte triangle records at arbitrary multiples of 48 straddle a line boundary every other leaf.  After the collapse
+// the leaves keep their order but get padding slots in front of them so that every leaf touches the fewest lines its size allows
+// (<= 2 triangles: one).  Addressing stays `first * 48`; only `first` changes.
+//   k_leaf_mark   leafCnt[first] = count for every leaf reference of the nodes and of the group roots
+//   k_leaf_place  one thread per chunk of SKH_LEAF_CHUNK leaf-order positions walks its leaves; pass 1 (chunkBase == nullptr) returns the
+//                 chunk's padded length (a multiple of 8 slots = 3 lines, so every chunk starts on a line), pass 2 writes remap[]
+//   k_leaf_patch  rewrites the references; k_leaf_scatter: sortedVals into slot order (0xffffffff = padding slot)
+#define SKH_LEAF_CHUNK 256u
+SKH_DI uint32_t leaf_place(uint32_t off, uint32_t cnt, uint32_t recBytes)
+{
+    const uint32_t bytes = cnt * recBytes, minLines = (bytes + 127u) >> 7;
+    for (;;)
+    {
+        const uint32_t b0 = off * recBytes;
+        if (((b0 + bytes - 1u) >> 7) - (b0 >> 7) + 1u <= minLines)
+            return off;
+        ++off;
+    }
+}
+__global__ void k_leaf_mark(const int* __restrict__ refs, uint32_t nRefs, uint32_t stride /*ints between the reference blocks*/, uint32_t perBlock,
+                            uint8_t* __restrict__ leafCnt)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nRefs)
+        return;
+    const int r = refs[(size_t)(i / perBlock) * stride + i % perBlock];
+    if (r < 0 && r != SKH_REF_SENTINEL)
+    {
+        const uint32_t enc = (uint32_t)~r;
+        leafCnt[enc >> 3] = (uint8_t)((enc & 7u) + 1u);
+    }
+}
+__global__ void k_leaf_place(const uint8_t* __restrict__ leafCnt, uint32_t n, uint32_t recBytes, const uint32_t* __restrict__ chunkBase,
+                             uint32_t* __restrict__ chunkLen, uint32_t* __restrict__ remap)
+{
+    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t j = ch * SKH_LEAF_CHUNK;
+    if (j >= n)
+        return;
+    const uint32_t end = min(n, j + SKH_LEAF_CHUNK);
+    while (j < end && leafCnt[j] == 0u) // (the tail of a leaf that started in the chunk before)
+        ++j;
+    uint32_t pos = chunkBase ? chunkBase[ch] : 0u;
+    while (j < end)
+    {
+        const uint32_t cnt = leafCnt[j];
+        pos = leaf_place(pos, cnt, recBytes);
+        if (remap)
+            for (uint32_t k = 0; k < cnt; ++k)
+                remap[j + k] = pos + k;
+        pos += cnt;
+        j += cnt;
+    }
+    if (!chunkBase)
+        chunkLen[ch] = (pos + 7u) & ~7u;
+}
+__global__ void k_leaf_patch(int* __restrict__ refs, uint32_t nRefs, uint32_t stride, uint32_t perBlock, const uint32_t* __restrict__ remap)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nRefs)
+        return;
+    int* p = refs + (size_t)(i / perBlock) * stride + i % perBlock;
+    const int r = *p;
+    if (r < 0 && r != SKH_REF_SENTINEL)
+    {
+        const uint32_t enc = (uint32_t)~r;
+        *p = ~(int)((remap[enc >> 3] << 3) | (enc & 7u));
+    }
+}
+__global__ void k_leaf_scatter(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ remap, uint32_t n, uint32_t* __restrict__ out)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n)
+        out[remap[j]] = vals[j];
+}
+
 SKH_DI uint32_t find_segment(const uint32_t* __restrict__ first, uint32_t count, uint32_t k) // largest j with first[j] <= k
 {
     uint32_t lo = 0, hi = count;
@@ -1047,7 +1125,9 @@ __global__ void k_gather_tris(const uint8_t* __restrict__ verts, const uint32_t*
         return;
     const uint32_t i = sortedVals[j];
     float4 r[3];
-    if (i < nMeshTris)
+    if (i == 0xffffffffu) // padding slot of the line layout (k_leaf_place): never referenced
+        r[0] = r[1] = r[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    else if (i < nMeshTris)
     {
         const uint32_t m = triMesh[i], t = triLocal[i];
         const uint4 me = meshes[m];

@@ -168,6 +168,8 @@ struct skh_context
     std::vector<uint8_t> baked; // per instance, valid after skh_build_accel
     int worldRoot = SKH_REF_INVALID, lightRoot = SKH_REF_INVALID; // roots of the two baked groups (mesh instances, light proxies) inside dTriNodes
     uint32_t nBakedTris = 0, nBakedInst = 0;
+    uint32_t leafLines = 0;   // 1: triangle leaves laid out by 128-byte line (skh_bvh.h: k_leaf_place): -11 % fetched lines, same time (docs/LOG.md)
+    uint32_t nTriSlots = 0;
     uint32_t leafMaxTris = 2; // measured on MI355X: 2 beats 1, 3, 4, 6, 8 (the kernel is ALU bound, wasted triangle tests cost more than extra nodes)
     uint32_t buildQuality = 1; // 0: Karras radix tree (fastest build), 1: PLOC clustering (SAH-class quality)
     float sceneLo[3] = { 0, 0, 0 }, sceneHi[3] = { 1, 1, 1 };
@@ -287,14 +289,16 @@ struct LbvhOut
     DevBuf nodes, sortedVals, groupRoot, groupBounds;
     std::vector<int> hostGroupRoot;
     uint32_t numNodes = 0;
+    uint32_t numSlots = 0; // entries of sortedVals: n, or more when the leaves were laid out by 128-byte line (0xffffffff = padding slot)
 };
 
 static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const std::vector<uint32_t>& groupCount,
                              const float4* dBoxLo, const float4* dBoxHi, const uint32_t* dGrp, int leafMax, bool ploc, LbvhOut& out,
-                             bool wideSearch = false)
+                             bool wideSearch = false, uint32_t lineRecBytes = 0 /* > 0: leaf records of this size, laid out by 128-byte line */)
 {
     hipStream_t st = c->stream;
     skh_status s;
+    out.numSlots = n;
     if ((s = dev_alloc(c, out.groupBounds, sizeof(float) * 6 * (size_t)std::max(1u, nGroups))) != SKH_OK)
         return s;
     if ((s = dev_alloc(c, out.groupRoot, sizeof(int) * (size_t)std::max(1u, nGroups))) != SKH_OK)
@@ -524,6 +528,78 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
             he = hipMemcpyAsync(valsA, vals2.p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st);
             if (he == hipSuccess)
                 he = hipStreamSynchronize(st);
+        }
+        if (he == hipSuccess && lineRecBytes && c->wide != 8)
+        {
+            // ---- leaves by 128-byte line (skh_bvh.h: k_leaf_place): padding slots in front of the leaves that would straddle ----
+            DevBuf leafCnt, chunk, remap, sums, vals3;
+            auto cleanup3 = [&]() {
+                for (DevBuf* b : { &leafCnt, &chunk, &remap, &sums, &vals3 })
+                    dev_free(*b);
+            };
+            const uint32_t nCh = (n + SKH_LEAF_CHUNK - 1u) / SKH_LEAF_CHUNK;
+            const uint32_t sb = (nCh + SKH_SCAN_BLOCK * SKH_SCAN_ITEMS - 1) / (SKH_SCAN_BLOCK * SKH_SCAN_ITEMS);
+            skh_status s3 = SKH_OK;
+            if ((s3 = dev_alloc(c, leafCnt, (size_t)n)) != SKH_OK || (s3 = dev_alloc(c, chunk, sizeof(uint32_t) * (size_t)nCh)) != SKH_OK ||
+                (s3 = dev_alloc(c, remap, sizeof(uint32_t) * (size_t)n)) != SKH_OK || (s3 = dev_alloc(c, sums, sizeof(uint32_t) * ((size_t)sb + 2))) != SKH_OK)
+            {
+                cleanup3();
+                cleanup2();
+                cleanup();
+                return s3;
+            }
+            int* nodeRefs = reinterpret_cast<int*>(out.nodes.p) + 12; // Node4::child
+            const uint32_t nRefs = hctr[0] * 4u;
+            he = hipMemsetAsync(leafCnt.p, 0, (size_t)n, st);
+            if (nRefs)
+                k_leaf_mark<<<(nRefs + B - 1) / B, B, 0, st>>>(nodeRefs, nRefs, 16u, 4u, leafCnt.as<uint8_t>());
+            k_leaf_mark<<<(nGroups + B - 1) / B, B, 0, st>>>(out.groupRoot.as<int>(), nGroups, 1u, 1u, leafCnt.as<uint8_t>());
+            k_leaf_place<<<(nCh + B - 1) / B, B, 0, st>>>(leafCnt.as<uint8_t>(), n, lineRecBytes, nullptr, chunk.as<uint32_t>(), nullptr);
+            uint32_t lastLen = 0, lastBase = 0;
+            if (he == hipSuccess)
+                he = hipMemcpyAsync(&lastLen, chunk.as<uint32_t>() + (nCh - 1u), sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+            k_scan_block<<<sb, SKH_SCAN_BLOCK, 0, st>>>(chunk.as<uint32_t>(), nCh, sums.as<uint32_t>());
+            k_rs_scan<<<1, 1024, 0, st>>>(sums.as<uint32_t>(), sb);
+            k_scan_add<<<sb, SKH_SCAN_BLOCK, 0, st>>>(chunk.as<uint32_t>(), nCh, sums.as<uint32_t>());
+            if (he == hipSuccess)
+                he = hipMemcpyAsync(&lastBase, chunk.as<uint32_t>() + (nCh - 1u), sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+            if (he == hipSuccess)
+                he = hipStreamSynchronize(st);
+            const uint64_t total = (uint64_t)lastBase + lastLen;
+            if (he == hipSuccess && total >= (1ull << 28))
+            {
+                cleanup3();
+                cleanup2();
+                cleanup();
+                c->err = "lbvh_build: more than 2^28 leaf slots";
+                return SKH_INVALID_ARGUMENT;
+            }
+            if (he == hipSuccess && (s3 = dev_alloc(c, vals3, sizeof(uint32_t) * (size_t)std::max<uint64_t>(1, total))) != SKH_OK)
+            {
+                cleanup3();
+                cleanup2();
+                cleanup();
+                return s3;
+            }
+            if (he == hipSuccess)
+            {
+                k_leaf_place<<<(nCh + B - 1) / B, B, 0, st>>>(leafCnt.as<uint8_t>(), n, lineRecBytes, chunk.as<uint32_t>(), nullptr, remap.as<uint32_t>());
+                if (nRefs)
+                    k_leaf_patch<<<(nRefs + B - 1) / B, B, 0, st>>>(nodeRefs, nRefs, 16u, 4u, remap.as<uint32_t>());
+                k_leaf_patch<<<(nGroups + B - 1) / B, B, 0, st>>>(out.groupRoot.as<int>(), nGroups, 1u, 1u, remap.as<uint32_t>());
+                he = hipMemsetAsync(vals3.p, 0xff, sizeof(uint32_t) * (size_t)total, st);
+                k_leaf_scatter<<<G1, B, 0, st>>>(valsA, remap.as<uint32_t>(), n, vals3.as<uint32_t>());
+                if (he == hipSuccess)
+                    he = hipMemcpyAsync(out.hostGroupRoot.data(), out.groupRoot.p, sizeof(int) * nGroups, hipMemcpyDeviceToHost, st);
+                if (he == hipSuccess)
+                    he = hipStreamSynchronize(st);
+                if (he == hipSuccess)
+                {
+                    std::swap(out.sortedVals, vals3); // (the unpadded order is freed with vals3)
+                    out.numSlots = (uint32_t)total;
+                }
+            }
+            cleanup3();
         }
         cleanup2();
         if (he != hipSuccess)
@@ -1225,12 +1301,15 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
                                                              (uint32_t)wInst.size(), c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(),
                                                              c->dMeshes.as<uint4>(), nBaked, nMeshTris, nMeshes, nBakedG[0], dBoxLo.as<float4>(),
                                                              dBoxHi.as<float4>(), dGrp.as<uint32_t>());
-    BA(lbvh_build(c, nTris, nMeshes + 2u, meshTriCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), (int)c->leafMaxTris, usePloc, triOut));
-    BA(dev_alloc(c, c->dTris, sizeof(float4) * 3 * (size_t)std::max(1u, nTris)));
-    if (nTris)
-        k_gather_tris<<<(nTris + B - 1) / B, B, 0, st>>>(c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(), c->dMeshes.as<uint4>(),
+    BA(lbvh_build(c, nTris, nMeshes + 2u, meshTriCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), (int)c->leafMaxTris, usePloc, triOut,
+                  false, c->leafLines ? 48u : 0u));
+    const uint32_t nTriSlots = triOut.numSlots; // >= nTris: the line layout pads in front of leaves that would straddle a 128-byte line
+    c->nTriSlots = nTriSlots;
+    BA(dev_alloc(c, c->dTris, sizeof(float4) * 3 * (size_t)std::max(1u, nTriSlots)));
+    if (nTriSlots)
+        k_gather_tris<<<(nTriSlots + B - 1) / B, B, 0, st>>>(c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(), c->dMeshes.as<uint4>(),
                                                               dTriMesh.as<uint32_t>(), dTriLocal.as<uint32_t>(),
-                                                              triOut.sortedVals.as<uint32_t>(), nTris, nMeshTris, c->dInstances.as<uint8_t>(),
+                                                              triOut.sortedVals.as<uint32_t>(), nTriSlots, nMeshTris, c->dInstances.as<uint8_t>(),
                                                               dWInst.as<uint32_t>(), dWFirst.as<uint32_t>(), (uint32_t)wInst.size(),
                                                               c->dTris.as<float4>());
     dev_free(c->dTriNodes);
@@ -2503,6 +2582,158 @@ __global__ void k_hits_soa_to_aos(HitQ hq, uint32_t n, uint32_t per, uint32_t re
     hits[k] = h;
 }
 
+// ---- memory ceilings of this GPU, measured with the access shapes of the hot path (include/strelka_hip.h: skh_probe_memory) ----
+__global__ __launch_bounds__(256) void k_probe_fill(uint4* __restrict__ buf, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    {
+        const uint32_t h = hash_murmur((uint32_t)i * 0x9e3779b9u + (uint32_t)(i >> 32));
+        buf[i] = make_uint4(h, h * 0x85ebca6bu, h ^ 0xc2b2ae35u, h * 0x27d4eb2fu + 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_probe_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+// one-wave workgroups like k_trace; every lane fetches `perLane` records of R uint4 (R = 4: 64 bytes = one BVH node) at pseudo-random,
+// record-aligned places of the buffer.  DEPENDENT: the next place comes out of the record just loaded (a traversal step); otherwise
+// four fetches are in flight.
+template <bool DEPENDENT, int R>
+__global__ __launch_bounds__(SKH_TRACE_BLOCK) void k_probe_gather(const uint4* __restrict__ buf, uint32_t nRec, uint32_t perLane, uint32_t* __restrict__ sink)
+{
+    uint32_t s = hash_murmur(blockIdx.x * SKH_TRACE_BLOCK + threadIdx.x + 1u);
+    uint32_t acc = 0u;
+    if (DEPENDENT)
+    {
+        for (uint32_t i = 0; i < perLane; ++i)
+        {
+            const uint4* p = buf + R * (size_t)__umulhi(s, nRec);
+            uint32_t x = 0u;
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+            {
+                const uint4 a = p[j];
+                x ^= a.x ^ a.y ^ a.z ^ a.w;
+            }
+            acc += x;
+            s = s * 1664525u + 1013904223u + x;
+        }
+    }
+    else
+    {
+        for (uint32_t i = 0; i < perLane; i += 4)
+        {
+            uint4 v[4][R];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                const uint4* p = buf + R * (size_t)__umulhi(s, nRec);
+                s = s * 1664525u + 1013904223u;
+#pragma unroll
+                for (int j = 0; j < R; ++j)
+                    v[k][j] = p[j];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < R; ++j)
+                    acc += v[k][j].x ^ v[k][j].y ^ v[k][j].z ^ v[k][j].w;
+        }
+    }
+    if (acc == 0x12345u) // (keeps the loads alive; practically never true)
+        sink[0] = s;
+}
+
+skh_status skh_probe_memory(skh_context* c, uint32_t kind, uint64_t bytes, uint32_t record_bytes, uint32_t repeat, double* out_gbps, double* out_ms)
+{
+    if (!c || kind > SKH_PROBE_CHASE || bytes < (1u << 20) || !out_gbps ||
+        (kind != SKH_PROBE_COPY && record_bytes != 32 && record_bytes != 64 && record_bytes != 128))
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    DevBuf a, b;
+    skh_status s;
+    const size_t n16 = (size_t)(bytes / 64) * 4; // uint4 elements, whole 64-byte records
+    if ((s = dev_alloc(c, a, n16 * 16)) != SKH_OK || (kind == SKH_PROBE_COPY && (s = dev_alloc(c, b, n16 * 16)) != SKH_OK))
+    {
+        dev_free(a);
+        dev_free(b);
+        return s;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        if (e0)
+            (void)hipEventDestroy(e0);
+        if (e1)
+            (void)hipEventDestroy(e1);
+        dev_free(a);
+        dev_free(b);
+    };
+    const uint32_t grid = (uint32_t)c->numCUs * c->wavesPerCU; // the trace kernels' grid
+    const uint32_t perLane = 256;
+    repeat = std::max(1u, repeat);
+    k_probe_fill<<<c->numCUs * 8, 256, 0, c->stream>>>(a.as<uint4>(), n16);
+    double moved = 0.0;
+    for (uint32_t r = 0; r <= repeat; ++r) // (pass 0 is the warm-up)
+    {
+        if (r == 1)
+        {
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, c->stream) != hipSuccess)
+            {
+                cleanup();
+                c->err = "skh_probe_memory: hipEvent";
+                return SKH_FAIL;
+            }
+        }
+        if (kind == SKH_PROBE_COPY)
+        {
+            k_probe_copy<<<c->numCUs * 16, 256, 0, c->stream>>>(a.as<uint4>(), b.as<uint4>(), n16);
+            moved = 2.0 * 16.0 * (double)n16;
+        }
+        else
+        {
+            const uint32_t nRec = (uint32_t)(n16 * 16 / record_bytes);
+            uint32_t* sink = a.as<uint32_t>();
+#define SKH_PROBE_LAUNCH(DEP, R) k_probe_gather<DEP, R><<<grid, SKH_TRACE_BLOCK, 0, c->stream>>>(a.as<uint4>(), nRec, perLane, sink)
+            if (kind == SKH_PROBE_CHASE)
+            {
+                if (record_bytes == 32)
+                    SKH_PROBE_LAUNCH(true, 2);
+                else if (record_bytes == 64)
+                    SKH_PROBE_LAUNCH(true, 4);
+                else
+                    SKH_PROBE_LAUNCH(true, 8);
+            }
+            else
+            {
+                if (record_bytes == 32)
+                    SKH_PROBE_LAUNCH(false, 2);
+                else if (record_bytes == 64)
+                    SKH_PROBE_LAUNCH(false, 4);
+                else
+                    SKH_PROBE_LAUNCH(false, 8);
+            }
+#undef SKH_PROBE_LAUNCH
+            moved = (double)record_bytes * perLane * SKH_TRACE_BLOCK * (double)grid;
+        }
+    }
+    float ms = 0.0f;
+    if (hipEventRecord(e1, c->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+    {
+        cleanup();
+        c->err = "skh_probe_memory: timing failed";
+        return SKH_FAIL;
+    }
+    cleanup();
+    ms /= (float)repeat;
+    *out_gbps = moved / (ms * 1e-3) / 1e9;
+    if (out_ms)
+        *out_ms = ms;
+    return SKH_OK;
+}
+
 skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays, uint32_t mode, void* d_hits, uint32_t repeat)
 {
     if (!c || (n_rays && (!d_rays || !d_hits)) || mode > 1)
@@ -2788,6 +3019,13 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 0 || value > (1 << 20))
             return SKH_INVALID_ARGUMENT;
         c->bakeSmallTris = (uint32_t)value;
+        c->accelBuilt = false;
+    }
+    else if (n == "leaf_lines")
+    {
+        if (value < 0 || value > 1)
+            return SKH_INVALID_ARGUMENT;
+        c->leafLines = (uint32_t)value;
         c->accelBuilt = false;
     }
     else if (n == "leaf_max_tris")
