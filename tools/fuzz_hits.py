@@ -130,6 +130,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     o = orklib.new_context(); o.set_bake(bk); o.set_scene(arr); want = o.trace(rays, 0)
     ctx = capi.Context(0); ctx.set_option("bake_world", bk)
     ctx.set_option("curve_split", 1 + seed % 4); ctx.set_option("leaf_max_tris", 1 + seed % 4)
+    ctx.set_option("leaf_lines", (seed // 5) % 2)  # triangle leaves laid out by 128-byte line: same records
     if (seed // 4) % 3 == 2:
         ctx.set_option("wide", 8)  # the 8-wide node layout (octant-ordered slots) must give the same records
     ctx.set_scene(arr); got = ctx.trace(rays, 0)
