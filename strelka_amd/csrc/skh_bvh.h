@@ -236,6 +236,17 @@ SKH_DI uint32_t expand_bits10(uint32_t v)
     return v;
 }
 
+SKH_DI uint64_t expand_bits21(uint64_t v) // bit k -> bit 3k
+{
+    v &= 0x1fffffull;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
 // ---- per-primitive boxes -------------------------------------------------------------------------------
 // triangles: box of the three object-space positions; group = mesh id
 __global__ void k_tri_boxes(const uint8_t* __restrict__ verts /*32 B stride*/, const uint32_t* __restrict__ indices,
@@ -397,8 +408,10 @@ __global__ void k_decode_group_bounds(const uint32_t* __restrict__ gb, float* __
     if (i < nGroups * 6)
         out[i] = float_from_ordered(gb[i]);
 }
+// key = group id << (3 * mb) | Morton code of the box centre inside the group's bounds, mb bits per axis (option morton_bits:
+// PLOC's neighbour search makes up for a coarse grid -- 10 to 20 bits measured equal on a 23 M-triangle world-space group)
 __global__ void k_morton(const float4* __restrict__ boxLo, const float4* __restrict__ boxHi, const uint32_t* __restrict__ grp,
-                         const float* __restrict__ gbounds, uint32_t n, uint64_t* __restrict__ keys,
+                         const float* __restrict__ gbounds, uint32_t n, uint32_t mb, uint64_t* __restrict__ keys,
                          uint32_t* __restrict__ vals)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -412,11 +425,12 @@ __global__ void k_morton(const float4* __restrict__ boxLo, const float4* __restr
     const float nx = ex > 0.0f ? (cx - b[0]) / ex : 0.0f;
     const float ny = ey > 0.0f ? (cy - b[1]) / ey : 0.0f;
     const float nz = ez > 0.0f ? (cz - b[2]) / ez : 0.0f;
-    const uint32_t qx = (uint32_t)fminf(fmaxf(nx * 1024.0f, 0.0f), 1023.0f);
-    const uint32_t qy = (uint32_t)fminf(fmaxf(ny * 1024.0f, 0.0f), 1023.0f);
-    const uint32_t qz = (uint32_t)fminf(fmaxf(nz * 1024.0f, 0.0f), 1023.0f);
-    const uint32_t code = (expand_bits10(qx) << 2) | (expand_bits10(qy) << 1) | expand_bits10(qz);
-    keys[i] = ((uint64_t)g << 32) | code;
+    const float cells = (float)(1u << mb);
+    const uint32_t qx = (uint32_t)fminf(fmaxf(nx * cells, 0.0f), cells - 1.0f);
+    const uint32_t qy = (uint32_t)fminf(fmaxf(ny * cells, 0.0f), cells - 1.0f);
+    const uint32_t qz = (uint32_t)fminf(fmaxf(nz * cells, 0.0f), cells - 1.0f);
+    const uint64_t code = (expand_bits21(qx) << 2) | (expand_bits21(qy) << 1) | expand_bits21(qz);
+    keys[i] = ((uint64_t)g << (3u * mb)) | code;
     vals[i] = i;
 }
 
@@ -652,13 +666,13 @@ __global__ void k_emit(const int* __restrict__ childL, const int* __restrict__ c
 }
 __global__ void k_group_roots(const int* __restrict__ rangeF, const int* __restrict__ rangeL,
                               const uint64_t* __restrict__ sortedKeys, const uint32_t* __restrict__ groupFirst,
-                              const uint32_t* __restrict__ groupCount, int n, int leafMax, int* __restrict__ groupRoot)
+                              const uint32_t* __restrict__ groupCount, int n, int leafMax, uint32_t keyShift, int* __restrict__ groupRoot)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1)
         return;
     const int f = rangeF[i], l = rangeL[i];
-    const uint32_t g = (uint32_t)(sortedKeys[f] >> 32);
+    const uint32_t g = (uint32_t)(sortedKeys[f] >> keyShift);
     if ((uint32_t)f == groupFirst[g] && (uint32_t)(l - f + 1) == groupCount[g] && (l - f + 1) > leafMax)
         groupRoot[g] = i;
 }
@@ -816,11 +830,14 @@ __global__ void k_permute_u32(const uint32_t* __restrict__ src, const uint32_t* 
 #ifndef SKH_PLOC_RADIUS
 #define SKH_PLOC_RADIUS 12
 #endif
+#ifndef SKH_PLOC_RADIUS_SEGS
+#define SKH_PLOC_RADIUS_SEGS 8
+#endif
 #define SKH_PLOC_BLOCK 256
 __global__ void k_ploc_init(const uint32_t* __restrict__ sortedVals, const uint64_t* __restrict__ sortedKeys,
                             const float4* __restrict__ boxLo, const float4* __restrict__ boxHi, uint32_t n,
                             float4* __restrict__ cLo, float4* __restrict__ cHi, float4* __restrict__ nodeLo,
-                            float4* __restrict__ nodeHi)
+                            float4* __restrict__ nodeHi, uint32_t keyShift)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n)
@@ -829,12 +846,15 @@ __global__ void k_ploc_init(const uint32_t* __restrict__ sortedVals, const uint6
     const float4 lo = boxLo[p], hi = boxHi[p];
     const int id = (int)(n - 1 + j);
     cLo[j] = make_float4(lo.x, lo.y, lo.z, __int_as_float(id));
-    cHi[j] = make_float4(hi.x, hi.y, hi.z, __uint_as_float((uint32_t)(sortedKeys[j] >> 32)));
+    cHi[j] = make_float4(hi.x, hi.y, hi.z, __uint_as_float((uint32_t)(sortedKeys[j] >> keyShift)));
     nodeLo[id] = lo;
     nodeHi[id] = hi;
 }
-// RADIUS: neighbours examined on either side.  12 for the BLASes (millions of primitives); the TLAS -- thousands of boxes of wildly
-// different sizes that EVERY ray walks -- searches 96 either side, close to exhaustive agglomerative clustering
+// RADIUS: neighbours examined on either side.  Triangles 12, curve sub-segments 8 (measured on MI355X, kitchen / hair stand-ins:
+// 4 / 8 / 12 / 16 / 24 / 48 -> 5313 / 5278 / 5355 / 5359 / 5432 / 5341 and 1549 / 1549 / 1521 / 1484 / 1440 / 1418 Mray/s -- thin
+// diagonal segments merge better with their neighbours along the strand than with anything a wider search finds; 24 costs the
+// kitchen WITHOUT mesh sharing the 2 % it gives the shared one); the TLAS --
+// thousands of boxes of wildly different sizes that EVERY ray walks -- searches 96 either side, close to exhaustive clustering
 #ifndef SKH_PLOC_RADIUS_TLAS
 #define SKH_PLOC_RADIUS_TLAS 96
 #endif

@@ -168,6 +168,7 @@ struct skh_context
     std::vector<uint8_t> baked; // per instance, valid after skh_build_accel
     int worldRoot = SKH_REF_INVALID, lightRoot = SKH_REF_INVALID; // roots of the two baked groups (mesh instances, light proxies) inside dTriNodes
     uint32_t nBakedTris = 0, nBakedInst = 0;
+    uint32_t mortonBits = 10; // per axis, in the builders' sort keys (option morton_bits 4..21: 10 / 13 / 16 / 20 measured within the +-1.5 % the tree's shape varies by anyway)
     uint32_t leafLines = 0;   // 1: triangle leaves laid out by 128-byte line (skh_bvh.h: k_leaf_place): -11 % fetched lines, same time (docs/LOG.md)
     uint32_t nTriSlots = 0;
     uint32_t leafMaxTris = 2; // measured on MI355X: 2 beats 1, 3, 4, 6, 8 (the kernel is ALU bound, wasted triangle tests cost more than extra nodes)
@@ -294,7 +295,7 @@ struct LbvhOut
 
 static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const std::vector<uint32_t>& groupCount,
                              const float4* dBoxLo, const float4* dBoxHi, const uint32_t* dGrp, int leafMax, bool ploc, LbvhOut& out,
-                             bool wideSearch = false, uint32_t lineRecBytes = 0 /* > 0: leaf records of this size, laid out by 128-byte line */)
+                             int search = 0 /* PLOC search radius: 0 triangles, 1 TLAS, 2 curve sub-segments */, uint32_t lineRecBytes = 0 /* > 0: leaf records of this size, laid out by 128-byte line */)
 {
     hipStream_t st = c->stream;
     skh_status s;
@@ -347,14 +348,16 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
     k_group_bounds<<<G1, B, 0, st>>>(dBoxLo, dBoxHi, dGrp, n, gbU.as<uint32_t>());
     k_decode_group_bounds<<<(nGroups * 6 + B - 1) / B, B, 0, st>>>(gbU.as<uint32_t>(), out.groupBounds.as<float>(), nGroups);
     uint32_t* valsA = out.sortedVals.as<uint32_t>();
-    k_morton<<<G1, B, 0, st>>>(dBoxLo, dBoxHi, dGrp, out.groupBounds.as<float>(), n, keysA.as<uint64_t>(), valsA);
-    // radix sort: 32 bits of Morton word + the group bits
+    // sort key: group id above a Morton code of `morton_bits` (10) bits per axis -- fewer when the group ids need the room
     uint32_t gbits = 0;
     while ((1ull << gbits) < (unsigned long long)nGroups)
         ++gbits;
-    std::vector<uint32_t> shifts = { 0, 8, 16, 24 };
-    for (uint32_t b = 0; b < gbits; b += 8)
-        shifts.push_back(32 + b);
+    const uint32_t mb = std::min<uint32_t>(c->mortonBits, (64u - gbits) / 3u), keyShift = 3u * mb;
+    k_morton<<<G1, B, 0, st>>>(dBoxLo, dBoxHi, dGrp, out.groupBounds.as<float>(), n, mb, keysA.as<uint64_t>(), valsA);
+    // radix sort over the Morton bits + the group bits
+    std::vector<uint32_t> shifts;
+    for (uint32_t b = 0; b < keyShift + gbits; b += 8)
+        shifts.push_back(b);
     uint64_t* kin = keysA.as<uint64_t>();
     uint64_t* kout = keysB.as<uint64_t>();
     uint32_t* vin = valsA;
@@ -419,14 +422,16 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
             uint32_t hc[4] = { 0, 0, 0, 0 }; // [2] PLOC node counter, [3] surviving cluster count
             he = hipMemcpyAsync(ctr.p, hc, sizeof(hc), hipMemcpyHostToDevice, st);
             k_ploc_init<<<G1, B, 0, st>>>(valsA, sortedKeys, dBoxLo, dBoxHi, n, cLo[0].as<float4>(), cHi[0].as<float4>(),
-                                          nodeLo.as<float4>(), nodeHi.as<float4>());
+                                          nodeLo.as<float4>(), nodeHi.as<float4>(), keyShift);
             uint32_t m = n;
             int cur = 0;
             for (int iter = 0; he == hipSuccess && m > nonEmpty && iter < 4096; ++iter)
             {
                 const uint32_t gm = (m + SKH_PLOC_BLOCK - 1) / SKH_PLOC_BLOCK;
-                if (wideSearch)
+                if (search == 1)
                     k_ploc_nn<SKH_PLOC_RADIUS_TLAS><<<gm, SKH_PLOC_BLOCK, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), m, nn.as<uint32_t>());
+                else if (search == 2)
+                    k_ploc_nn<SKH_PLOC_RADIUS_SEGS><<<gm, SKH_PLOC_BLOCK, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), m, nn.as<uint32_t>());
                 else
                     k_ploc_nn<SKH_PLOC_RADIUS><<<gm, SKH_PLOC_BLOCK, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), m, nn.as<uint32_t>());
                 k_ploc_merge<<<(m + B - 1) / B, B, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), nn.as<uint32_t>(), m, (int)n,
@@ -468,7 +473,7 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
                                       nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n);
             k_sizes_from_ranges<<<(n - 1 + B - 1) / B, B, 0, st>>>(rangeF.as<int>(), rangeL.as<int>(), (int)n, nodeSize.as<int>());
             k_group_roots<<<(n - 1 + B - 1) / B, B, 0, st>>>(rangeF.as<int>(), rangeL.as<int>(), sortedKeys, gFirst.as<uint32_t>(),
-                                                            gCount.as<uint32_t>(), (int)n, leafMax, out.groupRoot.as<int>());
+                                                            gCount.as<uint32_t>(), (int)n, leafMax, keyShift, out.groupRoot.as<int>());
         }
         // group roots come back as BINARY node ids; they seed the level-by-level collapse into 4-wide nodes
         if (he != hipSuccess || hipMemcpyAsync(out.hostGroupRoot.data(), out.groupRoot.p, sizeof(int) * nGroups, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -1302,7 +1307,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
                                                              c->dMeshes.as<uint4>(), nBaked, nMeshTris, nMeshes, nBakedG[0], dBoxLo.as<float4>(),
                                                              dBoxHi.as<float4>(), dGrp.as<uint32_t>());
     BA(lbvh_build(c, nTris, nMeshes + 2u, meshTriCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), (int)c->leafMaxTris, usePloc, triOut,
-                  false, c->leafLines ? 48u : 0u));
+                  0, c->leafLines ? 48u : 0u));
     const uint32_t nTriSlots = triOut.numSlots; // >= nTris: the line layout pads in front of leaves that would straddle a 128-byte line
     c->nTriSlots = nTriSlots;
     BA(dev_alloc(c, c->dTris, sizeof(float4) * 3 * (size_t)std::max(1u, nTriSlots)));
@@ -1387,7 +1392,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         k_seg_boxes<<<(nSub + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), c->dSegStartAll.as<uint32_t>(),
                                                       dSegCurve.as<uint32_t>(), nSub, K, dBoxLo.as<float4>(), dBoxHi.as<float4>(),
                                                       dGrp.as<uint32_t>());
-    BA(lbvh_build(c, nSub, nCurves, curveSubCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), (int)c->curveLeaf, usePloc, segOut));
+    BA(lbvh_build(c, nSub, nCurves, curveSubCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), (int)c->curveLeaf, usePloc, segOut, 2));
     BA(dev_alloc(c, c->dSegs, sizeof(float4) * 4 * (size_t)std::max(1u, nSub)));
     BA(dev_alloc(c, c->dSegPrim, sizeof(uint32_t) * (size_t)std::max(1u, nSub)));
     BA(dev_alloc(c, c->dSegBound, sizeof(float4) * 2 * (size_t)std::max(1u, nSub)));
@@ -1461,7 +1466,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
             k_tlas_leaves<<<(nLeaves + B - 1) / B, B, 0, st>>>(dLeafInst.as<uint32_t>(), nLeaves, c->dDevInst.as<DevInstance>(), dBoxLo.as<float4>(),
                                                                dBoxHi.as<float4>(), dLeafLo.as<float4>(), dLeafHi.as<float4>(), dLeafGrp.as<uint32_t>(),
                                                                dTinstTmp.as<DevInstance>());
-            BT(lbvh_build(c, nLeaves, 1, std::vector<uint32_t>{ nLeaves }, dLeafLo.as<float4>(), dLeafHi.as<float4>(), dLeafGrp.as<uint32_t>(), 1, true, tlasOut, true));
+            BT(lbvh_build(c, nLeaves, 1, std::vector<uint32_t>{ nLeaves }, dLeafLo.as<float4>(), dLeafHi.as<float4>(), dLeafGrp.as<uint32_t>(), 1, true, tlasOut, 1));
             // traversal records into leaf order (a TLAS leaf ref carries its position: sc.tinst + first)
             k_permute_instances<<<(nLeaves + B - 1) / B, B, 0, st>>>(dTinstTmp.as<DevInstance>(), tlasOut.sortedVals.as<uint32_t>(), nLeaves,
                                                                      c->dTravInst.as<DevInstance>());
@@ -3019,6 +3024,13 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 0 || value > (1 << 20))
             return SKH_INVALID_ARGUMENT;
         c->bakeSmallTris = (uint32_t)value;
+        c->accelBuilt = false;
+    }
+    else if (n == "morton_bits")
+    {
+        if (value < 4 || value > 21)
+            return SKH_INVALID_ARGUMENT;
+        c->mortonBits = (uint32_t)value;
         c->accelBuilt = false;
     }
     else if (n == "leaf_lines")
