@@ -245,7 +245,7 @@ def drop_in_leg(ctx, params, W, H, spp, torch, dev):
     ctx.host_unregister(host)
     return {"unit": "Mray/s", "pattern": f"{spp} x (skh_render_subframe of 1 spp + map() = D2H of the {W}x{H} float4 image), the reference "
             "caller's loop (RenderPass.cpp:441-447); the library traces up to 8 sub-frames ahead once the caller keeps continuing the "
-            "frame (option speculate), images bit-identical", **res}
+            "frame (option speculate) and traces the next pass while this one is collected (speculate_async), images bit-identical", **res}
 
 
 SCENE_RECIPES = {

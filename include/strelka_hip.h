@@ -202,8 +202,8 @@ enum
 
 typedef struct skh_stats
 {
-    uint64_t rays_radiance; /* closest-hit rays actually traced since the last reset */
-    uint64_t rays_shadow; /* any-hit rays actually traced since the last reset */
+    uint64_t rays_radiance; /* closest-hit rays traced since the last reset for sub-frames that were DELIVERED (see speculated_discarded) */
+    uint64_t rays_shadow; /* any-hit rays, likewise */
     /* traversal counters, counter build only (skh_set_option "count_traversal"); [0] closest-hit kernel,
      * [1] shadow (any-hit) kernel */
     uint64_t nodes_visited[2]; /* 64-byte BVH nodes fetched */
@@ -371,6 +371,9 @@ skh_status skh_bsdf_probe(skh_context* ctx, const skh_bsdf_query* queries, uint3
  *                 leaf_min (16: lanes for the minority kind of leaf work), curve_min (48: lanes parked in front of the
  *                 curve intersector before it runs), subframe_batch (0 = auto: ~64 M paths per pass),
  *                 speculate (8: sub-frames traced ahead when skh_render_subframe is called once per sub-frame; 0 = off),
+ *                 speculate_async 1|0 (the pass after the one being collected is traced meanwhile, on the render stream, into a second
+ *                 path-state buffer; accumulation steps and skh_buffer_download run beside it on their own stream: the caller's map()
+ *                 copies cost nothing any more.  A camera move waits for the pass in flight, <= `speculate` sub-frames),
  *                 overlap 0|1|2 (any-hit launches on a second stream beside the next closest-hit launch: off | small passes |
  *                 always), small_waves_closest / small_waves_shadow (16 / 16: waves per CU of the two overlapped launches)
  *   definition    bake_world 4|3|2|1|0 (mesh instances intersected in world space, no instance entry: 1 = instances whose mesh has one

@@ -108,7 +108,18 @@ struct skh_context
         skh_frame_params last; // the previous call's parameters
         bool haveLast = false;
         uint64_t passRadiance = 0, passShadow = 0; // rays the pass traced (all `count` sub-frames; counted when traced)
+        // option speculate_async: the pass AFTER the one being consumed is already being traced -- on c->stream, into the other
+        // path-state buffer -- while the caller collects this pass's sub-frames (accumulation steps and map() copies on stream3)
+        uint32_t buf = 0; // path-state buffer of the pass being consumed (0 = dPath, 1 = dPathB)
+        bool nextInFlight = false;
+        skh_frame_params nextParams;
+        uint32_t nextCount = 0;
+        unsigned long long statsMark[2] = { 0, 0 }; // dStats {raysRadiance, raysShadow} when the pass in flight was launched
     } spec;
+    uint32_t speculateAsync = 1; // option speculate_async: 224 -> 180 ms per frame in the reference caller's loop with map() (docs/LOG.md)
+    hipStream_t stream3 = nullptr; // accumulation steps + image copies beside a pass in flight (non-blocking: no implicit sync with the null stream)
+    DevBuf dPathB;
+    uint32_t pathBStride = 0;
     // sub-frames traced ahead and then thrown away (camera move, a setter, resize): their rays are taken out of the ray counts again,
     // so that a Mray/s figure from skh_get_stats only counts rays whose sub-frame was delivered
     uint64_t discardedRadiance = 0, discardedShadow = 0;
@@ -836,6 +847,19 @@ static int tlas_sah_build(const std::vector<HostBox>& boxes, const std::vector<u
 static void spec_drop(skh_context* c, bool keepLast = false)
 {
     skh_context::Speculation& sp = c->spec;
+    if (sp.nextInFlight)
+    {
+        // a whole pass traced ahead that nobody will collect: wait for it (its buffers are about to be reused), take its rays out again
+        unsigned long long after[2] = { 0, 0 };
+        (void)hipStreamSynchronize(c->stream);
+        if (hipMemcpy(after, c->dStats.p, sizeof(after), hipMemcpyDeviceToHost) == hipSuccess)
+        {
+            c->discardedRadiance += after[0] - sp.statsMark[0];
+            c->discardedShadow += after[1] - sp.statsMark[1];
+        }
+        c->discardedSubframes += sp.nextCount;
+        sp.nextInFlight = false;
+    }
     if (sp.valid && sp.consumed < sp.count && sp.count > 0)
     {
         const uint32_t left = sp.count - sp.consumed;
@@ -844,6 +868,7 @@ static void spec_drop(skh_context* c, bool keepLast = false)
         c->discardedSubframes += left;
     }
     sp.valid = false;
+    sp.buf = 0;
     if (!keepLast)
         sp.haveLast = false;
 }
@@ -863,7 +888,7 @@ skh_status skh_create(int device_ordinal, skh_context** out_ctx)
         return SKH_FAIL; // no GPU: the product path fails loudly, there is no CPU fallback
     skh_context* c = new skh_context();
     c->device = device_ordinal;
-    if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess ||
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->evShade, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evShadow, hipEventDisableTiming) != hipSuccess)
     {
         delete c;
@@ -909,19 +934,23 @@ void skh_destroy(skh_context* c)
         return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->stream3)
+        (void)hipStreamSynchronize(c->stream3);
     if (c->comm)
         (void)skh_comm_destroy(c);
     for (DevBuf* b : { &c->dShadeTris, &c->dShadeInst, &c->dVerts, &c->dIndices, &c->dMeshes, &c->dPoints, &c->dRadii, &c->dInstances, &c->dLights, &c->dMaterials,
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
                        &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
-                       &c->dCounts, &c->dOvf, &c->dOvf2, &c->dStats, &c->dScratchImage })
+                       &c->dCounts, &c->dOvf, &c->dOvf2, &c->dStats, &c->dScratchImage, &c->dPathB })
         dev_free(*b);
     for (hipEvent_t e : c->eventPool)
         (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     if (c->stream2)
         (void)hipStreamDestroy(c->stream2);
+    if (c->stream3)
+        (void)hipStreamDestroy(c->stream3);
     if (c->evShade)
         (void)hipEventDestroy(c->evShade);
     if (c->evShadow)
@@ -1971,7 +2000,8 @@ static skh_status check_stack_overflow(skh_context* c, const char* where)
 // One wavefront pass: either one launch of p->samples_this_launch samples (batch = 1), or `batch` consecutive sub-frames
 // of one sample each traced together (more rays per launch; results identical, see k_finalize_batch).
 static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t batch, void* d_image, bool trace = true, uint32_t finalFirst = 0,
-                             uint32_t finalCount = 0xffffffffu)
+                             uint32_t finalCount = 0xffffffffu, uint32_t pathSel = 0 /* 1: the second path-state buffer */, bool finalize = true,
+                             hipStream_t finStream = nullptr /* where the accumulation step runs (default: the render stream) */)
 {
     if (p->max_depth > 128 || p->samples_this_launch == 0)
     {
@@ -2009,7 +2039,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
         return SKH_OK;
     const uint32_t gridSlots = (c->numSlots + 255) / 256;
     const uint32_t* tiles = c->dTileXY.as<uint32_t>();
-    PathS ps{ c->dPath.as<float>(), N };
+    PathS ps{ pathSel ? c->dPathB.as<float>() : c->dPath.as<float>(), pathSel ? c->pathBStride : N };
     RayQ rq[2] = { RayQ{ c->dRayQ[0].as<float>(), NQ, c->queueRegion }, RayQ{ c->dRayQ[1].as<float>(), NQ, c->queueRegion } };
     RayQ shq{ c->dShadowQ.as<float>(), NQ, c->queueRegion };
     HitQ hq{ c->dHits.as<float>(), NQ };
@@ -2092,16 +2122,17 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                 k_collect<<<gridSlots, 256, 0, st>>>(fp, tiles, s, ps, c->dSums.as<float>());
         }
     }
-    if (batch > 1)
+    hipStream_t fs = finStream ? finStream : st;
+    if (finalize && batch > 1)
     {
-        SpanGuard g(c, KC_ACCUM);
-        k_finalize_batch<<<gridSlots, 256, 0, st>>>(fp, tiles, ps, c->dAccum.as<float4>(), c->dDiffuse.as<float4>(), c->dSpecular.as<float4>(),
+        SpanGuard g(c, KC_ACCUM, fs);
+        k_finalize_batch<<<gridSlots, 256, 0, fs>>>(fp, tiles, ps, c->dAccum.as<float4>(), c->dDiffuse.as<float4>(), c->dSpecular.as<float4>(),
                                                     c->dDiffCnt.as<uint16_t>(), c->dSpecCnt.as<uint16_t>(), reinterpret_cast<float4*>(d_image));
     }
-    else
+    else if (finalize)
     {
-        SpanGuard g(c, KC_ACCUM);
-        k_finalize<<<gridSlots, 256, 0, st>>>(fp, tiles, c->dSums.as<float>(), c->dAccum.as<float4>(), c->dDiffuse.as<float4>(),
+        SpanGuard g(c, KC_ACCUM, fs);
+        k_finalize<<<gridSlots, 256, 0, fs>>>(fp, tiles, c->dSums.as<float>(), c->dAccum.as<float4>(), c->dDiffuse.as<float4>(),
                                               c->dSpecular.as<float4>(), c->dDiffCnt.as<uint16_t>(), c->dSpecCnt.as<uint16_t>(),
                                               reinterpret_cast<float4*>(d_image));
     }
@@ -2158,6 +2189,37 @@ static bool same_frame(const skh_frame_params& a, const skh_frame_params& b, uin
     return memcmp(&x, &y, sizeof(x)) == 0;
 }
 
+// speculate_async: start tracing the pass that follows the one being consumed.  Nothing is in flight and c->stream is idle here.
+static skh_status spec_launch_next(skh_context* c)
+{
+    skh_context::Speculation& sp = c->spec;
+    if (!c->speculateAsync || !sp.valid || sp.nextInFlight || c->timing)
+        return SKH_OK; // (per-kernel hipEvent spans are harvested at every call: timing runs keep the synchronous scheme)
+    const uint32_t nextStart = sp.params.subframe_index + sp.count;
+    if (nextStart >= sp.params.spp_total)
+        return SKH_OK;
+    const uint32_t cap = std::min(c->speculateMax, c->batchCapacity);
+    const uint32_t n = std::min(std::min(std::max(2u, sp.count * 2u), cap), sp.params.spp_total - nextStart);
+    const uint32_t other = sp.buf ^ 1u;
+    if (other == 1u)
+    {
+        const uint32_t stride = c->numSlots * cap;
+        skh_status s = dev_alloc(c, c->dPathB, sizeof(float) * 8 * (size_t)stride);
+        if (s != SKH_OK)
+            return s;
+        c->pathBStride = stride;
+    }
+    SKH_TRY(c, hipMemcpy(sp.statsMark, c->dStats.p, sizeof(sp.statsMark), hipMemcpyDeviceToHost));
+    sp.nextParams = sp.params;
+    sp.nextParams.subframe_index = nextStart;
+    sp.nextCount = n;
+    skh_status s = render_one(c, &sp.nextParams, n, nullptr, true, 0, 0, other, false);
+    if (s != SKH_OK)
+        return s;
+    sp.nextInFlight = true;
+    return SKH_OK;
+}
+
 skh_status skh_render_subframe(skh_context* c, const skh_frame_params* params, void* d_image)
 {
     if (!c || !params)
@@ -2171,18 +2233,39 @@ skh_status skh_render_subframe(skh_context* c, const skh_frame_params* params, v
     }
     (void)hipSetDevice(c->device);
     skh_status s;
+    if (sp.nextInFlight && sp.valid && sp.consumed >= sp.count && same_frame(sp.nextParams, *params, 0))
+    {
+        // the caller has collected the whole pass and continues into the one in flight: wait for it, make it the current pass
+        unsigned long long after[2] = { 0, 0 };
+        SKH_TRY(c, hipStreamSynchronize(c->stream));
+        SKH_TRY(c, hipMemcpy(after, c->dStats.p, sizeof(after), hipMemcpyDeviceToHost));
+        sp.nextInFlight = false;
+        sp.passRadiance = after[0] - sp.statsMark[0];
+        sp.passShadow = after[1] - sp.statsMark[1];
+        sp.buf ^= 1u;
+        sp.params = sp.nextParams;
+        sp.count = sp.nextCount;
+        sp.consumed = 0;
+        sp.lastBatch = sp.nextCount;
+        if ((s = check_stack_overflow(c, "skh_render_subframe")) != SKH_OK)
+            return s;
+    }
     if (sp.valid && sp.consumed < sp.count && same_frame(sp.params, *params, sp.consumed))
     {
-        // this sub-frame was traced ahead: its radiances wait in the path state, only its accumulation step is left
-        if ((s = render_one(c, &sp.params, sp.count, d_image, false, sp.consumed, 1)) != SKH_OK)
+        // this sub-frame was traced ahead: its radiances wait in the path state, only its accumulation step is left (beside a pass in
+        // flight it runs on its own stream)
+        hipStream_t fin = sp.nextInFlight ? c->stream3 : c->stream;
+        if ((s = render_one(c, &sp.params, sp.count, d_image, false, sp.consumed, 1, sp.buf, true, fin)) != SKH_OK)
             return s;
         sp.consumed++;
         sp.last = *params;
         sp.haveLast = true;
         sp.streak++;
-        SKH_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->timing)
+        SKH_TRY(c, hipStreamSynchronize(fin));
+        if (c->timing && !sp.nextInFlight)
             harvest_spans(c);
+        if (sp.consumed == 1)
+            return spec_launch_next(c); // (first delivery of a pass that was itself traced in flight)
         return SKH_OK;
     }
     // a fresh pass.  How far ahead: nothing on the first call of a frame or after any change (interactive camera motion restarts at
@@ -2211,6 +2294,7 @@ skh_status skh_render_subframe(skh_context* c, const skh_frame_params* params, v
     sp.passRadiance = after[0] - before[0];
     sp.passShadow = after[1] - before[1];
     sp.valid = true;
+    sp.buf = 0;
     sp.params = *params;
     sp.count = ahead;
     sp.consumed = 1;
@@ -2220,7 +2304,9 @@ skh_status skh_render_subframe(skh_context* c, const skh_frame_params* params, v
     SKH_TRY(c, hipStreamSynchronize(c->stream));
     if (c->timing)
         harvest_spans(c);
-    return check_stack_overflow(c, "skh_render_subframe");
+    if ((s = check_stack_overflow(c, "skh_render_subframe")) != SKH_OK)
+        return s;
+    return spec_launch_next(c);
 }
 
 skh_status skh_tonemap(skh_context* c, void* d_image, uint32_t width, uint32_t height, uint32_t type, const float exposure[3], float gamma)
@@ -2259,6 +2345,14 @@ skh_status skh_buffer_download(skh_context* c, const void* d, void* host, size_t
     if (!c || !d || !host)
         return SKH_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
+    if (c->spec.nextInFlight)
+    {
+        // (the image was written by an accumulation step on stream3, which has completed; c->stream is busy with the pass traced
+        // ahead and a null-stream copy would wait for it)
+        SKH_TRY(c, hipMemcpyAsync(host, d, bytes, hipMemcpyDeviceToHost, c->stream3));
+        SKH_TRY(c, hipStreamSynchronize(c->stream3));
+        return SKH_OK;
+    }
     SKH_TRY(c, hipStreamSynchronize(c->stream));
     SKH_TRY(c, hipMemcpy(host, d, bytes, hipMemcpyDeviceToHost));
     return SKH_OK;
@@ -3026,6 +3120,13 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         c->bakeSmallTris = (uint32_t)value;
         c->accelBuilt = false;
     }
+    else if (n == "speculate_async")
+    {
+        if (value < 0 || value > 1)
+            return SKH_INVALID_ARGUMENT;
+        spec_drop(c);
+        c->speculateAsync = (uint32_t)value;
+    }
     else if (n == "morton_bits")
     {
         if (value < 4 || value > 21)
@@ -3101,9 +3202,24 @@ skh_status skh_get_stats(skh_context* c, skh_stats* out)
     SKH_TRY(c, hipStreamSynchronize(c->stream));
     SKH_TRY(c, hipMemcpy(&sd, c->dStats.p, sizeof(sd), hipMemcpyDeviceToHost));
     memset(out, 0, sizeof(*out));
-    // rays of sub-frames that were traced ahead and never delivered do not count (spec_drop); what is still pending does
-    out->rays_radiance = sd.raysRadiance - std::min<uint64_t>(sd.raysRadiance, c->discardedRadiance);
-    out->rays_shadow = sd.raysShadow - std::min<uint64_t>(sd.raysShadow, c->discardedShadow);
+    // rays count when their sub-frame is DELIVERED: what was traced ahead and thrown away (spec_drop) is out, and so is what is still
+    // waiting to be collected -- the rest of the current pass and the whole pass in flight (complete after the synchronize above)
+    uint64_t outR = c->discardedRadiance, outS = c->discardedShadow;
+    {
+        const skh_context::Speculation& sp = c->spec;
+        if (sp.valid && sp.consumed < sp.count && sp.count > 0)
+        {
+            outR += sp.passRadiance * (sp.count - sp.consumed) / sp.count;
+            outS += sp.passShadow * (sp.count - sp.consumed) / sp.count;
+        }
+        if (sp.nextInFlight)
+        {
+            outR += sd.raysRadiance - std::min<uint64_t>(sd.raysRadiance, sp.statsMark[0]);
+            outS += sd.raysShadow - std::min<uint64_t>(sd.raysShadow, sp.statsMark[1]);
+        }
+    }
+    out->rays_radiance = sd.raysRadiance - std::min<uint64_t>(sd.raysRadiance, outR);
+    out->rays_shadow = sd.raysShadow - std::min<uint64_t>(sd.raysShadow, outS);
     out->speculated_discarded = c->discardedSubframes;
     for (int k = 0; k < 2; ++k)
     {
@@ -3154,6 +3270,7 @@ skh_status skh_reset_stats(skh_context* c)
     if (!c)
         return SKH_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
+    spec_drop(c, true); // (what was traced ahead belongs to the counters being cleared)
     SKH_TRY(c, hipStreamSynchronize(c->stream));
     SKH_TRY(c, hipMemset(c->dStats.p, 0, sizeof(StatsDev)));
     c->stackOverflows = 0;

@@ -833,20 +833,25 @@ def test_speculative_subframes_are_exact(gpu):
     calls = [(cam, i) for i in range(9)] + [(cam2, i) for i in range(6)] + [(cam2, i) for i in range(8, spp)]
     img = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
     out = {}
-    for spec in (0, 8, 64):
-        gpu.set_option("speculate", spec)
+    for spec in (0, 8, 64, (8, 1), (64, 1)):  # (cap, 1): speculate_async -- the following pass is traced while this one is collected
+        cap, asy = spec if isinstance(spec, tuple) else (spec, 0)
+        gpu.set_option("speculate", cap)
+        gpu.set_option("speculate_async", asy)
         gpu.resize(w, h)
         gpu.reset_stats()
         frames = []
+        host = np.empty((h, w, 4), np.float32)
         for c_, i in calls:
             gpu.render_subframe(S.frame_params(c_, w, h, subframe_index=i, spp_total=spp, max_depth=4), img.data_ptr())
-            frames.append((img.cpu().numpy().copy(), gpu.read_accum(), gpu.read_aov(0), gpu.read_aov(1)))
+            gpu.buffer_download(img.data_ptr(), host)  # map(): beside a pass in flight it must not wait for that pass, and must see this image
+            frames.append((host.copy(), gpu.read_accum(), gpu.read_aov(0), gpu.read_aov(1)))
         st = gpu.stats()
         out[spec] = (frames, st["launches_trace_closest"], st["rays_radiance"] + st["rays_shadow"], st["speculated_discarded"])
     gpu.set_option("speculate", 8)
+    gpu.set_option("speculate_async", 0)
     base, launches0, rays0, dropped0 = out[0]
     assert dropped0 == 0
-    for spec in (8, 64):
+    for spec in (8, 64, (8, 1), (64, 1)):
         frames, launches, rays, dropped = out[spec]
         for k, (a, b) in enumerate(zip(base, frames)):
             for x, y in zip(a, b):
@@ -855,6 +860,8 @@ def test_speculative_subframes_are_exact(gpu):
         # the camera move and the index jump threw sub-frames away: they are reported, and their rays are NOT counted -- the ray
         # count of the delivered sub-frames is the one-pass-per-call count (equal shares per sub-frame of a pass: a fraction of a per cent)
         assert dropped > 0 and abs(rays - rays0) <= 0.005 * rays0, (spec, dropped, rays, rays0)
+    # a pass in flight when the camera moves is thrown away whole: the asynchronous scheme really had one
+    assert out[(8, 1)][3] > out[8][3] and out[(64, 1)][3] > out[64][3]
     assert not np.array_equal(base[8][0], base[9][0])
 
 
