@@ -2315,9 +2315,9 @@ skh_status skh_tonemap(skh_context* c, void* d_image, uint32_t width, uint32_t h
         return SKH_INVALID_ARGUMENT;
     (void)hipSetDevice(c->device);
     const uint32_t n = width * height; // the reference's kernels test `> n` (Tonemappers.cu:20); this build uses >= n
-    k_tonemap<<<(n + 255) / 256, 256, 0, c->stream>>>(reinterpret_cast<float4*>(d_image), n, type, exposure[0], exposure[1], exposure[2],
-                                                     gamma);
-    SKH_TRY(c, hipStreamSynchronize(c->stream));
+    hipStream_t st = c->spec.nextInFlight ? c->stream3 : c->stream; // (beside a pass traced ahead: not behind it)
+    k_tonemap<<<(n + 255) / 256, 256, 0, st>>>(reinterpret_cast<float4*>(d_image), n, type, exposure[0], exposure[1], exposure[2], gamma);
+    SKH_TRY(c, hipStreamSynchronize(st));
     return SKH_OK;
 }
 

@@ -49,6 +49,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         outs = []
         for cam_, i, act in calls:
             ctx.render_subframe(S.frame_params(cams[cam_], w, h, subframe_index=i, spp_total=spp, max_depth=depth), img.data_ptr())
+            if act == 5:
+                ctx.tonemap(img.data_ptr(), w, h, 1 + act % 3, (1.0, 1.0, 1.0), 2.2)  # OptiXRender::render ends with tonemap() when enabled
             if act < 6:
                 ctx.buffer_download(img.data_ptr(), host)  # map()
                 outs.append(host.copy())
