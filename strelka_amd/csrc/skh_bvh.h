@@ -742,6 +742,13 @@ __global__ void k_collapse(const CollapseItem* __restrict__ qin, uint32_t nIn, c
     float clo[W][3], chi[W][3];
     int refs[W];
     int first = it.first;
+    // the node's internal children get CONSECUTIVE output slots (one reservation): siblings a ray visits together share 128-byte lines
+    // (kitchen +1.3 ... 2.5 % against one reservation per child; starting groups on an even slot on top of that: nothing)
+    uint32_t nInternal = 0;
+    for (int k = 0; k < cnt; ++k)
+        nInternal += openable(slot[k]) ? 1u : 0u;
+    uint32_t nextOut = nInternal ? atomicAdd(allocCounter, nInternal) : 0u;
+    uint32_t nextQ = nInternal ? atomicAdd(nOut, nInternal) : 0u;
     for (int k = 0; k < cnt; ++k)
     {
         const int c = slot[k];
@@ -774,9 +781,9 @@ __global__ void k_collapse(const CollapseItem* __restrict__ qin, uint32_t nIn, c
         }
         else
         {
-            const uint32_t o = atomicAdd(allocCounter, 1u);
+            const uint32_t o = nextOut++;
             refs[k] = (int)o;
-            const uint32_t q = atomicAdd(nOut, 1u);
+            const uint32_t q = nextQ++;
             CollapseItem ni;
             ni.bin = c;
             ni.out = (int)o;
