@@ -15,7 +15,10 @@ bad = 0
 t0 = time.time()
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     rs = np.random.RandomState(seed)
-    sc = scenes.kitchen_standin(seed=seed, n_meshes=6, n_instances=20 + seed % 17, tri_lo=50, tri_hi=600) if seed % 3 else scenes.cornell_box()
+    if seed % 5 == 4:
+        sc = scenes.hair_standin(seed=seed, n_strands=200 + 30 * (seed % 7), n_cp=6 + seed % 4)  # the curve build of the kernels
+    else:
+        sc = scenes.kitchen_standin(seed=seed, n_meshes=6, n_instances=20 + seed % 17, tri_lo=50, tri_hi=600) if seed % 3 else scenes.cornell_box()
     arr = sc.arrays()
     w, h = int(rs.randint(24, 130)), int(rs.randint(16, 90))
     spp = int(rs.randint(3, 40))
