@@ -13,6 +13,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -175,16 +176,24 @@ def live_pmc(argv, spp, keep_dir=None):
     return fig
 
 
-def committed_pmc(workload, resolution):
+def pmc_file(scene, resolution):
+    """Where the counter figures of a workload are committed: the default workload in profiles/pmc_kernels.json, any other beside it."""
+    base = os.path.join(ROOT, "profiles", "pmc_kernels")
+    if scene == "kitchen" and resolution == "1920x1080":
+        return base + ".json"
+    return "%s_%s_%s.json" % (base, re.sub(r"[^A-Za-z0-9]+", "_", os.path.basename(str(scene))), resolution)
+
+
+def committed_pmc(workload, resolution, scene="kitchen"):
     """Fallback when the counters cannot be collected in this run: the last committed profile of the same workload."""
-    path = os.path.join(ROOT, "profiles", "pmc_kernels.json")
+    path = pmc_file(scene, resolution)
     try:
         j = json.load(open(path))
     except (OSError, ValueError):
         return None
     if j.get("workload") != workload or j.get("resolution") != resolution:
         return None
-    j["source"] = "replayed from profiles/pmc_kernels.json (tag %s), not measured in this run" % j.get("tag")
+    j["source"] = "replayed from profiles/%s (tag %s), not measured in this run" % (os.path.basename(path), j.get("tag"))
     j["replayed"] = True
     return j
 
@@ -551,7 +560,7 @@ def main():
         #   frac_valu_issue     VALU wave-instructions per second / (SIMDs x clock / 2): a wave64 VALU op issues over 2 cycles.
         #   cached_bw           SURVEY 8(d)'s algorithmic bytes / time: what L2 + Infinity Cache + HBM deliver together; it is
         #                       NOT divided by the HBM peak (most of those bytes never reach HBM).
-        pmc = PMC_RESULT if PMC_RESULT else committed_pmc(workload, f"{W}x{H}")
+        pmc = PMC_RESULT if PMC_RESULT else committed_pmc(workload, f"{W}x{H}", args.scene)
         info = ctx.device_info()
         clock_ghz = info["clock_khz"] / 1e6  # device maximum engine clock as this box's hipDeviceProp_t reports it
         simds = info["compute_units"] * info["simds_per_cu"]
@@ -665,7 +674,7 @@ def main():
             out["also"] = {"kitchen_unshared": extra}
         if args.pmc_save and PMC_RESULT:
             json.dump({**PMC_RESULT, "tag": args.pmc_save, "workload": workload, "resolution": f"{W}x{H}"},
-                      open(os.path.join(ROOT, "profiles", "pmc_kernels.json"), "w"), indent=1)
+                      open(pmc_file(args.scene, f"{W}x{H}"), "w"), indent=1)
         if os.environ.get("SKH_BENCH_CHECKSUM"):
             # CRC of the final accumulation image (tests: a tile-sharded N-rank run must reproduce the 1-rank image exactly)
             import zlib

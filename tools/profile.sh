@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pmc --no-drop-in "$@" > $OUT/bench_trace.log 2>&1
 cd $REPO
 python3 bench.py --steps 3 --warmup 1 --pmc-keep $OUT/pmc --pmc-save $TAG "$@" > $OUT/bench.json 2> $OUT/bench.err
-cp profiles/pmc_kernels.json $OUT/ 2>/dev/null
+cp profiles/pmc_kernels*.json $OUT/ 2>/dev/null   # (bench.py --pmc-save wrote the file of THIS workload: pmc_kernels.json for the default one)
 find $OUT -name "*.csv" | head -20
 tail -2 $OUT/bench_trace.log | cut -c1-400
 cat $OUT/bench.json

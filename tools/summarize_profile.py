@@ -3,7 +3,7 @@
   profiles/<tag>_kernel_stats.csv          rocprofv3 --kernel-trace --stats summary (per-kernel time)
   profiles/<tag>_pmc_hbm.csv               per-kernel FETCH_SIZE / WRITE_SIZE averages from the two --pmc passes
   profiles/<tag>_pmc_instructions.csv / _pmc_sq_utilisation.csv   SQ counters of the same passes
-  profiles/<tag>_bench.json, profiles/pmc_kernels.json     the bench line of that run and the counter figures bench.py replays
+  profiles/<tag>_bench.json, profiles/pmc_kernels[_<scene>_<res>].json   the bench line of that run and the counter figures bench.py replays
                                                                      (tagged as replayed) when it cannot run rocprofv3 itself
 Units/corrections follow /opt/skills/guides (MI355X_MICROARCH.md "HBM", cdna_hip_programming.md section 7):
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) reads, so
@@ -50,9 +50,18 @@ def main():
         lines = [l for l in open(logs) if l.startswith("{")]
         if lines:
             open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w").write(lines[-1])
-    for name, out in (("bench.json", f"{tag}_bench.json"), ("pmc_kernels.json", "pmc_kernels.json")):
-        if os.path.exists(os.path.join(src, name)):
-            shutil.copy(os.path.join(src, name), os.path.join(dst, out))
+    if os.path.exists(os.path.join(src, "bench.json")):
+        shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
+    # the counter figures bench.py replays: one file per workload (pmc_kernels.json = the default one), only the one this run wrote
+    import glob
+    import json
+
+    for f in glob.glob(os.path.join(src, "pmc_kernels*.json")):
+        try:
+            if json.load(open(f)).get("tag") == tag:
+                shutil.copy(f, os.path.join(dst, os.path.basename(f)))
+        except (OSError, ValueError):
+            pass
     # the counter passes bench.py ran itself (--pmc-keep): pass0 FETCH_SIZE, pass1 WRITE_SIZE, pass2 SQ counters
     fetch = pmc(os.path.join(src, "pmc", "pass0"), "FETCH_SIZE")
     write = pmc(os.path.join(src, "pmc", "pass1"), "WRITE_SIZE")
