@@ -90,3 +90,22 @@ def test_a_real_multi_gpu_run_never_times_the_fallback_gather():
     assert not bench.gather_fallback_allowed("nccl", {})  # one rank per GPU: no communicator below the C ABI = exit code 3
     assert bench.gather_fallback_allowed("nccl", {"SKH_ALLOW_GATHER_FALLBACK": "1"})
     assert bench.gather_fallback_allowed("gloo", {})  # the 1-GPU tests: two ranks share cuda:0, RCCL refuses that by design
+
+
+def test_committed_counter_files_are_kept_per_workload():
+    """profiles/pmc_kernels.json belongs to the default workload; a profile of another scene must not replace it (round 3: a hair
+    profile did), and a run that cannot collect counters only replays figures of ITS workload and resolution."""
+    import json
+    import os
+
+    import bench
+
+    assert os.path.basename(bench.pmc_file("kitchen", "1920x1080")) == "pmc_kernels.json"
+    assert os.path.basename(bench.pmc_file("hair", "1920x1080")) == "pmc_kernels_hair_1920x1080.json"
+    assert os.path.basename(bench.pmc_file("kitchen", "3840x2160")) == "pmc_kernels_kitchen_3840x2160.json"
+    j = json.load(open(bench.pmc_file("kitchen", "1920x1080")))
+    assert j["workload"].startswith("kitchen stand-in") and j["resolution"] == "1920x1080" and set(j["kernels"]) == {"closest", "shadow", "shade"}
+    got = bench.committed_pmc(j["workload"], "1920x1080", "kitchen")
+    assert got["replayed"] and "pmc_kernels.json" in got["source"]
+    assert bench.committed_pmc(j["workload"], "3840x2160", "kitchen") is None
+    assert bench.committed_pmc("some other scene", "1920x1080", "kitchen") is None
