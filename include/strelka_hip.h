@@ -265,7 +265,10 @@ skh_status skh_resize(skh_context* ctx, uint32_t width, uint32_t height);
 skh_status skh_set_tiles(skh_context* ctx, uint32_t tile_size, const uint32_t* tile_xy, uint32_t n_tiles);
 
 /* ---- OptiXRender::render's optixLaunch (OptixRender.cpp:1006-1021): one sub-frame batch.
- *      d_image may be NULL (only accum is updated).  Synchronous, like the reference. ---- */
+ *      d_image may be NULL (only accum is updated).  Synchronous, like the reference: the image is complete when the call returns.
+ *      Called once per sub-frame the library traces ahead (options speculate, speculate_async); the image is then written on a stream
+ *      of the library's own that does NOT wait for the caller's null-stream work: d_image must have no writes of the caller's still
+ *      pending when the call is made (the reference's callers only ever read it, RenderPass.cpp:441-447). ---- */
 skh_status skh_render_subframe(skh_context* ctx, const skh_frame_params* params, void* d_image);
 /* Called once per sub-frame, as HdStrelkaRenderPass::_Execute calls render() (RenderPass.cpp:441-447), the library traces ahead:
  * once two consecutive calls continue the same frame (identical parameters, subframe_index + 1) the next call traces 2, then 4,
