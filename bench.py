@@ -136,7 +136,8 @@ def live_pmc(argv, spp, keep_dir=None):
             pass
         else:
             child.append(a)
-    child += ["--pmc-child", "--steps", "1", "--warmup", "0", "--spp", str(min(spp, 32)), "--no-cpu-baseline", "--no-pmc", "--no-drop-in"]
+    # (the children trace the SAME pass size as the timed run -- all `spp` sub-frames in one pass: a launch there is a launch here)
+    child += ["--pmc-child", "--steps", "1", "--warmup", "0", "--spp", str(spp), "--no-cpu-baseline", "--no-pmc", "--no-drop-in"]
     root = os.path.abspath(keep_dir) if keep_dir else tempfile.mkdtemp(prefix="skh_pmc_", dir="/tmp")  # (absolute: the children run in /tmp)
     os.makedirs(root, exist_ok=True)
     env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "LD_PRELOAD"))}
@@ -154,7 +155,7 @@ def live_pmc(argv, spp, keep_dir=None):
         cmd = [rocprof, "--pmc", *group, "--output-format", "csv", "-d", outdir, "--", sys.executable, os.path.abspath(__file__)] + child
         t0 = time.time()
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
         except (OSError, subprocess.TimeoutExpired) as e:
             return fail("pass %d: %s" % (k, type(e).__name__))
         seconds.append(round(time.time() - t0, 1))
@@ -283,24 +284,34 @@ def scene_cache_path(name):
     return os.path.join("/tmp", "skh_bench_%s_%s_%d.skscene" % (name, h.hexdigest()[:12], os.getuid()))
 
 
-def load_workload(name, make=True):
-    """(scene, workload line).  Procedural scenes go through the /tmp cache (make=False: wait for another process to write it)."""
+def load_workload(name, make=True, writer="local rank 0"):
+    """(scene, workload line).  Procedural scenes go through the /tmp cache (make=False: wait for this NODE's writer -- local rank 0 --
+    to write it; a writer that fails leaves a `.failed` marker so that the waiters stop at once instead of timing out)."""
     from strelka_amd import scene_io, scenes
 
     if name in SCENE_RECIPES:
         gen, line = SCENE_RECIPES[name]
         path = scene_cache_path(name)
+        failed = path + ".failed"
         if not os.path.exists(path):
             if make:
-                sc = gen(scenes)
-                tmp = "%s.tmp.%d" % (path, os.getpid())
-                scene_io.save_scene(tmp, sc.arrays(), sc.getCamera())
-                os.replace(tmp, path)
+                try:
+                    if os.path.exists(failed):
+                        os.remove(failed)
+                    sc = gen(scenes)
+                    tmp = "%s.tmp.%d" % (path, os.getpid())
+                    scene_io.save_scene(tmp, sc.arrays(), sc.getCamera())
+                    os.replace(tmp, path)
+                except BaseException as e:
+                    open(failed, "w").write("%s: %s\n" % (type(e).__name__, e))
+                    raise
             else:
                 t0 = time.time()
                 while not os.path.exists(path):
-                    if time.time() - t0 > 600:
-                        raise RuntimeError("scene cache %s did not appear" % path)
+                    if os.path.exists(failed) and os.path.getmtime(failed) >= t0 - 1.0:
+                        raise RuntimeError("scene cache %s: the writer (%s) failed: %s" % (path, writer, open(failed).read().strip()))
+                    if time.time() - t0 > 300:
+                        raise RuntimeError("scene cache %s did not appear within 300 s (writer: %s of this node)" % (path, writer))
                     time.sleep(0.2)
         sc = scene_io.load_scene(path)
     elif name.endswith((".gltf", ".glb")):
@@ -349,6 +360,21 @@ def other_workload_leg(name, W, H, spp, depth, device_ordinal, steps=2):
             "scene_load_s": round(load_s, 1)}
 
 
+def roofline_fractions(algorithmic_bytes_per_launch, counter_bytes_per_launch, avg_launch_ms, peak_gbs=HBM_PEAK_GBS):
+    """The two fractions a reader may want, side by side:
+      algorithmic_frac    SURVEY 8(d)'s no-reuse byte model / launch time / HBM peak.  Above 1 (`model_exceeds_peak`) it has stopped
+                          being a roofline: L2 + Infinity Cache serve part of those bytes, the kernel is still doing all the work.
+      frac (elsewhere)    the TCC counter bytes / time / peak: `frac_kind` = "counter_upper_bound" (FETCH_SIZE counts Infinity-Cache hits).
+      l2_hit_share        1 - counter bytes / algorithmic bytes: the share of the model's bytes that never left the L2s (None without counters)."""
+    out = {"algorithmic_frac": None, "model_exceeds_peak": None, "l2_hit_share": None}
+    if avg_launch_ms and avg_launch_ms > 0 and algorithmic_bytes_per_launch:
+        out["algorithmic_frac"] = round(algorithmic_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 / peak_gbs, 4)
+        out["model_exceeds_peak"] = bool(out["algorithmic_frac"] > 1.0)
+        if counter_bytes_per_launch is not None:
+            out["l2_hit_share"] = round(1.0 - counter_bytes_per_launch / algorithmic_bytes_per_launch, 4)
+    return out
+
+
 def shade_bytes(rays, next_rays, shadow_rays):
     """k_shade, algorithmic: ray 36 r + hit record 32 r + path state 32 r + 32 w per ray; per surface hit (every ray counted as
     one: upper bound) instance 64 + 64, shading triangle 96, material 64; 36 w per continuation ray, 36 + 12 w per shadow ray."""
@@ -376,6 +402,7 @@ def main():
     ap.add_argument("--pmc-save", default=None, metavar="TAG", help="write the live counter figures to profiles/pmc_kernels.json under this tag")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the one-render()+map()-per-sub-frame leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the second workload (kitchen_unshared) timed beside the headline")
+    ap.add_argument("--strict", action="store_true", help="exit 4 when a LIVE counter fraction (HBM bytes or VALU issue) comes out above 1")
     args = ap.parse_args()
 
     rc = maybe_self_launch(args, sys.argv[1:])
@@ -387,7 +414,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # the scene: generated (or loaded from the /tmp cache) before the GPU is touched; one process of a job writes the cache
     t_scene = time.time()
-    sc, arr, workload = load_workload(args.scene, make=(rank == 0))
+    sc, arr, workload = load_workload(args.scene, make=(local_rank == 0))  # (per NODE: /tmp is not shared between nodes)
     t_scene = time.time() - t_scene
     global PMC_RESULT
     if world == 1 and not args.no_pmc and not args.pmc_child:
@@ -546,6 +573,7 @@ def main():
     else:
         rays_total = float(rays_local)
 
+    strict_fail = False
     drop_in = None
     if rank == 0 and world == 1 and not args.no_drop_in and not args.pmc_child:
         drop_in = drop_in_leg(ctx, params, W, H, args.spp, torch, dev)
@@ -581,13 +609,14 @@ def main():
             upl = units[name] * K / launches  # rays (paths for k_shade) per launch
             blk = {"kernel": {"closest": "k_trace<closest>", "shadow": "k_trace<shadow>", "shade": "k_shade"}[name], "bound": "hbm",
                    "avg_launch_ms": round(avg_ms, 4), "launches_per_frame": launches // K, "units_per_launch": int(upl),
-                   "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+                   "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "frac_kind": "counter_upper_bound", "traffic": None}
             pk = (pmc or {}).get("kernels", {}).get(name)
             if pk and pk.get("hbm_bytes_per_launch") and avg_ms > 0:
                 scale = upl / pk["rays_per_launch"] if pk.get("rays_per_launch") else 1.0
                 blk["traffic"] = int(pk["hbm_bytes_per_launch"] * scale)
                 blk["achieved"] = round(blk["traffic"] / (avg_ms * 1e-3) / 1e9, 2)
                 blk["frac"] = round(blk["achieved"] / HBM_PEAK_GBS, 5)
+                blk["counter_scale"] = round(scale, 4)  # timed launch size / the counter pass's launch size (1.0: same pass size)
                 blk["write_bytes_per_unit"] = round(pk["WRITE_SIZE_KiB"] * 1024.0 / max(1, pk["rays_per_launch"]), 1)
                 blk["fetch_bytes_per_unit"] = round(2.0 * pk["FETCH_SIZE_KiB"] * 1024.0 / max(1, pk["rays_per_launch"]), 1)
                 if blk["frac"] > 1.0:
@@ -606,6 +635,7 @@ def main():
             bpl = alg[name] * K / launches
             blk["cached_bw"] = {"GB/s": round(bpl / (avg_ms * 1e-3) / 1e9, 2) if avg_ms > 0 else 0.0, "algorithmic_bytes_per_launch": int(bpl),
                                 "algorithmic_bytes_per_unit": round(alg[name] / max(1, units[name]), 1)}
+            blk.update(roofline_fractions(bpl, blk["traffic"], avg_ms))
             kern[name] = blk
         # ---- measured memory ceilings of this box (skh_probe_memory; SURVEY 8(d) "report a measured STREAM-copy ceiling"): a uint4
         #      copy, and random aligned 64- / 128-byte record fetches from one-wave workgroups on the trace kernels' grid over a buffer
@@ -614,6 +644,8 @@ def main():
         #      L2-miss rate is compared in lines/s: FETCH_SIZE KiB x 1024 / 64 = requests = lines.
         ceilings = None
         try:
+            if args.pmc_child:
+                raise RuntimeError("counter child pass: not measured under the profiler")
             psize = 1792 << 20
             copy = ctx.probe_memory(0, psize)[0]
             g64, g128, c64 = ctx.probe_memory(1, psize, 64)[0], ctx.probe_memory(1, psize, 128)[0], ctx.probe_memory(2, psize, 64)[0]
@@ -634,7 +666,9 @@ def main():
         nrs = max(1, cst["rays_shadow"])
         c0 = kern["closest"]
         roofline = {"kernel": "k_trace<closest>", "bound": "hbm", "achieved": c0["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": c0["frac"],
-                    "frac_is": "upper bound on HBM use: FETCH_SIZE counts Infinity-Cache hits",
+                    "frac_kind": "counter_upper_bound", "frac_is": "upper bound on HBM use: FETCH_SIZE counts Infinity-Cache hits",
+                    "algorithmic_frac": c0["algorithmic_frac"], "model_exceeds_peak": c0["model_exceeds_peak"], "l2_hit_share": c0["l2_hit_share"],
+                    "algorithmic_frac_is": "SURVEY 8(d) no-reuse bytes / time / peak; above 1 = the caches serve part of the model's bytes",
                     "traffic": c0["traffic"], "traffic_source": pmc.get("source") if pmc else None,
                     "limiter": "valu_issue (divergence): see valu", "valu": c0.get("valu"),
                     "cached_bw": dict(c0["cached_bw"], note="SURVEY 8(d) bytes / time; served by L2 + Infinity Cache + HBM together, not an HBM fraction"),
@@ -684,10 +718,15 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(arr, cam, W, H, args.spp, args.depth, args.cpu_budget)
         print(json.dumps(out), flush=True)
+        if args.strict and flags and PMC_RESULT:
+            sys.stderr.write("[bench] --strict: a live counter fraction exceeds 1\n")
+            strict_fail = True
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if strict_fail:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

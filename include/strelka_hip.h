@@ -362,6 +362,37 @@ typedef struct skh_bsdf_result
 } skh_bsdf_result;
 skh_status skh_bsdf_probe(skh_context* ctx, const skh_bsdf_query* queries, uint32_t n, skh_bsdf_result* results);
 
+/* ---- unit probes (tests) ----
+ * The device functions of the sampler (A2), the light samplers / pdfs / MIS weight (A4, A5) and the accumulator (A10), run on the GPU
+ * one call per record, so that GPU tests can hold the HIP code against the fixtures the REFERENCE's own headers produced
+ * (tests/golden/, generated by oracle/ref_golden.cpp).  Reference code probed: RandomSampler.h:130-137,166-175,213-226;
+ * Lights.h:28-84,201-362; OptixRender.cu:60-78 + postprocessing/Utils.h:5-14.  Records are packed 32-bit words:
+ *   unit                    consts               in (per record)                          param                         out (per record)
+ *   SKH_UNIT_SAMPLER        --                   u32 x, y, sampleIndex, depth, dim        sppTotal                      u32 bits of random<dim>, bits of the same
+ *                                                                                                                       value through the LDS-table path k_shade uses, sampleIdx
+ *   SKH_UNIT_SOBOL          --                   u32 index, dim                           --                            u32 sobol_uint
+ *   SKH_UNIT_LIGHT_SAMPLE   UniformLight (112 B) f32 P[3], u[2]                           0 rect uniform | 1 spherical  f32 pointOnLight[3], pdf, normal[3], area,
+ *                                                                                         rect | 2 sphere | 3 distant   L[3], distToLight
+ *   SKH_UNIT_LIGHT_PDF      UniformLight         f32 lightHitPoint[3], surfacePoint[3]    --                            f32 getLightPdf
+ *   SKH_UNIT_LIGHT_NORMAL   UniformLight         f32 hitPoint[3]                          --                            f32 calcLightNormal[3], calcLightArea
+ *   SKH_UNIT_MIS            --                   f32 a, b                                 --                            f32 misWeightBalance(a, b)
+ *   SKH_UNIT_ACCUMULATE     f32 exposure[3]      f32 value[3]  (a SEQUENCE: record k is   first sub-frame index         f32 accumulator[3] after record k
+ *                                                folded into the result of 0..k-1)
+ *   SKH_UNIT_TONEMAP        f32 exposure[3]      f32 color[3]                             --                            f32 tonemap[3], inverseTonemap[3] */
+typedef enum skh_unit
+{
+    SKH_UNIT_SAMPLER = 0,
+    SKH_UNIT_SOBOL = 1,
+    SKH_UNIT_LIGHT_SAMPLE = 2,
+    SKH_UNIT_LIGHT_PDF = 3,
+    SKH_UNIT_LIGHT_NORMAL = 4,
+    SKH_UNIT_MIS = 5,
+    SKH_UNIT_ACCUMULATE = 6,
+    SKH_UNIT_TONEMAP = 7,
+    SKH_UNIT_COUNT = 8
+} skh_unit;
+skh_status skh_unit_probe(skh_context* ctx, uint32_t unit, uint32_t param, const void* consts, const void* in, uint32_t n, void* out);
+
 /* ---- options / stats ----
  * None of the options changes a result: hit records and images are bit-identical for every setting
  * (tests/test_gpu_parity.py::test_results_do_not_depend_on_the_acceleration_structure_or_scheduling) -- with ONE exception,

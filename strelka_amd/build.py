@@ -23,6 +23,8 @@ def hipcc():
 
 
 def needs_build():
+    if os.environ.get("SKH_LIB") and os.path.exists(LIB):
+        return False  # an A/B variant somebody built with its own -D flags: never rebuilt (with the default flags) behind their back
     return not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS)
 
 

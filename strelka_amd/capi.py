@@ -26,7 +26,7 @@ SYMBOLS = ["skh_create", "skh_destroy", "skh_last_error", "skh_abi_version", "sk
            "skh_render_subframe", "skh_render_subframes", "skh_tonemap", "skh_read_accum", "skh_read_aov",
            "skh_buffer_alloc", "skh_buffer_free", "skh_buffer_download", "skh_copy_accum", "skh_copy_accum_tiles", "skh_scatter_tiles", "skh_trace", "skh_trace_device",
            "skh_set_option", "skh_get_stats", "skh_reset_stats", "skh_synchronize", "skh_get_stream", "skh_bsdf_probe", "skh_get_device_info", "skh_comm_unique_id", "skh_comm_init",
-           "skh_comm_destroy", "skh_gather_tiles", "skh_host_register", "skh_host_unregister", "skh_get_baked", "skh_comm_info", "skh_probe_memory"]
+           "skh_comm_destroy", "skh_gather_tiles", "skh_host_register", "skh_host_unregister", "skh_get_baked", "skh_comm_info", "skh_probe_memory", "skh_unit_probe"]
 
 DEVICE_INFO = np.dtype([("compute_units", np.uint32), ("simds_per_cu", np.uint32), ("clock_khz", np.uint32), ("memory_clock_khz", np.uint32),
                         ("memory_bus_bits", np.uint32), ("wavefront_size", np.uint32), ("total_memory_bytes", np.uint64), ("name", "S64")])
@@ -85,6 +85,7 @@ def load():
     lib.skh_trace.argtypes = [vp, vp, u32, u32, vp]
     lib.skh_trace_device.argtypes = [vp, vp, u32, u32, vp, u32]
     lib.skh_bsdf_probe.argtypes = [vp, vp, u32, vp]
+    lib.skh_unit_probe.argtypes = [vp, u32, u32, vp, vp, u32, vp]
     lib.skh_get_device_info.argtypes = [vp, vp]
     lib.skh_host_register.argtypes = [vp, vp, C.c_size_t]
     lib.skh_host_unregister.argtypes = [vp, vp]
@@ -250,6 +251,21 @@ class Context:
         q = np.ascontiguousarray(queries, BSDF_QUERY)
         out = np.zeros(len(q), BSDF_RESULT)
         self._ck(self.lib.skh_bsdf_probe(self.h, _p(q), len(q), _p(out)), "skh_bsdf_probe")
+        return out
+
+    # skh_unit: (words in, words out) per record
+    UNITS = {"sampler": (0, 5, 3), "sobol": (1, 2, 1), "light_sample": (2, 5, 12), "light_pdf": (3, 6, 1), "light_normal": (4, 3, 4),
+             "mis": (5, 2, 1), "accumulate": (6, 3, 3), "tonemap": (7, 3, 6)}
+
+    def unit_probe(self, unit, records, param=0, consts=None):
+        """skh_unit_probe: one device call of the named function per record (include/strelka_hip.h lists the record layouts);
+        `records` is an (n, words_in) array of 32-bit words, the result an (n, words_out) uint32 array (view it as float32)."""
+        uid, win, wout = self.UNITS[unit]
+        r = np.ascontiguousarray(records).reshape(-1, win)
+        assert r.dtype.itemsize == 4
+        out = np.zeros((len(r), wout), np.uint32)
+        cst = None if consts is None else np.ascontiguousarray(consts)
+        self._ck(self.lib.skh_unit_probe(self.h, uid, int(param), None if cst is None else _p(cst), _p(r), len(r), _p(out)), "skh_unit_probe")
         return out
 
     @staticmethod

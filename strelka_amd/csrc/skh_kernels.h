@@ -242,6 +242,13 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 #ifndef SKH_TRACE_ATTR
 #define SKH_TRACE_ATTR
 #endif
+#ifndef SKH_POP_CULL
+#define SKH_POP_CULL 0 // 1: the world-only closest-hit build keeps a 16-bit rounded-down entry distance beside every LDS stack reference and drops a
+                       // popped entry whose box lies beyond the current best hit WITHOUT fetching its node (see docs/LOG.md, round 4)
+#endif
+#ifndef SKH_PREFETCH2
+#define SKH_PREFETCH2 0 // 1: touch load of the second-nearest hit child's line, issued behind the nearest child's node fetch
+#endif
 // The 8 ray-fetch cursors of a launch sit in separate 128-byte lines: returning atomics on ONE line serialise at ~88 per
 // microsecond chip-wide (measured), which eight cursors in the same line would share.
 #define SKH_FETCH_STRIDE 32
@@ -269,8 +276,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
             StatsDev* __restrict__ stats)
 {
-    static_assert(!WORLD || (!CURVES && !W8), "the world-only build is the 4-wide triangle kernel");
+    static_assert(!WORLD || !CURVES, "the world-only build is a triangle kernel");
     __shared__ int s_stack[SKH_STACK_LDS * SKH_TRACE_BLOCK];
+    constexpr bool CULL = SKH_POP_CULL && WORLD && !ANY_HIT && !W8;
+    __shared__ unsigned short s_tnear[CULL ? SKH_STACK_LDS * SKH_TRACE_BLOCK : 1]; // entry distance of the LDS stack entries, top 16 bits of the float (rounded down)
     const uint32_t fetchMin = fetchArg & 0xffu, curveMin = (fetchArg >> 8) & 0xffu, nodeBreak = (fetchArg >> 16) & 0xffu, leafMin = fetchArg >> 24;
     const uint32_t lane = threadIdx.x;
     uint32_t n = 0; // (countPtr: SKH_SHARDS queue-length words, SKH_COUNT_STRIDE apart)
@@ -284,6 +293,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
     uint32_t tries = 0;
     bool exhausted = false;
     int* lds = s_stack + lane;
+    unsigned short* ldsT = s_tnear + (CULL ? lane : 0u);
     int* ovf = ovfBase + (blockIdx.x * SKH_TRACE_BLOCK + lane);
     const uint32_t ovfStride = gridDim.x * SKH_TRACE_BLOCK;
     const uint32_t rayMask = CURVES ? (ANY_HIT ? 3u : 255u) : (ANY_HIT ? 1u : 253u);
@@ -314,6 +324,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
     bool inBlas = false;
     uint32_t curInst = 0, curType = 0;
     int sp = 0, cur = SKH_REF_INVALID;
+    constexpr bool PF2 = SKH_PREFETCH2 && WORLD && !ANY_HIT && !W8;
+    int pf = SKH_REF_INVALID; // (PF2) the second-nearest hit child of the node just processed: its line is touched behind the next node fetch
+    int pfv = 0;
     HitRec best;
     best.t = 0.0f, best.inst = best.prim = 0xffffffffu, best.u = best.v = 0.0f, best.found = false;
 
@@ -331,9 +344,19 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
     {                                                                \
         --sp;                                                        \
         if (sp < SKH_STACK_LDS)                                      \
+        {                                                            \
             dst = lds[sp * SKH_TRACE_BLOCK];                         \
+            /* pop-time culling: the same acceptance test the entry passed when it was pushed, against today's best.t; the stored distance is   \
+               rounded DOWN, so an entry is dropped only if the slab test would reject it now: results cannot change */                       \
+            if (CULL && __uint_as_float((uint32_t)ldsT[sp * SKH_TRACE_BLOCK] << 16) > best.t * SKH_SLAB_SLACK)                                 \
+                dst = SKH_REF_INVALID;                               \
+        }                                                            \
         else if (sp < SKH_STACK_LDS + SKH_STACK_OVF)                 \
+        {                                                            \
             dst = ovf[(size_t)(sp - SKH_STACK_LDS) * ovfStride];     \
+            if (PF2)                                                 \
+                asm volatile("" ::"v"(dst)); /* the wait for this (rare) global read stays inside its branch: at the join it would cover the touch load in flight too */ \
+        }                                                            \
         else                                                         \
             dst = SKH_REF_INVALID;                                   \
     }
@@ -438,6 +461,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                     if (wr0 != SKH_REF_INVALID && wr1 != SKH_REF_INVALID)
                     {
                         lds[sp * SKH_TRACE_BLOCK] = wr1;
+                        if (CULL)
+                            ldsT[sp * SKH_TRACE_BLOCK] = 0; // (no entry distance known: never culled)
                         ++sp;
                     }
                     cur = wr0 != SKH_REF_INVALID ? wr0 : wr1;
@@ -747,6 +772,18 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                 // one 64-byte fetch = four quantised child boxes
                 const float4* np = reinterpret_cast<const float4*>((WORLD ? sc.triNodes : nodes) + cur);
                 const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+                if (PF2)
+                {
+                    // issued AFTER this node's four loads: vector loads return in order, so the wait for the node (vmcnt(1)) leaves the touch in
+                    // flight; its value is "used" one iteration later, when it has long arrived behind that iteration's node
+                    asm volatile("" ::"v"(pfv));
+                    // branch-free (a conditional touch would make the wait for the node cover it too): no candidate = this node's own line again
+                    const bool isl = pf < 0;
+                    const uint32_t idx = isl ? (((uint32_t)~pf) >> 3) * 3u : (uint32_t)pf * 4u; // in 16-byte units
+                    const float4* base = isl ? sc.tris : reinterpret_cast<const float4*>(sc.triNodes);
+                    const float4* ta = pf != SKH_REF_INVALID ? base + idx : np;
+                    pfv = *reinterpret_cast<const int*>(ta); // (kept alive by the asm above, one iteration later)
+                }
                 if (COUNT)
                     tc.nodes++;
                 SKH_LP(if (!inBlas) tc.segs++;) // (profile build: TLAS share of the node visits, reported as "segs")
@@ -801,18 +838,41 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                         p[0] = c == 3 ? rf[3] : (c == 2 ? rf[2] : rf[1]);
                         p[SKH_TRACE_BLOCK] = c == 3 ? rf[2] : rf[1];
                         p[2 * SKH_TRACE_BLOCK] = rf[1];
+                        if (CULL)
+                        {
+                            unsigned short* q = ldsT + sp * SKH_TRACE_BLOCK;
+                            const uint32_t q1 = __float_as_uint(tn[1]) >> 16, q2 = __float_as_uint(tn[2]) >> 16, q3 = __float_as_uint(tn[3]) >> 16;
+                            q[0] = (unsigned short)(c == 3 ? q3 : (c == 2 ? q2 : q1));
+                            q[SKH_TRACE_BLOCK] = (unsigned short)(c == 3 ? q2 : q1);
+                            q[2 * SKH_TRACE_BLOCK] = (unsigned short)q1;
+                        }
                         sp += c;
                     }
                     else
                     {
+                        // (entries that go to the global overflow area carry no distance; LDS ones written here get 0 = never culled)
                         if (tn[3] < INFINITY)
+                        {
+                            if (CULL && sp < SKH_STACK_LDS)
+                                ldsT[sp * SKH_TRACE_BLOCK] = (unsigned short)(__float_as_uint(tn[3]) >> 16);
                             SKH_PUSH(rf[3]);
+                        }
                         if (tn[2] < INFINITY)
+                        {
+                            if (CULL && sp < SKH_STACK_LDS)
+                                ldsT[sp * SKH_TRACE_BLOCK] = (unsigned short)(__float_as_uint(tn[2]) >> 16);
                             SKH_PUSH(rf[2]);
+                        }
                         if (tn[1] < INFINITY)
+                        {
+                            if (CULL && sp < SKH_STACK_LDS)
+                                ldsT[sp * SKH_TRACE_BLOCK] = (unsigned short)(__float_as_uint(tn[1]) >> 16);
                             SKH_PUSH(rf[1]);
+                        }
                     }
                     cur = tn[0] < INFINITY ? rf[0] : SKH_REF_INVALID;
+                    if (PF2)
+                        pf = tn[1] < INFINITY ? rf[1] : SKH_REF_INVALID;
                 }
                 else
                 {
@@ -831,7 +891,12 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                 }
                 // a lane whose node had no hit child takes its next stack entry right here instead of idling until
                 // the whole wave leaves the node loop
-                if (cur == SKH_REF_INVALID && sp > 0)
+                if (CULL)
+                {
+                    while (cur == SKH_REF_INVALID && sp > 0)
+                        SKH_POP(cur);
+                }
+                else if (cur == SKH_REF_INVALID && sp > 0)
                     SKH_POP(cur);
                 // few lanes still descending while the rest wait at their leaves: let the leaves go first
                 if ((uint32_t)__popcll(__ballot(cur >= 0 && cur != SKH_REF_INVALID)) < breakBelow)
@@ -1050,6 +1115,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                         inBlas = false;
                         continue;
                     }
+                    if (CULL && cur == SKH_REF_INVALID)
+                        continue; // culled at pop time: take the next entry
                     break;
                 }
             }

@@ -1967,9 +1967,12 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
     StatsDev* sd = c->dStats.as<StatsDev>();
     const uint32_t fullGrid = (ANY && !c->nSegs) ? (uint32_t)c->numCUs * c->wavesPerCUShadow : c->traceBlocks;
     const uint32_t blocks = c->gridOverride ? std::min(c->gridOverride, fullGrid) : fullGrid;
-    if (c->wide != 8 && !c->nSegs && c->tlasRoot == SKH_REF_INVALID && (c->worldRoot != SKH_REF_INVALID || c->lightRoot != SKH_REF_INVALID) && c->worldKernel)
+    const bool worldOnly = !c->nSegs && c->tlasRoot == SKH_REF_INVALID && (c->worldRoot != SKH_REF_INVALID || c->lightRoot != SKH_REF_INVALID) && c->worldKernel;
+    if (worldOnly && c->wide != 8)
         // every instance is baked: the world-only build of the kernel (no instance entry, no object-space copy of the ray)
         k_trace<ANY, COUNT, false, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
+    else if (worldOnly)
+        k_trace<ANY, COUNT, false, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
     else if (c->wide == 8)
     {
         if (c->nSegs)
@@ -2994,6 +2997,129 @@ skh_status skh_bsdf_probe(skh_context* c, const skh_bsdf_query* queries, uint32_
     if (e != hipSuccess)
     {
         c->err = std::string("skh_bsdf_probe: ") + hipGetErrorString(e);
+        return SKH_FAIL;
+    }
+    return SKH_OK;
+}
+
+// ---- unit probes (tests): the device functions of the sampler, the light samplers and the accumulator, one call per record, so that
+// GPU tests can hold the HIP code against the reference-generated fixtures of tests/golden/ directly ----
+static const uint32_t kUnitIn[SKH_UNIT_COUNT] = { 20, 8, 20, 24, 12, 8, 12, 12 }, kUnitOut[SKH_UNIT_COUNT] = { 12, 4, 48, 4, 16, 4, 12, 24 };
+static const uint32_t kUnitConst[SKH_UNIT_COUNT] = { 0, 0, 112, 112, 112, 0, 12, 12 };
+__global__ void __launch_bounds__(256) k_unit_probe(uint32_t unit, uint32_t param, const float* __restrict__ consts, const uint32_t* __restrict__ in, uint32_t n,
+                                                    uint32_t* __restrict__ out)
+{
+    __shared__ uint32_t s_lut[SKH_SOBOL_LUT_WORDS]; // the byte-folded Sobol table as k_shade stages it
+    for (uint32_t k = threadIdx.x; k < SKH_SOBOL_LUT_WORDS; k += blockDim.x)
+        s_lut[k] = g_sobol_lut[k];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float* fin = reinterpret_cast<const float*>(in);
+    float* fout = reinterpret_cast<float*>(out);
+    Light l;
+    if (unit == SKH_UNIT_LIGHT_SAMPLE || unit == SKH_UNIT_LIGHT_PDF || unit == SKH_UNIT_LIGHT_NORMAL)
+        l = *reinterpret_cast<const Light*>(consts);
+    switch (unit)
+    {
+    case SKH_UNIT_SAMPLER: {
+        const uint32_t* r = in + 5 * (size_t)i;
+        Sampler s = init_sampler(r[0], r[1], r[2], param, 52u); // seed 52: OptixRender.cu:101
+        s.depth = r[3];
+        out[3 * (size_t)i] = __float_as_uint(sampler_random(s, r[4]));
+        out[3 * (size_t)i + 1] = __float_as_uint(sampler_random_lut(s, r[4], s_lut));
+        out[3 * (size_t)i + 2] = s.sampleIdx;
+        break;
+    }
+    case SKH_UNIT_SOBOL:
+        out[i] = sobol_uint(in[2 * (size_t)i], in[2 * (size_t)i + 1]);
+        break;
+    case SKH_UNIT_LIGHT_SAMPLE: {
+        const float* r = fin + 5 * (size_t)i;
+        const v3 P = mk3(r[0], r[1], r[2]);
+        LightSample d;
+        if (param == 0)
+            d = sample_rect_light_uniform(l, r[3], r[4], P);
+        else if (param == 1)
+            d = sample_rect_light(l, r[3], r[4], P);
+        else if (param == 2)
+            d = sample_sphere_light(l, r[3], r[4], P);
+        else
+            d = sample_distant_light(l, r[3], r[4]);
+        float* o = fout + 12 * (size_t)i;
+        o[0] = d.pointOnLight.x, o[1] = d.pointOnLight.y, o[2] = d.pointOnLight.z, o[3] = d.pdf;
+        o[4] = d.normal.x, o[5] = d.normal.y, o[6] = d.normal.z, o[7] = d.area;
+        o[8] = d.L.x, o[9] = d.L.y, o[10] = d.L.z, o[11] = d.distToLight;
+        break;
+    }
+    case SKH_UNIT_LIGHT_PDF: {
+        const float* r = fin + 6 * (size_t)i;
+        fout[i] = get_light_pdf(l, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]));
+        break;
+    }
+    case SKH_UNIT_LIGHT_NORMAL: {
+        const float* r = fin + 3 * (size_t)i;
+        const v3 nn = calc_light_normal(l, mk3(r[0], r[1], r[2]));
+        fout[4 * (size_t)i] = nn.x, fout[4 * (size_t)i + 1] = nn.y, fout[4 * (size_t)i + 2] = nn.z, fout[4 * (size_t)i + 3] = calc_light_area(l);
+        break;
+    }
+    case SKH_UNIT_MIS:
+        fout[i] = mis_weight_balance(fin[2 * (size_t)i], fin[2 * (size_t)i + 1]);
+        break;
+    case SKH_UNIT_ACCUMULATE: {
+        // a SEQUENCE: record k is folded into the running value of records 0..k-1 (sub-frame index param + k): one thread
+        if (i != 0)
+            return;
+        const v3 e = mk3(consts[0], consts[1], consts[2]);
+        v3 prev = mk3(0.0f);
+        for (uint32_t k = 0; k < n; ++k)
+        {
+            prev = accumulate(prev, mk3(fin[3 * (size_t)k], fin[3 * (size_t)k + 1], fin[3 * (size_t)k + 2]), e, param + k);
+            fout[3 * (size_t)k] = prev.x, fout[3 * (size_t)k + 1] = prev.y, fout[3 * (size_t)k + 2] = prev.z;
+        }
+        break;
+    }
+    case SKH_UNIT_TONEMAP: {
+        const v3 e = mk3(consts[0], consts[1], consts[2]);
+        const v3 c = mk3(fin[3 * (size_t)i], fin[3 * (size_t)i + 1], fin[3 * (size_t)i + 2]);
+        const v3 t = tonemap(c, e), iv = inverse_tonemap(c, e);
+        float* o = fout + 6 * (size_t)i;
+        o[0] = t.x, o[1] = t.y, o[2] = t.z, o[3] = iv.x, o[4] = iv.y, o[5] = iv.z;
+        break;
+    }
+    default:
+        break;
+    }
+}
+
+skh_status skh_unit_probe(skh_context* c, uint32_t unit, uint32_t param, const void* consts, const void* in, uint32_t n, void* out)
+{
+    if (!c || unit >= SKH_UNIT_COUNT || (n && (!in || !out)) || (kUnitConst[unit] && !consts))
+    {
+        if (c)
+            c->err = "skh_unit_probe: unknown unit, or a missing input / output / constants pointer";
+        return SKH_INVALID_ARGUMENT;
+    }
+    (void)hipSetDevice(c->device);
+    if (n == 0)
+        return SKH_OK;
+    skh_status s; // (the Sobol tables were uploaded by skh_create)
+    DevBuf di, dc, dout;
+    if ((s = dev_upload(c, di, in, (size_t)kUnitIn[unit] * n)) != SKH_OK || (s = dev_alloc(c, dout, (size_t)kUnitOut[unit] * n)) != SKH_OK ||
+        (kUnitConst[unit] && (s = dev_upload(c, dc, consts, kUnitConst[unit])) != SKH_OK))
+    {
+        dev_free(di), dev_free(dc), dev_free(dout);
+        return s;
+    }
+    k_unit_probe<<<(n + 255) / 256, 256, 0, c->stream>>>(unit, param, dc.as<float>(), di.as<uint32_t>(), n, dout.as<uint32_t>());
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess)
+        e = hipMemcpy(out, dout.p, (size_t)kUnitOut[unit] * n, hipMemcpyDeviceToHost);
+    dev_free(di), dev_free(dc), dev_free(dout);
+    if (e != hipSuccess)
+    {
+        c->err = std::string("skh_unit_probe: ") + hipGetErrorString(e);
         return SKH_FAIL;
     }
     return SKH_OK;

@@ -109,3 +109,39 @@ def test_committed_counter_files_are_kept_per_workload():
     assert got["replayed"] and "pmc_kernels.json" in got["source"]
     assert bench.committed_pmc(j["workload"], "3840x2160", "kitchen") is None
     assert bench.committed_pmc("some other scene", "1920x1080", "kitchen") is None
+
+
+def test_roofline_block_states_both_fractions():
+    """the counter fraction (`frac`, frac_kind counter_upper_bound) and SURVEY 8(d)'s algorithmic fraction must both be
+    readable from the line without arithmetic; a model fraction above 1 is labelled, and the cache's share of the model's bytes is stated."""
+    # round 3's closest-hit launch: 1649 B/ray x 130.8 M rays in 21.35 ms = 10.1 TB/s of model bytes; counters: 79.9 GB
+    f = bench.roofline_fractions(1649 * 130.8e6, 79.9e9, 21.35)
+    assert abs(f["algorithmic_frac"] - 1.263) < 2e-3 and f["model_exceeds_peak"] is True
+    assert abs(f["l2_hit_share"] - (1 - 79.9e9 / (1649 * 130.8e6))) < 1e-3 and 0.6 < f["l2_hit_share"] < 0.65
+    g = bench.roofline_fractions(4.0e9, None, 1.0)  # 4 TB/s of model bytes, no counters in this run
+    assert g["algorithmic_frac"] == 0.5 and g["model_exceeds_peak"] is False and g["l2_hit_share"] is None
+    assert bench.roofline_fractions(0, None, 0.0) == {"algorithmic_frac": None, "model_exceeds_peak": None, "l2_hit_share": None}
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"frac_kind": "counter_upper_bound"' in src and "str(min(spp, 32))" not in src  # counter children trace the timed run's pass size
+
+
+def test_scene_cache_waiter_stops_when_the_writer_failed(tmp_path, monkeypatch):
+    """a rank waiting for the node's writer must not sit out the whole time-out after the writer died."""
+    import pytest
+
+    monkeypatch.setattr(bench, "scene_cache_path", lambda name: str(tmp_path / (name + ".skscene")))
+
+    def boom(scenes):
+        raise ValueError("generator exploded")
+
+    monkeypatch.setitem(bench.SCENE_RECIPES, "cornell", (boom, "x %d %d %d"))
+    with pytest.raises(ValueError):
+        bench.load_workload("cornell", make=True)
+    assert os.path.exists(tmp_path / "cornell.skscene.failed")
+    import time
+
+    t0 = time.time()
+    os.utime(tmp_path / "cornell.skscene.failed")  # (a marker written while we wait)
+    with pytest.raises(RuntimeError, match="writer .* failed: ValueError: generator exploded"):
+        bench.load_workload("cornell", make=False)
+    assert time.time() - t0 < 5

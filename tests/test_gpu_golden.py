@@ -1,0 +1,148 @@
+"""The HIP device code against the REFERENCE's own numbers, directly.
+
+tests/golden/* were written by oracle/_ref/ref_golden -- the reference's RandomSampler.h, Lights.h, postprocessing/Utils.h and
+sutil compiled on the host from /root/reference (generator oracle/ref_golden.cpp, recipe oracle/Makefile).  The CPU suite holds the
+ORACLE against them (tests/test_oracle_golden.py); here `skh_unit_probe` runs the product's device functions (skh_device.h:
+sampler_random / sampler_random_lut / init_sampler / sobol_uint, the four light samplers, get_light_pdf, calc_light_normal / area,
+mis_weight_balance, accumulate, tonemap / inverse_tonemap) on the GPU, one call per fixture record.
+
+Bars: bit-exact for everything that is integer work or fp32 + - * / sqrt (sampler, Sobol words, sample index, uniform rectangle
+sampling, rect / sphere pdfs, normals, areas, MIS weight, the accumulation sequence, the tonemap pair); the CPU test's ulp bars where
+libm transcendentals enter (sphere / distant sampling: sin, cos; spherical rectangle: acos chains; distant pdf: cos).
+Reference code matched: RandomSampler.h:130-226, Lights.h:28-362, OptixRender.cu:60-78, postprocessing/Utils.h:5-14.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def g(name, dtype):
+    return np.fromfile(os.path.join(G, name), dtype=dtype)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from strelka_amd import capi
+
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _lights():
+    raw = g("lights_def.f32", np.float32).reshape(3, 28)
+    return [np.ascontiguousarray(r) for r in raw]
+
+
+def _close_ulp(a, b, ulps):
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    both_nan = np.isnan(a) & np.isnan(b)
+    tol = ulps * np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32))
+    return both_nan | (np.abs(a.astype(np.float64) - b.astype(np.float64)) <= tol) | (a == b)
+
+
+def test_sampler_bit_exact_on_the_device(ctx):
+    """random<D> for every (x, y, sample, depth, dim) tuple of the fixture: Morton index, murmur hash, Laine-Karras Owen scramble,
+    Sobol word, the % 5 dimension aliasing -- u32 work, bit for bit; and the LDS-table path k_shade really uses gives the same bits."""
+    inp = g("sampler_in.u32", np.uint32).reshape(-1, 5)
+    want = g("sampler_out.f32", np.float32).view(np.uint32)
+    idx = g("sampler_idx.u32", np.uint32)
+    out = ctx.unit_probe("sampler", inp, param=64)
+    assert np.array_equal(out[:, 0], want)
+    assert np.array_equal(out[:, 1], want)  # sampler_random_lut (byte-folded table in LDS)
+    assert np.array_equal(out[:, 2], idx)
+    # dims 5..9 alias dims 0..4 at every depth
+    v = out[:, 0].reshape(-1, 10)
+    assert np.array_equal(v[:, :5], v[:, 5:])
+
+
+def test_sampler_largest_index_does_not_wrap_on_the_device(ctx):
+    big = g("sampler_big.u32", np.uint32)
+    out = ctx.unit_probe("sampler", np.array([[3839, 2159, 255, 0, 0]], np.uint32), param=256)
+    assert int(out[0, 2]) == int(big[0]) == int(big[1]) * 256 + 255
+
+
+def test_sobol_words_bit_exact_on_the_device(ctx):
+    want = g("sobol_uint.u32", np.uint32)
+    rec = np.array([[(i * 2654435761 + d) & 0xFFFFFFFF, d] for d in range(5) for i in range(64)], np.uint32)
+    out = ctx.unit_probe("sobol", rec)
+    assert np.array_equal(out[:, 0], want)
+
+
+@pytest.mark.parametrize("method,fname,ulps", [(0, "lights_rect_uniform.f32", 0), (1, "lights_rect_sph.f32", 64),
+                                               (2, "lights_sphere.f32", 4), (3, "lights_distant.f32", 4)])
+def test_light_sampling_on_the_device(ctx, method, fname, ulps):
+    rect, sph, dist = _lights()
+    light = {0: rect, 1: rect, 2: sph, 3: dist}[method]
+    inp = g("lights_in.f32", np.float32).reshape(-1, 5)
+    want = g(fname, np.float32).reshape(-1, 12)
+    out = ctx.unit_probe("light_sample", inp, param=method, consts=light).view(np.float32)
+    if ulps == 0:
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32))  # SampleRectLightUniform: + - * / sqrt only
+    elif method == 1:
+        # the spherical-rectangle sampler chains acos / cos / sin (the CPU test's bar)
+        assert np.allclose(out, want, rtol=2e-4, atol=2e-5, equal_nan=True)
+    else:
+        assert _close_ulp(out, want, ulps).all()
+
+
+def test_light_pdfs_normals_areas_on_the_device(ctx):
+    rect, sph, dist = _lights()
+    inp = g("lights_in.f32", np.float32).reshape(-1, 5)
+    P = np.ascontiguousarray(inp[:, :3])
+    want = g("lights_pdf.f32", np.float32).reshape(-1, 4)
+    lp = g("lights_rect_uniform.f32", np.float32).reshape(-1, 12)[:, :3]  # the fixture's light hit points (the uniform samples)
+    rec = np.ascontiguousarray(np.concatenate([lp, P], axis=1), np.float32)
+    pdf = ctx.unit_probe("light_pdf", rec, consts=rect)[:, 0]
+    assert np.array_equal(pdf, want[:, 0].copy().view(np.uint32))  # rect: dist^2 / (cos * area), bit-exact
+    pdf = ctx.unit_probe("light_pdf", rec, consts=sph)[:, 0].view(np.float32)
+    assert np.array_equal(pdf, want[:, 2])  # 1 / 4 pi
+    pdf = ctx.unit_probe("light_pdf", rec, consts=dist)[:, 0].view(np.float32)
+    assert _close_ulp(pdf, want[:, 3], 2).all()  # cosf(halfAngle)
+    nrm = g("lights_normal.f32", np.float32).reshape(-1, 2, 3)
+    area = g("lights_area.f32", np.float32)
+    for k, l in enumerate((rect, sph)):
+        out = ctx.unit_probe("light_normal", P, consts=l).view(np.float32)
+        assert np.array_equal(out[:, :3].view(np.uint32), np.ascontiguousarray(nrm[:, k]).view(np.uint32))
+        assert np.all(out[:, 3].view(np.uint32) == area[k:k + 1].view(np.uint32))
+    out = ctx.unit_probe("light_normal", P[:1], consts=dist).view(np.float32)
+    assert out[0, 3].view(np.uint32) == area[2:3].view(np.uint32)[0]
+
+
+def test_mis_weight_bit_exact_on_the_device(ctx):
+    m = g("mis.f32", np.float32).reshape(-1, 3)
+    out = ctx.unit_probe("mis", np.ascontiguousarray(m[:, :2]))[:, 0]
+    assert np.array_equal(out, m[:, 2].copy().view(np.uint32))
+
+
+def test_accumulate_sequence_bit_exact_on_the_device(ctx):
+    """invTM(lerp(TM(prev), TM(new), 1 / (i + 1))) composed 64 times (OptixRender.cu:60-78): order-dependent, must match bit for bit"""
+    vin = g("accum_in.f32", np.float32).reshape(-1, 3)
+    want = g("accum_out.f32", np.float32).reshape(-1, 3)
+    e = np.full(3, 6.25e-4, np.float32)
+    out = ctx.unit_probe("accumulate", vin, param=0, consts=e)
+    assert np.array_equal(out, want.view(np.uint32))
+    tm = g("tonemap.f32", np.float32).reshape(-1, 2, 3)
+    t = ctx.unit_probe("tonemap", vin, consts=e).view(np.float32).reshape(-1, 2, 3)
+    assert np.array_equal(t[:, 0].view(np.uint32), np.ascontiguousarray(tm[:, 0]).view(np.uint32))
+    back = ctx.unit_probe("tonemap", np.ascontiguousarray(tm[:, 0]), consts=e).view(np.float32).reshape(-1, 2, 3)
+    assert np.array_equal(back[:, 1].view(np.uint32), np.ascontiguousarray(tm[:, 1]).view(np.uint32))
+    # the SURVEY probe (e = 0.0625)
+    probe = g("accum_probe.f32", np.float32)
+    e2 = np.full(3, 0.0625, np.float32)
+    seq = np.array([[1, 2, 3], [3, 2, 1]], np.float32)
+    got = ctx.unit_probe("accumulate", seq, param=0, consts=e2).view(np.float32)[1]
+    assert np.array_equal(got.view(np.uint32), probe.view(np.uint32))
+
+
+def test_unit_probe_refuses_bad_arguments(ctx):
+    from strelka_amd import capi
+
+    with pytest.raises(capi.SkhError):
+        ctx.unit_probe("light_sample", np.zeros((1, 5), np.float32), param=0, consts=None)  # a light sampler without a light
