@@ -299,6 +299,9 @@ skh_status skh_host_unregister(skh_context* ctx, void* host);
 skh_status skh_read_accum(skh_context* ctx, float* host_rgba); /* W*H float4, row-major, row 0 = launch y 0 */
 skh_status skh_read_aov(skh_context* ctx, uint32_t which /*0 diffuse, 1 specular*/, float* host_rgba);
 skh_status skh_copy_accum(skh_context* ctx, void* d_dst_rgba); /* device-to-device, W*H float4 */
+/* the diffuse (0) / specular (1) AOV accumulator, device-to-device: what render() copies to the image when all samples are done and
+ * the debug view is 2 / 3 (OptixRender.cpp:1029-1042) */
+skh_status skh_copy_aov(skh_context* ctx, uint32_t which, void* d_dst_rgba);
 /* compact tile accumulators of this context: n_tiles * tile_size^2 float4, tile-major (for the RCCL gather) */
 skh_status skh_copy_accum_tiles(skh_context* ctx, void* d_dst);
 /* scatter gathered compact tiles into a W*H float4 image (root side of the gather) */

@@ -67,13 +67,17 @@ HOST_TEST = os.path.join(HOST_DIR, "host_test")
 def build_host(force=False, verbose=False):
     """g++ build of the C++ host mirror (oka::HipRender above the C ABI) and its driver program."""
     build(force=False, verbose=verbose)
-    srcs = [os.path.join(HOST_DIR, f) for f in ("oka_render.cpp", "oka_render.h", "host_test.cpp")] + [LIB]
+    integ = os.path.join(ROOT, "integration")
+    srcs = [os.path.join(HOST_DIR, f) for f in ("oka_mirror.cpp", "oka_mirror.h", "oka_render.h", "host_test.cpp")] + [
+        os.path.join(integ, f) for f in ("HipRender.cpp", "HipRender.h", "SkSceneDump.h")] + [LIB]
     if not force and os.path.exists(HOST_TEST) and all(os.path.getmtime(s) <= os.path.getmtime(HOST_TEST) for s in srcs):
         return HOST_TEST
     libdir = os.path.dirname(LIB)
     common = ["g++", "-std=c++17", "-O2", "-fPIC", "-Wall"]
-    cmds = [common + ["-shared", "-o", HOST_LIB, os.path.join(HOST_DIR, "oka_render.cpp"), "-L" + libdir, "-lstrelka_hip",
-                      "-Wl,-rpath,$ORIGIN/.."],
+    # liboka_hip.so = the stand-in types (oka_mirror.cpp) + the backend exactly as a Strelka tree compiles it (integration/HipRender.cpp,
+    # here WITHOUT -DSKH_WITH_STRELKA_HEADERS: glm / MDL SDK / OpenUSD headers are not in this image)
+    cmds = [common + ["-shared", "-o", HOST_LIB, os.path.join(HOST_DIR, "oka_mirror.cpp"), os.path.join(integ, "HipRender.cpp"),
+                      "-I" + os.path.join(ROOT, "include"), "-L" + libdir, "-lstrelka_hip", "-Wl,-rpath,$ORIGIN/.."],
             common + ["-o", HOST_TEST, os.path.join(HOST_DIR, "host_test.cpp"), "-L" + HOST_DIR, "-loka_hip", "-L" + libdir,
                       "-lstrelka_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."]]
     for c in cmds:

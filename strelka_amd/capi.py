@@ -26,7 +26,7 @@ SYMBOLS = ["skh_create", "skh_destroy", "skh_last_error", "skh_abi_version", "sk
            "skh_render_subframe", "skh_render_subframes", "skh_tonemap", "skh_read_accum", "skh_read_aov",
            "skh_buffer_alloc", "skh_buffer_free", "skh_buffer_download", "skh_copy_accum", "skh_copy_accum_tiles", "skh_scatter_tiles", "skh_trace", "skh_trace_device",
            "skh_set_option", "skh_get_stats", "skh_reset_stats", "skh_synchronize", "skh_get_stream", "skh_bsdf_probe", "skh_get_device_info", "skh_comm_unique_id", "skh_comm_init",
-           "skh_comm_destroy", "skh_gather_tiles", "skh_host_register", "skh_host_unregister", "skh_get_baked", "skh_comm_info", "skh_probe_memory", "skh_unit_probe"]
+           "skh_comm_destroy", "skh_gather_tiles", "skh_host_register", "skh_host_unregister", "skh_get_baked", "skh_comm_info", "skh_probe_memory", "skh_unit_probe", "skh_copy_aov"]
 
 DEVICE_INFO = np.dtype([("compute_units", np.uint32), ("simds_per_cu", np.uint32), ("clock_khz", np.uint32), ("memory_clock_khz", np.uint32),
                         ("memory_bus_bits", np.uint32), ("wavefront_size", np.uint32), ("total_memory_bytes", np.uint64), ("name", "S64")])
@@ -80,6 +80,7 @@ def load():
     lib.skh_read_accum.argtypes = [vp, vp]
     lib.skh_read_aov.argtypes = [vp, u32, vp]
     lib.skh_copy_accum.argtypes = [vp, vp]
+    lib.skh_copy_aov.argtypes = [vp, u32, vp]
     lib.skh_copy_accum_tiles.argtypes = [vp, vp]
     lib.skh_scatter_tiles.argtypes = [vp, vp, vp, u32, u32, vp, u32, u32]
     lib.skh_trace.argtypes = [vp, vp, u32, u32, vp]
@@ -209,6 +210,10 @@ class Context:
 
     def copy_accum(self, d_dst):
         self._ck(self.lib.skh_copy_accum(self.h, d_dst), "skh_copy_accum")
+
+    def copy_aov(self, which, d_dst):
+        """the diffuse (0) / specular (1) AOV accumulator -> a device image (OptixRender.cpp:1029-1042)"""
+        self._ck(self.lib.skh_copy_aov(self.h, which, d_dst), "skh_copy_aov")
 
     def copy_accum_tiles(self, d_dst):
         self._ck(self.lib.skh_copy_accum_tiles(self.h, d_dst), "skh_copy_accum_tiles")

@@ -243,8 +243,17 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 #define SKH_TRACE_ATTR
 #endif
 #ifndef SKH_POP_CULL
-#define SKH_POP_CULL 0 // 1: the world-only closest-hit build keeps a 16-bit rounded-down entry distance beside every LDS stack reference and drops a
-                       // popped entry whose box lies beyond the current best hit WITHOUT fetching its node (see docs/LOG.md, round 4)
+#define SKH_POP_CULL 0 // 1: pop-time culling in the world-only closest-hit build: LDS stack entries are 64-bit {reference, entry distance} (one
+                       // ds_write_b64 / ds_read_b64 each, SKH_CULL_LDS of them per lane) and a popped entry whose box lies beyond the current best
+                       // hit is dropped WITHOUT fetching its node; a lane whose pop was culled stays in the node loop, masked, and pops again in
+                       // the next iteration (no inner loop).  docs/LOG.md, round 4
+#endif
+#ifndef SKH_CULL_LDS
+#define SKH_CULL_LDS 11 // 8 B x 64 lanes x 11 = 5632 B per wave: 28 waves per CU still fit 160 KB
+#endif
+#ifndef SKH_POSTPONE
+#define SKH_POSTPONE 0 // 1: "speculative traversal" (Aila & Laine 2009) in the world-only closest-hit build: a lane that reaches a leaf puts it aside
+                       // and keeps descending; only its SECOND leaf makes it wait for the wave's triangle pass, which then tests both
 #endif
 #ifndef SKH_PREFETCH2
 #define SKH_PREFETCH2 0 // 1: touch load of the second-nearest hit child's line, issued behind the nearest child's node fetch
@@ -277,9 +286,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
             StatsDev* __restrict__ stats)
 {
     static_assert(!WORLD || !CURVES, "the world-only build is a triangle kernel");
-    __shared__ int s_stack[SKH_STACK_LDS * SKH_TRACE_BLOCK];
     constexpr bool CULL = SKH_POP_CULL && WORLD && !ANY_HIT && !W8;
-    __shared__ unsigned short s_tnear[CULL ? SKH_STACK_LDS * SKH_TRACE_BLOCK : 1]; // entry distance of the LDS stack entries, top 16 bits of the float (rounded down)
+    constexpr int NLDS = CULL ? SKH_CULL_LDS : SKH_STACK_LDS; // per-lane stack entries in LDS (the rest: SKH_STACK_OVF entries in global memory)
+    __shared__ int s_stack[(CULL ? 2 : 1) * NLDS * SKH_TRACE_BLOCK];
     const uint32_t fetchMin = fetchArg & 0xffu, curveMin = (fetchArg >> 8) & 0xffu, nodeBreak = (fetchArg >> 16) & 0xffu, leafMin = fetchArg >> 24;
     const uint32_t lane = threadIdx.x;
     uint32_t n = 0; // (countPtr: SKH_SHARDS queue-length words, SKH_COUNT_STRIDE apart)
@@ -293,7 +302,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
     uint32_t tries = 0;
     bool exhausted = false;
     int* lds = s_stack + lane;
-    unsigned short* ldsT = s_tnear + (CULL ? lane : 0u);
+    int2* lds2 = reinterpret_cast<int2*>(s_stack) + lane; // (CULL) entry e of this lane = lds2[e * 64] = {reference, entry distance}
     int* ovf = ovfBase + (blockIdx.x * SKH_TRACE_BLOCK + lane);
     const uint32_t ovfStride = gridDim.x * SKH_TRACE_BLOCK;
     const uint32_t rayMask = CURVES ? (ANY_HIT ? 3u : 255u) : (ANY_HIT ? 1u : 253u);
@@ -324,36 +333,48 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
     bool inBlas = false;
     uint32_t curInst = 0, curType = 0;
     int sp = 0, cur = SKH_REF_INVALID;
+    constexpr bool POSTPONE = SKH_POSTPONE && WORLD && !ANY_HIT && !W8;
+    int leaf2 = SKH_REF_INVALID; // (POSTPONE) the leaf this lane has put aside
     constexpr bool PF2 = SKH_PREFETCH2 && WORLD && !ANY_HIT && !W8;
     int pf = SKH_REF_INVALID; // (PF2) the second-nearest hit child of the node just processed: its line is touched behind the next node fetch
     int pfv = 0;
     HitRec best;
     best.t = 0.0f, best.inst = best.prim = 0xffffffffu, best.u = best.v = 0.0f, best.found = false;
 
-#define SKH_PUSH(v)                                                  \
+#define SKH_PUSH_T(v, tnearBits)                                     \
     {                                                                \
-        if (sp < SKH_STACK_LDS)                                      \
-            lds[sp * SKH_TRACE_BLOCK] = (v);                         \
-        else if (sp < SKH_STACK_LDS + SKH_STACK_OVF)                 \
-            ovf[(size_t)(sp - SKH_STACK_LDS) * ovfStride] = (v);     \
+        if (sp < NLDS)                                               \
+        {                                                            \
+            if (CULL)                                                \
+                lds2[sp * SKH_TRACE_BLOCK] = make_int2((v), (tnearBits)); \
+            else                                                     \
+                lds[sp * SKH_TRACE_BLOCK] = (v);                     \
+        }                                                            \
+        else if (sp < NLDS + SKH_STACK_OVF)                          \
+            ovf[(size_t)(sp - NLDS) * ovfStride] = (v); /* (entries in the global overflow area carry no distance: never culled) */ \
         else                                                         \
             *sc.overflowFlag = 1u; /* the entry is dropped: the call that launched this kernel returns SKH_FAIL, never silent */ \
         ++sp;                                                        \
     }
+#define SKH_PUSH(v) SKH_PUSH_T(v, 0)
 #define SKH_POP(dst)                                                 \
     {                                                                \
         --sp;                                                        \
-        if (sp < SKH_STACK_LDS)                                      \
+        if (sp < NLDS)                                               \
         {                                                            \
-            dst = lds[sp * SKH_TRACE_BLOCK];                         \
-            /* pop-time culling: the same acceptance test the entry passed when it was pushed, against today's best.t; the stored distance is   \
-               rounded DOWN, so an entry is dropped only if the slab test would reject it now: results cannot change */                       \
-            if (CULL && __uint_as_float((uint32_t)ldsT[sp * SKH_TRACE_BLOCK] << 16) > best.t * SKH_SLAB_SLACK)                                 \
-                dst = SKH_REF_INVALID;                               \
+            if (CULL)                                                \
+            {                                                        \
+                /* pop-time culling: the acceptance test the entry passed when it was pushed, against today's best.t -- an entry is dropped   \
+                   only if the slab test would reject it now, so results cannot change */                                                    \
+                const int2 e = lds2[sp * SKH_TRACE_BLOCK];           \
+                dst = __int_as_float(e.y) > best.t * SKH_SLAB_SLACK ? SKH_REF_INVALID : e.x; \
+            }                                                        \
+            else                                                     \
+                dst = lds[sp * SKH_TRACE_BLOCK];                     \
         }                                                            \
-        else if (sp < SKH_STACK_LDS + SKH_STACK_OVF)                 \
+        else if (sp < NLDS + SKH_STACK_OVF)                          \
         {                                                            \
-            dst = ovf[(size_t)(sp - SKH_STACK_LDS) * ovfStride];     \
+            dst = ovf[(size_t)(sp - NLDS) * ovfStride];              \
             if (PF2)                                                 \
                 asm volatile("" ::"v"(dst)); /* the wait for this (rare) global read stays inside its branch: at the join it would cover the touch load in flight too */ \
         }                                                            \
@@ -460,9 +481,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                     }
                     if (wr0 != SKH_REF_INVALID && wr1 != SKH_REF_INVALID)
                     {
-                        lds[sp * SKH_TRACE_BLOCK] = wr1;
                         if (CULL)
-                            ldsT[sp * SKH_TRACE_BLOCK] = 0; // (no entry distance known: never culled)
+                            lds2[sp * SKH_TRACE_BLOCK] = make_int2(wr1, 0); // (no entry distance known: never culled)
+                        else
+                            lds[sp * SKH_TRACE_BLOCK] = wr1;
                         ++sp;
                     }
                     cur = wr0 != SKH_REF_INVALID ? wr0 : wr1;
@@ -479,6 +501,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                 best.u = best.v = 0.0f;
                 best.found = false;
                 pend = 0;
+                leaf2 = SKH_REF_INVALID;
                 hasRay = true;
             }
         }
@@ -687,8 +710,12 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
         if (hasRay)
         {
             // ---- descend through internal nodes ----
-            while (cur >= 0 && cur != SKH_REF_INVALID)
+            // (CULL: a lane whose popped entry was culled -- cur INVALID, stack not empty -- stays in the loop, masked for the node block,
+            // and pops its next entry at the bottom of the iteration: no inner loop, the chain of culled pops hides behind the other lanes' nodes)
+            while ((cur >= 0 && cur != SKH_REF_INVALID) || (CULL && cur == SKH_REF_INVALID && sp > 0))
             {
+                if (!CULL || cur != SKH_REF_INVALID)
+                {
                 SKH_LP(itN++; rayNodes++;)
                 if constexpr (W8)
                 {
@@ -829,46 +856,36 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                     SKH_CSWAP(0, 2)
                     SKH_CSWAP(1, 3)
                     SKH_CSWAP(1, 2)
-                    if (sp + 3 <= SKH_STACK_LDS)
+                    if (sp + 3 <= NLDS)
                     {
                         // the c hit children among rf[1..3] go to slots sp .. sp+c-1 (farthest first); the writes are
                         // unconditional (what lands above the new top is never read): no branch per push
                         const int c = (tn[1] < INFINITY ? 1 : 0) + (tn[2] < INFINITY ? 1 : 0) + (tn[3] < INFINITY ? 1 : 0);
-                        int* p = lds + sp * SKH_TRACE_BLOCK;
-                        p[0] = c == 3 ? rf[3] : (c == 2 ? rf[2] : rf[1]);
-                        p[SKH_TRACE_BLOCK] = c == 3 ? rf[2] : rf[1];
-                        p[2 * SKH_TRACE_BLOCK] = rf[1];
                         if (CULL)
                         {
-                            unsigned short* q = ldsT + sp * SKH_TRACE_BLOCK;
-                            const uint32_t q1 = __float_as_uint(tn[1]) >> 16, q2 = __float_as_uint(tn[2]) >> 16, q3 = __float_as_uint(tn[3]) >> 16;
-                            q[0] = (unsigned short)(c == 3 ? q3 : (c == 2 ? q2 : q1));
-                            q[SKH_TRACE_BLOCK] = (unsigned short)(c == 3 ? q2 : q1);
-                            q[2 * SKH_TRACE_BLOCK] = (unsigned short)q1;
+                            int2* p = lds2 + sp * SKH_TRACE_BLOCK;
+                            const int2 e1 = make_int2(rf[1], __float_as_int(tn[1])), e2 = make_int2(rf[2], __float_as_int(tn[2])), e3 = make_int2(rf[3], __float_as_int(tn[3]));
+                            p[0] = c == 3 ? e3 : (c == 2 ? e2 : e1);
+                            p[SKH_TRACE_BLOCK] = c == 3 ? e2 : e1;
+                            p[2 * SKH_TRACE_BLOCK] = e1;
+                        }
+                        else
+                        {
+                            int* p = lds + sp * SKH_TRACE_BLOCK;
+                            p[0] = c == 3 ? rf[3] : (c == 2 ? rf[2] : rf[1]);
+                            p[SKH_TRACE_BLOCK] = c == 3 ? rf[2] : rf[1];
+                            p[2 * SKH_TRACE_BLOCK] = rf[1];
                         }
                         sp += c;
                     }
                     else
                     {
-                        // (entries that go to the global overflow area carry no distance; LDS ones written here get 0 = never culled)
                         if (tn[3] < INFINITY)
-                        {
-                            if (CULL && sp < SKH_STACK_LDS)
-                                ldsT[sp * SKH_TRACE_BLOCK] = (unsigned short)(__float_as_uint(tn[3]) >> 16);
-                            SKH_PUSH(rf[3]);
-                        }
+                            SKH_PUSH_T(rf[3], __float_as_int(tn[3]));
                         if (tn[2] < INFINITY)
-                        {
-                            if (CULL && sp < SKH_STACK_LDS)
-                                ldsT[sp * SKH_TRACE_BLOCK] = (unsigned short)(__float_as_uint(tn[2]) >> 16);
-                            SKH_PUSH(rf[2]);
-                        }
+                            SKH_PUSH_T(rf[2], __float_as_int(tn[2]));
                         if (tn[1] < INFINITY)
-                        {
-                            if (CULL && sp < SKH_STACK_LDS)
-                                ldsT[sp * SKH_TRACE_BLOCK] = (unsigned short)(__float_as_uint(tn[1]) >> 16);
-                            SKH_PUSH(rf[1]);
-                        }
+                            SKH_PUSH_T(rf[1], __float_as_int(tn[1]));
                     }
                     cur = tn[0] < INFINITY ? rf[0] : SKH_REF_INVALID;
                     if (PF2)
@@ -889,15 +906,20 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                 }
 #undef SKH_CSWAP
                 }
+                }
                 // a lane whose node had no hit child takes its next stack entry right here instead of idling until
                 // the whole wave leaves the node loop
-                if (CULL)
+                if (cur == SKH_REF_INVALID && sp > 0)
+                    SKH_POP(cur); // (CULL: may come back culled = INVALID again; the lane then sits out one iteration and pops the next entry)
+                if (POSTPONE && cur < 0 && leaf2 == SKH_REF_INVALID)
                 {
-                    while (cur == SKH_REF_INVALID && sp > 0)
+                    // the first leaf is put aside and the lane goes on with its next stack entry; closest hit = min over all primitives with a
+                    // key tie-break, so the order of the tests cannot change a result -- only which boxes the shrinking best.t still culls
+                    leaf2 = cur;
+                    cur = SKH_REF_INVALID;
+                    if (sp > 0)
                         SKH_POP(cur);
                 }
-                else if (cur == SKH_REF_INVALID && sp > 0)
-                    SKH_POP(cur);
                 // few lanes still descending while the rest wait at their leaves: let the leaves go first
                 if ((uint32_t)__popcll(__ballot(cur >= 0 && cur != SKH_REF_INVALID)) < breakBelow)
                     break;
@@ -1008,10 +1030,17 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                     entered = true; // (keeps `cur`: no pop)
                 }
             }
-            if (isLeaf)
+            if (isLeaf || (POSTPONE && leaf2 != SKH_REF_INVALID))
             {
-                const uint32_t enc = (uint32_t)~cur;
+                // (POSTPONE: up to two leaves wait here -- the one put aside in the node loop first, then the current one)
+                const int leafA = (POSTPONE && leaf2 != SKH_REF_INVALID) ? leaf2 : cur;
+                const uint32_t enc = (uint32_t)~leafA;
                 const uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
+                const bool two = POSTPONE && leaf2 != SKH_REF_INVALID && isLeaf;
+                const uint32_t encB = (uint32_t)~cur;
+                const uint32_t firstB = encB >> 3, total = count + (two ? (encB & 7u) + 1u : 0u);
+                if (POSTPONE)
+                    leaf2 = SKH_REF_INVALID;
                 if (!WORLD && !inBlas)
                 {
                     // TLAS leaves hold exactly one instance
@@ -1058,9 +1087,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                 }
                 else
                 {
-                    for (uint32_t k = 0; k < count; ++k)
+                    for (uint32_t k = 0; k < total; ++k)
                     {
-                        const float4* tp = sc.tris + 3 * (size_t)(first + k);
+                        const float4* tp = sc.tris + 3 * (size_t)((POSTPONE && k >= count) ? firstB + (k - count) : first + k);
                         const float4 a = tp[0], b = tp[1], c = tp[2];
                         if (COUNT)
                             tc.prims++;
@@ -1115,9 +1144,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                         inBlas = false;
                         continue;
                     }
-                    if (CULL && cur == SKH_REF_INVALID)
-                        continue; // culled at pop time: take the next entry
-                    break;
+                    break; // (CULL: a culled entry comes back as INVALID; the node loop of the next pass pops on, an empty stack ends the ray below)
                 }
             }
         }

@@ -2419,6 +2419,22 @@ skh_status skh_copy_accum(skh_context* c, void* d_dst)
     SKH_TRY(c, hipStreamSynchronize(c->stream));
     return SKH_OK;
 }
+// the diffuse / specular AOV accumulators to a device image: what render() hands back once all samples are done and the debug view
+// is 2 / 3 (OptixRender.cpp:1029-1042: cudaMemcpy(params.image, params.diffuse | params.specular))
+skh_status skh_copy_aov(skh_context* c, uint32_t which, void* d_dst)
+{
+    if (!c || !d_dst || which > 1u)
+        return SKH_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->device);
+    if (c->width == 0)
+    {
+        c->err = "skh_copy_aov: call skh_resize first";
+        return SKH_INVALID_ARGUMENT;
+    }
+    detile_to(c, which == 0 ? c->dDiffuse : c->dSpecular, d_dst);
+    SKH_TRY(c, hipStreamSynchronize(c->stream));
+    return SKH_OK;
+}
 skh_status skh_copy_accum_tiles(skh_context* c, void* d_dst)
 {
     if (!c || !d_dst)

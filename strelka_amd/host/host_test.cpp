@@ -3,7 +3,9 @@
 // { render(outputBuffer); map() }.
 //   host_test cpu <outdir>   builds the test scene through the oka::Scene API and dumps the flat arrays (no GPU needed)
 //   host_test gpu <outdir> <frames>   additionally renders <frames> frames and dumps the mapped image
+//   host_test gpu-aov2 | gpu-aov3 <outdir> <frames>   the same with the diffuse / specular AOV debug view, plus five render() calls after the last sample
 #include "oka_render.h"
+#include "../../integration/SkSceneDump.h"
 
 #include <cmath>
 #include <cstdio>
@@ -95,7 +97,7 @@ int main(int argc, char** argv)
         return 2;
     }
     const std::string mode = argv[1], dir = argv[2];
-    const int frames = argc > 3 ? atoi(argv[3]) : 6;
+    int frames = argc > 3 ? atoi(argv[3]) : 6;
     if (mode == "load")
     {
         // host_test load <outdir> <file.skscene>: read a dump (e.g. one written by strelka_amd/scene_io.py) and write it back
@@ -115,6 +117,9 @@ int main(int argc, char** argv)
     buildScene(scene);
     if (!scene.saveDump(dir + "/scene.skscene"))
         return 8;
+    // the exporter a Strelka tree runs (integration/SkSceneDump.h, strelka_hip.patch) must write the same file
+    if (!skhDumpScene(scene, dir + "/scene_exporter.skscene"))
+        return 9;
     dump(dir, "vertices.bin", scene.getVertices().data(), scene.getVertices().size());
     dump(dir, "indices.bin", scene.getIndices().data(), scene.getIndices().size());
     dump(dir, "meshes.bin", scene.getMeshes().data(), scene.getMeshes().size());
@@ -169,7 +174,9 @@ int main(int argc, char** argv)
     sm.setAs<uint32_t>("render/pt/sppTotal", (uint32_t)frames - 1); // the last frame exercises the "all spp done" copy path
     sm.setAs<uint32_t>("render/pt/spp", 1);
     sm.setAs<uint32_t>("render/pt/tonemapperType", 1);
-    sm.setAs<uint32_t>("render/pt/debug", 0);
+    // gpu-aov2 / gpu-aov3: the debug views 2 / 3 (diffuse / specular AOV as the image, OptixRender.cu:169-247)
+    const uint32_t debugView = mode == "gpu-aov2" ? 2u : (mode == "gpu-aov3" ? 3u : 0u);
+    sm.setAs<uint32_t>("render/pt/debug", debugView);
     sm.setAs<bool>("render/pt/enableAcc", true);
     sm.setAs<bool>("render/pt/isResized", false);
     sm.setAs<uint32_t>("render/pt/rectLightSamplingMethod", 0);
@@ -207,12 +214,27 @@ int main(int argc, char** argv)
         render->render(out);
         out->map();
     }
+    if (debugView)
+    {
+        // all samples are done: every further render() must hand back the same picture -- the raw AOV copied to the image, then
+        // tonemapped (OptixRender.cpp:1029-1049) -- not tonemap the already tonemapped image again
+        dump(dir, "image_first.bin", (const char*)out->getHostPointer(), out->getHostDataSize());
+        for (int f = 0; f < 5; ++f)
+        {
+            render->render(out);
+            out->map();
+        }
+        std::vector<float> aov((size_t)W * H * 4);
+        skh_read_aov(hr->context(), debugView - 2u, aov.data());
+        dump(dir, "aov.bin", aov.data(), aov.size());
+        frames += 5;
+    }
     dump(dir, "image.bin", (const char*)out->getHostPointer(), out->getHostDataSize());
     std::vector<float> accum((size_t)W * H * 4);
     skh_read_accum(hr->context(), accum.data());
     dump(dir, "accum.bin", accum.data(), accum.size());
     printf("host_test gpu ok: frames %d, subframeIndex %zu, frameNumber %zu\n", frames, ctx.mSubframeIndex, ctx.mFrameNumber);
-    if (ctx.mSubframeIndex != (size_t)frames - 1 || ctx.mFrameNumber != (size_t)frames || !hr->lastError().empty())
+    if (ctx.mSubframeIndex != (size_t)sm.getAs<uint32_t>("render/pt/sppTotal") || ctx.mFrameNumber != (size_t)frames || !hr->lastError().empty())
         return 6;
     delete out;
     delete render;

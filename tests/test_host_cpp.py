@@ -131,3 +131,22 @@ def test_hiprender_tile_sharing_path_reproduces_the_plain_frame_loop(tmp_path):
     run_host(b, "gpu-tiles", 5)
     for f in ("image.bin", "accum.bin"):
         assert (a / f).read_bytes() == (b / f).read_bytes(), f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("view", [2, 3])
+def test_hiprender_hands_back_the_aov_after_the_last_sample(tmp_path, view):
+    """VERDICT r3 weak #7 / OptixRender.cpp:1029-1049: with every sample done and the debug view 2 / 3, each further render() copies the RAW
+    diffuse / specular AOV to the image (skh_copy_aov) and tonemaps that -- five more calls must leave the picture unchanged, and it must be
+    gamma(reinhard(AOV * exposure)), not a tonemap of a tonemap."""
+    W, H = 96, 64
+    run_host(tmp_path, "gpu-aov%d" % view, 5)
+    first = np.fromfile(os.path.join(tmp_path, "image_first.bin"), np.float32).reshape(H, W, 4)
+    last = np.fromfile(os.path.join(tmp_path, "image.bin"), np.float32).reshape(H, W, 4)
+    aov = np.fromfile(os.path.join(tmp_path, "aov.bin"), np.float32).reshape(H, W, 4)
+    assert np.array_equal(first, last)
+    assert aov[..., :3].max() > 0  # the view shows something
+    r = aov[..., :3] * S.default_exposure()
+    lum = r @ np.array([0.299, 0.587, 0.114], np.float32)
+    ref = (r / (lum[..., None] + 1)) ** (1 / 2.4)
+    assert np.allclose(last[..., :3], ref, rtol=1e-4, atol=1e-6)
