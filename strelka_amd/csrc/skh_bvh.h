@@ -352,46 +352,27 @@ __global__ void k_init_group_bounds(uint32_t* __restrict__ gb, uint32_t nGroups)
     if (i < nGroups * 6)
         gb[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
 }
-// per-group (mesh / curve set) bounds with ordered-uint atomics.  Primitives arrive grouped, so almost every wave holds a
-// single group: the wave reduces first and issues six atomics instead of 6 x 64 (1.7 M triangles: 12 ms -> well under 1 ms).
-__global__ void k_group_bounds(const float4* __restrict__ boxLo, const float4* __restrict__ boxHi,
-                               const uint32_t* __restrict__ grp, uint32_t n, uint32_t* __restrict__ gb)
+// per-group (mesh / curve set) bounds with ordered-uint atomics.  Primitives arrive grouped, so a wave walks SKH_GB_RUN consecutive
+// 64-primitive rows and keeps a running per-lane min / max while the rows stay inside one group; it reduces across its lanes and issues
+// six atomics only when the group changes and at the end of its run.  (Round 3's version reduced every 64-primitive row by itself: with the
+// default world-space bake all 23.1 M triangles belong to one or two groups, and 361 k waves x 6 returning atomics on the same six words
+// ran at the ~88 per microsecond one cache line sustains: 24.6 ms of a 73.8 ms build.)
+#define SKH_GB_RUN 32
+SKH_DI void group_bounds_flush(uint32_t g, uint32_t v[6], uint32_t* __restrict__ gb)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = i < n;
-    const uint32_t g = valid ? grp[i] : 0xffffffffu;
-    uint32_t v[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
-    if (valid)
-    {
-        const float4 lo = boxLo[i], hi = boxHi[i];
-        v[0] = ordered_from_float(lo.x), v[1] = ordered_from_float(lo.y), v[2] = ordered_from_float(lo.z);
-        v[3] = ordered_from_float(hi.x), v[4] = ordered_from_float(hi.y), v[5] = ordered_from_float(hi.z);
-    }
-    const uint32_t g0 = __shfl(g, __ffsll((long long)__ballot(valid)) - 1);
-    if (__all(!valid || g == g0))
+    if (g == 0xffffffffu)
+        return;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
     {
 #pragma unroll
-        for (int k = 0; k < 6; ++k)
+        for (int off = 32; off >= 1; off >>= 1)
         {
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1)
-            {
-                const uint32_t o = (uint32_t)__shfl_xor((int)v[k], off);
-                v[k] = k < 3 ? min(v[k], o) : max(v[k], o);
-            }
-        }
-        if ((threadIdx.x & 63u) == 0 && g0 != 0xffffffffu)
-        {
-            uint32_t* p = gb + 6 * (size_t)g0;
-            atomicMin(p + 0, v[0]);
-            atomicMin(p + 1, v[1]);
-            atomicMin(p + 2, v[2]);
-            atomicMax(p + 3, v[3]);
-            atomicMax(p + 4, v[4]);
-            atomicMax(p + 5, v[5]);
+            const uint32_t o = (uint32_t)__shfl_xor((int)v[k], off);
+            v[k] = k < 3 ? min(v[k], o) : max(v[k], o);
         }
     }
-    else if (valid)
+    if ((threadIdx.x & 63u) == 0)
     {
         uint32_t* p = gb + 6 * (size_t)g;
         atomicMin(p + 0, v[0]);
@@ -401,6 +382,56 @@ __global__ void k_group_bounds(const float4* __restrict__ boxLo, const float4* _
         atomicMax(p + 4, v[4]);
         atomicMax(p + 5, v[5]);
     }
+}
+__global__ void __launch_bounds__(256) k_group_bounds(const float4* __restrict__ boxLo, const float4* __restrict__ boxHi,
+                                                      const uint32_t* __restrict__ grp, uint32_t n, uint32_t* __restrict__ gb)
+{
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    const size_t first = (size_t)wave * 64u * SKH_GB_RUN;
+    uint32_t run = 0xffffffffu; // the group the running bounds belong to (wave-uniform)
+    uint32_t acc[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+    for (uint32_t r = 0; r < SKH_GB_RUN; ++r)
+    {
+        const size_t i = first + (size_t)r * 64u + lane;
+        if (first + (size_t)r * 64u >= n)
+            break; // (wave-uniform)
+        const bool valid = i < n;
+        const uint32_t g = valid ? grp[i] : 0xffffffffu;
+        uint32_t v[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+        if (valid)
+        {
+            const float4 lo = boxLo[i], hi = boxHi[i];
+            v[0] = ordered_from_float(lo.x), v[1] = ordered_from_float(lo.y), v[2] = ordered_from_float(lo.z);
+            v[3] = ordered_from_float(hi.x), v[4] = ordered_from_float(hi.y), v[5] = ordered_from_float(hi.z);
+        }
+        const uint32_t g0 = __shfl(g, __ffsll((long long)__ballot(valid)) - 1);
+        if (__all(!valid || g == g0))
+        {
+            if (g0 != run)
+            {
+                group_bounds_flush(run, acc, gb); // the row starts another group: hand the finished one over
+                run = g0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    acc[k] = k < 3 ? 0xffffffffu : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                acc[k] = k < 3 ? min(acc[k], v[k]) : max(acc[k], v[k]);
+        }
+        else if (valid)
+        {
+            // a row that straddles groups (at most one per group boundary): every lane for itself
+            uint32_t* p = gb + 6 * (size_t)g;
+            atomicMin(p + 0, v[0]);
+            atomicMin(p + 1, v[1]);
+            atomicMin(p + 2, v[2]);
+            atomicMax(p + 3, v[3]);
+            atomicMax(p + 4, v[4]);
+            atomicMax(p + 5, v[5]);
+        }
+    }
+    group_bounds_flush(run, acc, gb);
 }
 __global__ void k_decode_group_bounds(const uint32_t* __restrict__ gb, float* __restrict__ out, uint32_t nGroups)
 {

@@ -263,6 +263,46 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 #define SKH_FETCH_STRIDE 32
 #define SKH_COUNT_STRIDE 32 // same for the queue-length words the compaction atomics hit
 
+// The tail of a closest-hit launch (round 4).  A persistent launch ends when its LAST ray ends: once the queue is dry the waves thin out and
+// the launch waits ~0.3 ms for a few long rays at a handful of lanes per wave -- per bounce, before the dependent k_shade may start; a rank's
+// 1/8 share of a frame loses 9 % to that.  Continuations take the per-bounce barrier away from those rays: a wave that finds the queue dry
+// PARKS the rays it still carries (the ray, its best hit, current node and stack: a record in one of eight per-shard lists), marks their queue
+// entries (high bit of the id word: k_shade skips them) and exits.  The NEXT closest-hit launch takes the parked rays first (`resume`), 64 to
+// a wave again, among a full launch's worth of other work; their results go back into their records and the k_shade launch after it shades
+// them too ("late" rays, read from the records) -- one launch later than their queue mates, which their id word records as a LAG (bits 28-30):
+// the bounce index of a ray is `launch index - lag`, and what it emits inherits the lag.  A path may be parked `lagMax` times; that many extra
+// launch rounds at the end of the pass drain the stragglers.  Paths are independent, a path has one ray in flight, and every sum it takes
+// part in stays in its own bounce order: images are bit-identical (tests/test_gpu_parity.py::test_tail_passes_are_exact).
+// Record = SKH_TAIL_HDR + SKH_STACK_LDS words, in planes of SKH_SHARDS * capacity.
+#define SKH_TAIL_HDR 16 // id word (path | lag << 28) | cur | sp, found << 31 (0xffffffff: moved on to the next list) | best t u v inst prim | leaf put aside | o xyz d xyz tmin
+#define SKH_PARKED_BIT 0x80000000u
+#define SKH_LAG_SHIFT 28
+#define SKH_PATH_MASK 0x0fffffffu
+struct TailQ
+{
+    // one list per queue shard (a late ray is shaded into the output shard of ITS input shard, so that no shard can outgrow its region):
+    // list g = records [g * capacity, g * capacity + min(count[g], capacity)); a list that is full takes no more -- those rays stay in their wave
+    uint32_t* park; // records this launch parks
+    uint32_t* parkCount; // SKH_SHARDS words, SKH_COUNT_STRIDE apart (own 128-byte lines), then SKH_SHARDS copies of the "queue is dry" flag, same spacing
+    uint32_t* budget; // SKH_SHARDS words, same spacing: rays parked per shard in the whole PASS, capped at `capacity` -- so a shard never holds more
+                      // than `capacity` lagging rays, and the drain rounds' k_shade grids can be sized by it
+    uint32_t* resume; // records the launch before parked: taken first, results written back into them
+    const uint32_t* resumeCount; // their lists' lengths
+    uint32_t* resumeFetch; // SKH_SHARDS cursors, SKH_FETCH_STRIDE apart
+    uint32_t capacity; // records per list
+    uint32_t parkMax, lagMax;
+    // (kernel argument beside the pointer to this struct -- flags: 1 = may park (when the queue is dry and at most `parkMax` lanes of the wave still
+    // carry a ray), 2 = has parked rays to resume)
+    __device__ static uint32_t* plane(uint32_t* base, uint32_t cap, uint32_t k)
+    {
+        return base + (size_t)k * (SKH_SHARDS * cap);
+    }
+    __device__ uint32_t* dry(uint32_t g) const // (a copy per workgroup label: thousands of waves poll it)
+    {
+        return parkCount + (SKH_SHARDS + g) * SKH_COUNT_STRIDE;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------------------
 // k_trace: persistent waves over the ray queue, two-level BVH traversal (TLAS -> instance -> BLAS).
 //
@@ -278,12 +318,15 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 // ------------------------------------------------------------------------------------------------------------
 // WORLD: the build for scenes whose every instance is baked (no TLAS leaf, no curve set -- what a bake without mesh sharing gives,
 // HdStrelka's per-instance meshes): one world-space tree, no instance entry / exit, no object-space copy of the ray, no sentinel.
-template <bool ANY_HIT, bool COUNT, bool CURVES, bool W8 = false, bool WORLD = false>
+// TAILQ: the build with the continuation code in it (TailQ: park / resume); the launches that never park run the build without it -- the
+// extra paths cost the traversal loop registers (13 spilled dwords) even when they are never taken.
+template <bool ANY_HIT, bool COUNT, bool CURVES, bool W8 = false, bool WORLD = false, bool TAILQ = false>
 __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES : (CURVES ? SKH_CURVE_MIN_WAVES : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES))) SKH_TRACE_ATTR
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
             uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, 
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
-            StatsDev* __restrict__ stats)
+            StatsDev* __restrict__ stats, const TailQ* __restrict__ tailp /* this launch's continuation lists: read where they are used (rare paths), not
+            held in SGPRs through the traversal loop */, uint32_t tailFlagsArg)
 {
     static_assert(!WORLD || !CURVES, "the world-only build is a triangle kernel");
     constexpr bool CULL = SKH_POP_CULL && WORLD && !ANY_HIT && !W8;
@@ -291,10 +334,14 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
     __shared__ int s_stack[(CULL ? 2 : 1) * NLDS * SKH_TRACE_BLOCK];
     const uint32_t fetchMin = fetchArg & 0xffu, curveMin = (fetchArg >> 8) & 0xffu, nodeBreak = (fetchArg >> 16) & 0xffu, leafMin = fetchArg >> 24;
     const uint32_t lane = threadIdx.x;
+    constexpr bool TAILS = TAILQ && WORLD && !ANY_HIT && !W8 && !SKH_POP_CULL; // the build that can park / resume rays (TailQ)
+    const uint32_t tailFlags = TAILS ? tailFlagsArg : 0u;
+#define tail (*tailp)
+    uint32_t phase = (tailFlags & 2u) ? 0u : 1u; // where a refill looks: 0 = the parked rays of the launch before (first), 1 = the ray queue
     uint32_t n = 0; // (countPtr: SKH_SHARDS queue-length words, SKH_COUNT_STRIDE apart)
 #pragma unroll
     for (uint32_t g = 0; g < SKH_SHARDS; ++g)
-        n += countPtr[g * SKH_COUNT_STRIDE];
+        n += countPtr[g * SKH_COUNT_STRIDE] + ((tailFlags & 2u) ? tail.resumeCount[g * SKH_COUNT_STRIDE] : 0u);
     if (n == 0)
         return;
     const uint32_t perGroup = rq.region;
@@ -335,6 +382,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
     int sp = 0, cur = SKH_REF_INVALID;
     constexpr bool POSTPONE = SKH_POSTPONE && WORLD && !ANY_HIT && !W8;
     int leaf2 = SKH_REF_INVALID; // (POSTPONE) the leaf this lane has put aside
+    uint32_t dryNext = 0; // (TAILS) the "queue is dry" flag as loaded one iteration ago
+    uint32_t pollTick = 0;
+    bool parkTried = false; // (TAILS) a wave offers its rays to the tail lists once (a full list must not be hammered every iteration)
     constexpr bool PF2 = SKH_PREFETCH2 && WORLD && !ANY_HIT && !W8;
     int pf = SKH_REF_INVALID; // (PF2) the second-nearest hit child of the node just processed: its line is touched behind the next node fetch
     int pfv = 0;
@@ -416,6 +466,17 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
 #endif
                     }
                 }
+                else if (TAILS && (i & 0x80000000u))
+                {
+                    // a resumed ray: its hit goes back into its record, where the late part of k_shade finds it
+                    const uint32_t k = i & 0x7fffffffu;
+                    TailQ::plane(tail.resume, tail.capacity, 2)[k] = best.found ? 0x80000000u : 0u;
+                    TailQ::plane(tail.resume, tail.capacity, 3)[k] = __float_as_uint(best.t);
+                    TailQ::plane(tail.resume, tail.capacity, 4)[k] = __float_as_uint(best.u);
+                    TailQ::plane(tail.resume, tail.capacity, 5)[k] = __float_as_uint(best.v);
+                    TailQ::plane(tail.resume, tail.capacity, 6)[k] = best.inst;
+                    TailQ::plane(tail.resume, tail.capacity, 7)[k] = best.prim;
+                }
                 else
                 {
                     float4* hr = hq.rec(i);
@@ -429,29 +490,83 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
             SKH_LP(wv[4]++; wv[5] += want;)
             uint32_t base = 0, count = 0;
             const int leader = __ffsll((long long)needMask) - 1;
-            while (tries < 8u)
+            bool fromResume = false;
+            for (;;)
             {
-                const uint32_t g = (group + tries) & 7u;
-                uint32_t b = 0;
-                if ((int)lane == leader)
-                    b = atomicAdd(&fetch[g * SKH_FETCH_STRIDE], want);
-                b = __shfl(b, leader);
-                const uint32_t lo = g * perGroup;
-                const uint32_t hi = lo + countPtr[g * SKH_COUNT_STRIDE];
-                if (lo < hi && b < hi - lo)
+                // the work of this phase: the eight lists of parked rays (phase 0) or the eight shards of the queue (phase 1); same cursor logic
+                const bool ph0 = TAILS && phase == 0u;
+                const uint32_t* __restrict__ cntPtr = ph0 ? tail.resumeCount : countPtr;
+                uint32_t* cursors = ph0 ? tail.resumeFetch : fetch;
+                const uint32_t span = ph0 ? tail.capacity : perGroup;
+                while (tries < 8u)
                 {
-                    base = lo + b;
-                    count = min(want, hi - base);
-                    if (count < want)
-                        ++tries; // this range is now empty
-                    break;
+                    const uint32_t g = (group + tries) & 7u;
+                    uint32_t b = 0;
+                    if ((int)lane == leader)
+                        b = atomicAdd(&cursors[g * SKH_FETCH_STRIDE], want);
+                    b = __shfl(b, leader);
+                    const uint32_t lo = g * span;
+                    const uint32_t hi = lo + min(cntPtr[g * SKH_COUNT_STRIDE], span);
+                    if (lo < hi && b < hi - lo)
+                    {
+                        base = lo + b;
+                        count = min(want, hi - base);
+                        if (count < want)
+                            ++tries; // this range is now empty
+                        break;
+                    }
+                    ++tries;
                 }
-                ++tries;
+                fromResume = ph0;
+                if (ph0 && tries >= 8u && count == 0)
+                {
+                    phase = 1u; // no parked rays left: on to the queue, in this same refill
+                    tries = 0;
+                    continue;
+                }
+                break;
             }
             if (tries >= 8u && count == 0)
+            {
                 exhausted = true;
+                if (TAILS && (tailFlags & 1u) && lane < SKH_SHARDS)
+                    __hip_atomic_store(tail.dry(lane), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // every ray has been handed out: tell the other waves
+            }
             const uint32_t rank = (uint32_t)__popcll(needMask & ((1ull << lane) - 1ull));
-            if (!hasRay && rank < count)
+            if (TAILS && fromResume)
+            {
+                // ---- resume: a parked ray's record instead of a queue entry ----
+                if (!hasRay && rank < count)
+                {
+                    const uint32_t k = base + rank;
+                    uint32_t* R = tail.resume;
+                    const uint32_t C = tail.capacity;
+                    ridx = k | 0x80000000u; // (bit 31: "late" -- the result goes back into record k)
+                    cur = (int)TailQ::plane(R, C, 1)[k];
+                    const uint32_t spw = TailQ::plane(R, C, 2)[k];
+                    sp = (int)(spw & 0x7fffffffu);
+                    best.found = (spw >> 31) != 0u;
+                    best.t = __uint_as_float(TailQ::plane(R, C, 3)[k]), best.u = __uint_as_float(TailQ::plane(R, C, 4)[k]), best.v = __uint_as_float(TailQ::plane(R, C, 5)[k]);
+                    best.inst = TailQ::plane(R, C, 6)[k], best.prim = TailQ::plane(R, C, 7)[k];
+                    leaf2 = (int)TailQ::plane(R, C, 8)[k];
+                    ow = mk3(__uint_as_float(TailQ::plane(R, C, 9)[k]), __uint_as_float(TailQ::plane(R, C, 10)[k]), __uint_as_float(TailQ::plane(R, C, 11)[k]));
+                    dw = mk3(__uint_as_float(TailQ::plane(R, C, 12)[k]), __uint_as_float(TailQ::plane(R, C, 13)[k]), __uint_as_float(TailQ::plane(R, C, 14)[k]));
+                    tmin = __uint_as_float(TailQ::plane(R, C, 15)[k]);
+                    for (int e = 0; e < sp; ++e) // (parked with sp <= NLDS)
+                        lds[e * SKH_TRACE_BLOCK] = (int)TailQ::plane(R, C, SKH_TAIL_HDR + e)[k];
+                    o = ow;
+                    d = dw;
+                    inv = rcp3(d);
+                    sh = make_shear(dw);
+                    nodes = sc.triNodes;
+                    inBlas = true;
+                    curInst = 0xffffffffu;
+                    curType = 0;
+                    pend = 0;
+                    hasRay = true;
+                }
+            }
+            else if (!hasRay && rank < count)
             {
                 ridx = base + rank;
                 ow = mk3(rq.plane(0)[ridx], rq.plane(1)[ridx], rq.plane(2)[ridx]);
@@ -503,6 +618,74 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                 pend = 0;
                 leaf2 = SKH_REF_INVALID;
                 hasRay = true;
+            }
+        }
+        if (TAILS && (tailFlags & 1u))
+        {
+            // a wave learns that the queue is dry when its own refill fails -- which it only attempts with `fetchMin` idle lanes -- or from the
+            // flag the first such wave sets (lane 0 polls its label's copy every fourth iteration, one poll ahead: the load is never waited for)
+            if (!exhausted && phase == 1u && (++pollTick & 3u) == 0u)
+            {
+                if (__builtin_amdgcn_readfirstlane((int)dryNext) != 0)
+                    exhausted = true;
+                if (lane == 0u)
+                    dryNext = __hip_atomic_load(tail.dry(group), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // ---- park: the queue is dry and this wave is down to a few rays -- leave them to the next launch and go ----
+            const unsigned long long live = __ballot(hasRay);
+            if (exhausted && !parkTried && live != 0ull && (uint32_t)__popcll(live) <= tail.parkMax)
+            {
+                parkTried = true;
+                const bool late = (ridx & 0x80000000u) != 0u;
+                uint32_t idw = 0;
+                if (hasRay) // the ray's id word: path | lag << 28
+                    idw = late ? TailQ::plane(tail.resume, tail.capacity, 0)[ridx & 0x7fffffffu] : rq.ids()[ridx];
+                const uint32_t lag = (idw >> SKH_LAG_SHIFT) & 7u;
+                // (a ray with entries in the global overflow area stays: rare; so does a path that has used up its lag allowance)
+                const bool canPark = hasRay && sp <= NLDS && lag < tail.lagMax;
+                const uint32_t myShard = !canPark ? 0xffffffffu : (late ? (ridx & 0x7fffffffu) / tail.capacity : min(ridx / rq.region, SKH_SHARDS - 1u));
+                bool parked = false;
+                for (uint32_t g = 0; g < SKH_SHARDS; ++g)
+                {
+                    const unsigned long long m = __ballot(myShard == g);
+                    if (m == 0ull)
+                        continue;
+                    const int leader = __ffsll((long long)m) - 1;
+                    uint32_t b = 0xffffffffu;
+                    if ((int)lane == leader)
+                    {
+                        const uint32_t cnt = (uint32_t)__popcll(m);
+                        if (atomicAdd(&tail.budget[g * SKH_COUNT_STRIDE], cnt) + cnt <= tail.capacity) // (the pass's allowance for this shard)
+                            b = atomicAdd(&tail.parkCount[g * SKH_COUNT_STRIDE], cnt);
+                    }
+                    b = __shfl(b, leader);
+                    const uint32_t pos = b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (myShard == g && b != 0xffffffffu) // (allowance used up: the rays stay in their wave)
+                    {
+                        const uint32_t k = g * tail.capacity + pos;
+                        uint32_t* P = tail.park;
+                        const uint32_t C = tail.capacity;
+                        TailQ::plane(P, C, 0)[k] = (idw & SKH_PATH_MASK) | ((lag + 1u) << SKH_LAG_SHIFT); // shaded one launch later than it would have been
+                        TailQ::plane(P, C, 1)[k] = (uint32_t)cur;
+                        TailQ::plane(P, C, 2)[k] = (uint32_t)sp | (best.found ? 0x80000000u : 0u);
+                        TailQ::plane(P, C, 3)[k] = __float_as_uint(best.t), TailQ::plane(P, C, 4)[k] = __float_as_uint(best.u), TailQ::plane(P, C, 5)[k] = __float_as_uint(best.v);
+                        TailQ::plane(P, C, 6)[k] = best.inst, TailQ::plane(P, C, 7)[k] = best.prim;
+                        TailQ::plane(P, C, 8)[k] = (uint32_t)leaf2;
+                        TailQ::plane(P, C, 9)[k] = __float_as_uint(ow.x), TailQ::plane(P, C, 10)[k] = __float_as_uint(ow.y), TailQ::plane(P, C, 11)[k] = __float_as_uint(ow.z);
+                        TailQ::plane(P, C, 12)[k] = __float_as_uint(dw.x), TailQ::plane(P, C, 13)[k] = __float_as_uint(dw.y), TailQ::plane(P, C, 14)[k] = __float_as_uint(dw.z);
+                        TailQ::plane(P, C, 15)[k] = __float_as_uint(tmin);
+                        for (int e = 0; e < sp; ++e)
+                            TailQ::plane(P, C, SKH_TAIL_HDR + e)[k] = (uint32_t)lds[e * SKH_TRACE_BLOCK];
+                        if (late)
+                            TailQ::plane(tail.resume, C, 2)[ridx & 0x7fffffffu] = 0xffffffffu; // its old record: moved on, nothing to shade there
+                        else
+                            rq.ids()[ridx] = idw | SKH_PARKED_BIT; // k_shade leaves this queue entry alone
+                        hasRay = false; // (no result of its own: `pending` stays false)
+                        parked = true;
+                    }
+                }
+                if (__any(parked))
+                    continue; // (the top of the loop writes the results of the lanes that had finished before, if all 64 lanes are idle now)
             }
         }
         if (!__any(hasRay))
@@ -1171,7 +1354,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                 {
                     float* r = stats->slow[k];
                     r[0] = (float)rayNodes, r[1] = (float)rayTris, r[2] = (float)rayInsts, r[3] = ANY_HIT ? 1.0f : 0.0f;
-                    r[4] = ow.x, r[5] = ow.y, r[6] = ow.z, r[7] = dw.x, r[8] = dw.y, r[9] = dw.z, r[10] = tmin, r[11] = rq.plane(7)[ridx];
+                    r[4] = ow.x, r[5] = ow.y, r[6] = ow.z, r[7] = dw.x, r[8] = dw.y, r[9] = dw.z, r[10] = tmin, r[11] = (ridx & 0x80000000u) ? 0.0f : rq.plane(7)[ridx];
                 }
             }
             rayNodes = rayTris = rayInsts = 0;
@@ -1181,6 +1364,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
     }
 #undef SKH_PUSH
 #undef SKH_POP
+#undef tail
     if (COUNT)
     {
         const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.prims), c2 = wave_sum(tc.segs), d2 = wave_sum(tc.insts);
@@ -1466,11 +1650,17 @@ SKH_DI SurfaceHit fill_curve(const DevScene& sc, const HostInstance& hi, const f
 #ifndef SKH_SHADE_BLOCK
 #define SKH_SHADE_BLOCK 256 // 132 VGPRs = 3 waves/SIMD: 256-thread blocks (1 wave per SIMD) fill all three, 512-thread blocks only two
 #endif
-template <bool HAIR> // HAIR: the build with df::chiang_hair_bsdf in it (launched when the material list holds a hair material)
+// HAIR: the build with df::chiang_hair_bsdf in it (launched when the material list holds a hair material); LATE: the build that knows about
+// continuations (TailQ: parked queue entries are skipped, a ray's bounce index is launchDepth - its lag, the last workgroups shade late rays
+// from their records) -- passes without continuations run the build without it (its id words are plain path ids)
+template <bool HAIR, bool LATE = false>
 __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
-    k_shade(DevScene sc, FrameP fp, uint32_t sampleOffset, uint32_t depth, const uint32_t* __restrict__ tileXY, RayQ rq,
+    k_shade(DevScene sc, FrameP fp, uint32_t sampleOffset, uint32_t launchDepth /* bounce index of a ray = launchDepth - its lag */, const uint32_t* __restrict__ tileXY, RayQ rq,
             const uint32_t* __restrict__ countPtr, HitQ hq, PathS ps, RayQ nextQ, uint32_t* __restrict__ nextCount, RayQ shadowQ,
-            float* __restrict__ contrib, uint32_t* __restrict__ shadowCount)
+            float* __restrict__ contrib, uint32_t* __restrict__ shadowCount,
+            uint32_t lateBlocks /* the LAST lateBlocks workgroups shade the "late" rays: parked by the launch before, resumed by this bounce's closest-hit launch ... */,
+            const uint32_t* __restrict__ lateRec /* ... read from their records (TailQ) ... */, const uint32_t* __restrict__ lateCount /* ... a list per shard ... */,
+            uint32_t lateCap /* ... of this capacity */)
 {
     __shared__ uint32_t s_wave[2 * (SKH_COMPACT_MAX_WAVES + 1)];
     __shared__ uint32_t s_sobol[SKH_SOBOL_LUT_WORDS];
@@ -1479,13 +1669,16 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
     // Sobol table; a hit whose material lies beyond them reads global memory as before
     __shared__ float4 s_mat[SKH_MATERIALS_LDS * 4];
 #endif
-    // workgroup b works on shard b & 7 (and compacts into the same shard of both output queues)
-    const uint32_t shard = blockIdx.x & (SKH_SHARDS - 1u), lb = blockIdx.x / SKH_SHARDS;
-    const uint32_t n = countPtr[shard * SKH_COUNT_STRIDE]; // rays in this shard
+    // workgroup b works on shard b & 7 (and compacts into the same shard of both output queues); the late workgroups split the parked rays'
+    // per-shard lists the same way: a ray is shaded into the output shard of its input shard
+    const bool lateMode = LATE && blockIdx.x >= gridDim.x - lateBlocks;
+    const uint32_t bIdx = lateMode ? blockIdx.x - (gridDim.x - lateBlocks) : blockIdx.x;
+    const uint32_t shard = bIdx & (SKH_SHARDS - 1u), lb = bIdx / SKH_SHARDS;
+    const uint32_t n = lateMode ? min(lateCount[shard * SKH_COUNT_STRIDE], lateCap) : countPtr[shard * SKH_COUNT_STRIDE]; // rays in this shard
     if (lb * blockDim.x >= n)
         return; // whole block past the end of its shard
     const uint32_t il = lb * blockDim.x + threadIdx.x;
-    const uint32_t i = shard * rq.region + il;
+    const uint32_t i = lateMode ? shard * lateCap + il : shard * rq.region + il;
 #ifdef SKH_LANE_PROFILE
     unsigned long long spc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, spT = __builtin_readcyclecounter();
 #define SKH_SP(k)                                                    \
@@ -1520,17 +1713,48 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
 #endif
     }
     __syncthreads();
-    const bool valid = il < n;
+    bool valid = il < n;
     bool emitNext = false, emitShadow = false;
     v3 nextO = mk3(0.0f), nextD = mk3(0.0f), shO = mk3(0.0f), shD = mk3(0.0f), shC = mk3(0.0f);
     float shTmax = 0.0f;
-    uint32_t pid = 0;
+    uint32_t pid = 0, lag = 0;
+    uint32_t lateWord = 0;
     if (valid)
     {
-        pid = rq.ids()[i];
-        const v3 rayO = mk3(rq.plane(0)[i], rq.plane(1)[i], rq.plane(2)[i]);
-        const v3 rayD = mk3(rq.plane(3)[i], rq.plane(4)[i], rq.plane(5)[i]);
-        const float4 hr0 = hq.rec(i)[0], hr1 = hq.rec(i)[1];
+        // the id word: path | lag << 28 | parked << 31.  A ray the closest-hit launch parked has no hit yet (the next launch resumes it, the late
+        // workgroups of the NEXT k_shade shade it); a late record that was parked again has moved on to the next list
+        const uint32_t idw = lateMode ? TailQ::plane(const_cast<uint32_t*>(lateRec), lateCap, 0)[i] : rq.ids()[i];
+        if (LATE)
+        {
+            if (lateMode)
+                lateWord = TailQ::plane(const_cast<uint32_t*>(lateRec), lateCap, 2)[i];
+            if (lateMode ? lateWord == 0xffffffffu : (idw & SKH_PARKED_BIT) != 0u)
+                valid = false;
+            pid = idw & SKH_PATH_MASK;
+            lag = (idw >> SKH_LAG_SHIFT) & 7u;
+        }
+        else
+            pid = idw;
+    }
+    const uint32_t depth = launchDepth - lag; // (lag <= launchDepth: a ray is parked at most once per launch)
+    if (valid)
+    {
+        v3 rayO, rayD;
+        float4 hr0, hr1;
+        if (lateMode)
+        {
+            uint32_t* R = const_cast<uint32_t*>(lateRec);
+            rayO = mk3(__uint_as_float(TailQ::plane(R, lateCap, 9)[i]), __uint_as_float(TailQ::plane(R, lateCap, 10)[i]), __uint_as_float(TailQ::plane(R, lateCap, 11)[i]));
+            rayD = mk3(__uint_as_float(TailQ::plane(R, lateCap, 12)[i]), __uint_as_float(TailQ::plane(R, lateCap, 13)[i]), __uint_as_float(TailQ::plane(R, lateCap, 14)[i]));
+            hr0 = make_float4(__uint_as_float(TailQ::plane(R, lateCap, 3)[i]), __uint_as_float(TailQ::plane(R, lateCap, 4)[i]), __uint_as_float(TailQ::plane(R, lateCap, 5)[i]), 0.0f);
+            hr1 = make_float4(__uint_as_float(TailQ::plane(R, lateCap, 6)[i]), __uint_as_float(TailQ::plane(R, lateCap, 7)[i]), 0.0f, 0.0f);
+        }
+        else
+        {
+            rayO = mk3(rq.plane(0)[i], rq.plane(1)[i], rq.plane(2)[i]);
+            rayD = mk3(rq.plane(3)[i], rq.plane(4)[i], rq.plane(5)[i]);
+            hr0 = hq.rec(i)[0], hr1 = hq.rec(i)[1];
+        }
         const float ht = hr0.x, hu = hr0.y, hv = hr0.z;
         const uint32_t hinst = __float_as_uint(hr1.x), hprim = __float_as_uint(hr1.y);
         float* P = ps.base;
@@ -1824,7 +2048,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
         nextQ.plane(5)[ni] = nextD.z;
         nextQ.plane(6)[ni] = fp.materialTmin;
         nextQ.plane(7)[ni] = 1e16f;
-        nextQ.ids()[ni] = pid;
+        nextQ.ids()[ni] = LATE ? (pid | (lag << SKH_LAG_SHIFT)) : pid; // (what a late ray emits stays one launch behind its bounce index)
     }
     if (emitShadow)
     {

@@ -59,6 +59,11 @@ enum KernelClass
     KC_COUNT
 };
 
+// continuation words per closest-hit launch: the 8 park lists' lengths + 8 copies of the dry flag (SKH_COUNT_STRIDE apart), then the 8 cursors with
+// which the NEXT launch hands those lists out (SKH_FETCH_STRIDE apart)
+#define SKH_TAIL_WORDS (16 * SKH_COUNT_STRIDE + 8 * SKH_FETCH_STRIDE)
+#define SKH_MAX_LAUNCH_ROUNDS 140 // MAX_BOUNCES (128) + the drain rounds of the continuations + slack
+
 struct TimedSpan
 {
     int cls;
@@ -73,6 +78,14 @@ struct skh_context
     hipStream_t stream2 = nullptr; // any-hit launches when `overlap` is on: shadow[b] runs beside closest[b+1] and fills its tail
     int overlap = 1; // 0 off, 1 for small passes only (<= 8 M paths: the interactive one-sub-frame-per-call mode, +7 %), 2 always
     hipEvent_t evShade = nullptr, evShadow = nullptr;
+    // continuations (TailQ, skh_kernels.h): a closest-hit launch of an overlapped (small) pass parks the rays its thinning waves still carry once
+    // the queue is dry; the next closest-hit launch resumes them, the k_shade after it shades them ("late")
+    uint32_t tailPark = 0; // option tail_park: a wave parks when at most this many of its lanes still carry a ray (0 = no continuations: the default --
+                           // measured slower than the launch tails they remove, docs/LOG.md round 4)
+    uint32_t tailLag = 2; // option tail_lag: how often one path may be parked = extra launch rounds at the end of a pass
+    DevBuf dTail[2], dTailCounts, dTailDesc; // (dTailDesc: one TailQ per launch round, rewritten when what it describes changes)
+    std::vector<uint32_t> tailDescKey;
+    uint32_t tailCapacity = 0;
     ncclComm_t comm = nullptr; // multi-GPU tile gather (skh_comm_init)
     int commWorld = 1, commRank = 0;
     DevBuf dTileSend;
@@ -336,9 +349,9 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
         SKH_TRY(c, hipStreamSynchronize(st));
         return SKH_OK;
     }
-    DevBuf gbU, keysA, keysB, valsB, hist, childL, childR, parent, rangeF, rangeL, flags, nodeLo, nodeHi, gFirst, gCount;
+    DevBuf gbU, keysA, keysB, valsB, hist, histSums, childL, childR, parent, rangeF, rangeL, flags, nodeLo, nodeHi, gFirst, gCount;
     auto cleanup = [&]() {
-        for (DevBuf* b : { &gbU, &keysA, &keysB, &valsB, &hist, &childL, &childR, &parent, &rangeF, &rangeL, &flags, &nodeLo, &nodeHi,
+        for (DevBuf* b : { &gbU, &keysA, &keysB, &valsB, &hist, &histSums, &childL, &childR, &parent, &rangeF, &rangeL, &flags, &nodeLo, &nodeHi,
                            &gFirst, &gCount })
             dev_free(*b);
     };
@@ -354,9 +367,13 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
     LB_ALLOC(valsB, sizeof(uint32_t) * (size_t)n);
     const uint32_t rsBlocks = (n + SKH_RS_THREADS * SKH_RS_ITEMS - 1) / (SKH_RS_THREADS * SKH_RS_ITEMS);
     LB_ALLOC(hist, sizeof(uint32_t) * 256 * (size_t)rsBlocks);
+    // the digit histograms (256 x blocks words: 1.4 M for 23 M keys) are scanned by many workgroups -- blocks of 4096, a one-workgroup scan of
+    // the block sums, an add pass -- not by ONE workgroup walking the whole array (round 3: up to 2.5 ms per sort pass, eight passes)
+    const uint32_t histWords = 256u * rsBlocks, histBlocks = (histWords + SKH_SCAN_BLOCK * SKH_SCAN_ITEMS - 1) / (SKH_SCAN_BLOCK * SKH_SCAN_ITEMS);
+    LB_ALLOC(histSums, sizeof(uint32_t) * (size_t)(histBlocks + 1));
     const uint32_t B = 256, G1 = (n + B - 1) / B;
     k_init_group_bounds<<<(nGroups * 6 + B - 1) / B, B, 0, st>>>(gbU.as<uint32_t>(), nGroups);
-    k_group_bounds<<<G1, B, 0, st>>>(dBoxLo, dBoxHi, dGrp, n, gbU.as<uint32_t>());
+    k_group_bounds<<<(G1 + SKH_GB_RUN - 1) / SKH_GB_RUN, B, 0, st>>>(dBoxLo, dBoxHi, dGrp, n, gbU.as<uint32_t>()); // (a wave walks SKH_GB_RUN rows of 64)
     k_decode_group_bounds<<<(nGroups * 6 + B - 1) / B, B, 0, st>>>(gbU.as<uint32_t>(), out.groupBounds.as<float>(), nGroups);
     uint32_t* valsA = out.sortedVals.as<uint32_t>();
     // sort key: group id above a Morton code of `morton_bits` (10) bits per axis -- fewer when the group ids need the room
@@ -376,7 +393,14 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
     for (uint32_t shift : shifts)
     {
         k_rs_hist<<<rsBlocks, SKH_RS_THREADS, 0, st>>>(kin, n, shift, hist.as<uint32_t>(), rsBlocks, nullptr);
-        k_rs_scan<<<1, 1024, 0, st>>>(hist.as<uint32_t>(), 256 * rsBlocks);
+        if (histBlocks > 1)
+        {
+            k_scan_block<<<histBlocks, SKH_SCAN_BLOCK, 0, st>>>(hist.as<uint32_t>(), histWords, histSums.as<uint32_t>());
+            k_rs_scan<<<1, 1024, 0, st>>>(histSums.as<uint32_t>(), histBlocks);
+            k_scan_add<<<histBlocks, SKH_SCAN_BLOCK, 0, st>>>(hist.as<uint32_t>(), histWords, histSums.as<uint32_t>());
+        }
+        else
+            k_rs_scan<<<1, 1024, 0, st>>>(hist.as<uint32_t>(), histWords);
         k_rs_scatter<<<rsBlocks, SKH_RS_THREADS, 0, st>>>(kin, vin, kout, vout, n, shift, hist.as<uint32_t>(), rsBlocks, nullptr);
         std::swap(kin, kout);
         std::swap(vin, vout);
@@ -942,7 +966,7 @@ void skh_destroy(skh_context* c)
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
                        &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
-                       &c->dCounts, &c->dOvf, &c->dOvf2, &c->dStats, &c->dScratchImage, &c->dPathB })
+                       &c->dCounts, &c->dOvf, &c->dOvf2, &c->dStats, &c->dScratchImage, &c->dPathB, &c->dTail[0], &c->dTail[1], &c->dTailCounts, &c->dTailDesc })
         dev_free(*b);
     for (hipEvent_t e : c->eventPool)
         (void)hipEventDestroy(e);
@@ -1795,10 +1819,18 @@ static skh_status alloc_frame(skh_context* c)
     AF(dev_alloc(c, c->dHits, sizeof(float) * 8 * NQ));
     AF(dev_alloc(c, c->dShadowQ, sizeof(float) * 9 * NQ));
     AF(dev_alloc(c, c->dContrib, sizeof(float) * 3 * NQ));
-    AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * (SKH_COUNT_STRIDE * SKH_SHARDS * 2 * 130 + 16 * SKH_FETCH_STRIDE * 130)));
+    AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * (SKH_COUNT_STRIDE * SKH_SHARDS * 2 * SKH_MAX_LAUNCH_ROUNDS + 16 * SKH_FETCH_STRIDE * SKH_MAX_LAUNCH_ROUNDS)));
     c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
     AF(dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * std::max(c->traceBlocks, (uint32_t)c->numCUs * c->wavesPerCUShadow) * SKH_TRACE_BLOCK));
     AF(dev_alloc(c, c->dOvf2, sizeof(int) * (size_t)SKH_STACK_OVF * std::max(c->traceBlocks, (uint32_t)c->numCUs * c->wavesPerCUShadow) * SKH_TRACE_BLOCK));
+    // continuations: two sets (this launch parks into one, resumes the other) of a list of parked-ray records per queue shard; per launch the
+    // lists' lengths, the "queue is dry" flags and the next launch's eight cursors, each word in a 128-byte line of its own
+    c->tailCapacity = c->traceBlocks * SKH_TRACE_BLOCK / 2u; // per shard, per pass: the eight lists hold four times the lanes of the largest grid
+    AF(dev_alloc(c, c->dTail[0], sizeof(uint32_t) * (size_t)(SKH_TAIL_HDR + SKH_STACK_LDS) * SKH_SHARDS * c->tailCapacity));
+    AF(dev_alloc(c, c->dTail[1], sizeof(uint32_t) * (size_t)(SKH_TAIL_HDR + SKH_STACK_LDS) * SKH_SHARDS * c->tailCapacity));
+    AF(dev_alloc(c, c->dTailCounts, sizeof(uint32_t) * SKH_TAIL_WORDS * SKH_MAX_LAUNCH_ROUNDS));
+    AF(dev_alloc(c, c->dTailDesc, sizeof(TailQ) * SKH_MAX_LAUNCH_ROUNDS));
+    c->tailDescKey.clear();
 #undef AF
     SKH_TRY(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(float4) * N1, c->stream));
     SKH_TRY(c, hipMemsetAsync(c->dDiffuse.p, 0, sizeof(float4) * N1, c->stream));
@@ -1954,7 +1986,8 @@ static skh_status ensure_ready(skh_context* c)
 // one launch of the persistent trace kernel over a sharded queue: picks the build (world-only / general / curves / 8-wide) and the grid
 template <bool ANY, bool COUNT>
 static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint32_t* countPtr, uint32_t* fetch,
-                         HitQ hq, PathS ps, const float* contrib, uint32_t contribStride, hipStream_t st = nullptr)
+                         HitQ hq, PathS ps, const float* contrib, uint32_t contribStride, hipStream_t st = nullptr,
+                         const TailQ* tail = nullptr /* device copy of this launch's continuation lists */, uint32_t tailFlags = 0)
 {
     // scenes without curve instances run the build of the kernel that has no curve intersector in it (fewer VGPRs)
     const bool curveBuild = c->nSegs != 0;
@@ -1968,24 +2001,27 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
     const uint32_t fullGrid = (ANY && !c->nSegs) ? (uint32_t)c->numCUs * c->wavesPerCUShadow : c->traceBlocks;
     const uint32_t blocks = c->gridOverride ? std::min(c->gridOverride, fullGrid) : fullGrid;
     const bool worldOnly = !c->nSegs && c->tlasRoot == SKH_REF_INVALID && (c->worldRoot != SKH_REF_INVALID || c->lightRoot != SKH_REF_INVALID) && c->worldKernel;
-    if (worldOnly && c->wide != 8)
+    if (worldOnly && c->wide != 8 && !ANY && tailFlags != 0u)
+        // ... with the continuation code (park / resume: overlapped passes)
+        k_trace<false, COUNT, false, false, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, tail, tailFlags);
+    else if (worldOnly && c->wide != 8)
         // every instance is baked: the world-only build of the kernel (no instance entry, no object-space copy of the ray)
-        k_trace<ANY, COUNT, false, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
+        k_trace<ANY, COUNT, false, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, tail, tailFlags);
     else if (worldOnly)
-        k_trace<ANY, COUNT, false, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
+        k_trace<ANY, COUNT, false, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, tail, tailFlags);
     else if (c->wide == 8)
     {
         if (c->nSegs)
-            k_trace<ANY, COUNT, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
+            k_trace<ANY, COUNT, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, tail, tailFlags);
         else
-            k_trace<ANY, COUNT, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
+            k_trace<ANY, COUNT, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, tail, tailFlags);
     }
     else if (c->nSegs)
         k_trace<ANY, COUNT, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride,
-                                                                                      ovf, sd);
+                                                                                      ovf, sd, tail, tailFlags);
     else
         k_trace<ANY, COUNT, false><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride,
-                                                                                       ovf, sd);
+                                                                                       ovf, sd, tail, tailFlags);
 }
 
 // After a synchronisation: did any traversal of the calls since the last check drop a stack entry (its result may miss hits)?
@@ -2051,7 +2087,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     // that is the target of atomics has a 128-byte line of its own (returning atomics on one line serialise at ~88 per microsecond)
     uint32_t* counts = c->dCounts.as<uint32_t>();
     const uint32_t QW = SKH_COUNT_STRIDE * SKH_SHARDS; // words per queue's lengths
-    uint32_t* fetch = counts + QW * 2 * 130;
+    uint32_t* fetch = counts + QW * 2 * SKH_MAX_LAUNCH_ROUNDS;
     // shadow[b] on a second stream: it depends on shade[b] only, and so does closest[b+1]; each fills the other's tail.  Ray
     // sorting shares scratch buffers between the two and keeps everything on one stream.
     // overlap 1 (default): passes up to 32 M paths -- a rank's share of an N-GPU frame, the one-sub-frame-per-call pattern and its
@@ -2061,38 +2097,86 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     // per pass) gains 0.5 % and stays on one stream so that its per-kernel hipEvent spans do not overlap.  overlap 2: always, reduced grids.
     const bool smallPass = NP <= (1u << 23) || c->overlap == 2;
     const bool useOverlap = (c->overlap == 2 || (c->overlap == 1 && NP <= (1u << 25))) && fp.debug != 1;
+    // continuations (TailQ): overlapped passes only -- there the launch tails are what a rank's share of an N-GPU frame and the caller's
+    // small passes lose (docs/LOG.md); the world-only 4-wide closest-hit build is the one that can park and resume
+    const bool worldOnly4 = !c->nSegs && c->tlasRoot == SKH_REF_INVALID && (c->worldRoot != SKH_REF_INVALID || c->lightRoot != SKH_REF_INVALID) &&
+                            c->worldKernel && c->wide != 8;
+    const bool useTail = useOverlap && c->tailPark > 0 && c->tailLag > 0 && worldOnly4 && SKH_POP_CULL == 0;
+    // launch rounds of the pass: maxDepth of them carry every ray's bounces; with continuations a path may run `tailLag` rounds behind, and that
+    // many short rounds at the end drain the stragglers (their queues hold only lagging rays; a round without work costs three empty launches)
+    const uint32_t rounds = fp.maxDepth + (useTail ? c->tailLag : 0u);
+    uint32_t* tailCounts = c->dTailCounts.as<uint32_t>();
+    if (useTail)
+    {
+        // round b parks into record set b & 1 and resumes what round b - 1 parked into the other one
+        const std::vector<uint32_t> key = { rounds, c->tailPark, c->tailLag, c->tailCapacity, (uint32_t)(uintptr_t)c->dTail[0].p, (uint32_t)(uintptr_t)c->dTail[1].p,
+                                            (uint32_t)(uintptr_t)tailCounts };
+        if (key != c->tailDescKey)
+        {
+            std::vector<TailQ> desc(rounds);
+            for (uint32_t b = 0; b < rounds; ++b)
+                desc[b] = TailQ{ c->dTail[b & 1].as<uint32_t>(), tailCounts + b * SKH_TAIL_WORDS, tailCounts + rounds * SKH_TAIL_WORDS /* (the block after the last round's) */,
+                                 c->dTail[(b + 1) & 1].as<uint32_t>(), tailCounts + (b ? b - 1 : 0) * SKH_TAIL_WORDS,
+                                 tailCounts + (b ? b - 1 : 0) * SKH_TAIL_WORDS + 16 * SKH_COUNT_STRIDE, c->tailCapacity, c->tailPark, c->tailLag };
+            SKH_TRY(c, hipStreamSynchronize(st)); // (nothing may still read the old descriptors)
+            SKH_TRY(c, hipMemcpy(c->dTailDesc.p, desc.data(), sizeof(TailQ) * rounds, hipMemcpyHostToDevice));
+            c->tailDescKey = key;
+        }
+    }
+    const TailQ* tailDesc = c->dTailDesc.as<TailQ>();
+    const uint32_t lateGrid = SKH_SHARDS * ((c->tailCapacity + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK);
     for (uint32_t s = 0; trace && s < fp.samplesThisLaunch; ++s)
     {
-        SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (QW * 2 * 130 + 16 * SKH_FETCH_STRIDE * (fp.maxDepth + 1)), st));
+        SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (QW * 2 * SKH_MAX_LAUNCH_ROUNDS + 16 * SKH_FETCH_STRIDE * (rounds + 1)), st));
+        if (useTail)
+            SKH_TRY(c, hipMemsetAsync(tailCounts, 0, sizeof(uint32_t) * SKH_TAIL_WORDS * (rounds + 1), st));
         {
             SpanGuard g(c, KC_RAYGEN);
             k_raygen<<<c->raygenBlocksPerSub * fp.batch, 512, 0, st>>>(fp, tiles, s, rq[0], counts, ps, c->dRaygenBase.as<uint32_t>(),
                                                                        c->raygenBlocksPerSub, c->raygenValidPerSub);
         }
-        for (uint32_t b = 0; b < fp.maxDepth; ++b)
+        for (uint32_t b = 0; b < rounds; ++b)
         {
+            // the last round parks nothing, and a path is parked only while the drain rounds can still absorb its lag (lagMax)
+            const bool drain = b >= fp.maxDepth;
+            const uint32_t tflags = useTail ? ((b + 1 < rounds ? 1u : 0u) | (b > 0 ? 2u : 0u)) : 0u;
+            const uint32_t* lateRec = c->dTail[(b + 1) & 1].as<uint32_t>();
+            const uint32_t* lateCount = tailCounts + (b ? b - 1 : 0) * SKH_TAIL_WORDS;
             {
                 SpanGuard g(c, KC_TRACE_CLOSEST);
-                c->gridOverride = (useOverlap && smallPass) ? c->smallWavesClosest * (uint32_t)c->numCUs : 0u;
+                // (drain rounds: a handful of rays -- one wave per CU is plenty, and an empty launch of it costs next to nothing)
+                c->gridOverride = drain ? (uint32_t)c->numCUs : ((useOverlap && smallPass) ? c->smallWavesClosest * (uint32_t)c->numCUs : 0u);
                 if (c->countTraversal)
-                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, hq, ps, nullptr, 0);
+                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, hq, ps, nullptr, 0, nullptr, tailDesc + b, tflags);
                 else
-                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, hq, ps, nullptr, 0);
+                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, hq, ps, nullptr, 0, nullptr, tailDesc + b, tflags);
             }
             if (useOverlap && b > 0)
                 (void)hipStreamWaitEvent(st, c->evShadow, 0); // shade[b] reads the radiance shadow[b-1] adds to and reuses its queue
             {
                 SpanGuard g(c, KC_SHADE);
                 // a shard holds at most an eighth of the pass's paths (rounded up to whole waves): SKH_SHARDS x that many workgroups,
-                // workgroup b on shard b & 7; those past the end of their shard leave at once
-                const uint32_t perShard = (((NP + SKH_SHARDS - 1u) / SKH_SHARDS) + 63u) & ~63u;
-                const dim3 sg(SKH_SHARDS * ((perShard + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK));
+                // workgroup b on shard b & 7; those past the end of their shard leave at once.  With continuations the last workgroups
+                // shade the late rays -- parked by round b - 1, resumed by this round's closest-hit launch -- from their records; a drain
+                // round's queue holds at most what the lists held
+                const uint32_t perShard = drain ? c->tailCapacity : (((NP + SKH_SHARDS - 1u) / SKH_SHARDS) + 63u) & ~63u;
+                const uint32_t late = (useTail && b > 0) ? lateGrid : 0u;
+                const dim3 sg(SKH_SHARDS * ((perShard + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK) + late);
+#define SKH_SHADE_LAUNCH(HAIRB, LATEB)                                                                                                              \
+    k_shade<HAIRB, LATEB><<<sg, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b * QW, hq, ps, rq[(b + 1) & 1], counts + 2 * (b + 1) * QW, \
+                                                          shq, c->dContrib.as<float>(), counts + (2 * b + 1) * QW, late, lateRec, lateCount, c->tailCapacity)
                 if (c->hasHairMaterial)
-                    k_shade<true><<<sg, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b * QW, hq, ps, rq[(b + 1) & 1],
-                                                                  counts + 2 * (b + 1) * QW, shq, c->dContrib.as<float>(), counts + (2 * b + 1) * QW);
+                {
+                    if (useTail)
+                        SKH_SHADE_LAUNCH(true, true);
+                    else
+                        SKH_SHADE_LAUNCH(true, false);
+                }
+                else if (useTail)
+                    SKH_SHADE_LAUNCH(false, true);
                 else
-                    k_shade<false><<<sg, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b * QW, hq, ps, rq[(b + 1) & 1],
-                                                                   counts + 2 * (b + 1) * QW, shq, c->dContrib.as<float>(), counts + (2 * b + 1) * QW);
+                    SKH_SHADE_LAUNCH(false, false);
+#undef SKH_SHADE_LAUNCH
             }
             {
                 hipStream_t sst = useOverlap ? c->stream2 : st;
@@ -2103,7 +2187,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                 }
                 {
                     SpanGuard g(c, KC_TRACE_SHADOW, sst);
-                    c->gridOverride = (useOverlap && smallPass) ? c->smallWavesShadow * (uint32_t)c->numCUs : 0u;
+                    c->gridOverride = drain ? (uint32_t)c->numCUs : ((useOverlap && smallPass) ? c->smallWavesShadow * (uint32_t)c->numCUs : 0u);
                     if (c->countTraversal)
                         launch_trace<true, true>(c, sc, shq, counts + (2 * b + 1) * QW, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, nohq, ps, c->dContrib.as<float>(), NQ, sst);
                     else
@@ -2120,7 +2204,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
             (void)hipStreamWaitEvent(st, c->evShadow, 0);
         {
             SpanGuard g(c, KC_ACCUM);
-            k_add_stats<<<1, 64, 0, st>>>(counts, fp.maxDepth, c->dStats.as<StatsDev>());
+            k_add_stats<<<1, 64, 0, st>>>(counts, rounds, c->dStats.as<StatsDev>());
             if (batch == 1)
                 k_collect<<<gridSlots, 256, 0, st>>>(fp, tiles, s, ps, c->dSums.as<float>());
         }
@@ -3300,6 +3384,12 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
     {
         c->buildQuality = value != 0;
         c->accelBuilt = false;
+    }
+    else if (n == "tail_park" || n == "tail_lag")
+    {
+        if (value < 0 || value > (n == "tail_lag" ? 7 : 64))
+            return SKH_INVALID_ARGUMENT;
+        (n == "tail_park" ? c->tailPark : c->tailLag) = (uint32_t)value;
     }
     else if (n == "waves_per_cu" || n == "waves_per_cu_shadow")
     {

@@ -4,6 +4,7 @@ the flat ``oka::Scene`` arrays through strelka_amd.scene.Scene, exactly what the
 
     cornell_box()          C2: classic Cornell box, Lambert only, 1 rect light
     kitchen_standin()      C3/C4: >= 1.0 M unique triangles, >= 2000 instances of >= 150 meshes, mixed materials
+    kitchen_architectural() C3, less forgiving: big flat quads in two triangles, long thin triangles, nested cabinets, no mesh sharing
     hair_standin()         C5: 100 k strands x 16 control points (+2 phantom), hair BSDF
     coffeemaker_standin()  C1: ~50 k-triangle lathe object on a ground plane
 """
@@ -229,6 +230,172 @@ def kitchen_standin(seed=1234, n_meshes=150, n_instances=2000, tri_lo=200, tri_h
         sc.createLight({"type": 0, "xform": xf, "useXform": True, "width": 1.2, "height": 0.8,
                         "color": (1.0, 0.96, 0.9), "intensity": 30.0})
     # distant light (half-angle 5 deg): direction of travel = xform * (0,0,-1)
+    xf = S.rotate((0, 1, 0), math.radians(30)) @ S.rotate((1, 0, 0), math.radians(-55))
+    sc.createLight({"type": 3, "xform": xf, "useXform": True, "halfAngle": math.radians(5.0), "color": (1.0, 0.95, 0.85),
+                    "intensity": 2.0, "radius": 0.0})
+    cam = S.Camera(fov=60.0)
+    cam.lookAt((-4.2, 2.3, 2.3), (1.2, 0.7, -1.2))
+    sc.addCamera(cam)
+    return sc
+
+
+def kitchen_architectural(seed=4321, n_objects=1500, target_tris=1.6e6):
+    """A less forgiving stand-in for C3: what a USD kitchen looks like after HdStrelka's bake (Mesh.cpp:123-179:
+    triangulated, smooth normals, one mesh per instance) rather than a room full of round blobs --
+      * large flat quads cut into TWO triangles each: walls, floor, ceiling, counter tops, cabinet panels, doors, shelf boards (triangles
+        metres long next to objects centimetres across);
+      * long thin triangles: legs, rails, pipes, handles and blind slats -- cylinders with many segments around and ONE along (aspect
+        ratios of 50 : 1 and more), thin boxes;
+      * nested furniture-scale containment: cabinets (open boxes of thin panels) hold shelf boards, the shelves hold crockery; a table
+        stands over chairs; every object's box sits inside its shelf's, inside its cabinet's, inside the room's;
+      * no mesh sharing: every instance has its own mesh, so everything is baked to world space.
+    ~1.6 M triangles, ~2 100 instances, the same lights, camera and material mix as kitchen_standin()."""
+    rs = np.random.RandomState(seed)
+    sc = S.Scene()
+    sc.addMaterial(S.MAT_DIFFUSE, (0.8, 0.8, 0.8))
+    n_mat = 64
+    kinds = rs.choice(4, size=n_mat, p=[0.60, 0.25, 0.10, 0.05])
+    mats = []
+    for k in kinds:
+        col = tuple(rs.uniform(0.15, 0.9, 3))
+        if k == 0:
+            mats.append(sc.addMaterial(S.MAT_DIFFUSE, col))
+        elif k == 1:
+            mats.append(sc.addMaterial(S.MAT_PBR, col, roughness=rs.uniform(0.05, 0.6), metallic=0.0, specular=0.5))
+        elif k == 2:
+            mats.append(sc.addMaterial(S.MAT_PBR, col, roughness=rs.uniform(0.1, 0.5), metallic=1.0, specular=0.5))
+        else:
+            mats.append(sc.addMaterial(S.MAT_GLASS, (0.95, 0.97, 0.98), roughness=0.0, ior=1.5))
+    wood = [m for m, k in zip(mats, kinds) if k in (0, 1)]
+    metal = [m for m, k in zip(mats, kinds) if k == 2] or wood
+    RX, RY, RZ = 5.0, 2.0, 3.0
+    unit_box = _box_mesh((-1, -1, -1), (1, 1, 1))
+
+    def box(lo, hi, mat):
+        """one instance of its own 12-triangle mesh (a unit box scaled into place: the mesh is NOT shared)"""
+        lo, hi = np.asarray(lo, np.float64), np.asarray(hi, np.float64)
+        m = _add_mesh(sc, *unit_box)
+        sc.createInstance(S.INSTANCE_MESH, m, mat, S.translate(tuple((lo + hi) / 2)) @ S.scale(tuple((hi - lo) / 2)))
+
+    def rod(p0, p1, radius, mat, around=24):
+        """a cylinder with `around` segments around and ONE along its axis (2 x around long thin triangles + two fans of caps)"""
+        p0, p1 = np.asarray(p0, np.float64), np.asarray(p1, np.float64)
+        ax = p1 - p0
+        ln = np.linalg.norm(ax)
+        ax /= ln
+        ref = np.array([0.0, 1.0, 0.0]) if abs(ax[1]) < 0.9 else np.array([1.0, 0.0, 0.0])
+        e1 = np.cross(ax, ref)
+        e1 /= np.linalg.norm(e1)
+        e2 = np.cross(ax, e1)
+        ang = np.arange(around) * (2 * math.pi / around)
+        ring = np.cos(ang)[:, None] * e1 + np.sin(ang)[:, None] * e2
+        pos = np.concatenate([p0 + radius * ring, p1 + radius * ring, [p0], [p1]]).astype(np.float32)
+        tris = []
+        for k in range(around):
+            k1 = (k + 1) % around
+            tris += [(k, k1, around + k), (k1, around + k1, around + k), (2 * around, k1, k), (2 * around + 1, around + k, around + k1)]
+        sc.createInstance(S.INSTANCE_MESH, _add_mesh(sc, pos, np.array(tris)), mat, np.eye(4))
+
+    # room shell: six quads = 12 triangles, metres long
+    room = _add_mesh(sc, *_box_mesh((-RX, 0.0, -RZ), (RX, 2 * RY, RZ), inward=True))
+    sc.createInstance(S.INSTANCE_MESH, room, 0, np.eye(4))
+    # cabinets along the two long walls (floor units with a counter top, wall units above), and along one short wall
+    slots = []  # (lo, hi) of every shelf compartment an object may stand in
+    T = 0.018  # panel thickness
+
+    def cabinet(x0, x1, y0, y1, z_wall, depth, side, shelves):
+        """an open box of five thin panels facing the room, `shelves` boards inside, two door panels hanging half open, a rail handle"""
+        zf = z_wall + side * depth  # front
+        za, zb = min(z_wall, zf), max(z_wall, zf)
+        mat = wood[rs.randint(len(wood))]
+        box((x0, y0, za), (x0 + T, y1, zb), mat)
+        box((x1 - T, y0, za), (x1, y1, zb), mat)
+        box((x0, y0, za), (x1, y0 + T, zb), mat)
+        box((x0, y1 - T, za), (x1, y1, zb), mat)
+        box((x0, y0, z_wall - (T if side > 0 else 0)), (x1, y1, z_wall + (T if side < 0 else 0) + (T if side > 0 else 0)), mat)  # back panel
+        ys = np.linspace(y0, y1, shelves + 2)
+        for k in range(shelves + 1):
+            if k > 0:
+                box((x0 + T, ys[k] - T / 2, za + 0.01), (x1 - T, ys[k] + T / 2, zb - 0.01), mat)
+            slots.append(((x0 + T + 0.01, ys[k] + T, za + 0.03), (x1 - T - 0.01, ys[k + 1] - T, zb - 0.03)))
+        # door: a thin panel swung open about its outer edge + a rail handle (long thin triangles)
+        w = (x1 - x0) / 2
+        if side < 0 and x0 < -2.4:
+            return  # (the units next to the camera have lost their doors: an open one would fill the picture)
+        for hinge, sgn in ((x0, 1.0), (x1, -1.0)):
+            ang = rs.uniform(1.1, 2.2)  # (swung wide open: the shelves' contents are in view)
+            dx, dz = sgn * w * math.cos(ang), side * w * math.sin(ang)
+            m = _add_mesh(sc, *unit_box)
+            xf = (S.translate((hinge + dx / 2, (y0 + y1) / 2, zf + dz / 2)) @ S.rotate((0, 1, 0), -sgn * side * ang) @
+                  S.scale((w / 2, (y1 - y0) / 2 - 0.005, T / 2)))
+            sc.createInstance(S.INSTANCE_MESH, m, mat, xf)
+            hx, hz = hinge + 0.85 * dx, zf + 0.85 * dz + side * 0.03
+            rod((hx, y0 + 0.25 * (y1 - y0), hz), (hx, y0 + 0.75 * (y1 - y0), hz), 0.006, metal[rs.randint(len(metal))], around=16)
+
+    xs = np.arange(-RX + 0.1, RX - 0.7, 0.8)
+    for side, zw in ((1.0, -RZ + 0.02), (-1.0, RZ - 0.02)):
+        for x0 in xs:
+            cabinet(x0, x0 + 0.78, 0.1, 0.9, zw, 0.6, side, 1)  # floor unit
+            cabinet(x0, x0 + 0.78, 1.5, 2.4, zw, 0.35, side, 2)  # wall unit
+        # one counter top over the whole run: a slab 9 m long, 12 triangles; a splash-back behind it; a toe-kick below
+        box((-RX + 0.08, 0.9, min(zw, zw + side * 0.64)), (RX - 0.7 + 0.1, 0.94, max(zw, zw + side * 0.64)), wood[rs.randint(len(wood))])
+        for x0 in xs:  # things standing on the counter
+            slots.append(((x0 + 0.02, 0.94, min(zw + side * 0.05, zw + side * 0.6)), (x0 + 0.76, 1.45, max(zw + side * 0.05, zw + side * 0.6))))
+        box((-RX + 0.08, 0.94, min(zw, zw + side * 0.012)), (RX - 0.6, 1.5, max(zw, zw + side * 0.012)), mats[rs.randint(n_mat)])
+        box((-RX + 0.1, 0.0, min(zw + side * 0.05, zw + side * 0.55)), (RX - 0.62, 0.1, max(zw + side * 0.05, zw + side * 0.55)), wood[rs.randint(len(wood))])
+        # a pipe run under the ceiling and a curtain of blind slats in front of the wall units' gap: long thin geometry
+        rod((-RX + 0.1, 3.7, zw + side * 0.15), (RX - 0.1, 3.7, zw + side * 0.15), 0.03, metal[rs.randint(len(metal))], around=32)
+        rod((-RX + 0.1, 3.55, zw + side * 0.3), (RX - 0.1, 3.55, zw + side * 0.3), 0.015, metal[rs.randint(len(metal))], around=24)
+    for k in range(60):  # blind slats across the far short wall (a window): 60 boards 5.6 m x 2.5 cm x 2 mm
+        y = 1.0 + k * 0.03
+        m = _add_mesh(sc, *unit_box)
+        sc.createInstance(S.INSTANCE_MESH, m, mats[rs.randint(n_mat)],
+                          S.translate((RX - 0.06, y, 0.0)) @ S.rotate((0, 0, 1), 0.5) @ S.scale((0.0125, 0.001, RZ - 0.2)))
+    # table + chairs in the middle: a top over four legs, chairs of rods and thin boards pushed under it
+    tx, tz = 0.0, 0.0
+    box((tx - 1.1, 0.74, tz - 0.5), (tx + 1.1, 0.78, tz + 0.5), wood[rs.randint(len(wood))])
+    for sx_ in (-1.0, 1.0):
+        for sz_ in (-1.0, 1.0):
+            rod((tx + sx_ * 1.02, 0.0, tz + sz_ * 0.42), (tx + sx_ * 1.02, 0.74, tz + sz_ * 0.42), 0.025, wood[rs.randint(len(wood))])
+    slots.append(((tx - 1.05, 0.78, tz - 0.45), (tx + 1.05, 1.1, tz + 0.45)))
+    for k in range(6):
+        cx, cz = tx - 0.8 + 0.8 * (k % 3), tz + (0.75 if k < 3 else -0.75)
+        mat = wood[rs.randint(len(wood))]
+        box((cx - 0.2, 0.44, cz - 0.2), (cx + 0.2, 0.46, cz + 0.2), mat)
+        for sx_ in (-1.0, 1.0):
+            for sz_ in (-1.0, 1.0):
+                top = 0.95 if (sz_ > 0) == (k < 3) else 0.44
+                rod((cx + sx_ * 0.18, 0.0, cz + sz_ * 0.18), (cx + sx_ * 0.18, top, cz + sz_ * 0.18), 0.012, mat, around=12)
+        zb = cz + (0.18 if k < 3 else -0.18)
+        for yy in (0.6, 0.72, 0.84):
+            box((cx - 0.19, yy, zb - 0.008), (cx + 0.19, yy + 0.05, zb + 0.008), mat)
+    # crockery: every object its own mesh (the blobs of kitchen_standin, scaled to fit a compartment), several to a compartment
+    sizes = np.exp(rs.uniform(math.log(200), math.log(5000), n_objects))
+    sizes *= target_tris / sizes.sum()
+    order = rs.permutation(len(slots))
+    for i, nt in enumerate(sizes):
+        lo, hi = slots[order[i % len(slots)]]
+        lo, hi = np.asarray(lo), np.asarray(hi)
+        kind = i % 3
+        nt = max(int(nt), 16)
+        nu = max(4, int(round(math.sqrt(nt / 2.0 * 1.5))))
+        nv = max(3, int(round(nt / 2.0 / nu)))
+        fn = _sphere_fn(rs, rs.uniform(0.03, 0.2)) if kind == 0 else (_torus_fn(rs) if kind == 1 else _lathe_fn(rs))
+        pos, tris = _grid_mesh(fn, nu, nv)
+        pp = pos.astype(np.float64)
+        if np.einsum("ij,ij->i", pp[tris[:, 0]], np.cross(pp[tris[:, 1]], pp[tris[:, 2]])).sum() < 0:
+            tris = tris[:, ::-1]
+        h = float(hi[1] - lo[1])
+        sy = min(rs.uniform(0.04, 0.11), 0.45 * h)
+        sx = min(sy * rs.uniform(0.5, 1.0), 0.2 * float(min(hi[0] - lo[0], hi[2] - lo[2])))
+        x = rs.uniform(lo[0] + sx * 1.5, hi[0] - sx * 1.5)
+        z = rs.uniform(lo[2] + sx * 1.5, hi[2] - sx * 1.5)
+        xf = S.translate((x, lo[1] + 1.02 * sy, z)) @ S.rotate((0, 1, 0), rs.uniform(0, 2 * math.pi)) @ S.scale((sx, sy, sx))
+        sc.createInstance(S.INSTANCE_MESH, _add_mesh(sc, pos, tris), mats[rs.randint(n_mat)], xf)
+    for lx, lz in [(-2.5, -1.2), (2.5, -1.2), (-2.5, 1.2), (2.5, 1.2)]:
+        xf = S.translate((lx, 2 * RY - 0.02, lz)) @ S.rotate((1, 0, 0), math.radians(-90))
+        sc.createLight({"type": 0, "xform": xf, "useXform": True, "width": 1.2, "height": 0.8,
+                        "color": (1.0, 0.96, 0.9), "intensity": 30.0})
     xf = S.rotate((0, 1, 0), math.radians(30)) @ S.rotate((1, 0, 0), math.radians(-55))
     sc.createLight({"type": 3, "xform": xf, "useXform": True, "halfAngle": math.radians(5.0), "color": (1.0, 0.95, 0.85),
                     "intensity": 2.0, "radius": 0.0})

@@ -1,7 +1,8 @@
 """The remaining BASELINE.json configurations as parity cases (the bench line is C3, tests/test_gpu_fullsize.py):
   C1  coffeemaker stand-in, 512x512, 2 bounces, 16 spp   -- the whole configuration on both sides
   C2  Cornell box, 1024x1024, 4 bounces, 256 spp          -- oracle on 2 spp at full resolution; 256 spp through properties
-  C4  kitchen stand-in, 3840x2160, 6 bounces, 8 tile sets -- Russian roulette (depth > 3) and the 8-rank tile split at 4K
+  C4  kitchen stand-in, 3840x2160, 6 bounces, 8 tile sets -- Russian roulette (depth > 3) and the 8-rank tile split at 4K (16 spp);
+      the whole 256-spp frame once through properties + an oracle band of its 64-sub-frame prefix
   C5  hair stand-in, 1920x1080, 3 bounces                 -- full-resolution properties (hit parity is in test_gpu_fullsize)
 Tolerances are the ones of tests/test_gpu_parity.py (_image_close); ray counts and tile-sharded images are exact."""
 import numpy as np
@@ -113,6 +114,53 @@ def test_c4_kitchen_4k_depth6_roulette_and_eight_rank_tiles():
     # at 16 spp: 0.020 % of the band's pixels (24) hold one flipped path among their 16 samples -- about 1.3e-5 per path, the rate of
     # the 1-spp frames -- so the pixel bar scales with the sample count here
     _image_close(base[r0:r1], o.read_accum()[r0:r1], l2_tol=2e-3, frac_tol=6e-4)
+
+
+def test_c4_kitchen_4k_full_256_spp_frame_properties():
+    """The whole C4 frame once on one GPU (the suite ran 16 of its 256 spp): 3840x2160, depth 6, 256 sub-frames of
+    1 spp = 2.1 G paths, Russian roulette active.  Properties as for C5's full frame -- every pixel finite and non-negative, ray counts
+    inside their bounds and per sample within 1 % of a 16-spp run's, the uint16 AOV counters intact (diffuse + specular first events
+    <= 256 per pixel), no traversal-stack overflow, the converged image smoother than the 16-spp one with the same mean -- plus a 32-row
+    band of a 64-sub-frame prefix of the SAME frame (spp_total 256) against the oracle."""
+    from strelka_amd import capi
+    from tests import orklib
+    from tests.test_gpu_parity import _image_close
+
+    sc = scenes.kitchen_standin()
+    arr = sc.arrays()
+    W, H, DEPTH, SPP = 3840, 2160, 6, 256
+    few, stf = _gpu_frame(arr, sc.getCamera(), W, H, 16, DEPTH, total=SPP)
+    ctx = capi.Context(0)
+    ctx.set_scene(arr)
+    ctx.resize(W, H)
+    p = S.frame_params(sc.getCamera(), W, H, subframe_index=0, samples_this_launch=1, spp_total=SPP, max_depth=DEPTH)
+    ctx.render_subframes(p, 64, None)
+    band64 = ctx.read_accum()[1024:1056].copy()  # the frame after its first 64 sub-frames
+    p["subframe_index"] = 64
+    ctx.render_subframes(p, SPP - 64, None)  # ... continued to the end
+    st = ctx.stats()
+    full, dif, spec = ctx.read_accum(), ctx.read_aov(0), ctx.read_aov(1)
+    ctx.close()
+    assert st["stack_overflows"] == 0
+    for img in (full, dif, spec):
+        assert np.isfinite(img).all() and img[..., :3].min() >= 0.0
+    assert W * H * SPP <= st["rays_radiance"] <= W * H * SPP * DEPTH and st["rays_shadow"] <= st["rays_radiance"]
+    assert abs(st["rays_radiance"] / SPP - stf["rays_radiance"] / 16) < 0.01 * stf["rays_radiance"] / 16
+    assert abs(full[..., :3].mean() - few[..., :3].mean()) < 0.05 * few[..., :3].mean()
+
+    def rough(img):
+        g = img[..., 1]
+        return np.abs(4 * g[1:-1, 1:-1] - g[:-2, 1:-1] - g[2:, 1:-1] - g[1:-1, :-2] - g[1:-1, 2:]).mean()
+
+    assert rough(full) < 0.6 * rough(few)
+    o = orklib.new_context()
+    o.set_scene(arr)
+    o.resize(W, H)
+    for i in range(64):
+        o.render_subframe(S.frame_params(sc.getCamera(), W, H, subframe_index=i, samples_this_launch=1, spp_total=SPP, max_depth=DEPTH), rows=(1024, 1056))
+    # (flipped paths at ~1.3e-5 per path as in the 16-spp band above: with 64 samples per pixel ~0.08 % of the band's pixels hold one,
+    # each worth 1/64 of a pixel -- below the 2e-3 pixel bar for most of them)
+    _image_close(band64, o.read_accum()[1024:1056], l2_tol=2e-3, frac_tol=1e-3)
 
 
 def test_c5_hair_1080p_depth3_properties():

@@ -817,6 +817,35 @@ def test_subframe_batching_is_exact(gpu):
             assert np.array_equal(a, b)
 
 
+def test_tail_passes_are_exact(gpu):
+    """Continuations (TailQ, skh_kernels.h): in overlapped passes a closest-hit wave that finds the queue dry parks the
+    rays it still carries; the next closest-hit launch resumes them and the k_shade after it shades them one launch late (bounce index =
+    launch index - lag, drained by extra rounds at the end of the pass).  Which rays take that detour depends on scheduling -- the image,
+    the AOVs and the ray counts must not: paths are independent and every sum a path takes part in stays in its own bounce order."""
+    sc = small_kitchen()
+    gpu.set_scene(sc.arrays())
+    w, h, spp = 192, 128, 6
+    out = []
+    for park, lag, overlap, depth in ((0, 2, 1, 5), (64, 2, 1, 5), (64, 1, 2, 5), (8, 7, 1, 5), (64, 2, 0, 5), (64, 3, 1, 1), (0, 2, 1, 1)):
+        gpu.set_option("tail_park", park)
+        gpu.set_option("tail_lag", lag)
+        gpu.set_option("overlap", overlap)
+        gpu.resize(w, h)
+        gpu.reset_stats()
+        gpu.render_subframes(S.frame_params(sc.getCamera(), w, h, subframe_index=0, spp_total=spp, max_depth=depth), spp)
+        st = gpu.stats()
+        out.append((depth, gpu.read_accum(), gpu.read_aov(0), gpu.read_aov(1), st["rays_radiance"], st["rays_shadow"]))
+    gpu.set_option("tail_park", 64)
+    gpu.set_option("tail_lag", 2)
+    gpu.set_option("overlap", 1)
+    gpu.resize(w, h)
+    for other in out[1:]:
+        ref = next(o for o in out if o[0] == other[0])
+        for a, b in zip(ref[1:4], other[1:4]):
+            assert np.array_equal(a, b)
+        assert other[4] == ref[4] and other[5] == ref[5]
+
+
 def test_speculative_subframes_are_exact(gpu):
     """The reference's call pattern is one render() per sub-frame (RenderPass.cpp:441-447).  skh_render_subframe traces ahead once
     the caller keeps continuing a frame; every call must still hand back exactly the image one-pass-per-call rendering gives --
