@@ -255,6 +255,14 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 #define SKH_POSTPONE 0 // 1: "speculative traversal" (Aila & Laine 2009) in the world-only closest-hit build: a lane that reaches a leaf puts it aside
                        // and keeps descending; only its SECOND leaf makes it wait for the wave's triangle pass, which then tests both
 #endif
+#ifndef SKH_TRI_COOP
+#define SKH_TRI_COOP 1 // 1: the triangle pass of the world-only builds is shared -- lanes that are NOT at a leaf take the second triangle of the
+                       // two-triangle leaves (the owner's ray pulled with ds_bpermute, their own ray state parked in the free part of their LDS stack
+                       // column meanwhile), so that one pass does what took two at 30 + 17 of 64 lanes
+#endif
+#ifndef SKH_PK_NODE
+#define SKH_PK_NODE 0 // 1: the near / far plane distances of a 4-wide node as v_pk_fma_f32 pairs (12 packed FMAs instead of 24)
+#endif
 #ifndef SKH_PREFETCH2
 #define SKH_PREFETCH2 0 // 1: touch load of the second-nearest hit child's line, issued behind the nearest child's node fetch
 #endif
@@ -330,8 +338,12 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
 {
     static_assert(!WORLD || !CURVES, "the world-only build is a triangle kernel");
     constexpr bool CULL = SKH_POP_CULL && WORLD && !ANY_HIT && !W8;
-    constexpr int NLDS = CULL ? SKH_CULL_LDS : SKH_STACK_LDS; // per-lane stack entries in LDS (the rest: SKH_STACK_OVF entries in global memory)
+    constexpr bool TRICOOP = SKH_TRI_COOP && WORLD && !W8 && !SKH_POSTPONE && !SKH_POP_CULL; // (closest-hit and any-hit builds of the world-only kernel)
+    // per-lane stack entries in LDS (the rest: SKH_STACK_OVF entries in global memory); TRICOOP gives one up for its two 64-byte lane tables
+    // (LDS is handed out in 1280-byte granules here: 20 x 256 B = 4 granules exactly, 128 B more would cost a fifth = 25 instead of 28 waves per CU)
+    constexpr int NLDS = CULL ? SKH_CULL_LDS : (TRICOOP ? SKH_STACK_LDS - 1 : SKH_STACK_LDS);
     __shared__ int s_stack[(CULL ? 2 : 1) * NLDS * SKH_TRACE_BLOCK];
+    __shared__ unsigned char s_tab[TRICOOP ? 128 : 1]; // [0..63] owner lanes by rank, [64..127] helper lanes by rank
     const uint32_t fetchMin = fetchArg & 0xffu, curveMin = (fetchArg >> 8) & 0xffu, nodeBreak = (fetchArg >> 16) & 0xffu, leafMin = fetchArg >> 24;
     const uint32_t lane = threadIdx.x;
     constexpr bool TAILS = TAILQ && WORLD && !ANY_HIT && !W8 && !SKH_POP_CULL; // the build that can park / resume rays (TailQ)
@@ -890,12 +902,12 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
         SKH_LP(uint32_t itN = 0, itT = 0; { const unsigned long long t = __builtin_readcyclecounter(); cy[0] += t - cyA; cyA = t; })
         // (lanes parked in front of the curve intersector do not count: they are not waiting for the node loop to end)
         const uint32_t breakBelow = ((uint32_t)__popcll(__ballot(hasRay && !(CURVES && pend != 0u))) * nodeBreak) >> 6;
-        if (hasRay)
+        if (hasRay || TRICOOP) // (TRICOOP: every lane comes along to the triangle pass; the node loop and the pop stay with the lanes that have a ray)
         {
             // ---- descend through internal nodes ----
             // (CULL: a lane whose popped entry was culled -- cur INVALID, stack not empty -- stays in the loop, masked for the node block,
             // and pops its next entry at the bottom of the iteration: no inner loop, the chain of culled pops hides behind the other lanes' nodes)
-            while ((cur >= 0 && cur != SKH_REF_INVALID) || (CULL && cur == SKH_REF_INVALID && sp > 0))
+            while ((!TRICOOP || hasRay) && ((cur >= 0 && cur != SKH_REF_INVALID) || (CULL && cur == SKH_REF_INVALID && sp > 0)))
             {
                 if (!CULL || cur != SKH_REF_INVALID)
                 {
@@ -1011,9 +1023,20 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                 {
+#if SKH_PK_NODE
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    const f2 qx = { (float)((nxw >> (8 * k)) & 0xffu), (float)((fxw >> (8 * k)) & 0xffu) };
+                    const f2 qy = { (float)((nyw >> (8 * k)) & 0xffu), (float)((fyw >> (8 * k)) & 0xffu) };
+                    const f2 qz = { (float)((nzw >> (8 * k)) & 0xffu), (float)((fzw >> (8 * k)) & 0xffu) };
+                    const f2 tx = __builtin_elementwise_fma(qx, (f2){ ax, ax }, (f2){ bx, bx });
+                    const f2 ty = __builtin_elementwise_fma(qy, (f2){ ay, ay }, (f2){ by, by });
+                    const f2 tz = __builtin_elementwise_fma(qz, (f2){ az, az }, (f2){ bz, bz });
+                    const float nx = tx.x, fx = tx.y, ny = ty.x, fy = ty.y, nz = tz.x, fz = tz.y;
+#else
                     const float nx = fmaf((float)((nxw >> (8 * k)) & 0xffu), ax, bx), fx = fmaf((float)((fxw >> (8 * k)) & 0xffu), ax, bx);
                     const float ny = fmaf((float)((nyw >> (8 * k)) & 0xffu), ay, by), fy = fmaf((float)((fyw >> (8 * k)) & 0xffu), ay, by);
                     const float nz = fmaf((float)((nzw >> (8 * k)) & 0xffu), az, bz), fz = fmaf((float)((fzw >> (8 * k)) & 0xffu), az, bz);
+#endif
                     const float tnear = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
                     const float tfar = fminf(fminf(fx, fy), fminf(fz, best.t));
                     // (an empty slot is stored as the inverted box 255 > 0 on every axis and fails this test by itself; should rounding
@@ -1143,7 +1166,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
             bool entered = false;
             // Two kinds of leaf work (instance entry, primitive tests) are two branches of the same wave.  When one of them has
             // only a few takers it is postponed: those lanes keep their leaf and meet the next pass's takers (leafMin = 0/1: off)
-            bool isLeaf = cur < 0 && cur != SKH_REF_SENTINEL;
+            bool isLeaf = (!TRICOOP || hasRay) && cur < 0 && cur != SKH_REF_SENTINEL;
             if (CURVES)
             {
                 // The iterative curve intersector costs ~1000 instructions; run for the one or two lanes that happen to need it, it
@@ -1213,6 +1236,128 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                     entered = true; // (keeps `cur`: no pop)
                 }
             }
+            uint32_t kStart = 0; // (TRICOOP) triangles of this lane's leaf the shared pass has dealt with
+            if constexpr (TRICOOP)
+            {
+                // ---- the shared triangle pass ----
+                // Lanes at a leaf test its first triangle; lanes that are NOT at a leaf (descending ones taken out of the node loop, lanes without a
+                // ray) test the SECOND triangle of the two-triangle leaves, one each, in the same instructions: a helper parks its own o / shear /
+                // tmin / best.t in the free part of its LDS stack column, pulls the owner's with ds_bpermute, and restores.  The owner merges its own
+                // result first, then the helper's, by the rule of the sequential loop -- a candidate is accepted if it is nearer than the best hit
+                // so far, or equally near with the smaller (instance, primitive) key -- the helper's test only saw a STALE, i.e. larger, tmax, so it
+                // reports every candidate the sequential loop could have accepted: same records, bit for bit.
+                uint32_t cfirst = 0, ccount = 0;
+                if (isLeaf)
+                {
+                    const uint32_t e = (uint32_t)~cur;
+                    cfirst = e >> 3, ccount = (e & 7u) + 1u;
+                }
+                const bool has2 = ccount >= 2u;
+                const int freeFrom = hasRay ? sp : 0;
+                const bool canHelp = !isLeaf && (ANY_HIT || freeFrom + 9 <= NLDS);
+                const unsigned long long mB = __ballot(has2), mI = __ballot(canHelp);
+                const uint32_t nH = min((uint32_t)__popcll(mB), (uint32_t)__popcll(mI));
+                bool helped = false, helper = false;
+                int partner = (int)lane;
+                if (nH != 0u)
+                {
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    const uint32_t rankB = (uint32_t)__popcll(mB & below), rankI = (uint32_t)__popcll(mI & below);
+                    helped = has2 && rankB < nH;
+                    helper = canHelp && rankI < nH;
+                    if (helped)
+                        s_tab[rankB] = (unsigned char)lane;
+                    if (helper)
+                        s_tab[64u + rankI] = (unsigned char)lane;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    partner = helped ? (int)s_tab[64u + rankB] : (helper ? (int)s_tab[rankI] : (int)lane);
+                }
+                // Where the helper keeps the owner's ray: the any-hit build has registers to spare (63 + 9 <= 72: a copy, nothing to park); the
+                // closest-hit build sits at its 72-VGPR limit, so there a helper OVERWRITES its own o / shear / tmin / best.t after parking them
+                // in the free part of its LDS stack column, and restores them after the test.
+                constexpr bool COOP_REGS = ANY_HIT;
+                int* park = lds + freeFrom * SKH_TRACE_BLOCK;
+                if (!COOP_REGS && helper)
+                {
+                    park[0] = __float_as_int(o.x), park[SKH_TRACE_BLOCK] = __float_as_int(o.y), park[2 * SKH_TRACE_BLOCK] = __float_as_int(o.z);
+                    park[3 * SKH_TRACE_BLOCK] = sh.perm, park[4 * SKH_TRACE_BLOCK] = __float_as_int(sh.Sx), park[5 * SKH_TRACE_BLOCK] = __float_as_int(sh.Sy);
+                    park[6 * SKH_TRACE_BLOCK] = __float_as_int(sh.Sz), park[7 * SKH_TRACE_BLOCK] = __float_as_int(tmin), park[8 * SKH_TRACE_BLOCK] = __float_as_int(best.t);
+                }
+                uint32_t triIdx = cfirst;
+                v3 to = o;
+                RayShear tsh = sh;
+                float ttmin = tmin, ttmax = best.t;
+                if (nH != 0u)
+                {
+                    // (every lane takes part in the exchange: a disabled source lane would read as zero)
+                    const float pox = __shfl(o.x, partner), poy = __shfl(o.y, partner), poz = __shfl(o.z, partner);
+                    const int pperm = __shfl(sh.perm, partner);
+                    const float psx = __shfl(sh.Sx, partner), psy = __shfl(sh.Sy, partner), psz = __shfl(sh.Sz, partner);
+                    const float ptmin = __shfl(tmin, partner), pbt = __shfl(best.t, partner);
+                    const uint32_t pfirst = (uint32_t)__shfl((int)cfirst, partner);
+                    if (helper)
+                    {
+                        if (COOP_REGS)
+                        {
+                            to = mk3(pox, poy, poz);
+                            tsh.perm = pperm, tsh.Sx = psx, tsh.Sy = psy, tsh.Sz = psz;
+                            ttmin = ptmin, ttmax = pbt;
+                        }
+                        else
+                        {
+                            o = mk3(pox, poy, poz);
+                            sh.perm = pperm, sh.Sx = psx, sh.Sy = psy, sh.Sz = psz;
+                            tmin = ptmin;
+                            best.t = pbt;
+                        }
+                        triIdx = pfirst + 1u;
+                    }
+                }
+                bool ih = false;
+                float ht = 0.0f, hu = 0.0f, hv = 0.0f;
+                uint32_t hprim = 0, hinst = 0;
+                if (isLeaf || helper)
+                {
+                    const float4* tp = sc.tris + 3 * (size_t)triIdx;
+                    const float4 a = tp[0], b = tp[1], c = tp[2];
+                    if (COUNT)
+                        tc.prims++;
+                    if (COOP_REGS)
+                        ih = intersect_triangle(to, tsh, ttmin, ttmax, mk3(a), mk3(b), mk3(c), ht, hu, hv);
+                    else
+                        ih = intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), ht, hu, hv);
+                    hprim = __float_as_uint(a.w), hinst = __float_as_uint(b.w);
+                }
+                if (!COOP_REGS && helper)
+                {
+                    o = mk3(__int_as_float(park[0]), __int_as_float(park[SKH_TRACE_BLOCK]), __int_as_float(park[2 * SKH_TRACE_BLOCK]));
+                    sh.perm = park[3 * SKH_TRACE_BLOCK], sh.Sx = __int_as_float(park[4 * SKH_TRACE_BLOCK]), sh.Sy = __int_as_float(park[5 * SKH_TRACE_BLOCK]);
+                    sh.Sz = __int_as_float(park[6 * SKH_TRACE_BLOCK]), tmin = __int_as_float(park[7 * SKH_TRACE_BLOCK]), best.t = __int_as_float(park[8 * SKH_TRACE_BLOCK]);
+                }
+#define SKH_MERGE_HIT(H, T, U, V, PRIM, INST)                                                                                         \
+    if ((H) && (best.found ? ((T) < best.t || ((T) == best.t && ((INST) < best.inst || ((INST) == best.inst && (PRIM) < best.prim)))) \
+                           : (T) < best.t)) /* (open at tmax: best.t is the ray's tmax until a hit is found) */                       \
+    {                                                                                                                                 \
+        best.t = (T), best.inst = (INST), best.prim = (PRIM), best.u = (U), best.v = (V), best.found = true;                          \
+    }
+                if (isLeaf)
+                    SKH_MERGE_HIT(ih, ht, hu, hv, hprim, hinst)
+                kStart = 1u;
+                if (nH != 0u)
+                {
+                    const bool rh = __shfl((int)ih, partner) != 0;
+                    const float rt = __shfl(ht, partner), ru = __shfl(hu, partner), rv = __shfl(hv, partner);
+                    const uint32_t rprim = (uint32_t)__shfl((int)hprim, partner), rinst = (uint32_t)__shfl((int)hinst, partner);
+                    if (helped)
+                    {
+                        SKH_MERGE_HIT(rh, rt, ru, rv, rprim, rinst)
+                        kStart = 2u;
+                    }
+                }
+#undef SKH_MERGE_HIT
+            }
             if (isLeaf || (POSTPONE && leaf2 != SKH_REF_INVALID))
             {
                 // (POSTPONE: up to two leaves wait here -- the one put aside in the node loop first, then the current one)
@@ -1270,7 +1415,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                 }
                 else
                 {
-                    for (uint32_t k = 0; k < total; ++k)
+                    for (uint32_t k = (TRICOOP ? kStart : 0u); k < total; ++k)
                     {
                         const float4* tp = sc.tris + 3 * (size_t)((POSTPONE && k >= count) ? firstB + (k - count) : first + k);
                         const float4 a = tp[0], b = tp[1], c = tp[2];
@@ -1306,9 +1451,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
             }
             SKH_LP(if (entered) itT |= 0x10000u; { const unsigned long long t = __builtin_readcyclecounter(); cy[2] += t - cyA; cyA = t; })
             // ---- pop ----
-            if (ANY_HIT && best.found)
+            if (ANY_HIT && (!TRICOOP || hasRay) && best.found)
                 terminated = true;
-            else if (!entered && !(cur >= 0 && cur != SKH_REF_INVALID)) // (a lane taken out of the node loop early keeps its node)
+            else if ((!TRICOOP || hasRay) && !entered && !(cur >= 0 && cur != SKH_REF_INVALID)) // (a lane taken out of the node loop early keeps its node)
             {
                 for (;;)
                 {

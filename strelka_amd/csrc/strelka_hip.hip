@@ -2944,6 +2944,9 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
     skh_status s = ensure_ready(c);
     if (s != SKH_OK || n_rays == 0)
         return s;
+    // a speculative pass in flight shares the stack-overflow flag and the overflow area with this query: wait for it and drop it first, so
+    // that an overflow is attributed to the call that caused it
+    spec_drop(c, true);
     DevBuf q, h, cnt;
     auto cleanup = [&]() {
         dev_free(q);
@@ -3232,6 +3235,10 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
     const std::string n(name);
     if (n != "timing" && n != "count_traversal")
         spec_drop(c);
+    else if ((n == "count_traversal" && c->countTraversal != (value != 0)) || (n == "timing" && c->timing != (value != 0)))
+        // a pass traced ahead with the OTHER setting must not be delivered under this one: its traversal counters would be missing from the
+        // per-ray figures while its rays count; the pass in flight is waited for and dropped too
+        spec_drop(c, true);
     if (n == "count_traversal")
         c->countTraversal = value != 0;
     else if (n == "timing")

@@ -507,7 +507,7 @@ def test_bake_world_modes_match_oracle(mode, small):
     ctx.set_option("bake_small_tris", small)
     ctx.set_option("leaf_lines", mode % 2)  # (the line layout of the triangle leaves under object-space and world-space groups alike)
     counts = []
-    for sc in (small_kitchen(), scenes.light_zoo(), scenes.kitchen_standin(seed=3, n_meshes=40, n_instances=40, tri_lo=50, tri_hi=600)):
+    for k, sc in enumerate((small_kitchen(), scenes.light_zoo(), scenes.kitchen_standin(seed=3, n_meshes=40, n_instances=40, tri_lo=50, tri_hi=600))):
         arr = sc.arrays()
         o = orklib.new_context()
         o.set_bake(mode, small)
@@ -531,10 +531,13 @@ def test_bake_world_modes_match_oracle(mode, small):
             o.render_subframe(p)
         # One path of this room re-hits the wall it starts on at t = 7.7e-6 (a grazing transmission exit; found with
         # orklib.debug_path): whether it does hangs on the last bit of its origin, which the BSDF's transcendentals decide
-        # differently on the two sides.  At most that one pixel may be off by a sample; everything else meets the image bar.
+        # differently on the two sides.  It exists in the two kitchen rooms (same room, same camera) once the room is baked to world
+        # space (modes 2 - 4), and it is pixel (row 13, column 63) in both -- exactly that pixel may be off by a sample there
+        # (measured in round 4 over all 18 mode x scene cases); everywhere else every pixel meets the image bar.
         got, want = ctx.read_accum(), o.read_accum()
         off = np.abs(got[..., :3] - want[..., :3]).max(axis=-1) > 2e-3 * (np.abs(want[..., :3]).max(axis=-1) + 1e-3)
-        assert off.sum() <= 1, off.sum()
+        allowed = [(13, 63)] if (mode >= 2 and k in (0, 2)) else []
+        assert [tuple(int(v) for v in x) for x in np.argwhere(off)] in ([], allowed), (mode, small, k, np.argwhere(off))
         got[off] = want[off]
         _image_close(got, want)
     ctx.close()
