@@ -404,7 +404,7 @@ skh_status skh_unit_probe(skh_context* ctx, uint32_t unit, uint32_t param, const
  * takes the same setting and the bit-exact contract holds per setting).
  *   measurement   count_traversal 0|1 (counter build of the trace kernels), timing 0|1 (per-kernel hipEvent spans)
  *   scheduling    waves_per_cu (28) / waves_per_cu_shadow (28) (7 waves per SIMD), fetch_min_closest / fetch_min_shadow (24 / 48, scenes with curves 16 / 24: idle lanes before a wave refills),
- *                 node_break_closest / node_break_shadow (32 / 20, curves 20 / 20: leave the node loop below x/64 descending rays),
+ *                 node_break_closest / node_break_shadow (32 / 28, curves 20 / 20: leave the node loop below x/64 descending rays),
  *                 leaf_min (16: lanes for the minority kind of leaf work), curve_min (48: lanes parked in front of the
  *                 curve intersector before it runs), subframe_batch (0 = auto: ~64 M paths per pass),
  *                 speculate (8: sub-frames traced ahead when skh_render_subframe is called once per sub-frame; 0 = off),

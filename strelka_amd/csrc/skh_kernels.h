@@ -261,7 +261,8 @@ SKH_DI uint32_t wave_sum(uint32_t v)
                        // column meanwhile), so that one pass does what took two at 30 + 17 of 64 lanes
 #endif
 #ifndef SKH_PK_NODE
-#define SKH_PK_NODE 0 // 1: the near / far plane distances of a 4-wide node as v_pk_fma_f32 pairs (12 packed FMAs instead of 24)
+#define SKH_PK_NODE 0 // 1: the near / far plane distances of a 4-wide node as v_pk_fma_f32 pairs (12 packed FMAs instead of 24).  Measured in round 4:
+                      // the register pairs cost the closest-hit build 5 spilled dwords -- kitchen 81.3 -> 87.3 ms, unshared 70.8 -> 77.2; off
 #endif
 #ifndef SKH_PREFETCH2
 #define SKH_PREFETCH2 0 // 1: touch load of the second-nearest hit child's line, issued behind the nearest child's node fetch

@@ -160,7 +160,8 @@ struct skh_context
     uint32_t gridOverride = 0; // set by render_one around its launches
     uint32_t fetchMinClosest = 24, fetchMinShadow = 48; // idle lanes before a wave pulls new rays from the queue (round 3, world-space hierarchy: any-hit 32 -> 48: 39.7 -> 36.2 ms, 56: 37.5, 64: 51; closest 12..40 within 1 %)
     uint32_t curveFetchMinClosest = 16, curveFetchMinShadow = 24, curveNodeBreakClosest = 20; // the same three for the curve build (6 waves/SIMD): hair 482 vs 465 Mray/s
-    uint32_t nodeBreakClosest = 32, nodeBreakShadow = 20; // (closest: 24 -> 32 in round 3 for the world-only kernel: kitchen 86.6 -> 85.9 ms, unshared 74.7 -> 73.6, three runs each)
+    uint32_t nodeBreakClosest = 32, nodeBreakShadow = 28; // (closest: 24 -> 32 in round 3 for the world-only kernel: kitchen 86.6 -> 85.9 ms, unshared 74.7 -> 73.6, three runs each;
+                                                          // shadow: 20 -> 28 in round 4, with the shared triangle pass: kitchen 34.85 -> 34.3 ms, unshared 29.3 -> 28.55, three runs each; 36: 34.35 / 28.7)
     // leave the node loop when fewer than x/64 of the wave's rays are still descending
     uint32_t curveMin = 48; // (cooperative curve block) end-point runs queued by the parked lanes before the block runs, one run per lane (round 3, Mray/s on the hair
                             // stand-in: 16: 712, 32: 907, 40: 958, 48: 984, 56: 971, 64: 887; round 2 counted parked LANES whose owners ran their own runs: 48: 334)
@@ -1992,7 +1993,8 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
     // scenes without curve instances run the build of the kernel that has no curve intersector in it (fewer VGPRs)
     const bool curveBuild = c->nSegs != 0;
     const uint32_t fetchMin = ANY ? (curveBuild ? c->curveFetchMinShadow : c->fetchMinShadow) : (curveBuild ? c->curveFetchMinClosest : c->fetchMinClosest);
-    const uint32_t nodeBreak = ANY ? c->nodeBreakShadow : (curveBuild ? c->curveNodeBreakClosest : c->nodeBreakClosest);
+    const uint32_t nodeBreak = ANY ? (curveBuild ? std::min(c->nodeBreakShadow, 20u) /* (the curve build keeps round 3's 20) */ : c->nodeBreakShadow)
+                                   : (curveBuild ? c->curveNodeBreakClosest : c->nodeBreakClosest);
     const uint32_t fm = fetchMin | (c->curveMin << 8) | (nodeBreak << 16) | (c->leafMin << 24);
     if (!st)
         st = c->stream;
