@@ -53,8 +53,6 @@ def main():
     if os.path.exists(os.path.join(src, "bench.json")):
         shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
     # the counter figures bench.py replays: one file per workload (pmc_kernels.json = the default one), only the one this run wrote
-    import glob
-    import json
 
     for f in glob.glob(os.path.join(src, "pmc_kernels*.json")):
         try:
