@@ -1838,12 +1838,14 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
 #endif
     {
         // 20 KB table -> LDS: the block's five fetches go out together (a rolled loop waited for each in turn)
-        static_assert((SKH_SOBOL_LUT_WORDS / 4) % SKH_SHADE_BLOCK == 0, "table staging assumes whole passes");
-        constexpr int passes = (SKH_SOBOL_LUT_WORDS / 4) / SKH_SHADE_BLOCK;
+        constexpr int passes = ((SKH_SOBOL_LUT_WORDS / 4) + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK; // (256 threads: five whole passes; 512: the third is half one)
         uint4 lut[passes];
 #pragma unroll
         for (int k = 0; k < passes; ++k)
-            lut[k] = reinterpret_cast<const uint4*>(g_sobol_lut)[threadIdx.x + k * SKH_SHADE_BLOCK];
+            if ((k + 1) * SKH_SHADE_BLOCK <= SKH_SOBOL_LUT_WORDS / 4 || threadIdx.x + k * SKH_SHADE_BLOCK < SKH_SOBOL_LUT_WORDS / 4)
+                lut[k] = reinterpret_cast<const uint4*>(g_sobol_lut)[threadIdx.x + k * SKH_SHADE_BLOCK];
+            else
+                lut[k] = make_uint4(0u, 0u, 0u, 0u);
 #if SKH_MATERIALS_LDS
         float4 mrow = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         static_assert(SKH_MATERIALS_LDS * 4 <= SKH_SHADE_BLOCK, "one float4 of the material table per thread");
@@ -1852,7 +1854,8 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
 #endif
 #pragma unroll
         for (int k = 0; k < passes; ++k)
-            reinterpret_cast<uint4*>(s_sobol)[threadIdx.x + k * SKH_SHADE_BLOCK] = lut[k];
+            if ((k + 1) * SKH_SHADE_BLOCK <= SKH_SOBOL_LUT_WORDS / 4 || threadIdx.x + k * SKH_SHADE_BLOCK < SKH_SOBOL_LUT_WORDS / 4)
+                reinterpret_cast<uint4*>(s_sobol)[threadIdx.x + k * SKH_SHADE_BLOCK] = lut[k];
 #if SKH_MATERIALS_LDS
         if (threadIdx.x < SKH_MATERIALS_LDS * 4)
             s_mat[threadIdx.x] = mrow;
