@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SKH_ABI_VERSION 2
+#define SKH_ABI_VERSION 3 /* 3 (round 4): + skh_unit_probe, skh_copy_aov; options tail_park, tail_lag */
 
 /* mirrors oka::Result (include/render/common.h:30-35) */
 typedef enum skh_status
