@@ -179,3 +179,28 @@ def test_sutil_semantics(ork):
     d = (d + a[:, 2] * a[:, 2]).astype(np.float32)
     il = (np.float32(1.0) / np.sqrt(d).astype(np.float32)).astype(np.float32)
     assert np.array_equal((a * il[:, None]).astype(np.float32), nrm)
+
+
+def test_curve_polynomial_matches_the_published_bspline_basis(ork):
+    """cuda/curve.h:177-187,237-275 restated (CubicInterpolator::initializeFromBSpline / position4 / velocity4 / acceleration4 /
+    curveTangent) against an INDEPENDENT statement of the same mathematics: the uniform cubic B-spline basis and its derivatives evaluated
+    in fp64 with numpy, on 200 random segments x 7 parameters away from the end-point adjustments of velocity4 (curve.h:252-260).  This does
+    not pin the restatement to the reference's bits (that needs <optix.h>; SURVEY 8(c)'s six probe values do what can be done) -- it pins it
+    to the definition the reference implements."""
+    rs = np.random.RandomState(9)
+    for _ in range(200):
+        q = np.concatenate([rs.uniform(-2, 2, (4, 3)), rs.uniform(0.01, 0.3, (4, 1))], 1).astype(np.float32)
+        q64 = q.astype(np.float64)
+        for u in (0.07, 0.2, 0.35, 0.5, 0.65, 0.8, 0.93):
+            out = np.zeros(21, np.float32)
+            ps = np.zeros(3, np.float32)
+            ork.ork_curve_eval(p(np.ascontiguousarray(q.reshape(-1))), float(u), p(ps), p(out))
+            b = np.array([(1 - u) ** 3, 3 * u ** 3 - 6 * u ** 2 + 4, -3 * u ** 3 + 3 * u ** 2 + 3 * u + 1, u ** 3]) / 6.0
+            db = np.array([-3 * (1 - u) ** 2, 9 * u ** 2 - 12 * u, -9 * u ** 2 + 6 * u + 3, 3 * u ** 2]) / 6.0
+            ddb = np.array([6 * (1 - u), 18 * u - 12, -18 * u + 6, 6 * u]) / 6.0
+            scale = np.abs(q64).max()
+            assert np.allclose(out[0:4], b @ q64, rtol=0, atol=4e-6 * scale)
+            assert np.allclose(out[4:8], db @ q64, rtol=0, atol=2e-5 * scale)
+            assert np.allclose(out[8:12], ddb @ q64, rtol=0, atol=6e-5 * scale)
+            v = (db @ q64)[:3]
+            assert np.allclose(out[15:18], v / np.linalg.norm(v), rtol=0, atol=2e-5)
