@@ -1827,8 +1827,9 @@ static skh_status alloc_frame(skh_context* c)
     // continuations: two sets (this launch parks into one, resumes the other) of a list of parked-ray records per queue shard; per launch the
     // lists' lengths, the "queue is dry" flags and the next launch's eight cursors, each word in a 128-byte line of its own
     c->tailCapacity = c->traceBlocks * SKH_TRACE_BLOCK / 2u; // per shard, per pass: the eight lists hold four times the lanes of the largest grid
-    AF(dev_alloc(c, c->dTail[0], sizeof(uint32_t) * (size_t)(SKH_TAIL_HDR + SKH_STACK_LDS) * SKH_SHARDS * c->tailCapacity));
-    AF(dev_alloc(c, c->dTail[1], sizeof(uint32_t) * (size_t)(SKH_TAIL_HDR + SKH_STACK_LDS) * SKH_SHARDS * c->tailCapacity));
+    // (the record sets -- 2 x 265 MB at the default grid -- are allocated by the first pass that uses continuations: option tail_park, off by default)
+    dev_free(c->dTail[0]);
+    dev_free(c->dTail[1]);
     AF(dev_alloc(c, c->dTailCounts, sizeof(uint32_t) * SKH_TAIL_WORDS * SKH_MAX_LAUNCH_ROUNDS));
     AF(dev_alloc(c, c->dTailDesc, sizeof(TailQ) * SKH_MAX_LAUNCH_ROUNDS));
     c->tailDescKey.clear();
@@ -2110,6 +2111,13 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     uint32_t* tailCounts = c->dTailCounts.as<uint32_t>();
     if (useTail)
     {
+        for (int k = 0; k < 2; ++k)
+            if (!c->dTail[k].p)
+            {
+                const skh_status as = dev_alloc(c, c->dTail[k], sizeof(uint32_t) * (size_t)(SKH_TAIL_HDR + SKH_STACK_LDS) * SKH_SHARDS * c->tailCapacity);
+                if (as != SKH_OK)
+                    return as;
+            }
         // round b parks into record set b & 1 and resumes what round b - 1 parked into the other one
         const std::vector<uint32_t> key = { rounds, c->tailPark, c->tailLag, c->tailCapacity, (uint32_t)(uintptr_t)c->dTail[0].p, (uint32_t)(uintptr_t)c->dTail[1].p,
                                             (uint32_t)(uintptr_t)tailCounts };
