@@ -10,65 +10,87 @@
 //   OmniGlass.{glass_color, glass_ior, frosting_roughness} (gltfloader.cpp:354-406)                                      -> SKH_MAT_GLASS
 //   UsdPreviewSurface parameter sets (HdStrelka's eMaterialX descriptions, HdStrelka/Material.cpp:52-150)                -> PBR | GLASS
 //   names containing "hair" (the `hair` sub-expression, materialmanager/mdlPtxCodeGen.cpp:143-155)                       -> SKH_MAT_HAIR
-// NOT compiled in this repository's own builds (MaterialManager::Param needs the MDL SDK headers): checked by reading, kept short.
+// The functions are templates over the description type -- anything with {file, name, params[{type, name, value}]} and the reference's
+// Param::Type numbering (eFloat 0, eInt 1, eBool 2, eFloat2 3, eFloat3 4, eFloat4 5, eTexture 6: materialmanager.h:35-44) -- so that
+// tests/test_integration_files.py can run them on a local look-alike of the reference's two structs and compare every case with the
+// Python statement; inside the Strelka tree they are instantiated with oka::Scene::MaterialDescription itself (HipRender.cpp).
 #pragma once
 #ifdef SKH_WITH_STRELKA_HEADERS
-#    include <scene/scene.h>
 #    include <strelka_hip.h>
+#else
+#    include "../include/strelka_hip.h"
+#endif
 
-#    include <algorithm>
-#    include <cmath>
-#    include <cstring>
-#    include <string>
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstring>
+#include <string>
 
 namespace oka
 {
 namespace skhmat
 {
-using Param = MaterialManager::Param;
-
-inline const Param* find(const Scene::MaterialDescription& d, const char* name)
+enum : uint32_t
 {
-    for (const Param& p : d.params)
+    kFloat = 0,
+    kInt = 1,
+    kBool = 2,
+    kFloat2 = 3,
+    kFloat3 = 4,
+    kFloat4 = 5,
+    kTexture = 6
+};
+
+template <class Desc>
+inline auto find(const Desc& d, const char* name) -> decltype(&d.params[0])
+{
+    for (const auto& p : d.params)
         if (p.name == name)
             return &p;
     return nullptr;
 }
-inline float scalar(const Scene::MaterialDescription& d, const char* name, float def)
+template <class Desc>
+inline float scalar(const Desc& d, const char* name, float def)
 {
-    const Param* p = find(d, name);
-    if (!p || p->value.size() < sizeof(float))
+    const auto* p = find(d, name);
+    if (!p)
         return def;
-    if (p->type == Param::Type::eInt)
+    if ((uint32_t)p->type == kBool)
+        return (!p->value.empty() && p->value[0]) ? 1.0f : 0.0f;
+    if (p->value.size() < sizeof(float))
+        return def;
+    if ((uint32_t)p->type == kInt)
     {
         int v;
         memcpy(&v, p->value.data(), sizeof(v));
         return (float)v;
     }
-    if (p->type == Param::Type::eBool)
-        return p->value[0] ? 1.0f : 0.0f;
     float v;
     memcpy(&v, p->value.data(), sizeof(v));
     return v;
 }
-inline void color(const Scene::MaterialDescription& d, const char* name, float out[3], float r, float g, float b)
+template <class Desc>
+inline void color(const Desc& d, const char* name, float out[3], float r, float g, float b)
 {
     out[0] = r, out[1] = g, out[2] = b;
-    const Param* p = find(d, name);
+    const auto* p = find(d, name);
     if (p && p->value.size() >= 3 * sizeof(float))
         memcpy(out, p->value.data(), 3 * sizeof(float));
 }
 // the path of an eTexture parameter ("" if the material has none); the caller loads it (stbi_load(..., STBI_rgb_alpha), resolved
 // against `resource/searchPath` as OptixRender.cpp:1346-1362 does) and passes the 1-based texture id back in
-inline std::string texturePath(const Scene::MaterialDescription& d, const char* name)
+template <class Desc>
+inline std::string texturePath(const Desc& d, const char* name)
 {
-    const Param* p = find(d, name);
-    if (!p || p->type != Param::Type::eTexture)
+    const auto* p = find(d, name);
+    if (!p || (uint32_t)p->type != kTexture)
         return std::string();
     return std::string(reinterpret_cast<const char*>(p->value.data()), p->value.size());
 }
 
-inline skh_material translate(const Scene::MaterialDescription& d, uint32_t diffuseTextureId = 0, uint32_t normalTextureId = 0)
+template <class Desc>
+inline skh_material translate(const Desc& d, uint32_t diffuseTextureId = 0, uint32_t normalTextureId = 0)
 {
     skh_material m;
     memset(&m, 0, sizeof(m));
@@ -140,4 +162,3 @@ inline skh_material translate(const Scene::MaterialDescription& d, uint32_t diff
 }
 } // namespace skhmat
 } // namespace oka
-#endif

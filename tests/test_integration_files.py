@@ -62,3 +62,66 @@ def test_exporter_header_writes_the_same_file_as_the_mirror_scene(tmp_path):
     assert a == b and len(a) > 1000
     sc = scene_io.load_scene(os.path.join(tmp_path, "scene_exporter.skscene"))
     assert len(sc.arrays()["instances"]) == 5
+
+
+def test_cpp_material_translation_equals_the_python_statement(tmp_path):
+    """integration/SkhMaterials.h (what HipRender.cpp uses inside the Strelka tree to turn MaterialDescription {file, name, params} into the
+    64-byte skh_material) against strelka_amd/scene_io.py::material_from_description on the same descriptions: the default material,
+    OmniPBR with and without textures, OmniGlass (clear / frosted / with glass_ior), UsdPreviewSurface (opaque / glass), hair with colour
+    and with explicit absorption, an unknown material.  The header is instantiated with a local look-alike of the reference's two structs
+    (tests/cpp/skhmaterials_main.cpp): the reference's own headers need glm, which this image lacks."""
+    import struct
+
+    import numpy as np
+
+    from strelka_amd import scene as S, scene_io
+
+    T = {"float": 0, "int": 1, "bool": 2, "float2": 3, "float3": 4, "float4": 5, "texture": 6}
+
+    def P(name, typ, value):
+        return {"name": name, "type": typ, "value": value}
+
+    cases = [
+        {"file": "default.mdl", "name": "default_material", "params": [P("diffuse_color", "float3", [0.3, 0.5, 0.7])]},
+        {"file": "default.mdl", "name": "default_material", "params": []},
+        {"file": "OmniPBR.mdl", "name": "OmniPBR", "params": [P("diffuse_color_constant", "float3", [0.9, 0.1, 0.2]), P("reflection_roughness_constant", "float", 0.35),
+                                                               P("metallic_constant", "float", 1.0)]},
+        {"file": "OmniPBR.mdl", "name": "OmniPBR", "params": [P("diffuse_color_constant", "float3", [0.5, 0.5, 0.5]), P("diffuse_texture", "texture", "wood.png"),
+                                                               P("normalmap_texture", "texture", "wood_n.png")]},
+        {"file": "OmniPBR.mdl", "name": "OmniPBR", "params": []},
+        {"file": "OmniGlass.mdl", "name": "OmniGlass", "params": [P("enable_opacity", "bool", True), P("thin_walled", "bool", False), P("frosting_roughness", "float", 0.0)]},
+        {"file": "OmniGlass.mdl", "name": "OmniGlass", "params": [P("glass_color", "float3", [0.9, 1.0, 0.95]), P("glass_ior", "float", 1.33), P("frosting_roughness", "float", 0.4)]},
+        {"file": "", "name": "UsdPreviewSurface", "params": [P("diffuseColor", "float3", [0.2, 0.4, 0.6]), P("roughness", "float", 0.25), P("metallic", "float", 0.5)]},
+        {"file": "", "name": "preview_glass", "params": [P("diffuseColor", "float3", [1.0, 1.0, 1.0]), P("opacity", "float", 0.1), P("ior", "float", 1.45)]},
+        {"file": "hair.mdl", "name": "hair_material", "params": [P("diffuse_color", "float3", [0.35, 0.2, 0.1]), P("roughness_R", "float", 0.25), P("roughness_azimuthal", "float", 0.4)]},
+        {"file": "hair.mdl", "name": "hair_material", "params": [P("absorption_coefficient", "float3", [0.4, 0.9, 1.8]), P("cuticle_angle", "float", 0.05), P("diffuse_reflection_weight", "float", 0.2),
+                                                                  P("diffuse_reflection_tint", "float3", [0.5, 0.4, 0.3]), P("ior", "float", 1.5)]},
+        {"file": "something.mdl", "name": "unknown_thing", "params": [P("foo", "int", 3)]},
+    ]
+    lines = []
+    for c in cases:
+        lines.append("D %s|%s|%d" % (c["file"], c["name"], len(c["params"])))
+        for p_ in c["params"]:
+            v = p_["value"]
+            if p_["type"] == "texture":
+                raw = v.encode()
+            elif p_["type"] == "bool":
+                raw = bytes([1 if v else 0])
+            elif p_["type"] == "int":
+                raw = struct.pack("<i", v)
+            else:
+                raw = np.asarray(v, np.float32).tobytes()
+            lines.append("P %d %s %s" % (T[p_["type"]], p_["name"], raw.hex() or "-"))
+    exe = str(tmp_path / "skhmat")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "cpp", "skhmaterials_main.cpp")])
+    out = subprocess.run([exe], input="\n".join(lines).encode(), capture_output=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    got = np.frombuffer(out.stdout, dtype=S.MATERIAL)
+    assert len(got) == len(cases)
+    for k, c in enumerate(cases):
+        want = scene_io.material_from_description(c)
+        assert got[k]["type"] == want["type"], (k, c["name"])
+        for f in ("base_color", "roughness", "metallic", "specular", "ior", "reserved"):
+            assert np.allclose(got[k][f], want[f], rtol=2e-6, atol=1e-7), (k, c["name"], f, got[k][f], want[f])
+    # texture ids: the caller numbers the textures it loaded; a material without texture parameters gets none
+    assert (got[3]["base_color_texture"], got[3]["normal_texture"]) == (1, 2) and got[2]["base_color_texture"] == 0
