@@ -198,6 +198,12 @@ struct StatsDev
 #endif
 };
 
+// number of set bits of `mask` in the lanes below this one: v_mbcnt_lo / v_mbcnt_hi on the ballot's two scalar halves -- two instructions and
+// no per-lane "lanes below me" mask to keep (popcount(mask & ((1 << lane) - 1)) holds that 64-bit mask in two VGPRs or rebuilds it with a 64-bit shift)
+SKH_DI uint32_t rank_below(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
 SKH_DI uint32_t wave_max(uint32_t v)
 {
 #pragma unroll
@@ -234,7 +240,17 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 #define SKH_SHADOW_ATOMIC 0 // fire-and-forget float atomics for the shadow contribution instead of load / add / store: measured equal (40.87 vs 40.90 ms)
 #endif
 #ifndef SKH_WORLD_MIN_WAVES
-#define SKH_WORLD_MIN_WAVES 7
+#define SKH_WORLD_MIN_WAVES 7 // world-only builds that do not fit 64 VGPRs: 8-wide nodes, the continuation (TAILQ) build
+#endif
+#ifndef SKH_WORLD_ANYHIT_MIN_WAVES
+#define SKH_WORLD_ANYHIT_MIN_WAVES 8 // the world-only any-hit build fits 64 VGPRs without scratch (59; 27 SGPRs go to lanes): 32 waves per CU -- any-hit 28.7 -> 27.85 ms
+                                     // without mesh sharing, 22.85 -> 21.95 architectural, 34.5 -> 34.4 on the kitchen (docs/LOG.md round 4)
+#endif
+#ifndef SKH_WORLD_CLOSEST_MIN_WAVES
+#define SKH_WORLD_CLOSEST_MIN_WAVES 8 // the world-only closest-hit build at 64 VGPRs (one dword of the refill path in scratch, 16 SGPRs in lanes) and 32 waves per CU:
+                                      // closest-hit 71.3 -> 70.2 ms without mesh sharing, 56.55 -> 55.35 architectural, 81.9 -> 81.95 kitchen.  It took lane ranks by
+                                      // v_mbcnt (rank_below) and the overflow area addressed where it is used to get there: with the 64-bit "lanes below me" mask
+                                      // and the overflow pointer spilled (5 dwords, two reloads per outer iteration) the same build ran 81.7 -> 85.7 ms
 #endif
 #ifndef SKH_SORT_ANYHIT
 #define SKH_SORT_ANYHIT 0
@@ -330,7 +346,7 @@ struct TailQ
 // TAILQ: the build with the continuation code in it (TailQ: park / resume); the launches that never park run the build without it -- the
 // extra paths cost the traversal loop registers (13 spilled dwords) even when they are never taken.
 template <bool ANY_HIT, bool COUNT, bool CURVES, bool W8 = false, bool WORLD = false, bool TAILQ = false>
-__global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES : (CURVES ? SKH_CURVE_MIN_WAVES : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES))) SKH_TRACE_ATTR
+__global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WORLD_MIN_WAVES : (ANY_HIT ? SKH_WORLD_ANYHIT_MIN_WAVES : SKH_WORLD_CLOSEST_MIN_WAVES)) : (CURVES ? SKH_CURVE_MIN_WAVES : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES))) SKH_TRACE_ATTR
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
             uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, 
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
@@ -363,7 +379,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
     bool exhausted = false;
     int* lds = s_stack + lane;
     int2* lds2 = reinterpret_cast<int2*>(s_stack) + lane; // (CULL) entry e of this lane = lds2[e * 64] = {reference, entry distance}
-    int* ovf = ovfBase + (blockIdx.x * SKH_TRACE_BLOCK + lane);
+    // (the overflow area is addressed from ovfBase where it is used -- rare paths -- instead of through a per-lane 64-bit pointer held across the loops)
+#define SKH_OVF_AT(e) ovfBase[(size_t)(e) * ovfStride + (blockIdx.x * SKH_TRACE_BLOCK + threadIdx.x)]
     const uint32_t ovfStride = gridDim.x * SKH_TRACE_BLOCK;
     const uint32_t rayMask = CURVES ? (ANY_HIT ? 3u : 255u) : (ANY_HIT ? 1u : 253u);
     TraceCounters tc = { 0, 0, 0, 0 };
@@ -414,7 +431,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                 lds[sp * SKH_TRACE_BLOCK] = (v);                     \
         }                                                            \
         else if (sp < NLDS + SKH_STACK_OVF)                          \
-            ovf[(size_t)(sp - NLDS) * ovfStride] = (v); /* (entries in the global overflow area carry no distance: never culled) */ \
+            SKH_OVF_AT(sp - NLDS) = (v); /* (entries in the global overflow area carry no distance: never culled) */ \
         else                                                         \
             *sc.overflowFlag = 1u; /* the entry is dropped: the call that launched this kernel returns SKH_FAIL, never silent */ \
         ++sp;                                                        \
@@ -437,7 +454,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
         }                                                            \
         else if (sp < NLDS + SKH_STACK_OVF)                          \
         {                                                            \
-            dst = ovf[(size_t)(sp - NLDS) * ovfStride];              \
+            dst = SKH_OVF_AT(sp - NLDS);              \
             if (PF2)                                                 \
                 asm volatile("" ::"v"(dst)); /* the wait for this (rare) global read stays inside its branch: at the join it would cover the touch load in flight too */ \
         }                                                            \
@@ -545,7 +562,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                 if (TAILS && (tailFlags & 1u) && lane < SKH_SHARDS)
                     __hip_atomic_store(tail.dry(lane), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // every ray has been handed out: tell the other waves
             }
-            const uint32_t rank = (uint32_t)__popcll(needMask & ((1ull << lane) - 1ull));
+            const uint32_t rank = rank_below(needMask);
             if (TAILS && fromResume)
             {
                 // ---- resume: a parked ray's record instead of a queue entry ----
@@ -672,7 +689,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                             b = atomicAdd(&tail.parkCount[g * SKH_COUNT_STRIDE], cnt);
                     }
                     b = __shfl(b, leader);
-                    const uint32_t pos = b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    const uint32_t pos = b + rank_below(m);
                     if (myShard == g && b != 0xffffffffu) // (allowance used up: the rays stay in their wave)
                     {
                         const uint32_t k = g * tail.capacity + pos;
@@ -1262,8 +1279,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
                 int partner = (int)lane;
                 if (nH != 0u)
                 {
-                    const unsigned long long below = (1ull << lane) - 1ull;
-                    const uint32_t rankB = (uint32_t)__popcll(mB & below), rankI = (uint32_t)__popcll(mI & below);
+                    const uint32_t rankB = rank_below(mB), rankI = rank_below(mI);
                     helped = has2 && rankB < nH;
                     helper = canHelp && rankI < nH;
                     if (helped)
@@ -1510,6 +1526,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? SKH_WORLD_MIN_WAVES :
     }
 #undef SKH_PUSH
 #undef SKH_POP
+#undef SKH_OVF_AT
 #undef tail
     if (COUNT)
     {
@@ -1579,7 +1596,7 @@ SKH_DI uint32_t block_compact(bool emit, uint32_t* counter, uint32_t* s_wave /*[
         s_wave[SKH_COMPACT_MAX_WAVES] = tot ? atomicAdd(counter, tot) : 0u;
     }
     __syncthreads();
-    const uint32_t r = s_wave[SKH_COMPACT_MAX_WAVES] + s_wave[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const uint32_t r = s_wave[SKH_COMPACT_MAX_WAVES] + s_wave[wave] + rank_below(m);
     __syncthreads(); // s_wave is reused by the next call
     return r;
 }
@@ -1616,9 +1633,8 @@ SKH_DI void block_compact2(bool emitA, uint32_t* counterA, bool emitB, uint32_t*
         sb[SKH_COMPACT_MAX_WAVES] = tot ? atomicAdd(counterB, tot) : 0u;
     }
     __syncthreads();
-    const unsigned long long below = (1ull << lane) - 1ull;
-    ia = sa[SKH_COMPACT_MAX_WAVES] + sa[wave] + (uint32_t)__popcll(ma & below);
-    ib = sb[SKH_COMPACT_MAX_WAVES] + sb[wave] + (uint32_t)__popcll(mb & below);
+    ia = sa[SKH_COMPACT_MAX_WAVES] + sa[wave] + rank_below(ma);
+    ib = sb[SKH_COMPACT_MAX_WAVES] + sb[wave] + rank_below(mb);
 }
 
 // Ray generation without atomics: which slots of a tile set fall inside the image is known on the host, so the first queue
@@ -1663,7 +1679,7 @@ __global__ void __launch_bounds__(512) k_raygen(FrameP fp, const uint32_t* __res
     for (uint32_t w = 0; w < wave; ++w)
         before += s_wave[w];
     // dense index in slot order -> shard: the queue is cut into SKH_SHARDS equal runs of `per` rays (the last one shorter)
-    const uint32_t dense = sub * validPerSub + blockBase[bi] + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const uint32_t dense = sub * validPerSub + blockBase[bi] + before + rank_below(m);
     const uint32_t total = validPerSub * fp.batch;
     const uint32_t per = (((total + SKH_SHARDS - 1u) / SKH_SHARDS) + 63u) & ~63u;
     const uint32_t shard = per ? dense / per : 0u;

@@ -156,6 +156,8 @@ struct skh_context
     // scheduling of the persistent trace kernels, measured on MI355X (kitchen C3, 32 sub-frames per pass):
     uint32_t wavesPerCU = 28; // resident waves per CU (7 per SIMD at <= 72 VGPRs; the curve build is resident 16 at a time whatever is asked: 128 VGPRs)
     uint32_t wavesPerCUShadow = 28; // the any-hit build of the triangle kernel fits 7 per SIMD
+    uint32_t wavesPerCUShadowWorld = 32; // ... its world-only build 8 (SKH_WORLD_ANYHIT_MIN_WAVES)
+    uint32_t wavesPerCUWorld = 32; // the world-only closest-hit build: 64 VGPRs, 8 per SIMD (SKH_WORLD_CLOSEST_MIN_WAVES)
     uint32_t smallWavesClosest = 16, smallWavesShadow = 16; // overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24
     uint32_t gridOverride = 0; // set by render_one around its launches
     uint32_t fetchMinClosest = 24, fetchMinShadow = 48; // idle lanes before a wave pulls new rays from the queue (round 3, world-space hierarchy: any-hit 32 -> 48: 39.7 -> 36.2 ms, 56: 37.5, 64: 51; closest 12..40 within 1 %)
@@ -1822,8 +1824,8 @@ static skh_status alloc_frame(skh_context* c)
     AF(dev_alloc(c, c->dContrib, sizeof(float) * 3 * NQ));
     AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * (SKH_COUNT_STRIDE * SKH_SHARDS * 2 * SKH_MAX_LAUNCH_ROUNDS + 16 * SKH_FETCH_STRIDE * SKH_MAX_LAUNCH_ROUNDS)));
     c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
-    AF(dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * std::max(c->traceBlocks, (uint32_t)c->numCUs * c->wavesPerCUShadow) * SKH_TRACE_BLOCK));
-    AF(dev_alloc(c, c->dOvf2, sizeof(int) * (size_t)SKH_STACK_OVF * std::max(c->traceBlocks, (uint32_t)c->numCUs * c->wavesPerCUShadow) * SKH_TRACE_BLOCK));
+    AF(dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * (uint32_t)c->numCUs * std::max(std::max(c->wavesPerCU, c->wavesPerCUWorld), std::max(c->wavesPerCUShadow, c->wavesPerCUShadowWorld)) * SKH_TRACE_BLOCK));
+    AF(dev_alloc(c, c->dOvf2, sizeof(int) * (size_t)SKH_STACK_OVF * (uint32_t)c->numCUs * std::max(std::max(c->wavesPerCU, c->wavesPerCUWorld), std::max(c->wavesPerCUShadow, c->wavesPerCUShadowWorld)) * SKH_TRACE_BLOCK));
     // continuations: two sets (this launch parks into one, resumes the other) of a list of parked-ray records per queue shard; per launch the
     // lists' lengths, the "queue is dry" flags and the next launch's eight cursors, each word in a 128-byte line of its own
     c->tailCapacity = c->traceBlocks * SKH_TRACE_BLOCK / 2u; // per shard, per pass: the eight lists hold four times the lanes of the largest grid
@@ -2001,9 +2003,11 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
         st = c->stream;
     int* ovf = st == c->stream ? c->dOvf.as<int>() : c->dOvf2.as<int>(); // (two trace kernels may be in flight)
     StatsDev* sd = c->dStats.as<StatsDev>();
-    const uint32_t fullGrid = (ANY && !c->nSegs) ? (uint32_t)c->numCUs * c->wavesPerCUShadow : c->traceBlocks;
-    const uint32_t blocks = c->gridOverride ? std::min(c->gridOverride, fullGrid) : fullGrid;
     const bool worldOnly = !c->nSegs && c->tlasRoot == SKH_REF_INVALID && (c->worldRoot != SKH_REF_INVALID || c->lightRoot != SKH_REF_INVALID) && c->worldKernel;
+    const bool world8 = worldOnly && c->wide != 8 && (ANY || tailFlags == 0u); // the builds that run 8 waves per SIMD
+    const uint32_t fullGrid = (ANY && !c->nSegs) ? (uint32_t)c->numCUs * (world8 ? c->wavesPerCUShadowWorld : c->wavesPerCUShadow)
+                                                 : (world8 ? (uint32_t)c->numCUs * c->wavesPerCUWorld : c->traceBlocks);
+    const uint32_t blocks = c->gridOverride ? std::min(c->gridOverride, fullGrid) : fullGrid;
     if (worldOnly && c->wide != 8 && !ANY && tailFlags != 0u)
         // ... with the continuation code (park / resume: overlapped passes)
         k_trace<false, COUNT, false, false, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, tail, tailFlags);
@@ -2973,7 +2977,7 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
     }
     if (!c->traceBlocks)
         c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
-    if ((s = dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * std::max(c->traceBlocks, (uint32_t)c->numCUs * c->wavesPerCUShadow) * SKH_TRACE_BLOCK)) != SKH_OK)
+    if ((s = dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * (uint32_t)c->numCUs * std::max(std::max(c->wavesPerCU, c->wavesPerCUWorld), std::max(c->wavesPerCUShadow, c->wavesPerCUShadowWorld)) * SKH_TRACE_BLOCK)) != SKH_OK)
     {
         cleanup();
         return s;
@@ -3408,11 +3412,11 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
             return SKH_INVALID_ARGUMENT;
         (n == "tail_park" ? c->tailPark : c->tailLag) = (uint32_t)value;
     }
-    else if (n == "waves_per_cu" || n == "waves_per_cu_shadow")
+    else if (n == "waves_per_cu" || n == "waves_per_cu_shadow" || n == "waves_per_cu_world" || n == "waves_per_cu_shadow_world")
     {
         if (value < 1 || value > 32)
             return SKH_INVALID_ARGUMENT;
-        (n == "waves_per_cu" ? c->wavesPerCU : c->wavesPerCUShadow) = (uint32_t)value;
+        (n == "waves_per_cu" ? c->wavesPerCU : (n == "waves_per_cu_shadow" ? c->wavesPerCUShadow : (n == "waves_per_cu_world" ? c->wavesPerCUWorld : c->wavesPerCUShadowWorld))) = (uint32_t)value;
         if (c->width)
             return alloc_frame(c);
     }
