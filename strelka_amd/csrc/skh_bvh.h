@@ -24,6 +24,7 @@ namespace skh
 
 #define SKH_REF_INVALID 0x7fffffff
 #define SKH_REF_SENTINEL ((int)0x80000000)
+#define SKH_PRIM_DIRECT 0x80000000u // primitive word of a hit on a BAKED triangle: the low 31 bits index its shading record (k_gather_tris)
 
 struct Node64
 {
@@ -1171,11 +1172,12 @@ __global__ void k_baked_tri_boxes(const uint8_t* __restrict__ instances /*64 B*/
 }
 
 // gather triangles into leaf order: 48 B records {v0.xyz, primId | v1.xyz, 0 | v2.xyz, 0}; primitives >= nMeshTris are baked
-// ones: WORLD-space vertices, {v0, primId | v1, instance id | v2, 0}
+// ones: WORLD-space vertices, {v0, shading-record index | SKH_PRIM_DIRECT | v1, instance id | v2, 0}
 __global__ void k_gather_tris(const uint8_t* __restrict__ verts, const uint32_t* __restrict__ indices,
                                     const uint4* __restrict__ meshes, const uint32_t* __restrict__ triMesh,
                                     const uint32_t* __restrict__ triLocal, const uint32_t* __restrict__ sortedVals, uint32_t n,
-                                    uint32_t nMeshTris, const uint8_t* __restrict__ instances, const uint32_t* __restrict__ wInst,
+                                    uint32_t nMeshTris, const uint8_t* __restrict__ instances, const uint8_t* __restrict__ shadeInstances /* the copy whose
+                                    light word holds a mesh instance's first shading record */, const uint32_t* __restrict__ wInst,
                                     const uint32_t* __restrict__ wFirst, uint32_t nW, float4* __restrict__ out)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1204,6 +1206,7 @@ __global__ void k_gather_tris(const uint8_t* __restrict__ verts, const uint32_t*
         const uint32_t inst = wInst[w], t = kk - wFirst[w];
         const float* m = reinterpret_cast<const float*>(instances + (size_t)inst * 64);
         const uint32_t geom = reinterpret_cast<const uint32_t*>(instances + (size_t)inst * 64)[13];
+        const uint32_t tvBase = reinterpret_cast<const uint32_t*>(shadeInstances + (size_t)inst * 64)[15];
         const uint4 me = meshes[geom];
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -1211,7 +1214,11 @@ __global__ void k_gather_tris(const uint8_t* __restrict__ verts, const uint32_t*
             const uint32_t vi = me.z + indices[me.x + 3 * t + k];
             const float* p = reinterpret_cast<const float*>(verts + (size_t)vi * 32);
             const v3 q = xform_point(m, mk3(p[0], p[1], p[2]));
-            r[k] = make_float4(q.x, q.y, q.z, k == 0 ? __uint_as_float(t) : (k == 1 ? __uint_as_float(inst) : 0.0f));
+            // word 0 of a baked triangle = the index of its shading record (mesh base + t: the base sits in the shading copy of the instance
+            // record, build_shading_tables) with SKH_PRIM_DIRECT set: k_shade fetches the record straight from the hit, beside the instance
+            // record instead of behind it; the traversal treats the word as opaque (within an instance it orders like t, so ties break alike),
+            // the raw-query output turns it back into t (k_hits_soa_to_aos)
+            r[k] = make_float4(q.x, q.y, q.z, k == 0 ? __uint_as_float((tvBase + t) | SKH_PRIM_DIRECT) : (k == 1 ? __uint_as_float(inst) : 0.0f));
         }
     }
     out[3 * (size_t)j + 0] = r[0];

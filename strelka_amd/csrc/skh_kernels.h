@@ -1951,6 +1951,17 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
             SKH_SP(0) // queue / path-state loads, sampler
             const HostInstance hi = sc.instances[hinst];
             const float* w2o = sc.inst[hinst].w2o;
+            // A hit on a baked triangle names its shading record itself (SKH_PRIM_DIRECT, k_gather_tris): the 96-byte fetch -- the one that
+            // misses the caches -- goes out BESIDE the instance record's instead of behind it (chain: queue -> {instance, triangle} -> material,
+            // was queue -> instance -> {triangle, material}).  Other hits read record 0 here for nothing and theirs below.
+            const bool directTv = (hprim & SKH_PRIM_DIRECT) != 0u;
+            float4 tv[6];
+            {
+                const float4* tp = sc.shadeTris + 6 * (size_t)(directTv ? (hprim & ~SKH_PRIM_DIRECT) : 0u);
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    tv[k] = tp[k];
+            }
             // (the whole record now: the compiler sinks the loads of `material` / `light` below the type test = one more round trip)
             asm volatile("" ::"v"(hi.type), "v"(hi.material), "v"(hi.light));
             if (hi.type == 1)
@@ -1994,9 +2005,9 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
 #endif
                 // the triangle's shading record goes out together with the material's (both hang off the instance record only);
                 // a curve hit fetches record 0 for nothing
-                float4 tv[6];
+                if (!directTv && hi.type != 2)
                 {
-                    const float4* tp = sc.shadeTris + 6 * (size_t)(hi.type == 2 ? 0u : hi.light + hprim);
+                    const float4* tp = sc.shadeTris + 6 * (size_t)(hi.light + hprim);
 #pragma unroll
                     for (int k = 0; k < 6; ++k)
                         tv[k] = tp[k];

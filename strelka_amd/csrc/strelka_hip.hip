@@ -1370,7 +1370,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     if (nTriSlots)
         k_gather_tris<<<(nTriSlots + B - 1) / B, B, 0, st>>>(c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(), c->dMeshes.as<uint4>(),
                                                               dTriMesh.as<uint32_t>(), dTriLocal.as<uint32_t>(),
-                                                              triOut.sortedVals.as<uint32_t>(), nTriSlots, nMeshTris, c->dInstances.as<uint8_t>(),
+                                                              triOut.sortedVals.as<uint32_t>(), nTriSlots, nMeshTris, c->dInstances.as<uint8_t>(), c->dShadeInst.as<uint8_t>(),
                                                               dWInst.as<uint32_t>(), dWFirst.as<uint32_t>(), (uint32_t)wInst.size(),
                                                               c->dTris.as<float4>());
     dev_free(c->dTriNodes);
@@ -2775,7 +2775,8 @@ __global__ void k_rays_aos_to_soa(const skh_ray* __restrict__ rays, uint32_t n, 
     rq.plane(7)[i] = r.tmax;
     rq.ids()[i] = k;
 }
-__global__ void k_hits_soa_to_aos(HitQ hq, uint32_t n, uint32_t per, uint32_t region, uint32_t mode, skh_hit* __restrict__ hits)
+__global__ void k_hits_soa_to_aos(HitQ hq, uint32_t n, uint32_t per, uint32_t region, uint32_t mode, skh_hit* __restrict__ hits,
+                                  const skh_instance* __restrict__ shadeInst /* light_id of a mesh instance = its first shading record */)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n)
@@ -2794,6 +2795,9 @@ __global__ void k_hits_soa_to_aos(HitQ hq, uint32_t n, uint32_t per, uint32_t re
         h.t = r0.x, h.u = r0.y, h.v = r0.z;
         h.instance_id = __float_as_uint(r1.x);
         h.prim_id = __float_as_uint(r1.y);
+        // a hit on a baked triangle carries the index of its shading record (k_gather_tris): back to the primitive index inside the mesh
+        if (h.instance_id != 0xffffffffu && (h.prim_id & SKH_PRIM_DIRECT))
+            h.prim_id = (h.prim_id & ~SKH_PRIM_DIRECT) - shadeInst[h.instance_id].light_id;
     }
     hits[k] = h;
 }
@@ -3013,7 +3017,7 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
                 launch_trace<false, false>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
         }
     }
-    k_hits_soa_to_aos<<<(n_rays + 255) / 256, 256, 0, c->stream>>>(hq, n_rays, per, per, mode, reinterpret_cast<skh_hit*>(d_hits));
+    k_hits_soa_to_aos<<<(n_rays + 255) / 256, 256, 0, c->stream>>>(hq, n_rays, per, per, mode, reinterpret_cast<skh_hit*>(d_hits), c->dShadeInst.as<skh_instance>());
     hipError_t e = hipStreamSynchronize(c->stream);
     cleanup();
     if (e != hipSuccess || (e = hipGetLastError()) != hipSuccess)
