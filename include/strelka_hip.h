@@ -422,7 +422,7 @@ skh_status skh_unit_probe(skh_context* ctx, uint32_t unit, uint32_t param, const
  *                 triangles when that empties the top level, 3 = every mesh instance, 4 (default) = 3 while the instanced triangles stay
  *                 within bake_budget_mtris (64) million, else 2; 0 = every instance keeps its TLAS leaf), world_kernel 1|0 (scenes
  *                 with an empty top level run the world-only build of the traversal kernel)
- *   build         build_quality 1|0 (PLOC | Karras radix tree), morton_bits (10 per axis in the sort keys; 4..21), leaf_max_tris (2), leaf_lines 0|1 (triangle leaves padded so that none
+ *   build         build_quality 1|0 (PLOC | Karras radix tree), morton_bits (10 per axis in the sort keys; 4..21), ploc_top (0: clusters left at which the triangle build widens PLOC's neighbour search from 12 to 96), leaf_max_tris (2), leaf_lines 0|1 (triangle leaves padded so that none
  *                 straddles a 128-byte line it need not: -11 % fetched lines, same time, more memory), curve_leaf (1), curve_split (4: parameter sub-ranges
  *                 per curve segment), tlas_build 1|0|2 (GPU PLOC over the instance boxes (default) | exact sweep SAH on the host: 5 % fewer instance
  *                 entries, single-threaded | the sweep up to 8192 instances, the GPU beyond), tlas_open (1: TLAS leaves per instance budget),

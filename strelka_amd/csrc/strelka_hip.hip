@@ -157,6 +157,7 @@ struct skh_context
     uint32_t wavesPerCU = 28; // resident waves per CU (7 per SIMD at <= 72 VGPRs; the curve build is resident 16 at a time whatever is asked: 128 VGPRs)
     uint32_t wavesPerCUShadow = 28; // the any-hit build of the triangle kernel fits 7 per SIMD
     uint32_t wavesPerCUShadowWorld = 32; // ... its world-only build 8 (SKH_WORLD_ANYHIT_MIN_WAVES)
+    uint32_t plocTop = 0; // triangle build: clusters left at which PLOC switches to the wide neighbour search (option ploc_top; 0 = never)
     uint32_t wavesPerCUWorld = 32; // the world-only closest-hit build: 64 VGPRs, 8 per SIMD (SKH_WORLD_CLOSEST_MIN_WAVES)
     uint32_t smallWavesClosest = 16, smallWavesShadow = 16; // overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24
     uint32_t gridOverride = 0; // set by render_one around its launches
@@ -470,6 +471,9 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
                     k_ploc_nn<SKH_PLOC_RADIUS_TLAS><<<gm, SKH_PLOC_BLOCK, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), m, nn.as<uint32_t>());
                 else if (search == 2)
                     k_ploc_nn<SKH_PLOC_RADIUS_SEGS><<<gm, SKH_PLOC_BLOCK, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), m, nn.as<uint32_t>());
+                else if (m <= c->plocTop)
+                    // the top of the tree -- the levels every ray walks -- clustered with the wide search of the TLAS builder (few clusters left: cheap)
+                    k_ploc_nn<SKH_PLOC_RADIUS_TLAS><<<gm, SKH_PLOC_BLOCK, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), m, nn.as<uint32_t>());
                 else
                     k_ploc_nn<SKH_PLOC_RADIUS><<<gm, SKH_PLOC_BLOCK, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), m, nn.as<uint32_t>());
                 k_ploc_merge<<<(m + B - 1) / B, B, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), nn.as<uint32_t>(), m, (int)n,
@@ -3408,6 +3412,13 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
     else if (n == "build_quality")
     {
         c->buildQuality = value != 0;
+        c->accelBuilt = false;
+    }
+    else if (n == "ploc_top")
+    {
+        if (value < 0)
+            return SKH_INVALID_ARGUMENT;
+        c->plocTop = (uint32_t)value;
         c->accelBuilt = false;
     }
     else if (n == "tail_park" || n == "tail_lag")

@@ -462,7 +462,7 @@ def test_tonemap_kernels_match_oracle(gpu, ork):
                                   {"fetch_min_closest": 1, "fetch_min_shadow": 64, "waves_per_cu": 8},
                                   {"waves_per_cu_world": 5, "waves_per_cu_shadow_world": 17, "waves_per_cu_shadow": 3},
                                   {"node_break_closest": 0, "node_break_shadow": 48, "leaf_min": 0}, {"leaf_min": 40}, {"tlas_open": 8}, {"tlas_build": 0}, {"tlas_build": 1}, {"wide": 8}, {"wide": 8, "leaf_max_tris": 4, "build_quality": 0}, {"curve_split": 1}, {"curve_split": 5, "curve_min": 1}, {"curve_min": 64}, {"tight_instance_boxes": 0}, {"overlap": 2}, {"overlap": 0}, {"leaf_lines": 1}, {"leaf_lines": 1, "leaf_max_tris": 4},
-                                  {"leaf_lines": 1, "leaf_max_tris": 7, "build_quality": 0}, {"morton_bits": 18}, {"morton_bits": 21, "build_quality": 0}, {"morton_bits": 5}])
+                                  {"leaf_lines": 1, "leaf_max_tris": 7, "build_quality": 0}, {"morton_bits": 18}, {"morton_bits": 21, "build_quality": 0}, {"morton_bits": 5}, {"ploc_top": 4096}])
 def test_results_do_not_depend_on_the_acceleration_structure_or_scheduling(opts):
     """Closest hit = min t with (instance, primitive) tie-break and conservative boxes, any-hit = existence: builder
     (PLOC / radix tree), hierarchy shape (opened TLAS leaves, 8-wide nodes), leaf size, ray order, refill and
