@@ -209,14 +209,48 @@ struct Instance
 uint32_t packNormals(const float3& normal); // scene.cpp:111-117
 uint32_t packUV(float u, float v); // HdStrelka/RenderPass.cpp:61-67
 
+#ifdef SKH_MIRROR_REFERENCE_MATERIALS
+class MaterialManager // (tests only, see Scene::MaterialDescription below: materialmanager.h:33-48)
+{
+public:
+    struct Param
+    {
+        enum class Type : uint32_t
+        {
+            eFloat = 0,
+            eInt,
+            eBool,
+            eFloat2,
+            eFloat3,
+            eFloat4,
+            eTexture
+        };
+        Type type;
+        std::string name;
+        std::vector<uint8_t> value;
+    };
+};
+#endif
 class Scene
 {
 public:
+#ifdef SKH_MIRROR_REFERENCE_MATERIALS
+    // (tests only: tests/cpp/strelka_lookalike/) the REFERENCE's shape of the description (scene.h:65-78) instead of the argument block, so that the
+    // SKH_WITH_STRELKA_HEADERS branches of integration/*.{h,cpp} can be pushed through a compiler (-fsyntax-only) without glm / MDL / OpenUSD
+    struct MaterialDescription
+    {
+        std::string code, file, name;
+        bool hasColor = false;
+        float3 color;
+        std::vector<MaterialManager::Param> params;
+    };
+#else
     struct MaterialDescription // the MDL code / params of the reference are replaced by the fixed argument block
     {
         std::string name;
         skh_material args;
     };
+#endif
     struct Vertex
     {
         float3 pos;
