@@ -1925,7 +1925,12 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
         float* P = ps.base;
         const size_t S = ps.stride;
         v3 throughput = mk3(P[pid], P[pid + S], P[pid + 2 * S]);
-        v3 radiance = mk3(P[pid + 3 * S], P[pid + 4 * S], P[pid + 5 * S]);
+        // prd.radiance stays in the path state and is read-modify-written only by the branches that change it (a light hit, the debug and error
+        // colours; the miss program's `+= throughput * 0` only when that product is not zero, i.e. a non-finite throughput): most paths of most
+        // bounces leave it alone, and 12 B read + 12 B written per path were a tenth of this kernel's traffic.  Same values in the same order.
+        v3 radiance = mk3(0.0f);
+        bool radianceDirty = false;
+#define SKH_RADIANCE_LOAD() radiance = mk3(P[pid + 3 * S], P[pid + 4 * S], P[pid + 5 * S]), radianceDirty = true
         float lastBsdfPdf = P[pid + 6 * S];
         uint32_t flags = reinterpret_cast<uint32_t*>(P)[pid + 7 * S];
         bool inside = (flags & PF_INSIDE) != 0;
@@ -1942,7 +1947,12 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
         if (hinst == 0xffffffffu)
         {
             // __miss__ms: bg_color = 0 (OptixRender.cpp:739)
-            radiance = radiance + throughput * mk3(0.0f);
+            const v3 bg = throughput * mk3(0.0f);
+            if (!(bg.x == 0.0f && bg.y == 0.0f && bg.z == 0.0f))
+            {
+                SKH_RADIANCE_LOAD();
+                radiance = radiance + bg;
+            }
             throughput = mk3(0.0f);
             prdDepth = fp.maxDepth;
         }
@@ -1972,6 +1982,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
                 const v3 lightNormal = calc_light_normal(l, hitPoint);
                 if (-dot(rayD, lightNormal) > 0.0f)
                 {
+                    SKH_RADIANCE_LOAD();
                     if (depth == 0 || specularBounce)
                         radiance = radiance + throughput * mk3(l.color) * -dot(rayD, lightNormal);
                     else
@@ -2042,7 +2053,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
                     }
                 }
                 if (fp.debug == 1)
-                    radiance = (sh.normal + mk3(1.0f)) * 0.5f;
+                    radiance = (sh.normal + mk3(1.0f)) * 0.5f, radianceDirty = true;
                 else
                 {
                     const float xi0 = sampler_random_lut(smp, DIM_BSDF0, s_sobol), xi1 = sampler_random_lut(smp, DIM_BSDF1, s_sobol),
@@ -2124,7 +2135,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
                             }
                             if (isnan3(lrad) || isnan(lightPdf))
                             {
-                                radiance = mk3(10000.0f, 0.0f, 0.0f);
+                                radiance = mk3(10000.0f, 0.0f, 0.0f), radianceDirty = true;
                                 throughput = mk3(0.0f);
                                 errorOut = true;
                             }
@@ -2139,7 +2150,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
                                     SKH_SP(4) // bsdf_evaluate
                                     if (isnan3(ev.bsdf_diffuse) || isnan3(ev.bsdf_glossy))
                                     {
-                                        radiance = mk3(10000.0f, 0.0f, 0.0f);
+                                        radiance = mk3(10000.0f, 0.0f, 0.0f), radianceDirty = true;
                                         throughput = mk3(0.0f);
                                         errorOut = true;
                                     }
@@ -2201,9 +2212,13 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
         P[pid] = throughput.x;
         P[pid + S] = throughput.y;
         P[pid + 2 * S] = throughput.z;
-        P[pid + 3 * S] = radiance.x;
-        P[pid + 4 * S] = radiance.y;
-        P[pid + 5 * S] = radiance.z;
+        if (radianceDirty)
+        {
+            P[pid + 3 * S] = radiance.x;
+            P[pid + 4 * S] = radiance.y;
+            P[pid + 5 * S] = radiance.z;
+        }
+#undef SKH_RADIANCE_LOAD
         P[pid + 6 * S] = lastBsdfPdf;
         reinterpret_cast<uint32_t*>(P)[pid + 7 * S] =
             (inside ? PF_INSIDE : 0u) | (specularBounce ? PF_SPECULAR : 0u) | (firstEvent << PF_EVENT_SHIFT);
