@@ -1694,8 +1694,8 @@ __global__ void __launch_bounds__(512) k_raygen(FrameP fp, const uint32_t* __res
         rq.plane(3)[idx] = d.x;
         rq.plane(4)[idx] = d.y;
         rq.plane(5)[idx] = d.z;
-        rq.plane(6)[idx] = fp.materialTmin; // OptixRender.cu:121
-        rq.plane(7)[idx] = 1e16f; // OptixRender.cu:122
+        // (planes 6 / 7 -- tmin = materialTmin, tmax = 1e16, OptixRender.cu:121-122 -- hold the same two constants for every radiance ray of every
+        // bounce: the host fills them once per queue and per value, k_fill_f32 in render_one; nobody rewrites them per ray)
         rq.ids()[idx] = path;
     }
 }
@@ -2237,8 +2237,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
         nextQ.plane(3)[ni] = nextD.x;
         nextQ.plane(4)[ni] = nextD.y;
         nextQ.plane(5)[ni] = nextD.z;
-        nextQ.plane(6)[ni] = fp.materialTmin;
-        nextQ.plane(7)[ni] = 1e16f;
+        // (planes 6 / 7, tmin / tmax: constants of the pass, filled once by the host -- k_fill_f32 in render_one)
         nextQ.ids()[ni] = LATE ? (pid | (lag << SKH_LAG_SHIFT)) : pid; // (what a late ray emits stays one launch behind its bounce index)
     }
     if (emitShadow)
@@ -2249,7 +2248,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
         shadowQ.plane(3)[si] = shD.x;
         shadowQ.plane(4)[si] = shD.y;
         shadowQ.plane(5)[si] = shD.z;
-        shadowQ.plane(6)[si] = fp.shadowTmin;
+        // (plane 6 = shadowTmin: filled once by the host)
         shadowQ.plane(7)[si] = shTmax;
         shadowQ.ids()[si] = pid;
         contrib[si] = shC.x;
@@ -2266,6 +2265,14 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
     }
 #endif
 #undef SKH_SP
+}
+
+// a constant plane of a ray queue (tmin / tmax of the radiance queues, tmin of the shadow queue): written when the queues are allocated or the
+// value changes, instead of once per ray per bounce by k_raygen / k_shade
+__global__ void __launch_bounds__(256) k_fill_f32(float* __restrict__ p, size_t n, float v)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = v;
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -157,6 +157,8 @@ struct skh_context
     uint32_t wavesPerCU = 28; // resident waves per CU (7 per SIMD at <= 72 VGPRs; the curve build is resident 16 at a time whatever is asked: 128 VGPRs)
     uint32_t wavesPerCUShadow = 28; // the any-hit build of the triangle kernel fits 7 per SIMD
     uint32_t wavesPerCUShadowWorld = 32; // ... its world-only build 8 (SKH_WORLD_ANYHIT_MIN_WAVES)
+    uint32_t queueConstBits[2] = { 0, 0 }; // materialTmin / shadowTmin the constant planes of the ray queues hold (bit patterns)
+    bool queueConstFilled = false; // ... and whether they hold them at all (alloc_frame resets it)
     uint32_t plocTop = 0; // triangle build: clusters left at which PLOC switches to the wide neighbour search (option ploc_top; 0 = never)
     uint32_t wavesPerCUWorld = 32; // the world-only closest-hit build: 64 VGPRs, 8 per SIMD (SKH_WORLD_CLOSEST_MIN_WAVES)
     uint32_t smallWavesClosest = 16, smallWavesShadow = 16; // overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24
@@ -1826,6 +1828,7 @@ static skh_status alloc_frame(skh_context* c)
     AF(dev_alloc(c, c->dHits, sizeof(float) * 8 * NQ));
     AF(dev_alloc(c, c->dShadowQ, sizeof(float) * 9 * NQ));
     AF(dev_alloc(c, c->dContrib, sizeof(float) * 3 * NQ));
+    c->queueConstFilled = false;
     AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * (SKH_COUNT_STRIDE * SKH_SHARDS * 2 * SKH_MAX_LAUNCH_ROUNDS + 16 * SKH_FETCH_STRIDE * SKH_MAX_LAUNCH_ROUNDS)));
     c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
     AF(dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * (uint32_t)c->numCUs * std::max(std::max(c->wavesPerCU, c->wavesPerCUWorld), std::max(c->wavesPerCUShadow, c->wavesPerCUShadowWorld)) * SKH_TRACE_BLOCK));
@@ -2094,6 +2097,26 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     RayQ shq{ c->dShadowQ.as<float>(), NQ, c->queueRegion };
     HitQ hq{ c->dHits.as<float>(), NQ };
     HitQ nohq{ nullptr, 0 };
+    {
+        // tmin / tmax of every radiance ray and tmin of every shadow ray are constants of the frame parameters (OptixRender.cu:121-122, closest_hit.cu):
+        // their queue planes are filled here, when the queues are new or a value has changed, and never written per ray (8 + 8 + 4 B per path and bounce)
+        uint32_t bits[2];
+        memcpy(&bits[0], &fp.materialTmin, 4);
+        memcpy(&bits[1], &fp.shadowTmin, 4);
+        if (!c->queueConstFilled || bits[0] != c->queueConstBits[0] || bits[1] != c->queueConstBits[1])
+        {
+            const uint32_t fb = (uint32_t)c->numCUs * 8u;
+            for (int k = 0; k < 2; ++k)
+            {
+                k_fill_f32<<<fb, 256, 0, st>>>(rq[k].base + (size_t)6 * NQ, NQ, fp.materialTmin);
+                k_fill_f32<<<fb, 256, 0, st>>>(rq[k].base + (size_t)7 * NQ, NQ, 1e16f);
+            }
+            k_fill_f32<<<fb, 256, 0, st>>>(shq.base + (size_t)6 * NQ, NQ, fp.shadowTmin);
+            c->queueConstFilled = true;
+            c->queueConstBits[0] = bits[0];
+            c->queueConstBits[1] = bits[1];
+        }
+    }
     // dCounts: 260 queues (2 per bounce) x SKH_SHARDS queue-length words, then the ray-fetch cursors (8 per trace launch); every word
     // that is the target of atomics has a 128-byte line of its own (returning atomics on one line serialise at ~88 per microsecond)
     uint32_t* counts = c->dCounts.as<uint32_t>();
