@@ -1660,15 +1660,12 @@ __global__ void __launch_bounds__(512) k_raygen(FrameP fp, const uint32_t* __res
         const Sampler s = init_sampler(px, py, fp.subframeIndex + sampleOffset + sub, fp.sppTotal, 52u); // OptixRender.cu:101
         generate_camera_ray(px, py, fp.width, fp.height, fp.clipToView, fp.viewToWorld, sampler_random(s, DIM_PIXEL_X),
                             sampler_random(s, DIM_PIXEL_Y), o, d);
-        // PerRayData init: OptixRender.cu:96-109
-        ps.base[path] = 1.0f;
-        ps.base[path + ps.stride] = 1.0f;
-        ps.base[path + 2 * (size_t)ps.stride] = 1.0f;
+        // PerRayData init: OptixRender.cu:96-109.  Throughput = 1 and lastBsdfPdf = 0 are not stored: k_shade ASSUMES the initial
+        // values at depth 0 instead of reading them, and writes its own for every path of that bounce, misses included
         ps.base[path + 3 * (size_t)ps.stride] = 0.0f;
         ps.base[path + 4 * (size_t)ps.stride] = 0.0f;
         ps.base[path + 5 * (size_t)ps.stride] = 0.0f;
-        ps.base[path + 6 * (size_t)ps.stride] = 0.0f; // lastBsdfPdf
-        reinterpret_cast<uint32_t*>(ps.base)[path + 7 * (size_t)ps.stride] = 0u; // flags: outside, eUndef
+        reinterpret_cast<uint32_t*>(ps.base)[path + 7 * (size_t)ps.stride] = 0u; // flags: outside, eUndef (k_collect reads them even when max_depth = 0 launches no k_shade)
     }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long m = __ballot(active);
@@ -1924,15 +1921,16 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
         const uint32_t hinst = __float_as_uint(hr1.x), hprim = __float_as_uint(hr1.y);
         float* P = ps.base;
         const size_t S = ps.stride;
-        v3 throughput = mk3(P[pid], P[pid + S], P[pid + 2 * S]);
+        // (depth 0: the PerRayData initial values, OptixRender.cu:96-109 -- k_raygen does not store them)
+        v3 throughput = depth == 0u ? mk3(1.0f) : mk3(P[pid], P[pid + S], P[pid + 2 * S]);
         // prd.radiance stays in the path state and is read-modify-written only by the branches that change it (a light hit, the debug and error
         // colours; the miss program's `+= throughput * 0` only when that product is not zero, i.e. a non-finite throughput): most paths of most
         // bounces leave it alone, and 12 B read + 12 B written per path were a tenth of this kernel's traffic.  Same values in the same order.
         v3 radiance = mk3(0.0f);
         bool radianceDirty = false;
 #define SKH_RADIANCE_LOAD() radiance = mk3(P[pid + 3 * S], P[pid + 4 * S], P[pid + 5 * S]), radianceDirty = true
-        float lastBsdfPdf = P[pid + 6 * S];
-        uint32_t flags = reinterpret_cast<uint32_t*>(P)[pid + 7 * S];
+        float lastBsdfPdf = depth == 0u ? 0.0f : P[pid + 6 * S];
+        uint32_t flags = depth == 0u ? 0u : reinterpret_cast<uint32_t*>(P)[pid + 7 * S];
         bool inside = (flags & PF_INSIDE) != 0;
         bool specularBounce = (flags & PF_SPECULAR) != 0;
         uint32_t firstEvent = (flags >> PF_EVENT_SHIFT) & 3u;
