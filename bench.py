@@ -390,9 +390,11 @@ def roofline_fractions(algorithmic_bytes_per_launch, counter_bytes_per_launch, a
 
 
 def shade_bytes(rays, next_rays, shadow_rays):
-    """k_shade, algorithmic: ray 36 r + hit record 32 r + path state 32 r + 32 w per ray; per surface hit (every ray counted as
-    one: upper bound) instance 64 + 64, shading triangle 96, material 64; 36 w per continuation ray, 36 + 12 w per shadow ray."""
-    return rays * (36 + 32 + 64) + rays * (128 + 96 + 64) + next_rays * 36 + shadow_rays * 48
+    """k_shade, algorithmic (what the kernel asks for since round 4: the path's radiance stays in place unless a branch changes it, the constant tmin /
+    tmax planes are not rewritten): ray 28 r (origin, direction, path id) + hit record 32 r + path state 20 r + 20 w (throughput, lastBsdfPdf, flags)
+    per ray; per surface hit (every ray counted as one: upper bound) instance 64 + 64, shading triangle 96, material 64; 28 w per continuation ray,
+    32 + 12 w per shadow ray."""
+    return rays * (28 + 32 + 40) + rays * (128 + 96 + 64) + next_rays * 28 + shadow_rays * 44
 
 
 def main():
