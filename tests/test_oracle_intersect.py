@@ -383,3 +383,66 @@ def test_triangle_intersector_against_exact_rational_arithmetic(ork):
             assert abs(out[1] - float(u)) <= BAR * cond and abs(out[2] - float(v)) <= BAR * cond, (case, out[1:], float(u), float(v), cond)
     assert decided > 1800 and hits > 1000 and agreed == decided
     assert worst < 2e-7  # (measured 8.6e-8 = 1.4 x 2^-24 of the conditioned quantity)
+
+
+def test_curve_intersector_finds_the_first_entry_into_the_swept_volume(ork):
+    """A6 / A8, curves: OptiX's round cubic B-spline primitive is closed, so the oracle's phantom intersector (`ork_intersect_curve`) is held
+    against a brute-force fp64 statement of what it must find: the FIRST point along the ray that lies inside the union of the spheres
+    (C(u), r(u)), u in [0, 1] -- located by a dense scan (1 500 ray steps x 2 001 curve parameters, then 40 bisections).  Rays are aimed at the
+    middle of the segment (u0 in [0.15, 0.85]) from outside, at a random offset from the axis: those that pass within 0.8 r must hit at the scan's
+    t (bar 3e-4, the on-surface test's; measured worst 1.7e-5), those that pass farther than 1.25 r from every point of the curve must miss."""
+    rs = np.random.RandomState(11)
+    q = f32(0, 0, 0, 0.05, 1, 0.3, 0, 0.06, 2, -0.2, 0.4, 0.04, 3, 0, 0, 0.03)
+    cp = q.reshape(4, 4).astype(np.float64)
+    us = np.linspace(0.0, 1.0, 2001)
+    # uniform cubic B-spline basis (the published one; tests/test_oracle_golden.py pins ork_curve_eval to it)
+    B = np.stack([(1 - us) ** 3, 3 * us ** 3 - 6 * us ** 2 + 4, -3 * us ** 3 + 3 * us ** 2 + 3 * us + 1, us ** 3], axis=1) / 6.0
+    CU = B @ cp  # [2001, 4]: centre xyz, radius
+
+    def depth(P):  # P [n, 3] -> min over u of |P - C(u)| - r(u)   (< 0 inside the swept volume)
+        dist = np.linalg.norm(P[:, None, :] - CU[None, :, :3], axis=2) - CU[None, :, 3]
+        return dist.min(axis=1)
+
+    out = np.zeros(2, np.float32)
+    hits = misses = 0
+    worst = 0.0
+    for _ in range(110):
+        k = rs.randint(300, 1700)
+        c, r = CU[k, :3], CU[k, 3]
+        off = rs.normal(size=3)
+        off *= rs.choice([rs.uniform(0.0, 0.8), rs.uniform(1.6, 3.0)]) * r / np.linalg.norm(off)
+        target = c + off
+        o = (target + rs.normal(size=3) * 1.5).astype(np.float32)
+        d = target - o.astype(np.float64)
+        d = (d / np.linalg.norm(d)).astype(np.float32)
+        o64, d64 = o.astype(np.float64), d.astype(np.float64)
+        ts = np.linspace(0.0, 6.0, 1501)
+        dep = depth(o64[None, :] + ts[:, None] * d64[None, :])
+        if dep[0] < 0:
+            continue  # (origin inside the tube: not this test's case)
+        got = ork.ork_intersect_curve(p(o), p(d), 0.0, 1e16, p(q), p(out))
+        inside = np.nonzero(dep < 0)[0]
+        if len(inside) == 0:
+            if dep.min() > 0.25 * CU[:, 3].min():
+                assert got == 0, (o, d, dep.min())
+                misses += 1
+            continue
+        lo, hi = ts[inside[0] - 1], ts[inside[0]]
+        for _ in range(40):
+            mid = 0.5 * (lo + hi)
+            if depth((o64 + mid * d64)[None, :])[0] < 0:
+                hi = mid
+            else:
+                lo = mid
+        t_ref = 0.5 * (lo + hi)
+        # entry through the side of the tube, not through the opening of its uncapped ends
+        P = o64 + t_ref * d64
+        u_ref = us[np.argmin(np.linalg.norm(P[None, :] - CU[:, :3], axis=1) - CU[:, 3])]
+        if u_ref < 0.02 or u_ref > 0.98 or dep.min() > -0.2 * r:
+            continue
+        assert got == 1, (o, d, t_ref, u_ref)
+        worst = max(worst, abs(float(out[0]) - t_ref))
+        assert abs(float(out[0]) - t_ref) < 3e-4, (float(out[0]), t_ref, u_ref, float(out[1]))
+        assert abs(float(out[1]) - u_ref) < 5e-3
+        hits += 1
+    assert hits > 35 and misses > 20, (hits, misses, worst)
