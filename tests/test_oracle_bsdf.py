@@ -162,3 +162,59 @@ def test_rough_glass_smooth_limit_is_snell(ork):
     # below the threshold the delta branch answers (specular events, pdf 0): the round-1 behaviour for clear glass
     d = sample(ork, glass_mat(0.0), n, k1, f32(0.5, 0.5, 0.99, 0))
     assert int(d[7]) == (4 | 16) and d[6] == 0 and abs(math.hypot(d[0], d[1]) - 0.4) < 1e-6
+
+
+def test_pbr_lobes_against_the_published_microfacet_formulas(ork):
+    """A9, the OmniPBR-equivalent material (type 1): its glossy lobe is the GGX microfacet BRDF, its diffuse lobe Lambert under the Fresnel layer.
+    The oracle's evaluation -- which the HIP code is compared with call by call (`skh_bsdf_probe`) -- is held here against the PUBLISHED terms, typed
+    independently in fp64: D = a^2 / (pi ((n.h)^2 (a^2 - 1) + 1)^2) (Walter et al. 2007), Lambda = (sqrt(1 + a^2 tan^2) - 1) / 2 and the
+    height-correlated G2 = 1 / (1 + Lambda_o + Lambda_i) (Heitz 2014), F = f0 + (1 - f0)(1 - o.h)^5 (Schlick 1994), visible-normal pdf
+    G1 D / (4 n.o) (Heitz 2018); a = max(roughness, 0.05)^2, f0 = lerp(0.08 specular, base, metallic), diffuse albedo = base (1 - metallic), lobe
+    selection 0.5 + 0.5 metallic (include/strelka_hip.h).  400 random (material, normal, k1, k2) cases, both lobes times cos and the pdf: 2e-5."""
+    rs = np.random.RandomState(9)
+
+    def unit(v):
+        return v / np.linalg.norm(v)
+
+    checked = 0
+    for _ in range(400):
+        base = rs.uniform(0.05, 0.95, 3)
+        rough, metallic, specular = rs.uniform(0.02, 1.0), rs.choice([0.0, 1.0, rs.uniform()]), rs.uniform(0.0, 1.0)
+        m = np.zeros((), S.MATERIAL)
+        m["type"], m["base_color"], m["roughness"], m["metallic"], m["specular"], m["ior"] = 1, base, rough, metallic, specular, 1.5
+        n = unit(rs.normal(size=3))
+        # both directions in the upper hemisphere of n
+        k1 = unit(rs.normal(size=3))
+        k2 = unit(rs.normal(size=3))
+        k1 = k1 if k1 @ n > 0 else -k1
+        k2 = k2 if k2 @ n > 0 else -k2
+        if k1 @ n < 0.05 or k2 @ n < 0.05:
+            continue
+        n32, k132, k232 = n.astype(np.float32), k1.astype(np.float32), k2.astype(np.float32)
+        got = evaluate(ork, m, n32, k132, k232)
+        # published terms in fp64, on the float32 inputs the oracle saw
+        n_, o, i = n32.astype(np.float64), k132.astype(np.float64), k232.astype(np.float64)
+        n_, o, i = unit(n_), unit(o), unit(i)
+        base32 = np.asarray(m["base_color"], np.float64)
+        rough32, metal32, spec32 = float(m["roughness"]), float(m["metallic"]), float(m["specular"])
+        a = max(rough32, 0.05) ** 2
+        h = unit(o + i)
+        no, ni, nh, oh = n_ @ o, n_ @ i, n_ @ h, max(o @ h, 0.0)
+        f0 = 0.08 * spec32 + (base32 - 0.08 * spec32) * metal32
+        Fh = f0 + (1.0 - f0) * (1.0 - oh) ** 5
+        Fo = f0 + (1.0 - f0) * (1.0 - no) ** 5
+        D = a * a / (math.pi * (nh * nh * (a * a - 1.0) + 1.0) ** 2)
+
+        def lam(c):
+            return 0.5 * (math.sqrt(1.0 + a * a * (1.0 - c * c) / (c * c)) - 1.0)
+
+        G2, G1 = 1.0 / (1.0 + lam(no) + lam(ni)), 1.0 / (1.0 + lam(no))
+        glossy = Fh * D * G2 / (4.0 * no)  # f cos(i): the n.i of the BRDF's denominator cancels
+        diffuse = base32 * (1.0 - metal32) * (1.0 - Fo) * ni / math.pi
+        ps = 0.5 + 0.5 * metal32
+        pdf = ps * G1 * D / (4.0 * no) + (1.0 - ps) * ni / math.pi
+        assert np.allclose(got[0:3], diffuse, rtol=2e-5, atol=1e-7), (got[0:3], diffuse)
+        assert np.allclose(got[3:6], glossy, rtol=2e-4, atol=1e-6), (got[3:6], glossy, a, nh)  # (D's denominator cancels near the peak at small alpha)
+        assert abs(got[6] - pdf) <= 2e-4 * pdf + 1e-6, (got[6], pdf)
+        checked += 1
+    assert checked > 300
