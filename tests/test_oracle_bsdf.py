@@ -218,3 +218,39 @@ def test_pbr_lobes_against_the_published_microfacet_formulas(ork):
         assert abs(got[6] - pdf) <= 2e-4 * pdf + 1e-6, (got[6], pdf)
         checked += 1
     assert checked > 300
+
+
+@pytest.mark.parametrize("inside", [0, 1])
+def test_smooth_glass_reflects_with_the_exact_fresnel_probability(ork, inside):
+    """OmniGlass without frosting: the reflection event is chosen with probability F, the unpolarised Fresnel reflectance of a dielectric
+    interface -- F = ((n1 c1 - n2 c2) / (n1 c1 + n2 c2))^2 / 2 + ((n1 c2 - n2 c1) / (n1 c2 + n2 c1))^2 / 2 with Snell's c2, 1 beyond the critical
+    angle (Born & Wolf) -- located here by bisection on the selection variable xi.z and compared with that formula in fp64, from outside and
+    from inside (total internal reflection included); the refracted direction obeys Snell's law to 1e-6."""
+    ior = 1.5
+    mat = glass_mat(0.0, ior=ior)
+    n = f32(0, 0, 1)
+    n1, n2 = (ior, 1.0) if inside else (1.0, ior)
+    for c1 in (1.0, 0.9, 0.7, 0.5, 0.3, 0.15, 0.05):
+        k1 = f32(math.sqrt(1 - c1 * c1), 0, c1)
+        s2 = n1 / n2 * math.sqrt(1 - c1 * c1)
+        if s2 >= 1.0:
+            want = 1.0
+        else:
+            c2 = math.sqrt(1 - s2 * s2)
+            rs_ = ((n1 * c1 - n2 * c2) / (n1 * c1 + n2 * c2)) ** 2
+            rp_ = ((n1 * c2 - n2 * c1) / (n1 * c2 + n2 * c1)) ** 2
+            want = 0.5 * (rs_ + rp_)
+        lo, hi = 0.0, 1.0  # reflect iff xi.z < F
+        for _ in range(30):
+            mid = 0.5 * (lo + hi)
+            out = sample(ork, mat, n, k1, f32(0.3, 0.6, mid, 0.0), inside)
+            reflected = out[2] > 0  # k2.z on the side of k1
+            if reflected:
+                lo = mid
+            else:
+                hi = mid
+        got = 0.5 * (lo + hi)
+        assert abs(got - want) < 2e-6, (inside, c1, got, want)
+        if want < 1.0:
+            out = sample(ork, mat, n, k1, f32(0.3, 0.6, 0.999999, 0.0), inside)
+            assert out[2] < 0 and abs(math.hypot(out[0], out[1]) - s2) < 1e-6  # Snell: sin(t) = n1 / n2 sin(i)
