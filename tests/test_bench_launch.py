@@ -145,3 +145,30 @@ def test_scene_cache_waiter_stops_when_the_writer_failed(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError, match="writer .* failed: ValueError: generator exploded"):
         bench.load_workload("cornell", make=False)
     assert time.time() - t0 < 5
+
+
+def test_committed_round_profile_is_self_consistent():
+    """The newest profiles/rNNx_bench.json and the rocprofv3 --kernel-trace --stats summary committed beside it describe the same code: the dominant
+    kernel's average launch in the bench line (hipEvents inside bench.py) agrees with the profiler's (within 5 %), the fractions follow from the
+    line's own bytes / time / peak, and the per-kernel times add up to the step."""
+    import csv
+    import glob
+    import json
+    import re
+
+    prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    tags = sorted({re.match(r"(r\d+[a-z]?)_bench\.json$", os.path.basename(f)).group(1) for f in glob.glob(os.path.join(prof, "r*_bench.json"))
+                   if re.match(r"r\d+[a-z]?_bench\.json$", os.path.basename(f))})
+    tag = tags[-1]
+    line = json.load(open(os.path.join(prof, tag + "_bench.json")))
+    roof = line["roofline"]
+    rows = list(csv.DictReader(open(os.path.join(prof, tag + "_kernel_stats.csv"))))
+    closest = [r for r in rows if "k_trace<false, false" in r["Name"]]
+    assert closest, "closest-hit kernel missing from the committed kernel stats"
+    avg_ms = float(closest[0]["AverageNs"]) / 1e6
+    assert abs(avg_ms - roof["avg_launch_ms"]) <= 0.05 * roof["avg_launch_ms"], (avg_ms, roof["avg_launch_ms"])
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["unit"] == "GB/s" and roof["bound"] == "hbm"
+    assert abs(roof["achieved"] - roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9) <= 0.01 * roof["achieved"]
+    k = line["kernel_ms_per_frame"]
+    assert abs(sum(k.values()) - line["ms_per_step"]) <= 0.02 * line["ms_per_step"]
+    assert abs(line["value"] - line["config"]["rays_per_frame"] / line["ms_per_step"] / 1e3) <= 0.01 * line["value"]
