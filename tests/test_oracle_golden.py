@@ -235,3 +235,48 @@ def test_post_tonemappers_match_the_published_curves(ork):
             assert np.allclose(got[:, :3], w, rtol=2e-6 if typ != 2 else 2e-5, atol=2e-7 if typ != 2 else 2e-6), (typ, gamma, np.abs(got[:, :3] - w).max())
             if typ or gamma:
                 assert np.all(got[:, 3] == 1.0)
+
+
+def test_camera_ray_matches_the_reference_formula_in_fp64(ork):
+    """A1: generateCameraRay (OptixRender.cu:38-58) restated in the oracle (`generate_camera_ray`, which the HIP raygen kernel is compared with
+    through every image test), held against an independent fp64 statement of the same seven lines: pixel + jitter -> NDC in [-1, 1] ->
+    clipToView * (x, y, 1, 1) -> viewToWorld * (view.xyz, 0), normalised; origin = viewToWorld * (0, 0, 0, 1); sutil::Matrix4x4 is row-major.
+    Random perspective cameras (clip_to_view from the oracle's own ork_clip_to_view AND raw random matrices), poses, resolutions, pixels, jitters."""
+    import ctypes as C
+
+    rs = np.random.RandomState(21)
+
+    def P(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    for case in range(300):
+        w, h = int(rs.randint(1, 4000)), int(rs.randint(1, 2500))
+        px, py = int(rs.randint(0, w)), int(rs.randint(0, h))
+        jx, jy = np.float32(rs.rand()), np.float32(rs.rand())
+        if case % 2:
+            c2v = np.zeros(16, np.float32)
+            ork.ork_clip_to_view(float(rs.uniform(20, 100)), float(w) / float(h), 0.1, 1000.0, P(c2v))
+        else:
+            c2v = rs.normal(size=16).astype(np.float32)
+        # a rigid pose (rotation + translation), row-major 4x4
+        q = rs.normal(size=4)
+        q /= np.linalg.norm(q)
+        a, b, c, d = q
+        R = np.array([[a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)],
+                      [2 * (b * c + a * d), a * a - b * b + c * c - d * d, 2 * (c * d - a * b)],
+                      [2 * (b * d - a * c), 2 * (c * d + a * b), a * a - b * b - c * c + d * d]])
+        v2w = np.eye(4)
+        v2w[:3, :3] = R
+        v2w[:3, 3] = rs.normal(size=3) * 10
+        v2w32 = v2w.astype(np.float32).reshape(16)
+        o, dirn = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        ork.ork_camera_ray(px, py, w, h, P(c2v), P(v2w32), float(jx), float(jy), P(o), P(dirn))
+        # fp64, on the float32 inputs
+        M, V = c2v.astype(np.float64).reshape(4, 4), v2w32.astype(np.float64).reshape(4, 4)
+        ndc = np.array([(px + float(jx)) / w, (py + float(jy)) / h]) * 2.0 - 1.0
+        view = M @ np.array([ndc[0], ndc[1], 1.0, 1.0])
+        wd = V @ np.array([view[0], view[1], view[2], 0.0])
+        want_d = wd[:3] / np.linalg.norm(wd[:3])
+        want_o = (V @ np.array([0.0, 0.0, 0.0, 1.0]))[:3]
+        assert np.allclose(o, want_o, rtol=1e-6, atol=1e-6)
+        assert np.allclose(dirn, want_d, rtol=0, atol=3e-6), (case, dirn, want_d)
