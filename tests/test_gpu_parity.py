@@ -1119,3 +1119,27 @@ def test_randomised_scenes_transforms_and_rays_bit_exact():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_hits.py"), "1208", "1220"], cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "12 seeds" in r.stdout and " 0 seeds with mismatches" in r.stdout, r.stdout[-2000:]
+
+
+def test_hip_integrator_against_the_closed_form_of_a_floor_under_a_rect_light(gpu):
+    """The HIP path against PHYSICS rather than against the oracle: the scene of tests/test_oracle_render.py's closed-form test (a diffuse floor
+    under a parallel rectangular light; L_o = rho L / pi x Integral H^3 / r^5 dA by fp64 quadrature) rendered by k_raygen / k_trace / k_shade with
+    1024 samples in one launch, both rect sampling methods: within the same 1.5 % Monte-Carlo bar -- and, the sampler being shared bit for bit,
+    within 1e-5 of the oracle's number for the same samples."""
+    from tests import orklib
+    from tests.test_oracle_render import floor_under_rect_light
+
+    sc, want = floor_under_rect_light()
+    arr = sc.arrays()
+    for method in (0, 1):
+        p = S.frame_params(sc.getCamera(), 8, 8, subframe_index=0, samples_this_launch=1024, spp_total=1024, max_depth=2, rect_light_sampling_method=method)
+        gpu.set_scene(arr)
+        gpu.resize(8, 8)
+        gpu.render_subframe(p)
+        got = float(gpu.read_accum()[..., :3].mean())
+        assert abs(got - want) <= 0.015 * want, (method, got, want)
+        o = orklib.new_context()
+        o.set_scene(arr)
+        o.resize(8, 8)
+        o.render_subframe(p)
+        assert abs(got - float(o.read_accum()[..., :3].mean())) <= 1e-5 * want

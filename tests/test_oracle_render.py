@@ -96,6 +96,22 @@ def test_direct_lighting_of_a_floor_under_a_rect_light_has_its_closed_form():
     evaluated here by fp64 quadrature.  max_depth 2 (direct light only: the flat floor cannot light itself), one launch of many samples (a linear
     mean: the sub-frame accumulator is a tonemapped lerp), both rect sampling methods.  Monte-Carlo bar 1.5 % (65 536 samples per method;
     measured 0.3751 and 0.3752 against 0.3771: -0.5 %, of which ~0.2 % is the pixels' footprint around the origin)."""
+    sc, want = floor_under_rect_light()
+    for method in (0, 1):
+        o = orklib.new_context()
+        o.set_scene(sc.arrays())
+        o.resize(8, 8)
+        spp = 1024
+        o.render_subframe(S.frame_params(sc.getCamera(), 8, 8, subframe_index=0, samples_this_launch=spp, spp_total=spp, max_depth=2,
+                                         rect_light_sampling_method=method))
+        img = o.read_accum()[..., :3]
+        got = float(img.mean())
+        assert np.allclose(img.mean(axis=(0, 1)), got, rtol=1e-6)  # grey in, grey out
+        assert abs(got - want) <= 0.015 * want, (method, got, want)
+
+
+def floor_under_rect_light():
+    """the scene of the closed-form test and its fp64 answer (also rendered by the HIP path: tests/test_gpu_parity.py)"""
     import math
 
     rho, L, H, a, b = 0.5, 10.0, 1.5, 1.0, 0.6
@@ -114,15 +130,4 @@ def test_direct_lighting_of_a_floor_under_a_rect_light_has_its_closed_form():
     zs = (np.arange(n) + 0.5) / n * b - b / 2
     X, Z = np.meshgrid(xs, zs, indexing="ij")
     r2 = X * X + Z * Z + H * H
-    want = rho * L / math.pi * float((H ** 3 / r2 ** 2.5).sum() * (a / n) * (b / n))
-    for method in (0, 1):
-        o = orklib.new_context()
-        o.set_scene(sc.arrays())
-        o.resize(8, 8)
-        spp = 1024
-        o.render_subframe(S.frame_params(sc.getCamera(), 8, 8, subframe_index=0, samples_this_launch=spp, spp_total=spp, max_depth=2,
-                                         rect_light_sampling_method=method))
-        img = o.read_accum()[..., :3]
-        got = float(img.mean())
-        assert np.allclose(img.mean(axis=(0, 1)), got, rtol=1e-6)  # grey in, grey out
-        assert abs(got - want) <= 0.015 * want, (method, got, want)
+    return sc, rho * L / math.pi * float((H ** 3 / r2 ** 2.5).sum() * (a / n) * (b / n))
