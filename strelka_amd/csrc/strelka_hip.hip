@@ -1151,6 +1151,11 @@ static skh_status build_shading_tables(skh_context* c)
         base[m + 1] = base[m] + c->meshes[m].index_count / 3u;
     const uint32_t nTris = base[nMeshes];
     skh_status s;
+    if (nTris >= SKH_PRIM_DIRECT)
+    {
+        c->err = "skh_build_accel: more than 2^31 - 1 triangles (the primitive word of a hit keeps its top bit for SKH_PRIM_DIRECT)";
+        return SKH_INVALID_ARGUMENT;
+    }
     if ((s = dev_alloc(c, c->dShadeTris, std::max<size_t>(96, (size_t)nTris * 96))) != SKH_OK)
         return s;
     if (nTris)
