@@ -404,7 +404,7 @@ skh_status skh_unit_probe(skh_context* ctx, uint32_t unit, uint32_t param, const
  * takes the same setting and the bit-exact contract holds per setting).
  *   measurement   count_traversal 0|1 (counter build of the trace kernels), timing 0|1 (per-kernel hipEvent spans)
  *   scheduling    waves_per_cu (28) / waves_per_cu_shadow (28) (7 waves per SIMD) / waves_per_cu_world, waves_per_cu_shadow_world (32 / 32: the world-only builds run 8), fetch_min_closest / fetch_min_shadow (24 / 48, scenes with curves 16 / 24: idle lanes before a wave refills),
- *                 node_break_closest / node_break_shadow (32 / 28, curves 20 / 20: leave the node loop below x/64 descending rays),
+ *                 node_break_closest / node_break_shadow (32 / 28, curves 20 / 20 until one is set explicitly: leave the node loop below x/64 descending rays),
  *                 leaf_min (16: lanes for the minority kind of leaf work), curve_min (48: lanes parked in front of the
  *                 curve intersector before it runs), subframe_batch (0 = auto: ~64 M paths per pass),
  *                 speculate (8: sub-frames traced ahead when skh_render_subframe is called once per sub-frame; 0 = off),
@@ -412,11 +412,7 @@ skh_status skh_unit_probe(skh_context* ctx, uint32_t unit, uint32_t param, const
  *                 path-state buffer; accumulation steps and skh_buffer_download run beside it on their own stream: the caller's map()
  *                 copies cost nothing any more.  A camera move waits for the pass in flight, <= `speculate` sub-frames),
  *                 overlap 0|1|2 (any-hit launches on a second stream beside the next closest-hit launch: off | small passes |
- *                 always), small_waves_closest / small_waves_shadow (16 / 16: waves per CU of the two overlapped launches),
- *                 tail_park (64; 0 = off: in overlapped passes a closest-hit wave that finds the ray queue dry and carries at most this many
- *                 rays parks them -- ray, best hit, node, stack -- and exits; the NEXT closest-hit launch resumes them first, the k_shade
- *                 after it shades them one launch late: the launch no longer waits for its longest rays), tail_lag (2; 0 = off: how
- *                 often one path may be parked = extra launch rounds that drain the stragglers at the end of a pass)
+ *                 always), small_waves_closest / small_waves_shadow (16 / 16: waves per CU of the two overlapped launches)
  *   definition    bake_world 4|3|2|1|0 (mesh instances intersected in world space, no instance entry: 1 = instances whose mesh has one
  *                 user -- what HdStrelka's per-instance meshes are --, 2 = also instances of meshes with <= bake_small_tris (64)
  *                 triangles when that empties the top level, 3 = every mesh instance, 4 (default) = 3 while the instanced triangles stay
@@ -426,8 +422,8 @@ skh_status skh_unit_probe(skh_context* ctx, uint32_t unit, uint32_t param, const
  *                 straddles a 128-byte line it need not: -11 % fetched lines, same time, more memory), curve_leaf (1), curve_split (4: parameter sub-ranges
  *                 per curve segment), tlas_build 1|0|2 (GPU PLOC over the instance boxes (default) | exact sweep SAH on the host: 5 % fewer instance
  *                 entries, single-threaded | the sweep up to 8192 instances, the GPU beyond), tlas_open (1: TLAS leaves per instance budget),
- *                 tight_instance_boxes 1|0, wide 4|8 (node width: 64-byte 4-wide nodes | 96-byte
- *                 8-wide nodes with octant-ordered slots; two-level hierarchy only, measured slower: docs/LOG.md)
+ *                 tight_instance_boxes 1|0
+ *   (round 4's `wide` 8, `tail_park`, `tail_lag` are gone: measured negatives, experiments/README.md)
  * Unknown names and out-of-range values return SKH_INVALID_ARGUMENT. */
 skh_status skh_set_option(skh_context* ctx, const char* name, int64_t value);
 /* what the context's device reports (hipDeviceProp_t): the measurement code prices instruction rates against these */

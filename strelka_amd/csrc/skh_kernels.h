@@ -230,17 +230,8 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 #ifndef SKH_TRACE_MIN_WAVES
 #define SKH_TRACE_MIN_WAVES 7 // 72 VGPRs (2 dwords spilled): the launch runs 28 one-wave blocks per CU (closest 103.3 -> 100.6 ms over 6 waves at 77 VGPRs)
 #endif
-#ifndef SKH_CURVE_COOP
-#define SKH_CURVE_COOP 1 // the curve intersector as a wave-cooperative block: one (candidate, end point) run per lane (0 = every parked lane runs its own candidates)
-#endif
 #ifndef SKH_MATERIALS_LDS
 #define SKH_MATERIALS_LDS 64 // material argument blocks k_shade stages in LDS beside the Sobol table (0 = all from global memory: measured equal, 31.3 vs 31.2 ms -- the fetch was never on the critical path; on because north_star asks for it)
-#endif
-#ifndef SKH_SHADOW_ATOMIC
-#define SKH_SHADOW_ATOMIC 0 // fire-and-forget float atomics for the shadow contribution instead of load / add / store: measured equal (40.87 vs 40.90 ms)
-#endif
-#ifndef SKH_WORLD_MIN_WAVES
-#define SKH_WORLD_MIN_WAVES 7 // world-only builds that do not fit 64 VGPRs: 8-wide nodes, the continuation (TAILQ) build
 #endif
 #ifndef SKH_WORLD_ANYHIT_MIN_WAVES
 #define SKH_WORLD_ANYHIT_MIN_WAVES 8 // the world-only any-hit build fits 64 VGPRs without scratch (59; 27 SGPRs go to lanes): 32 waves per CU -- any-hit 28.7 -> 27.85 ms
@@ -252,81 +243,18 @@ SKH_DI uint32_t wave_sum(uint32_t v)
                                       // v_mbcnt (rank_below) and the overflow area addressed where it is used to get there: with the 64-bit "lanes below me" mask
                                       // and the overflow pointer spilled (5 dwords, two reloads per outer iteration) the same build ran 81.7 -> 85.7 ms
 #endif
-#ifndef SKH_SORT_ANYHIT
-#define SKH_SORT_ANYHIT 0
-#endif
 #ifndef SKH_TRACE_ATTR
 #define SKH_TRACE_ATTR
-#endif
-#ifndef SKH_POP_CULL
-#define SKH_POP_CULL 0 // 1: pop-time culling in the world-only closest-hit build: LDS stack entries are 64-bit {reference, entry distance} (one
-                       // ds_write_b64 / ds_read_b64 each, SKH_CULL_LDS of them per lane) and a popped entry whose box lies beyond the current best
-                       // hit is dropped WITHOUT fetching its node; a lane whose pop was culled stays in the node loop, masked, and pops again in
-                       // the next iteration (no inner loop).  docs/LOG.md, round 4
-#endif
-#ifndef SKH_CULL_LDS
-#define SKH_CULL_LDS 11 // 8 B x 64 lanes x 11 = 5632 B per wave: 28 waves per CU still fit 160 KB
-#endif
-#ifndef SKH_POSTPONE
-#define SKH_POSTPONE 0 // 1: "speculative traversal" (Aila & Laine 2009) in the world-only closest-hit build: a lane that reaches a leaf puts it aside
-                       // and keeps descending; only its SECOND leaf makes it wait for the wave's triangle pass, which then tests both
 #endif
 #ifndef SKH_TRI_COOP
 #define SKH_TRI_COOP 1 // 1: the triangle pass of the world-only builds is shared -- lanes that are NOT at a leaf take the second triangle of the
                        // two-triangle leaves (the owner's ray pulled with ds_bpermute, their own ray state parked in the free part of their LDS stack
                        // column meanwhile), so that one pass does what took two at 30 + 17 of 64 lanes
 #endif
-#ifndef SKH_PK_NODE
-#define SKH_PK_NODE 0 // 1: the near / far plane distances of a 4-wide node as v_pk_fma_f32 pairs (12 packed FMAs instead of 24).  Measured in round 4:
-                      // the register pairs cost the closest-hit build 5 spilled dwords -- kitchen 81.3 -> 87.3 ms, unshared 70.8 -> 77.2; off
-#endif
-#ifndef SKH_PREFETCH2
-#define SKH_PREFETCH2 0 // 1: touch load of the second-nearest hit child's line, issued behind the nearest child's node fetch
-#endif
 // The 8 ray-fetch cursors of a launch sit in separate 128-byte lines: returning atomics on ONE line serialise at ~88 per
 // microsecond chip-wide (measured), which eight cursors in the same line would share.
 #define SKH_FETCH_STRIDE 32
 #define SKH_COUNT_STRIDE 32 // same for the queue-length words the compaction atomics hit
-
-// The tail of a closest-hit launch (round 4).  A persistent launch ends when its LAST ray ends: once the queue is dry the waves thin out and
-// the launch waits ~0.3 ms for a few long rays at a handful of lanes per wave -- per bounce, before the dependent k_shade may start; a rank's
-// 1/8 share of a frame loses 9 % to that.  Continuations take the per-bounce barrier away from those rays: a wave that finds the queue dry
-// PARKS the rays it still carries (the ray, its best hit, current node and stack: a record in one of eight per-shard lists), marks their queue
-// entries (high bit of the id word: k_shade skips them) and exits.  The NEXT closest-hit launch takes the parked rays first (`resume`), 64 to
-// a wave again, among a full launch's worth of other work; their results go back into their records and the k_shade launch after it shades
-// them too ("late" rays, read from the records) -- one launch later than their queue mates, which their id word records as a LAG (bits 28-30):
-// the bounce index of a ray is `launch index - lag`, and what it emits inherits the lag.  A path may be parked `lagMax` times; that many extra
-// launch rounds at the end of the pass drain the stragglers.  Paths are independent, a path has one ray in flight, and every sum it takes
-// part in stays in its own bounce order: images are bit-identical (tests/test_gpu_parity.py::test_tail_passes_are_exact).
-// Record = SKH_TAIL_HDR + SKH_STACK_LDS words, in planes of SKH_SHARDS * capacity.
-#define SKH_TAIL_HDR 16 // id word (path | lag << 28) | cur | sp, found << 31 (0xffffffff: moved on to the next list) | best t u v inst prim | leaf put aside | o xyz d xyz tmin
-#define SKH_PARKED_BIT 0x80000000u
-#define SKH_LAG_SHIFT 28
-#define SKH_PATH_MASK 0x0fffffffu
-struct TailQ
-{
-    // one list per queue shard (a late ray is shaded into the output shard of ITS input shard, so that no shard can outgrow its region):
-    // list g = records [g * capacity, g * capacity + min(count[g], capacity)); a list that is full takes no more -- those rays stay in their wave
-    uint32_t* park; // records this launch parks
-    uint32_t* parkCount; // SKH_SHARDS words, SKH_COUNT_STRIDE apart (own 128-byte lines), then SKH_SHARDS copies of the "queue is dry" flag, same spacing
-    uint32_t* budget; // SKH_SHARDS words, same spacing: rays parked per shard in the whole PASS, capped at `capacity` -- so a shard never holds more
-                      // than `capacity` lagging rays, and the drain rounds' k_shade grids can be sized by it
-    uint32_t* resume; // records the launch before parked: taken first, results written back into them
-    const uint32_t* resumeCount; // their lists' lengths
-    uint32_t* resumeFetch; // SKH_SHARDS cursors, SKH_FETCH_STRIDE apart
-    uint32_t capacity; // records per list
-    uint32_t parkMax, lagMax;
-    // (kernel argument beside the pointer to this struct -- flags: 1 = may park (when the queue is dry and at most `parkMax` lanes of the wave still
-    // carry a ray), 2 = has parked rays to resume)
-    __device__ static uint32_t* plane(uint32_t* base, uint32_t cap, uint32_t k)
-    {
-        return base + (size_t)k * (SKH_SHARDS * cap);
-    }
-    __device__ uint32_t* dry(uint32_t g) const // (a copy per workgroup label: thousands of waves poll it)
-    {
-        return parkCount + (SKH_SHARDS + g) * SKH_COUNT_STRIDE;
-    }
-};
 
 // ------------------------------------------------------------------------------------------------------------
 // k_trace: persistent waves over the ray queue, two-level BVH traversal (TLAS -> instance -> BLAS).
@@ -343,34 +271,28 @@ struct TailQ
 // ------------------------------------------------------------------------------------------------------------
 // WORLD: the build for scenes whose every instance is baked (no TLAS leaf, no curve set -- what a bake without mesh sharing gives,
 // HdStrelka's per-instance meshes): one world-space tree, no instance entry / exit, no object-space copy of the ray, no sentinel.
-// TAILQ: the build with the continuation code in it (TailQ: park / resume); the launches that never park run the build without it -- the
-// extra paths cost the traversal loop registers (13 spilled dwords) even when they are never taken.
-template <bool ANY_HIT, bool COUNT, bool CURVES, bool W8 = false, bool WORLD = false, bool TAILQ = false>
-__global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WORLD_MIN_WAVES : (ANY_HIT ? SKH_WORLD_ANYHIT_MIN_WAVES : SKH_WORLD_CLOSEST_MIN_WAVES)) : (CURVES ? SKH_CURVE_MIN_WAVES : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES))) SKH_TRACE_ATTR
+// (The measured-negative variants of round 4 -- pop-time culling, postponed leaves, the touch prefetch, packed node FMAs, 8-wide nodes, continuations --
+// live in experiments/skh_trace_r04_variants.h with their numbers; three builds ship: world-only, two-level, two-level + curves.)
+template <bool ANY_HIT, bool COUNT, bool CURVES, bool WORLD = false>
+__global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (ANY_HIT ? SKH_WORLD_ANYHIT_MIN_WAVES : SKH_WORLD_CLOSEST_MIN_WAVES) : (CURVES ? SKH_CURVE_MIN_WAVES : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES))) SKH_TRACE_ATTR
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
             uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, 
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
-            StatsDev* __restrict__ stats, const TailQ* __restrict__ tailp /* this launch's continuation lists: read where they are used (rare paths), not
-            held in SGPRs through the traversal loop */, uint32_t tailFlagsArg)
+            StatsDev* __restrict__ stats)
 {
     static_assert(!WORLD || !CURVES, "the world-only build is a triangle kernel");
-    constexpr bool CULL = SKH_POP_CULL && WORLD && !ANY_HIT && !W8;
-    constexpr bool TRICOOP = SKH_TRI_COOP && WORLD && !W8 && !SKH_POSTPONE && !SKH_POP_CULL; // (closest-hit and any-hit builds of the world-only kernel)
+    constexpr bool TRICOOP = SKH_TRI_COOP && WORLD; // (closest-hit and any-hit builds of the world-only kernel)
     // per-lane stack entries in LDS (the rest: SKH_STACK_OVF entries in global memory); TRICOOP gives one up for its two 64-byte lane tables
     // (LDS is handed out in 1280-byte granules here: 20 x 256 B = 4 granules exactly, 128 B more would cost a fifth = 25 instead of 28 waves per CU)
-    constexpr int NLDS = CULL ? SKH_CULL_LDS : (TRICOOP ? SKH_STACK_LDS - 1 : SKH_STACK_LDS);
-    __shared__ int s_stack[(CULL ? 2 : 1) * NLDS * SKH_TRACE_BLOCK];
+    constexpr int NLDS = TRICOOP ? SKH_STACK_LDS - 1 : SKH_STACK_LDS;
+    __shared__ int s_stack[NLDS * SKH_TRACE_BLOCK];
     __shared__ unsigned char s_tab[TRICOOP ? 128 : 1]; // [0..63] owner lanes by rank, [64..127] helper lanes by rank
     const uint32_t fetchMin = fetchArg & 0xffu, curveMin = (fetchArg >> 8) & 0xffu, nodeBreak = (fetchArg >> 16) & 0xffu, leafMin = fetchArg >> 24;
     const uint32_t lane = threadIdx.x;
-    constexpr bool TAILS = TAILQ && WORLD && !ANY_HIT && !W8 && !SKH_POP_CULL; // the build that can park / resume rays (TailQ)
-    const uint32_t tailFlags = TAILS ? tailFlagsArg : 0u;
-#define tail (*tailp)
-    uint32_t phase = (tailFlags & 2u) ? 0u : 1u; // where a refill looks: 0 = the parked rays of the launch before (first), 1 = the ray queue
     uint32_t n = 0; // (countPtr: SKH_SHARDS queue-length words, SKH_COUNT_STRIDE apart)
 #pragma unroll
     for (uint32_t g = 0; g < SKH_SHARDS; ++g)
-        n += countPtr[g * SKH_COUNT_STRIDE] + ((tailFlags & 2u) ? tail.resumeCount[g * SKH_COUNT_STRIDE] : 0u);
+        n += countPtr[g * SKH_COUNT_STRIDE];
     if (n == 0)
         return;
     const uint32_t perGroup = rq.region;
@@ -378,7 +300,6 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
     uint32_t tries = 0;
     bool exhausted = false;
     int* lds = s_stack + lane;
-    int2* lds2 = reinterpret_cast<int2*>(s_stack) + lane; // (CULL) entry e of this lane = lds2[e * 64] = {reference, entry distance}
     // (the overflow area is addressed from ovfBase where it is used -- rare paths -- instead of through a per-lane 64-bit pointer held across the loops)
 #define SKH_OVF_AT(e) ovfBase[(size_t)(e) * ovfStride + (blockIdx.x * SKH_TRACE_BLOCK + threadIdx.x)]
     const uint32_t ovfStride = gridDim.x * SKH_TRACE_BLOCK;
@@ -410,54 +331,26 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
     bool inBlas = false;
     uint32_t curInst = 0, curType = 0;
     int sp = 0, cur = SKH_REF_INVALID;
-    constexpr bool POSTPONE = SKH_POSTPONE && WORLD && !ANY_HIT && !W8;
-    int leaf2 = SKH_REF_INVALID; // (POSTPONE) the leaf this lane has put aside
-    uint32_t dryNext = 0; // (TAILS) the "queue is dry" flag as loaded one iteration ago
-    uint32_t pollTick = 0;
-    bool parkTried = false; // (TAILS) a wave offers its rays to the tail lists once (a full list must not be hammered every iteration)
-    constexpr bool PF2 = SKH_PREFETCH2 && WORLD && !ANY_HIT && !W8;
-    int pf = SKH_REF_INVALID; // (PF2) the second-nearest hit child of the node just processed: its line is touched behind the next node fetch
-    int pfv = 0;
     HitRec best;
     best.t = 0.0f, best.inst = best.prim = 0xffffffffu, best.u = best.v = 0.0f, best.found = false;
 
-#define SKH_PUSH_T(v, tnearBits)                                     \
+#define SKH_PUSH(v)                                                  \
     {                                                                \
         if (sp < NLDS)                                               \
-        {                                                            \
-            if (CULL)                                                \
-                lds2[sp * SKH_TRACE_BLOCK] = make_int2((v), (tnearBits)); \
-            else                                                     \
-                lds[sp * SKH_TRACE_BLOCK] = (v);                     \
-        }                                                            \
+            lds[sp * SKH_TRACE_BLOCK] = (v);                         \
         else if (sp < NLDS + SKH_STACK_OVF)                          \
-            SKH_OVF_AT(sp - NLDS) = (v); /* (entries in the global overflow area carry no distance: never culled) */ \
+            SKH_OVF_AT(sp - NLDS) = (v);                             \
         else                                                         \
             *sc.overflowFlag = 1u; /* the entry is dropped: the call that launched this kernel returns SKH_FAIL, never silent */ \
         ++sp;                                                        \
     }
-#define SKH_PUSH(v) SKH_PUSH_T(v, 0)
 #define SKH_POP(dst)                                                 \
     {                                                                \
         --sp;                                                        \
         if (sp < NLDS)                                               \
-        {                                                            \
-            if (CULL)                                                \
-            {                                                        \
-                /* pop-time culling: the acceptance test the entry passed when it was pushed, against today's best.t -- an entry is dropped   \
-                   only if the slab test would reject it now, so results cannot change */                                                    \
-                const int2 e = lds2[sp * SKH_TRACE_BLOCK];           \
-                dst = __int_as_float(e.y) > best.t * SKH_SLAB_SLACK ? SKH_REF_INVALID : e.x; \
-            }                                                        \
-            else                                                     \
-                dst = lds[sp * SKH_TRACE_BLOCK];                     \
-        }                                                            \
+            dst = lds[sp * SKH_TRACE_BLOCK];                         \
         else if (sp < NLDS + SKH_STACK_OVF)                          \
-        {                                                            \
-            dst = SKH_OVF_AT(sp - NLDS);              \
-            if (PF2)                                                 \
-                asm volatile("" ::"v"(dst)); /* the wait for this (rare) global read stays inside its branch: at the join it would cover the touch load in flight too */ \
-        }                                                            \
+            dst = SKH_OVF_AT(sp - NLDS);                             \
         else                                                         \
             dst = SKH_REF_INVALID;                                   \
     }
@@ -483,29 +376,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
                     {
                         const uint32_t pid = rq.ids()[i];
                         float* rad = ps.base + (size_t)3 * ps.stride;
-#if SKH_SHADOW_ATOMIC
-                        // a path has at most one shadow ray in a launch, so a fire-and-forget add gives the bits `+=` gives -- without the
-                        // wave sitting through the load -> add -> store round trip at every refill
-                        unsafeAtomicAdd(&rad[pid], contrib[i]);
-                        unsafeAtomicAdd(&rad[pid + ps.stride], contrib[i + contribStride]);
-                        unsafeAtomicAdd(&rad[pid + 2 * (size_t)ps.stride], contrib[i + 2 * (size_t)contribStride]);
-#else
                         rad[pid] += contrib[i];
                         rad[pid + ps.stride] += contrib[i + contribStride];
                         rad[pid + 2 * (size_t)ps.stride] += contrib[i + 2 * (size_t)contribStride];
-#endif
                     }
-                }
-                else if (TAILS && (i & 0x80000000u))
-                {
-                    // a resumed ray: its hit goes back into its record, where the late part of k_shade finds it
-                    const uint32_t k = i & 0x7fffffffu;
-                    TailQ::plane(tail.resume, tail.capacity, 2)[k] = best.found ? 0x80000000u : 0u;
-                    TailQ::plane(tail.resume, tail.capacity, 3)[k] = __float_as_uint(best.t);
-                    TailQ::plane(tail.resume, tail.capacity, 4)[k] = __float_as_uint(best.u);
-                    TailQ::plane(tail.resume, tail.capacity, 5)[k] = __float_as_uint(best.v);
-                    TailQ::plane(tail.resume, tail.capacity, 6)[k] = best.inst;
-                    TailQ::plane(tail.resume, tail.capacity, 7)[k] = best.prim;
                 }
                 else
                 {
@@ -520,83 +394,29 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
             SKH_LP(wv[4]++; wv[5] += want;)
             uint32_t base = 0, count = 0;
             const int leader = __ffsll((long long)needMask) - 1;
-            bool fromResume = false;
-            for (;;)
+            while (tries < 8u)
             {
-                // the work of this phase: the eight lists of parked rays (phase 0) or the eight shards of the queue (phase 1); same cursor logic
-                const bool ph0 = TAILS && phase == 0u;
-                const uint32_t* __restrict__ cntPtr = ph0 ? tail.resumeCount : countPtr;
-                uint32_t* cursors = ph0 ? tail.resumeFetch : fetch;
-                const uint32_t span = ph0 ? tail.capacity : perGroup;
-                while (tries < 8u)
+                const uint32_t g = (group + tries) & 7u;
+                uint32_t b = 0;
+                if ((int)lane == leader)
+                    b = atomicAdd(&fetch[g * SKH_FETCH_STRIDE], want);
+                b = __shfl(b, leader);
+                const uint32_t lo = g * perGroup;
+                const uint32_t hi = lo + min(countPtr[g * SKH_COUNT_STRIDE], perGroup);
+                if (lo < hi && b < hi - lo)
                 {
-                    const uint32_t g = (group + tries) & 7u;
-                    uint32_t b = 0;
-                    if ((int)lane == leader)
-                        b = atomicAdd(&cursors[g * SKH_FETCH_STRIDE], want);
-                    b = __shfl(b, leader);
-                    const uint32_t lo = g * span;
-                    const uint32_t hi = lo + min(cntPtr[g * SKH_COUNT_STRIDE], span);
-                    if (lo < hi && b < hi - lo)
-                    {
-                        base = lo + b;
-                        count = min(want, hi - base);
-                        if (count < want)
-                            ++tries; // this range is now empty
-                        break;
-                    }
-                    ++tries;
+                    base = lo + b;
+                    count = min(want, hi - base);
+                    if (count < want)
+                        ++tries; // this range is now empty
+                    break;
                 }
-                fromResume = ph0;
-                if (ph0 && tries >= 8u && count == 0)
-                {
-                    phase = 1u; // no parked rays left: on to the queue, in this same refill
-                    tries = 0;
-                    continue;
-                }
-                break;
+                ++tries;
             }
             if (tries >= 8u && count == 0)
-            {
                 exhausted = true;
-                if (TAILS && (tailFlags & 1u) && lane < SKH_SHARDS)
-                    __hip_atomic_store(tail.dry(lane), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // every ray has been handed out: tell the other waves
-            }
             const uint32_t rank = rank_below(needMask);
-            if (TAILS && fromResume)
-            {
-                // ---- resume: a parked ray's record instead of a queue entry ----
-                if (!hasRay && rank < count)
-                {
-                    const uint32_t k = base + rank;
-                    uint32_t* R = tail.resume;
-                    const uint32_t C = tail.capacity;
-                    ridx = k | 0x80000000u; // (bit 31: "late" -- the result goes back into record k)
-                    cur = (int)TailQ::plane(R, C, 1)[k];
-                    const uint32_t spw = TailQ::plane(R, C, 2)[k];
-                    sp = (int)(spw & 0x7fffffffu);
-                    best.found = (spw >> 31) != 0u;
-                    best.t = __uint_as_float(TailQ::plane(R, C, 3)[k]), best.u = __uint_as_float(TailQ::plane(R, C, 4)[k]), best.v = __uint_as_float(TailQ::plane(R, C, 5)[k]);
-                    best.inst = TailQ::plane(R, C, 6)[k], best.prim = TailQ::plane(R, C, 7)[k];
-                    leaf2 = (int)TailQ::plane(R, C, 8)[k];
-                    ow = mk3(__uint_as_float(TailQ::plane(R, C, 9)[k]), __uint_as_float(TailQ::plane(R, C, 10)[k]), __uint_as_float(TailQ::plane(R, C, 11)[k]));
-                    dw = mk3(__uint_as_float(TailQ::plane(R, C, 12)[k]), __uint_as_float(TailQ::plane(R, C, 13)[k]), __uint_as_float(TailQ::plane(R, C, 14)[k]));
-                    tmin = __uint_as_float(TailQ::plane(R, C, 15)[k]);
-                    for (int e = 0; e < sp; ++e) // (parked with sp <= NLDS)
-                        lds[e * SKH_TRACE_BLOCK] = (int)TailQ::plane(R, C, SKH_TAIL_HDR + e)[k];
-                    o = ow;
-                    d = dw;
-                    inv = rcp3(d);
-                    sh = make_shear(dw);
-                    nodes = sc.triNodes;
-                    inBlas = true;
-                    curInst = 0xffffffffu;
-                    curType = 0;
-                    pend = 0;
-                    hasRay = true;
-                }
-            }
-            else if (!hasRay && rank < count)
+            if (!hasRay && rank < count)
             {
                 ridx = base + rank;
                 ow = mk3(rq.plane(0)[ridx], rq.plane(1)[ridx], rq.plane(2)[ridx]);
@@ -625,13 +445,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
                         sp = 2;
                     }
                     if (wr0 != SKH_REF_INVALID && wr1 != SKH_REF_INVALID)
-                    {
-                        if (CULL)
-                            lds2[sp * SKH_TRACE_BLOCK] = make_int2(wr1, 0); // (no entry distance known: never culled)
-                        else
-                            lds[sp * SKH_TRACE_BLOCK] = wr1;
-                        ++sp;
-                    }
+                        lds[(sp++) * SKH_TRACE_BLOCK] = wr1;
                     cur = wr0 != SKH_REF_INVALID ? wr0 : wr1;
                 }
                 else
@@ -646,76 +460,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
                 best.u = best.v = 0.0f;
                 best.found = false;
                 pend = 0;
-                leaf2 = SKH_REF_INVALID;
                 hasRay = true;
-            }
-        }
-        if (TAILS && (tailFlags & 1u))
-        {
-            // a wave learns that the queue is dry when its own refill fails -- which it only attempts with `fetchMin` idle lanes -- or from the
-            // flag the first such wave sets (lane 0 polls its label's copy every fourth iteration, one poll ahead: the load is never waited for)
-            if (!exhausted && phase == 1u && (++pollTick & 3u) == 0u)
-            {
-                if (__builtin_amdgcn_readfirstlane((int)dryNext) != 0)
-                    exhausted = true;
-                if (lane == 0u)
-                    dryNext = __hip_atomic_load(tail.dry(group), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            // ---- park: the queue is dry and this wave is down to a few rays -- leave them to the next launch and go ----
-            const unsigned long long live = __ballot(hasRay);
-            if (exhausted && !parkTried && live != 0ull && (uint32_t)__popcll(live) <= tail.parkMax)
-            {
-                parkTried = true;
-                const bool late = (ridx & 0x80000000u) != 0u;
-                uint32_t idw = 0;
-                if (hasRay) // the ray's id word: path | lag << 28
-                    idw = late ? TailQ::plane(tail.resume, tail.capacity, 0)[ridx & 0x7fffffffu] : rq.ids()[ridx];
-                const uint32_t lag = (idw >> SKH_LAG_SHIFT) & 7u;
-                // (a ray with entries in the global overflow area stays: rare; so does a path that has used up its lag allowance)
-                const bool canPark = hasRay && sp <= NLDS && lag < tail.lagMax;
-                const uint32_t myShard = !canPark ? 0xffffffffu : (late ? (ridx & 0x7fffffffu) / tail.capacity : min(ridx / rq.region, SKH_SHARDS - 1u));
-                bool parked = false;
-                for (uint32_t g = 0; g < SKH_SHARDS; ++g)
-                {
-                    const unsigned long long m = __ballot(myShard == g);
-                    if (m == 0ull)
-                        continue;
-                    const int leader = __ffsll((long long)m) - 1;
-                    uint32_t b = 0xffffffffu;
-                    if ((int)lane == leader)
-                    {
-                        const uint32_t cnt = (uint32_t)__popcll(m);
-                        if (atomicAdd(&tail.budget[g * SKH_COUNT_STRIDE], cnt) + cnt <= tail.capacity) // (the pass's allowance for this shard)
-                            b = atomicAdd(&tail.parkCount[g * SKH_COUNT_STRIDE], cnt);
-                    }
-                    b = __shfl(b, leader);
-                    const uint32_t pos = b + rank_below(m);
-                    if (myShard == g && b != 0xffffffffu) // (allowance used up: the rays stay in their wave)
-                    {
-                        const uint32_t k = g * tail.capacity + pos;
-                        uint32_t* P = tail.park;
-                        const uint32_t C = tail.capacity;
-                        TailQ::plane(P, C, 0)[k] = (idw & SKH_PATH_MASK) | ((lag + 1u) << SKH_LAG_SHIFT); // shaded one launch later than it would have been
-                        TailQ::plane(P, C, 1)[k] = (uint32_t)cur;
-                        TailQ::plane(P, C, 2)[k] = (uint32_t)sp | (best.found ? 0x80000000u : 0u);
-                        TailQ::plane(P, C, 3)[k] = __float_as_uint(best.t), TailQ::plane(P, C, 4)[k] = __float_as_uint(best.u), TailQ::plane(P, C, 5)[k] = __float_as_uint(best.v);
-                        TailQ::plane(P, C, 6)[k] = best.inst, TailQ::plane(P, C, 7)[k] = best.prim;
-                        TailQ::plane(P, C, 8)[k] = (uint32_t)leaf2;
-                        TailQ::plane(P, C, 9)[k] = __float_as_uint(ow.x), TailQ::plane(P, C, 10)[k] = __float_as_uint(ow.y), TailQ::plane(P, C, 11)[k] = __float_as_uint(ow.z);
-                        TailQ::plane(P, C, 12)[k] = __float_as_uint(dw.x), TailQ::plane(P, C, 13)[k] = __float_as_uint(dw.y), TailQ::plane(P, C, 14)[k] = __float_as_uint(dw.z);
-                        TailQ::plane(P, C, 15)[k] = __float_as_uint(tmin);
-                        for (int e = 0; e < sp; ++e)
-                            TailQ::plane(P, C, SKH_TAIL_HDR + e)[k] = (uint32_t)lds[e * SKH_TRACE_BLOCK];
-                        if (late)
-                            TailQ::plane(tail.resume, C, 2)[ridx & 0x7fffffffu] = 0xffffffffu; // its old record: moved on, nothing to shade there
-                        else
-                            rq.ids()[ridx] = idw | SKH_PARKED_BIT; // k_shade leaves this queue entry alone
-                        hasRay = false; // (no result of its own: `pending` stays false)
-                        parked = true;
-                    }
-                }
-                if (__any(parked))
-                    continue; // (the top of the loop writes the results of the lanes that had finished before, if all 64 lanes are idle now)
             }
         }
         if (!__any(hasRay))
@@ -724,7 +469,6 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
                 break;
             continue;
         }
-#if SKH_CURVE_COOP
         if constexpr (CURVES)
         {
             // ---- the iterative curve intersector, wave-cooperative ----
@@ -915,7 +659,6 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
                 __builtin_amdgcn_wave_barrier(); // (s_runs is rewritten by the next block)
             }
         }
-#endif
         bool terminated = false;
         SKH_LP(uint32_t itN = 0, itT = 0; { const unsigned long long t = __builtin_readcyclecounter(); cy[0] += t - cyA; cyA = t; })
         // (lanes parked in front of the curve intersector do not count: they are not waiting for the node loop to end)
@@ -923,107 +666,12 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
         if (hasRay || TRICOOP) // (TRICOOP: every lane comes along to the triangle pass; the node loop and the pop stay with the lanes that have a ray)
         {
             // ---- descend through internal nodes ----
-            // (CULL: a lane whose popped entry was culled -- cur INVALID, stack not empty -- stays in the loop, masked for the node block,
-            // and pops its next entry at the bottom of the iteration: no inner loop, the chain of culled pops hides behind the other lanes' nodes)
-            while ((!TRICOOP || hasRay) && ((cur >= 0 && cur != SKH_REF_INVALID) || (CULL && cur == SKH_REF_INVALID && sp > 0)))
+            while ((!TRICOOP || hasRay) && cur >= 0 && cur != SKH_REF_INVALID)
             {
-                if (!CULL || cur != SKH_REF_INVALID)
-                {
                 SKH_LP(itN++; rayNodes++;)
-                if constexpr (W8)
-                {
-                    // one 96-byte fetch = eight quantised child boxes; slot order is traversal order (Node8, skh_bvh.h): no sorting network
-                    const float4* np = reinterpret_cast<const float4*>(nodes) + 6 * (size_t)cur;
-                    const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3], w4 = np[4], w5 = np[5];
-                    if (COUNT)
-                        tc.nodes++;
-                    SKH_LP(if (!inBlas) tc.segs++;)
-                    const uint32_t ex = __float_as_uint(w0.w);
-                    const float ax = __uint_as_float((ex & 0xffu) << 23) * inv.x, bx = (w0.x - o.x) * inv.x;
-                    const float ay = __uint_as_float((ex & 0xff00u) << 15) * inv.y, by = (w0.y - o.y) * inv.y;
-                    const float az = __uint_as_float((ex & 0xff0000u) << 7) * inv.z, bz = (w0.z - o.z) * inv.z;
-                    const bool px = inv.x >= 0.0f, py = inv.y >= 0.0f, pz = inv.z >= 0.0f;
-                    uint32_t nxw[2], fxw[2], nyw[2], fyw[2], nzw[2], fzw[2];
-                    nxw[0] = __float_as_uint(px ? w1.x : w1.z), nxw[1] = __float_as_uint(px ? w1.y : w1.w);
-                    fxw[0] = __float_as_uint(px ? w1.z : w1.x), fxw[1] = __float_as_uint(px ? w1.w : w1.y);
-                    nyw[0] = __float_as_uint(py ? w2.x : w2.z), nyw[1] = __float_as_uint(py ? w2.y : w2.w);
-                    fyw[0] = __float_as_uint(py ? w2.z : w2.x), fyw[1] = __float_as_uint(py ? w2.w : w2.y);
-                    nzw[0] = __float_as_uint(pz ? w3.x : w3.z), nzw[1] = __float_as_uint(pz ? w3.y : w3.w);
-                    fzw[0] = __float_as_uint(pz ? w3.z : w3.x), fzw[1] = __float_as_uint(pz ? w3.w : w3.y);
-                    int r[8];
-                    r[0] = __float_as_int(w4.x), r[1] = __float_as_int(w4.y), r[2] = __float_as_int(w4.z), r[3] = __float_as_int(w4.w);
-                    r[4] = __float_as_int(w5.x), r[5] = __float_as_int(w5.y), r[6] = __float_as_int(w5.z), r[7] = __float_as_int(w5.w);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                    {
-                        const int h = k >> 2, sft = 8 * (k & 3);
-                        const float nx = fmaf((float)((nxw[h] >> sft) & 0xffu), ax, bx), fx = fmaf((float)((fxw[h] >> sft) & 0xffu), ax, bx);
-                        const float ny = fmaf((float)((nyw[h] >> sft) & 0xffu), ay, by), fy = fmaf((float)((fyw[h] >> sft) & 0xffu), ay, by);
-                        const float nz = fmaf((float)((nzw[h] >> sft) & 0xffu), az, bz), fz = fmaf((float)((fzw[h] >> sft) & 0xffu), az, bz);
-                        const float tnear = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
-                        const float tfar = fminf(fminf(fx, fy), fminf(fz, best.t));
-                        r[k] = tnear <= tfar * SKH_SLAB_SLACK ? r[k] : SKH_REF_INVALID;
-                    }
-                    if (!ANY_HIT)
-                    {
-                        // visit order k <-> slot k ^ oct, oct = signs of the direction: three conditional butterfly stages
-#define SKH_BFLY(a, b, keep)                  \
-    {                                         \
-        const int ta = keep ? r[a] : r[b];    \
-        const int tb = keep ? r[b] : r[a];    \
-        r[a] = ta, r[b] = tb;                 \
-    }
-                        SKH_BFLY(0, 1, px) SKH_BFLY(2, 3, px) SKH_BFLY(4, 5, px) SKH_BFLY(6, 7, px)
-                        SKH_BFLY(0, 2, py) SKH_BFLY(1, 3, py) SKH_BFLY(4, 6, py) SKH_BFLY(5, 7, py)
-                        SKH_BFLY(0, 4, pz) SKH_BFLY(1, 5, pz) SKH_BFLY(2, 6, pz) SKH_BFLY(3, 7, pz)
-#undef SKH_BFLY
-                    }
-                    // the hit children go on the stack last-to-visit first; the first-to-visit one (the last written) is taken back as `cur`
-                    int top = SKH_REF_INVALID;
-                    if (sp + 8 <= SKH_STACK_LDS)
-                    {
-                        int* p = lds + sp * SKH_TRACE_BLOCK;
-#pragma unroll
-                        for (int k = 7; k >= 0; --k)
-                        {
-                            const bool v = r[k] != SKH_REF_INVALID;
-                            *p = r[k]; // (unconditional: what lands above the top is never read)
-                            top = v ? r[k] : top;
-                            p += v ? SKH_TRACE_BLOCK : 0;
-                            sp += v ? 1 : 0;
-                        }
-                    }
-                    else
-                    {
-#pragma unroll
-                        for (int k = 7; k >= 0; --k)
-                            if (r[k] != SKH_REF_INVALID)
-                            {
-                                SKH_PUSH(r[k]);
-                                top = r[k];
-                            }
-                    }
-                    if (top != SKH_REF_INVALID)
-                        --sp;
-                    cur = top;
-                }
-                else
-                {
                 // one 64-byte fetch = four quantised child boxes
                 const float4* np = reinterpret_cast<const float4*>((WORLD ? sc.triNodes : nodes) + cur);
                 const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-                if (PF2)
-                {
-                    // issued AFTER this node's four loads: vector loads return in order, so the wait for the node (vmcnt(1)) leaves the touch in
-                    // flight; its value is "used" one iteration later, when it has long arrived behind that iteration's node
-                    asm volatile("" ::"v"(pfv));
-                    // branch-free (a conditional touch would make the wait for the node cover it too): no candidate = this node's own line again
-                    const bool isl = pf < 0;
-                    const uint32_t idx = isl ? (((uint32_t)~pf) >> 3) * 3u : (uint32_t)pf * 4u; // in 16-byte units
-                    const float4* base = isl ? sc.tris : reinterpret_cast<const float4*>(sc.triNodes);
-                    const float4* ta = pf != SKH_REF_INVALID ? base + idx : np;
-                    pfv = *reinterpret_cast<const int*>(ta); // (kept alive by the asm above, one iteration later)
-                }
                 if (COUNT)
                     tc.nodes++;
                 SKH_LP(if (!inBlas) tc.segs++;) // (profile build: TLAS share of the node visits, reported as "segs")
@@ -1041,20 +689,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                 {
-#if SKH_PK_NODE
-                    typedef float f2 __attribute__((ext_vector_type(2)));
-                    const f2 qx = { (float)((nxw >> (8 * k)) & 0xffu), (float)((fxw >> (8 * k)) & 0xffu) };
-                    const f2 qy = { (float)((nyw >> (8 * k)) & 0xffu), (float)((fyw >> (8 * k)) & 0xffu) };
-                    const f2 qz = { (float)((nzw >> (8 * k)) & 0xffu), (float)((fzw >> (8 * k)) & 0xffu) };
-                    const f2 tx = __builtin_elementwise_fma(qx, (f2){ ax, ax }, (f2){ bx, bx });
-                    const f2 ty = __builtin_elementwise_fma(qy, (f2){ ay, ay }, (f2){ by, by });
-                    const f2 tz = __builtin_elementwise_fma(qz, (f2){ az, az }, (f2){ bz, bz });
-                    const float nx = tx.x, fx = tx.y, ny = ty.x, fy = ty.y, nz = tz.x, fz = tz.y;
-#else
                     const float nx = fmaf((float)((nxw >> (8 * k)) & 0xffu), ax, bx), fx = fmaf((float)((fxw >> (8 * k)) & 0xffu), ax, bx);
                     const float ny = fmaf((float)((nyw >> (8 * k)) & 0xffu), ay, by), fy = fmaf((float)((fyw >> (8 * k)) & 0xffu), ay, by);
                     const float nz = fmaf((float)((nzw >> (8 * k)) & 0xffu), az, bz), fz = fmaf((float)((fzw >> (8 * k)) & 0xffu), az, bz);
-#endif
                     const float tnear = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
                     const float tfar = fminf(fminf(fx, fy), fminf(fz, best.t));
                     // (an empty slot is stored as the inverted box 255 > 0 on every axis and fails this test by itself; should rounding
@@ -1073,7 +710,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
         tn[a] = ta, tn[b] = tb;              \
         rf[a] = ra, rf[b] = rb;              \
     }
-                if (!ANY_HIT || SKH_SORT_ANYHIT)
+                if (!ANY_HIT)
                 {
                     SKH_CSWAP(0, 1)
                     SKH_CSWAP(2, 3)
@@ -1085,35 +722,22 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
                         // the c hit children among rf[1..3] go to slots sp .. sp+c-1 (farthest first); the writes are
                         // unconditional (what lands above the new top is never read): no branch per push
                         const int c = (tn[1] < INFINITY ? 1 : 0) + (tn[2] < INFINITY ? 1 : 0) + (tn[3] < INFINITY ? 1 : 0);
-                        if (CULL)
-                        {
-                            int2* p = lds2 + sp * SKH_TRACE_BLOCK;
-                            const int2 e1 = make_int2(rf[1], __float_as_int(tn[1])), e2 = make_int2(rf[2], __float_as_int(tn[2])), e3 = make_int2(rf[3], __float_as_int(tn[3]));
-                            p[0] = c == 3 ? e3 : (c == 2 ? e2 : e1);
-                            p[SKH_TRACE_BLOCK] = c == 3 ? e2 : e1;
-                            p[2 * SKH_TRACE_BLOCK] = e1;
-                        }
-                        else
-                        {
-                            int* p = lds + sp * SKH_TRACE_BLOCK;
-                            p[0] = c == 3 ? rf[3] : (c == 2 ? rf[2] : rf[1]);
-                            p[SKH_TRACE_BLOCK] = c == 3 ? rf[2] : rf[1];
-                            p[2 * SKH_TRACE_BLOCK] = rf[1];
-                        }
+                        int* p = lds + sp * SKH_TRACE_BLOCK;
+                        p[0] = c == 3 ? rf[3] : (c == 2 ? rf[2] : rf[1]);
+                        p[SKH_TRACE_BLOCK] = c == 3 ? rf[2] : rf[1];
+                        p[2 * SKH_TRACE_BLOCK] = rf[1];
                         sp += c;
                     }
                     else
                     {
                         if (tn[3] < INFINITY)
-                            SKH_PUSH_T(rf[3], __float_as_int(tn[3]));
+                            SKH_PUSH(rf[3]);
                         if (tn[2] < INFINITY)
-                            SKH_PUSH_T(rf[2], __float_as_int(tn[2]));
+                            SKH_PUSH(rf[2]);
                         if (tn[1] < INFINITY)
-                            SKH_PUSH_T(rf[1], __float_as_int(tn[1]));
+                            SKH_PUSH(rf[1]);
                     }
                     cur = tn[0] < INFINITY ? rf[0] : SKH_REF_INVALID;
-                    if (PF2)
-                        pf = tn[1] < INFINITY ? rf[1] : SKH_REF_INVALID;
                 }
                 else
                 {
@@ -1129,21 +753,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
                         }
                 }
 #undef SKH_CSWAP
-                }
-                }
                 // a lane whose node had no hit child takes its next stack entry right here instead of idling until
                 // the whole wave leaves the node loop
                 if (cur == SKH_REF_INVALID && sp > 0)
-                    SKH_POP(cur); // (CULL: may come back culled = INVALID again; the lane then sits out one iteration and pops the next entry)
-                if (POSTPONE && cur < 0 && leaf2 == SKH_REF_INVALID)
-                {
-                    // the first leaf is put aside and the lane goes on with its next stack entry; closest hit = min over all primitives with a
-                    // key tie-break, so the order of the tests cannot change a result -- only which boxes the shrinking best.t still culls
-                    leaf2 = cur;
-                    cur = SKH_REF_INVALID;
-                    if (sp > 0)
-                        SKH_POP(cur);
-                }
+                    SKH_POP(cur);
                 // few lanes still descending while the rest wait at their leaves: let the leaves go first
                 if ((uint32_t)__popcll(__ballot(cur >= 0 && cur != SKH_REF_INVALID)) < breakBelow)
                     break;
@@ -1157,28 +770,6 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
                 inBlas = false;
                 cur = SKH_REF_INVALID;
             }
-#ifdef SKH_EXCHANGE_PROBE
-            // (measurement only, docs/LOG.md "re-binning": the LDS traffic of handing a ray to another lane at every phase change --
-            // SKH_EXCHANGE_PROBE dwords of state out and back through the dead part of the lane's own stack column, no result changes)
-            {
-                volatile int* xs = lds;
-                float* st[16] = { &o.x, &o.y, &o.z, &inv.x, &inv.y, &inv.z, &tmin, &best.t, &best.u, &best.v, &sh.Sx, &sh.Sy, &sh.Sz, &d.x, &d.y, &d.z };
-                const int top = sp < SKH_STACK_LDS - SKH_EXCHANGE_PROBE ? sp : 0; // (a full stack: the probe borrows the bottom, and restores it)
-                int saved[SKH_EXCHANGE_PROBE];
-#pragma unroll
-                for (int k = 0; k < SKH_EXCHANGE_PROBE; ++k)
-                {
-                    saved[k] = xs[(top + k) * SKH_TRACE_BLOCK];
-                    xs[(top + k) * SKH_TRACE_BLOCK] = __float_as_int(*st[k]);
-                }
-#pragma unroll
-                for (int k = 0; k < SKH_EXCHANGE_PROBE; ++k)
-                {
-                    *st[k] = __int_as_float(xs[(top + k) * SKH_TRACE_BLOCK]);
-                    xs[(top + k) * SKH_TRACE_BLOCK] = saved[k];
-                }
-            }
-#endif
             // ---- leaf ----
             SKH_LP({ const unsigned long long t = __builtin_readcyclecounter(); cy[1] += t - cyA; cyA = t; })
             bool entered = false;
@@ -1191,58 +782,11 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
                 // owns the wave (measured on the hair stand-in: 89 % of the kernel time at ~3 active lanes).  Lanes whose segment
                 // passed the cheap cylinder test PARK in front of it (`pend`) and the block runs once `curveMin` lanes wait, or
                 // when no other lane of the wave can make progress.
-#if SKH_CURVE_COOP
                 if (pend != 0u)
                 {
                     isLeaf = false;
                     entered = true; // parked: waits for the cooperative block at the top of the loop (no pop)
                 }
-#else
-                const uint32_t nParked = (uint32_t)__popcll(__ballot(pend != 0u)), nActive = (uint32_t)__popcll(__ballot(pend == 0u));
-                if (pend != 0u)
-                {
-                    isLeaf = false;
-                    if (nParked >= curveMin || nActive == 0u)
-                    {
-                        const uint32_t first = ((uint32_t)~cur) >> 3;
-                        for (uint32_t k = 0; k < 8u; ++k)
-                        {
-                            if (!((pend >> k) & 1u))
-                                continue;
-                            const float4* cp = sc.segs + 4 * (size_t)(first + k);
-                            const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
-                            if (COUNT)
-                                tc.segs++;
-                            v4 q[4];
-                            q[0] = mk4(c0.x, c0.y, c0.z, c0.w);
-                            q[1] = mk4(c1.x, c1.y, c1.z, c1.w);
-                            q[2] = mk4(c2.x, c2.y, c2.z, c2.w);
-                            q[3] = mk4(c3.x, c3.y, c3.z, c3.w);
-                            float t, u;
-                            if (intersect_curve_segment(o, d, tmin, best.t, q, t, u) && (best.found || t < best.t)) // (open at tmax: best.t is the ray's tmax until a hit is found)
-                            {
-                                const uint32_t sp = sc.segPrim[first + k];
-                                const uint32_t prim = sp & 0x0fffffffu;
-                                // a sub-range leaf keeps the hit only if u is its own (the leaf that owns u reports the same bits)
-                                if (min((uint32_t)(u * (float)sc.curveSplit), sc.curveSplit - 1u) != (sp >> 28))
-                                    continue;
-                                if (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim))
-                                {
-                                    best.t = t;
-                                    best.inst = curInst;
-                                    best.prim = prim;
-                                    best.u = u;
-                                    best.v = 0.0f;
-                                    best.found = true;
-                                }
-                            }
-                        }
-                        pend = 0u; // leaf done: falls through to the pop below
-                    }
-                    else
-                        entered = true; // keep waiting (no pop)
-                }
-#endif
             }
             if (!WORLD && leafMin > 1u)
             {
@@ -1375,17 +919,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
                 }
 #undef SKH_MERGE_HIT
             }
-            if (isLeaf || (POSTPONE && leaf2 != SKH_REF_INVALID))
+            if (isLeaf)
             {
-                // (POSTPONE: up to two leaves wait here -- the one put aside in the node loop first, then the current one)
-                const int leafA = (POSTPONE && leaf2 != SKH_REF_INVALID) ? leaf2 : cur;
-                const uint32_t enc = (uint32_t)~leafA;
+                const uint32_t enc = (uint32_t)~cur;
                 const uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
-                const bool two = POSTPONE && leaf2 != SKH_REF_INVALID && isLeaf;
-                const uint32_t encB = (uint32_t)~cur;
-                const uint32_t firstB = encB >> 3, total = count + (two ? (encB & 7u) + 1u : 0u);
-                if (POSTPONE)
-                    leaf2 = SKH_REF_INVALID;
                 if (!WORLD && !inBlas)
                 {
                     // TLAS leaves hold exactly one instance
@@ -1432,9 +969,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
                 }
                 else
                 {
-                    for (uint32_t k = (TRICOOP ? kStart : 0u); k < total; ++k)
+                    for (uint32_t k = (TRICOOP ? kStart : 0u); k < count; ++k)
                     {
-                        const float4* tp = sc.tris + 3 * (size_t)((POSTPONE && k >= count) ? firstB + (k - count) : first + k);
+                        const float4* tp = sc.tris + 3 * (size_t)(first + k);
                         const float4 a = tp[0], b = tp[1], c = tp[2];
                         if (COUNT)
                             tc.prims++;
@@ -1489,7 +1026,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
                         inBlas = false;
                         continue;
                     }
-                    break; // (CULL: a culled entry comes back as INVALID; the node loop of the next pass pops on, an empty stack ends the ray below)
+                    break;
                 }
             }
         }
@@ -1527,7 +1064,6 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (W8 || TAILQ ? SKH_WO
 #undef SKH_PUSH
 #undef SKH_POP
 #undef SKH_OVF_AT
-#undef tail
     if (COUNT)
     {
         const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.prims), c2 = wave_sum(tc.segs), d2 = wave_sum(tc.insts);
@@ -1809,17 +1345,12 @@ SKH_DI SurfaceHit fill_curve(const DevScene& sc, const HostInstance& hi, const f
 #ifndef SKH_SHADE_BLOCK
 #define SKH_SHADE_BLOCK 256 // 132 VGPRs = 3 waves/SIMD: 256-thread blocks (1 wave per SIMD) fill all three, 512-thread blocks only two
 #endif
-// HAIR: the build with df::chiang_hair_bsdf in it (launched when the material list holds a hair material); LATE: the build that knows about
-// continuations (TailQ: parked queue entries are skipped, a ray's bounce index is launchDepth - its lag, the last workgroups shade late rays
-// from their records) -- passes without continuations run the build without it (its id words are plain path ids)
-template <bool HAIR, bool LATE = false>
+// HAIR: the build with df::chiang_hair_bsdf in it (launched when the material list holds a hair material)
+template <bool HAIR>
 __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
-    k_shade(DevScene sc, FrameP fp, uint32_t sampleOffset, uint32_t launchDepth /* bounce index of a ray = launchDepth - its lag */, const uint32_t* __restrict__ tileXY, RayQ rq,
+    k_shade(DevScene sc, FrameP fp, uint32_t sampleOffset, uint32_t depth /* bounce index */, const uint32_t* __restrict__ tileXY, RayQ rq,
             const uint32_t* __restrict__ countPtr, HitQ hq, PathS ps, RayQ nextQ, uint32_t* __restrict__ nextCount, RayQ shadowQ,
-            float* __restrict__ contrib, uint32_t* __restrict__ shadowCount,
-            uint32_t lateBlocks /* the LAST lateBlocks workgroups shade the "late" rays: parked by the launch before, resumed by this bounce's closest-hit launch ... */,
-            const uint32_t* __restrict__ lateRec /* ... read from their records (TailQ) ... */, const uint32_t* __restrict__ lateCount /* ... a list per shard ... */,
-            uint32_t lateCap /* ... of this capacity */)
+            float* __restrict__ contrib, uint32_t* __restrict__ shadowCount)
 {
     __shared__ uint32_t s_wave[2 * (SKH_COMPACT_MAX_WAVES + 1)];
     __shared__ uint32_t s_sobol[SKH_SOBOL_LUT_WORDS];
@@ -1828,16 +1359,13 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
     // Sobol table; a hit whose material lies beyond them reads global memory as before
     __shared__ float4 s_mat[SKH_MATERIALS_LDS * 4];
 #endif
-    // workgroup b works on shard b & 7 (and compacts into the same shard of both output queues); the late workgroups split the parked rays'
-    // per-shard lists the same way: a ray is shaded into the output shard of its input shard
-    const bool lateMode = LATE && blockIdx.x >= gridDim.x - lateBlocks;
-    const uint32_t bIdx = lateMode ? blockIdx.x - (gridDim.x - lateBlocks) : blockIdx.x;
-    const uint32_t shard = bIdx & (SKH_SHARDS - 1u), lb = bIdx / SKH_SHARDS;
-    const uint32_t n = lateMode ? min(lateCount[shard * SKH_COUNT_STRIDE], lateCap) : countPtr[shard * SKH_COUNT_STRIDE]; // rays in this shard
+    // workgroup b works on shard b & 7 (and compacts into the same shard of both output queues)
+    const uint32_t shard = blockIdx.x & (SKH_SHARDS - 1u), lb = blockIdx.x / SKH_SHARDS;
+    const uint32_t n = countPtr[shard * SKH_COUNT_STRIDE]; // rays in this shard
     if (lb * blockDim.x >= n)
         return; // whole block past the end of its shard
     const uint32_t il = lb * blockDim.x + threadIdx.x;
-    const uint32_t i = lateMode ? shard * lateCap + il : shard * rq.region + il;
+    const uint32_t i = shard * rq.region + il;
 #ifdef SKH_LANE_PROFILE
     unsigned long long spc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, spT = __builtin_readcyclecounter();
 #define SKH_SP(k)                                                    \
@@ -1879,44 +1407,13 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
     bool emitNext = false, emitShadow = false;
     v3 nextO = mk3(0.0f), nextD = mk3(0.0f), shO = mk3(0.0f), shD = mk3(0.0f), shC = mk3(0.0f);
     float shTmax = 0.0f;
-    uint32_t pid = 0, lag = 0;
-    uint32_t lateWord = 0;
+    uint32_t pid = 0;
     if (valid)
     {
-        // the id word: path | lag << 28 | parked << 31.  A ray the closest-hit launch parked has no hit yet (the next launch resumes it, the late
-        // workgroups of the NEXT k_shade shade it); a late record that was parked again has moved on to the next list
-        const uint32_t idw = lateMode ? TailQ::plane(const_cast<uint32_t*>(lateRec), lateCap, 0)[i] : rq.ids()[i];
-        if (LATE)
-        {
-            if (lateMode)
-                lateWord = TailQ::plane(const_cast<uint32_t*>(lateRec), lateCap, 2)[i];
-            if (lateMode ? lateWord == 0xffffffffu : (idw & SKH_PARKED_BIT) != 0u)
-                valid = false;
-            pid = idw & SKH_PATH_MASK;
-            lag = (idw >> SKH_LAG_SHIFT) & 7u;
-        }
-        else
-            pid = idw;
-    }
-    const uint32_t depth = launchDepth - lag; // (lag <= launchDepth: a ray is parked at most once per launch)
-    if (valid)
-    {
-        v3 rayO, rayD;
-        float4 hr0, hr1;
-        if (lateMode)
-        {
-            uint32_t* R = const_cast<uint32_t*>(lateRec);
-            rayO = mk3(__uint_as_float(TailQ::plane(R, lateCap, 9)[i]), __uint_as_float(TailQ::plane(R, lateCap, 10)[i]), __uint_as_float(TailQ::plane(R, lateCap, 11)[i]));
-            rayD = mk3(__uint_as_float(TailQ::plane(R, lateCap, 12)[i]), __uint_as_float(TailQ::plane(R, lateCap, 13)[i]), __uint_as_float(TailQ::plane(R, lateCap, 14)[i]));
-            hr0 = make_float4(__uint_as_float(TailQ::plane(R, lateCap, 3)[i]), __uint_as_float(TailQ::plane(R, lateCap, 4)[i]), __uint_as_float(TailQ::plane(R, lateCap, 5)[i]), 0.0f);
-            hr1 = make_float4(__uint_as_float(TailQ::plane(R, lateCap, 6)[i]), __uint_as_float(TailQ::plane(R, lateCap, 7)[i]), 0.0f, 0.0f);
-        }
-        else
-        {
-            rayO = mk3(rq.plane(0)[i], rq.plane(1)[i], rq.plane(2)[i]);
-            rayD = mk3(rq.plane(3)[i], rq.plane(4)[i], rq.plane(5)[i]);
-            hr0 = hq.rec(i)[0], hr1 = hq.rec(i)[1];
-        }
+        pid = rq.ids()[i];
+        const v3 rayO = mk3(rq.plane(0)[i], rq.plane(1)[i], rq.plane(2)[i]);
+        const v3 rayD = mk3(rq.plane(3)[i], rq.plane(4)[i], rq.plane(5)[i]);
+        const float4 hr0 = hq.rec(i)[0], hr1 = hq.rec(i)[1];
         const float ht = hr0.x, hu = hr0.y, hv = hr0.z;
         const uint32_t hinst = __float_as_uint(hr1.x), hprim = __float_as_uint(hr1.y);
         float* P = ps.base;
@@ -2236,7 +1733,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
         nextQ.plane(4)[ni] = nextD.y;
         nextQ.plane(5)[ni] = nextD.z;
         // (planes 6 / 7, tmin / tmax: constants of the pass, filled once by the host -- k_fill_f32 in render_one)
-        nextQ.ids()[ni] = LATE ? (pid | (lag << SKH_LAG_SHIFT)) : pid; // (what a late ray emits stays one launch behind its bounce index)
+        nextQ.ids()[ni] = pid;
     }
     if (emitShadow)
     {

@@ -59,10 +59,7 @@ enum KernelClass
     KC_COUNT
 };
 
-// continuation words per closest-hit launch: the 8 park lists' lengths + 8 copies of the dry flag (SKH_COUNT_STRIDE apart), then the 8 cursors with
-// which the NEXT launch hands those lists out (SKH_FETCH_STRIDE apart)
-#define SKH_TAIL_WORDS (16 * SKH_COUNT_STRIDE + 8 * SKH_FETCH_STRIDE)
-#define SKH_MAX_LAUNCH_ROUNDS 140 // MAX_BOUNCES (128) + the drain rounds of the continuations + slack
+#define SKH_MAX_LAUNCH_ROUNDS 140 // MAX_BOUNCES (128) + slack
 
 struct TimedSpan
 {
@@ -78,14 +75,6 @@ struct skh_context
     hipStream_t stream2 = nullptr; // any-hit launches when `overlap` is on: shadow[b] runs beside closest[b+1] and fills its tail
     int overlap = 1; // 0 off, 1 for small passes only (<= 8 M paths: the interactive one-sub-frame-per-call mode, +7 %), 2 always
     hipEvent_t evShade = nullptr, evShadow = nullptr;
-    // continuations (TailQ, skh_kernels.h): a closest-hit launch of an overlapped (small) pass parks the rays its thinning waves still carry once
-    // the queue is dry; the next closest-hit launch resumes them, the k_shade after it shades them ("late")
-    uint32_t tailPark = 0; // option tail_park: a wave parks when at most this many of its lanes still carry a ray (0 = no continuations: the default --
-                           // measured slower than the launch tails they remove, docs/LOG.md round 4)
-    uint32_t tailLag = 2; // option tail_lag: how often one path may be parked = extra launch rounds at the end of a pass
-    DevBuf dTail[2], dTailCounts, dTailDesc; // (dTailDesc: one TailQ per launch round, rewritten when what it describes changes)
-    std::vector<uint32_t> tailDescKey;
-    uint32_t tailCapacity = 0;
     ncclComm_t comm = nullptr; // multi-GPU tile gather (skh_comm_init)
     int commWorld = 1, commRank = 0;
     DevBuf dTileSend;
@@ -164,7 +153,7 @@ struct skh_context
     uint32_t smallWavesClosest = 16, smallWavesShadow = 16; // overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24
     uint32_t gridOverride = 0; // set by render_one around its launches
     uint32_t fetchMinClosest = 24, fetchMinShadow = 48; // idle lanes before a wave pulls new rays from the queue (round 3, world-space hierarchy: any-hit 32 -> 48: 39.7 -> 36.2 ms, 56: 37.5, 64: 51; closest 12..40 within 1 %)
-    uint32_t curveFetchMinClosest = 16, curveFetchMinShadow = 24, curveNodeBreakClosest = 20; // the same three for the curve build (6 waves/SIMD): hair 482 vs 465 Mray/s
+    uint32_t curveFetchMinClosest = 16, curveFetchMinShadow = 24, curveNodeBreakClosest = 20, curveNodeBreakShadow = 20; // the same four for the curve build (6 waves/SIMD): hair 482 vs 465 Mray/s
     uint32_t nodeBreakClosest = 32, nodeBreakShadow = 28; // (closest: 24 -> 32 in round 3 for the world-only kernel: kitchen 86.6 -> 85.9 ms, unshared 74.7 -> 73.6, three runs each;
                                                           // shadow: 20 -> 28 in round 4, with the shared triangle pass: kitchen 34.85 -> 34.3 ms, unshared 29.3 -> 28.55, three runs each; 36: 34.35 / 28.7)
     // leave the node loop when fewer than x/64 of the wave's rays are still descending
@@ -185,8 +174,6 @@ struct skh_context
     // only exists for curve sets, for light proxies beside them, and for scenes with more than bake_budget_mtris instanced triangles:
     // every structure the bench workloads traverse is built by GPU kernels.  2: the sweep up to 8192 TLAS leaves, the GPU beyond.
     uint32_t tlasBuild = 1;
-    uint32_t wide = 4; // node width: 4 = Node4 (64 B, children sorted by entry distance in the traversal), 8 = Node8 (96 B, slot order = traversal order;
-                       // two-level hierarchy only, TLAS by the GPU builder, no TLAS opening)
     uint32_t tlasOpen = 1; // TLAS opening: up to tlasOpen x numInstances leaves; 1 = one leaf per instance (default: on the kitchen stand-in 2..16 were 4-9 % slower, more instance entries for no fewer nodes)
     // bake_world: mesh instances that skip the TLAS -- their triangles are carried to world space once and join ONE extra
     // group of the triangle build that every ray walks first, with no instance entry (DESIGN.md section 2 "bake_world").
@@ -334,7 +321,7 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
         return s;
     if ((s = dev_alloc(c, out.groupRoot, sizeof(int) * (size_t)std::max(1u, nGroups))) != SKH_OK)
         return s;
-    if ((s = dev_alloc(c, out.nodes, (c->wide == 8 ? sizeof(Node8) : sizeof(Node4)) * ((size_t)std::max(1u, n) + 1))) != SKH_OK)
+    if ((s = dev_alloc(c, out.nodes, sizeof(Node4) * ((size_t)std::max(1u, n) + 1))) != SKH_OK)
         return s;
     if ((s = dev_alloc(c, out.sortedVals, sizeof(uint32_t) * (size_t)std::max(1u, n))) != SKH_OK)
         return s;
@@ -551,14 +538,9 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
         int cur = 0;
         while (he == hipSuccess && cnt > 0)
         {
-            if (c->wide == 8)
-                k_collapse<8><<<(cnt + B - 1) / B, B, 0, st>>>(q[cur].as<CollapseItem>(), cnt, childL.as<int>(), childR.as<int>(), nodeSize.as<int>(),
-                                                               nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n, leafMax, out.nodes.p, ctr.as<uint32_t>(),
-                                                               q[cur ^ 1].as<CollapseItem>(), ctr.as<uint32_t>() + 1, leafOrder.as<uint32_t>());
-            else
-                k_collapse<4><<<(cnt + B - 1) / B, B, 0, st>>>(q[cur].as<CollapseItem>(), cnt, childL.as<int>(), childR.as<int>(), nodeSize.as<int>(),
-                                                               nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n, leafMax, out.nodes.p, ctr.as<uint32_t>(),
-                                                               q[cur ^ 1].as<CollapseItem>(), ctr.as<uint32_t>() + 1, leafOrder.as<uint32_t>());
+            k_collapse<<<(cnt + B - 1) / B, B, 0, st>>>(q[cur].as<CollapseItem>(), cnt, childL.as<int>(), childR.as<int>(), nodeSize.as<int>(),
+                                                           nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n, leafMax, out.nodes.p, ctr.as<uint32_t>(),
+                                                           q[cur ^ 1].as<CollapseItem>(), ctr.as<uint32_t>() + 1, leafOrder.as<uint32_t>());
             he = hipMemcpyAsync(hctr, ctr.p, sizeof(hctr), hipMemcpyDeviceToHost, st);
             if (he == hipSuccess)
                 he = hipStreamSynchronize(st);
@@ -578,7 +560,7 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
             if (he == hipSuccess)
                 he = hipStreamSynchronize(st);
         }
-        if (he == hipSuccess && lineRecBytes && c->wide != 8)
+        if (he == hipSuccess && lineRecBytes)
         {
             // ---- leaves by 128-byte line (skh_bvh.h: k_leaf_place): padding slots in front of the leaves that would straddle ----
             DevBuf leafCnt, chunk, remap, sums, vals3;
@@ -817,7 +799,7 @@ static int tlas_sah_build(const std::vector<HostBox>& boxes, const std::vector<u
         else
             bin[t.parent].right = ref;
     }
-    // collapse the binary tree into 4-wide nodes (same greedy rule as k_collapse<4>)
+    // collapse the binary tree into 4-wide nodes (same greedy rule as k_collapse)
     struct Item
     {
         int bin, out;
@@ -975,7 +957,7 @@ void skh_destroy(skh_context* c)
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
                        &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
-                       &c->dCounts, &c->dOvf, &c->dOvf2, &c->dStats, &c->dScratchImage, &c->dPathB, &c->dTail[0], &c->dTail[1], &c->dTailCounts, &c->dTailDesc })
+                       &c->dCounts, &c->dOvf, &c->dOvf2, &c->dStats, &c->dScratchImage, &c->dPathB })
         dev_free(*b);
     for (hipEvent_t e : c->eventPool)
         (void)hipEventDestroy(e);
@@ -1486,8 +1468,8 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     uint32_t nValidHost = 0;
     for (uint32_t i = 0; i < nInst; ++i)
         nValidHost += valid[i] ? 1u : 0u;
-    const bool tlasOnGpu = c->tlasBuild == 1 || (c->tlasBuild == 2 && nValidHost > 8192u) || c->wide == 8;
-    if (nInst > 0 && tlasOnGpu && (c->tlasOpen <= 1 || c->wide == 8))
+    const bool tlasOnGpu = c->tlasBuild == 1 || (c->tlasBuild == 2 && nValidHost > 8192u);
+    if (nInst > 0 && tlasOnGpu && c->tlasOpen <= 1)
     {
         // ---- TLAS on the GPU: the same PLOC + 4-wide collapse that builds the BLASes, over the instance boxes.  Which instances
         //      take part is known on the host without reading anything back: a finite inverse and a non-empty BLAS. ----
@@ -1838,15 +1820,6 @@ static skh_status alloc_frame(skh_context* c)
     c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
     AF(dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * (uint32_t)c->numCUs * std::max(std::max(c->wavesPerCU, c->wavesPerCUWorld), std::max(c->wavesPerCUShadow, c->wavesPerCUShadowWorld)) * SKH_TRACE_BLOCK));
     AF(dev_alloc(c, c->dOvf2, sizeof(int) * (size_t)SKH_STACK_OVF * (uint32_t)c->numCUs * std::max(std::max(c->wavesPerCU, c->wavesPerCUWorld), std::max(c->wavesPerCUShadow, c->wavesPerCUShadowWorld)) * SKH_TRACE_BLOCK));
-    // continuations: two sets (this launch parks into one, resumes the other) of a list of parked-ray records per queue shard; per launch the
-    // lists' lengths, the "queue is dry" flags and the next launch's eight cursors, each word in a 128-byte line of its own
-    c->tailCapacity = c->traceBlocks * SKH_TRACE_BLOCK / 2u; // per shard, per pass: the eight lists hold four times the lanes of the largest grid
-    // (the record sets -- 2 x 265 MB at the default grid -- are allocated by the first pass that uses continuations: option tail_park, off by default)
-    dev_free(c->dTail[0]);
-    dev_free(c->dTail[1]);
-    AF(dev_alloc(c, c->dTailCounts, sizeof(uint32_t) * SKH_TAIL_WORDS * SKH_MAX_LAUNCH_ROUNDS));
-    AF(dev_alloc(c, c->dTailDesc, sizeof(TailQ) * SKH_MAX_LAUNCH_ROUNDS));
-    c->tailDescKey.clear();
 #undef AF
     SKH_TRY(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(float4) * N1, c->stream));
     SKH_TRY(c, hipMemsetAsync(c->dDiffuse.p, 0, sizeof(float4) * N1, c->stream));
@@ -1999,48 +1972,32 @@ static skh_status ensure_ready(skh_context* c)
     return SKH_OK;
 }
 
-// one launch of the persistent trace kernel over a sharded queue: picks the build (world-only / general / curves / 8-wide) and the grid
+// one launch of the persistent trace kernel over a sharded queue: picks the build (world-only / two-level / two-level + curves) and the grid
 template <bool ANY, bool COUNT>
 static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint32_t* countPtr, uint32_t* fetch,
-                         HitQ hq, PathS ps, const float* contrib, uint32_t contribStride, hipStream_t st = nullptr,
-                         const TailQ* tail = nullptr /* device copy of this launch's continuation lists */, uint32_t tailFlags = 0)
+                         HitQ hq, PathS ps, const float* contrib, uint32_t contribStride, hipStream_t st = nullptr)
 {
     // scenes without curve instances run the build of the kernel that has no curve intersector in it (fewer VGPRs)
     const bool curveBuild = c->nSegs != 0;
     const uint32_t fetchMin = ANY ? (curveBuild ? c->curveFetchMinShadow : c->fetchMinShadow) : (curveBuild ? c->curveFetchMinClosest : c->fetchMinClosest);
-    const uint32_t nodeBreak = ANY ? (curveBuild ? std::min(c->nodeBreakShadow, 20u) /* (the curve build keeps round 3's 20) */ : c->nodeBreakShadow)
-                                   : (curveBuild ? c->curveNodeBreakClosest : c->nodeBreakClosest);
+    const uint32_t nodeBreak = ANY ? (curveBuild ? c->curveNodeBreakShadow : c->nodeBreakShadow) : (curveBuild ? c->curveNodeBreakClosest : c->nodeBreakClosest);
     const uint32_t fm = fetchMin | (c->curveMin << 8) | (nodeBreak << 16) | (c->leafMin << 24);
     if (!st)
         st = c->stream;
     int* ovf = st == c->stream ? c->dOvf.as<int>() : c->dOvf2.as<int>(); // (two trace kernels may be in flight)
     StatsDev* sd = c->dStats.as<StatsDev>();
     const bool worldOnly = !c->nSegs && c->tlasRoot == SKH_REF_INVALID && (c->worldRoot != SKH_REF_INVALID || c->lightRoot != SKH_REF_INVALID) && c->worldKernel;
-    const bool world8 = worldOnly && c->wide != 8 && (ANY || tailFlags == 0u); // the builds that run 8 waves per SIMD
-    const uint32_t fullGrid = (ANY && !c->nSegs) ? (uint32_t)c->numCUs * (world8 ? c->wavesPerCUShadowWorld : c->wavesPerCUShadow)
-                                                 : (world8 ? (uint32_t)c->numCUs * c->wavesPerCUWorld : c->traceBlocks);
+    // (the world-only builds run 8 waves per SIMD)
+    const uint32_t fullGrid = (ANY && !c->nSegs) ? (uint32_t)c->numCUs * (worldOnly ? c->wavesPerCUShadowWorld : c->wavesPerCUShadow)
+                                                 : (worldOnly ? (uint32_t)c->numCUs * c->wavesPerCUWorld : c->traceBlocks);
     const uint32_t blocks = c->gridOverride ? std::min(c->gridOverride, fullGrid) : fullGrid;
-    if (worldOnly && c->wide != 8 && !ANY && tailFlags != 0u)
-        // ... with the continuation code (park / resume: overlapped passes)
-        k_trace<false, COUNT, false, false, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, tail, tailFlags);
-    else if (worldOnly && c->wide != 8)
+    if (worldOnly)
         // every instance is baked: the world-only build of the kernel (no instance entry, no object-space copy of the ray)
-        k_trace<ANY, COUNT, false, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, tail, tailFlags);
-    else if (worldOnly)
-        k_trace<ANY, COUNT, false, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, tail, tailFlags);
-    else if (c->wide == 8)
-    {
-        if (c->nSegs)
-            k_trace<ANY, COUNT, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, tail, tailFlags);
-        else
-            k_trace<ANY, COUNT, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, tail, tailFlags);
-    }
+        k_trace<ANY, COUNT, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
     else if (c->nSegs)
-        k_trace<ANY, COUNT, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride,
-                                                                                      ovf, sd, tail, tailFlags);
+        k_trace<ANY, COUNT, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
     else
-        k_trace<ANY, COUNT, false><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride,
-                                                                                       ovf, sd, tail, tailFlags);
+        k_trace<ANY, COUNT, false><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
 }
 
 // After a synchronisation: did any traversal of the calls since the last check drop a stack entry (its result may miss hits)?
@@ -2136,46 +2093,10 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     // per pass) gains 0.5 % and stays on one stream so that its per-kernel hipEvent spans do not overlap.  overlap 2: always, reduced grids.
     const bool smallPass = NP <= (1u << 23) || c->overlap == 2;
     const bool useOverlap = (c->overlap == 2 || (c->overlap == 1 && NP <= (1u << 25))) && fp.debug != 1;
-    // continuations (TailQ): overlapped passes only -- there the launch tails are what a rank's share of an N-GPU frame and the caller's
-    // small passes lose (docs/LOG.md); the world-only 4-wide closest-hit build is the one that can park and resume
-    const bool worldOnly4 = !c->nSegs && c->tlasRoot == SKH_REF_INVALID && (c->worldRoot != SKH_REF_INVALID || c->lightRoot != SKH_REF_INVALID) &&
-                            c->worldKernel && c->wide != 8;
-    const bool useTail = useOverlap && c->tailPark > 0 && c->tailLag > 0 && worldOnly4 && SKH_POP_CULL == 0;
-    // launch rounds of the pass: maxDepth of them carry every ray's bounces; with continuations a path may run `tailLag` rounds behind, and that
-    // many short rounds at the end drain the stragglers (their queues hold only lagging rays; a round without work costs three empty launches)
-    const uint32_t rounds = fp.maxDepth + (useTail ? c->tailLag : 0u);
-    uint32_t* tailCounts = c->dTailCounts.as<uint32_t>();
-    if (useTail)
-    {
-        for (int k = 0; k < 2; ++k)
-            if (!c->dTail[k].p)
-            {
-                const skh_status as = dev_alloc(c, c->dTail[k], sizeof(uint32_t) * (size_t)(SKH_TAIL_HDR + SKH_STACK_LDS) * SKH_SHARDS * c->tailCapacity);
-                if (as != SKH_OK)
-                    return as;
-            }
-        // round b parks into record set b & 1 and resumes what round b - 1 parked into the other one
-        const std::vector<uint32_t> key = { rounds, c->tailPark, c->tailLag, c->tailCapacity, (uint32_t)(uintptr_t)c->dTail[0].p, (uint32_t)(uintptr_t)c->dTail[1].p,
-                                            (uint32_t)(uintptr_t)tailCounts };
-        if (key != c->tailDescKey)
-        {
-            std::vector<TailQ> desc(rounds);
-            for (uint32_t b = 0; b < rounds; ++b)
-                desc[b] = TailQ{ c->dTail[b & 1].as<uint32_t>(), tailCounts + b * SKH_TAIL_WORDS, tailCounts + rounds * SKH_TAIL_WORDS /* (the block after the last round's) */,
-                                 c->dTail[(b + 1) & 1].as<uint32_t>(), tailCounts + (b ? b - 1 : 0) * SKH_TAIL_WORDS,
-                                 tailCounts + (b ? b - 1 : 0) * SKH_TAIL_WORDS + 16 * SKH_COUNT_STRIDE, c->tailCapacity, c->tailPark, c->tailLag };
-            SKH_TRY(c, hipStreamSynchronize(st)); // (nothing may still read the old descriptors)
-            SKH_TRY(c, hipMemcpy(c->dTailDesc.p, desc.data(), sizeof(TailQ) * rounds, hipMemcpyHostToDevice));
-            c->tailDescKey = key;
-        }
-    }
-    const TailQ* tailDesc = c->dTailDesc.as<TailQ>();
-    const uint32_t lateGrid = SKH_SHARDS * ((c->tailCapacity + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK);
+    const uint32_t rounds = fp.maxDepth;
     for (uint32_t s = 0; trace && s < fp.samplesThisLaunch; ++s)
     {
         SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (QW * 2 * SKH_MAX_LAUNCH_ROUNDS + 16 * SKH_FETCH_STRIDE * (rounds + 1)), st));
-        if (useTail)
-            SKH_TRY(c, hipMemsetAsync(tailCounts, 0, sizeof(uint32_t) * SKH_TAIL_WORDS * (rounds + 1), st));
         {
             SpanGuard g(c, KC_RAYGEN);
             k_raygen<<<c->raygenBlocksPerSub * fp.batch, 512, 0, st>>>(fp, tiles, s, rq[0], counts, ps, c->dRaygenBase.as<uint32_t>(),
@@ -2183,45 +2104,29 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
         }
         for (uint32_t b = 0; b < rounds; ++b)
         {
-            // the last round parks nothing, and a path is parked only while the drain rounds can still absorb its lag (lagMax)
-            const bool drain = b >= fp.maxDepth;
-            const uint32_t tflags = useTail ? ((b + 1 < rounds ? 1u : 0u) | (b > 0 ? 2u : 0u)) : 0u;
-            const uint32_t* lateRec = c->dTail[(b + 1) & 1].as<uint32_t>();
-            const uint32_t* lateCount = tailCounts + (b ? b - 1 : 0) * SKH_TAIL_WORDS;
             {
                 SpanGuard g(c, KC_TRACE_CLOSEST);
-                // (drain rounds: a handful of rays -- one wave per CU is plenty, and an empty launch of it costs next to nothing)
-                c->gridOverride = drain ? (uint32_t)c->numCUs : ((useOverlap && smallPass) ? c->smallWavesClosest * (uint32_t)c->numCUs : 0u);
+                c->gridOverride = (useOverlap && smallPass) ? c->smallWavesClosest * (uint32_t)c->numCUs : 0u;
                 if (c->countTraversal)
-                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, hq, ps, nullptr, 0, nullptr, tailDesc + b, tflags);
+                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, hq, ps, nullptr, 0);
                 else
-                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, hq, ps, nullptr, 0, nullptr, tailDesc + b, tflags);
+                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, hq, ps, nullptr, 0);
             }
             if (useOverlap && b > 0)
                 (void)hipStreamWaitEvent(st, c->evShadow, 0); // shade[b] reads the radiance shadow[b-1] adds to and reuses its queue
             {
                 SpanGuard g(c, KC_SHADE);
                 // a shard holds at most an eighth of the pass's paths (rounded up to whole waves): SKH_SHARDS x that many workgroups,
-                // workgroup b on shard b & 7; those past the end of their shard leave at once.  With continuations the last workgroups
-                // shade the late rays -- parked by round b - 1, resumed by this round's closest-hit launch -- from their records; a drain
-                // round's queue holds at most what the lists held
-                const uint32_t perShard = drain ? c->tailCapacity : (((NP + SKH_SHARDS - 1u) / SKH_SHARDS) + 63u) & ~63u;
-                const uint32_t late = (useTail && b > 0) ? lateGrid : 0u;
-                const dim3 sg(SKH_SHARDS * ((perShard + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK) + late);
-#define SKH_SHADE_LAUNCH(HAIRB, LATEB)                                                                                                              \
-    k_shade<HAIRB, LATEB><<<sg, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b * QW, hq, ps, rq[(b + 1) & 1], counts + 2 * (b + 1) * QW, \
-                                                          shq, c->dContrib.as<float>(), counts + (2 * b + 1) * QW, late, lateRec, lateCount, c->tailCapacity)
+                // workgroup b on shard b & 7; those past the end of their shard leave at once
+                const uint32_t perShard = (((NP + SKH_SHARDS - 1u) / SKH_SHARDS) + 63u) & ~63u;
+                const dim3 sg(SKH_SHARDS * ((perShard + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK));
+#define SKH_SHADE_LAUNCH(HAIRB)                                                                                                                      \
+    k_shade<HAIRB><<<sg, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b * QW, hq, ps, rq[(b + 1) & 1], counts + 2 * (b + 1) * QW, \
+                                                   shq, c->dContrib.as<float>(), counts + (2 * b + 1) * QW)
                 if (c->hasHairMaterial)
-                {
-                    if (useTail)
-                        SKH_SHADE_LAUNCH(true, true);
-                    else
-                        SKH_SHADE_LAUNCH(true, false);
-                }
-                else if (useTail)
-                    SKH_SHADE_LAUNCH(false, true);
+                    SKH_SHADE_LAUNCH(true);
                 else
-                    SKH_SHADE_LAUNCH(false, false);
+                    SKH_SHADE_LAUNCH(false);
 #undef SKH_SHADE_LAUNCH
             }
             {
@@ -2233,7 +2138,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                 }
                 {
                     SpanGuard g(c, KC_TRACE_SHADOW, sst);
-                    c->gridOverride = drain ? (uint32_t)c->numCUs : ((useOverlap && smallPass) ? c->smallWavesShadow * (uint32_t)c->numCUs : 0u);
+                    c->gridOverride = (useOverlap && smallPass) ? c->smallWavesShadow * (uint32_t)c->numCUs : 0u;
                     if (c->countTraversal)
                         launch_trace<true, true>(c, sc, shq, counts + (2 * b + 1) * QW, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, nohq, ps, c->dContrib.as<float>(), NQ, sst);
                     else
@@ -3361,9 +3266,9 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
     {
         if (value < 0 || value > 64)
             return SKH_INVALID_ARGUMENT;
+        // (an explicitly set value applies to the curve build too: its own defaults -- 20 / 20 -- hold until then)
         (n == "node_break_closest" ? c->nodeBreakClosest : c->nodeBreakShadow) = (uint32_t)value;
-        if (n == "node_break_closest")
-            c->curveNodeBreakClosest = (uint32_t)value;
+        (n == "node_break_closest" ? c->curveNodeBreakClosest : c->curveNodeBreakShadow) = (uint32_t)value;
     }
     else if (n == "subframe_batch")
     {
@@ -3372,13 +3277,6 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         c->subframeBatch = (uint32_t)value;
         if (c->width)
             return alloc_frame(c);
-    }
-    else if (n == "wide")
-    {
-        if (value != 4 && value != 8)
-            return SKH_INVALID_ARGUMENT;
-        c->wide = (uint32_t)value;
-        c->accelBuilt = false;
     }
     else if (n == "bake_world")
     {
@@ -3448,12 +3346,6 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
             return SKH_INVALID_ARGUMENT;
         c->plocTop = (uint32_t)value;
         c->accelBuilt = false;
-    }
-    else if (n == "tail_park" || n == "tail_lag")
-    {
-        if (value < 0 || value > (n == "tail_lag" ? 7 : 64))
-            return SKH_INVALID_ARGUMENT;
-        (n == "tail_park" ? c->tailPark : c->tailLag) = (uint32_t)value;
     }
     else if (n == "waves_per_cu" || n == "waves_per_cu_shadow" || n == "waves_per_cu_world" || n == "waves_per_cu_shadow_world")
     {

@@ -461,11 +461,11 @@ def test_tonemap_kernels_match_oracle(gpu, ork):
 @pytest.mark.parametrize("opts", [{"build_quality": 0}, {"leaf_max_tris": 4}, {"subframe_batch": 3},
                                   {"fetch_min_closest": 1, "fetch_min_shadow": 64, "waves_per_cu": 8},
                                   {"waves_per_cu_world": 5, "waves_per_cu_shadow_world": 17, "waves_per_cu_shadow": 3},
-                                  {"node_break_closest": 0, "node_break_shadow": 48, "leaf_min": 0}, {"leaf_min": 40}, {"tlas_open": 8}, {"tlas_build": 0}, {"tlas_build": 1}, {"wide": 8}, {"wide": 8, "leaf_max_tris": 4, "build_quality": 0}, {"curve_split": 1}, {"curve_split": 5, "curve_min": 1}, {"curve_min": 64}, {"tight_instance_boxes": 0}, {"overlap": 2}, {"overlap": 0}, {"leaf_lines": 1}, {"leaf_lines": 1, "leaf_max_tris": 4},
+                                  {"node_break_closest": 0, "node_break_shadow": 48, "leaf_min": 0}, {"leaf_min": 40}, {"tlas_open": 8}, {"tlas_build": 0}, {"tlas_build": 1}, {"curve_split": 1}, {"curve_split": 5, "curve_min": 1}, {"curve_min": 64}, {"tight_instance_boxes": 0}, {"overlap": 2}, {"overlap": 0}, {"leaf_lines": 1}, {"leaf_lines": 1, "leaf_max_tris": 4},
                                   {"leaf_lines": 1, "leaf_max_tris": 7, "build_quality": 0}, {"morton_bits": 18}, {"morton_bits": 21, "build_quality": 0}, {"morton_bits": 5}, {"ploc_top": 4096}])
 def test_results_do_not_depend_on_the_acceleration_structure_or_scheduling(opts):
     """Closest hit = min t with (instance, primitive) tie-break and conservative boxes, any-hit = existence: builder
-    (PLOC / radix tree), hierarchy shape (opened TLAS leaves, 8-wide nodes), leaf size, ray order, refill and
+    (PLOC / radix tree), hierarchy shape (opened TLAS leaves), leaf size, ray order, refill and
     node-loop exit policy may change
     speed only.  Hit records AND the accumulated image must be bit-identical to the default configuration."""
     from strelka_amd import capi
@@ -638,7 +638,7 @@ def _zoomed_out_rays(arr, ratio, n, seed):
 @pytest.mark.parametrize("bake", [0, 4])
 def test_hit_records_are_hierarchy_independent_inside_the_stated_envelope(bake):
     """The contract "hit records do not depend on the hierarchy" holds up to 10^3 THINNEST instance extents between the ray origin
-    and what it is aimed at: inside it the GPU (4-wide, 8-wide, another leaf size), the oracle's BVH and brute
+    and what it is aimed at: inside it the GPU (PLOC with leaves of two, the radix tree with leaves of four, PLOC with single-triangle leaves), the oracle's BVH and brute
     force agree bit for bit even on vertex- and edge-grazing rays at strongly squashed, sheared instances.  Beyond it (here 10^5) the
     triangle test's own noise exceeds the slack of the boxes; the test only records that such rays EXIST and differ in at most the
     grazing cases -- so that a change which silently moves the envelope inwards shows up here, not in a fuzz campaign."""
@@ -660,7 +660,7 @@ def test_hit_records_are_hierarchy_independent_inside_the_stated_envelope(bake):
     o.set_bake(bake)
     o.set_scene(arr)
     gpus = []
-    for opts in ({}, {"wide": 8}, {"leaf_max_tris": 4, "build_quality": 0}):
+    for opts in ({}, {"leaf_max_tris": 1}, {"leaf_max_tris": 4, "build_quality": 0}):
         ctx = capi.Context(0)
         ctx.set_option("bake_world", bake)
         for k, v in opts.items():
@@ -819,35 +819,6 @@ def test_subframe_batching_is_exact(gpu):
     for other in imgs[1:]:
         for a, b in zip(imgs[0], other):
             assert np.array_equal(a, b)
-
-
-def test_tail_passes_are_exact(gpu):
-    """Continuations (TailQ, skh_kernels.h): in overlapped passes a closest-hit wave that finds the queue dry parks the
-    rays it still carries; the next closest-hit launch resumes them and the k_shade after it shades them one launch late (bounce index =
-    launch index - lag, drained by extra rounds at the end of the pass).  Which rays take that detour depends on scheduling -- the image,
-    the AOVs and the ray counts must not: paths are independent and every sum a path takes part in stays in its own bounce order."""
-    sc = small_kitchen()
-    gpu.set_scene(sc.arrays())
-    w, h, spp = 192, 128, 6
-    out = []
-    for park, lag, overlap, depth in ((0, 2, 1, 5), (64, 2, 1, 5), (64, 1, 2, 5), (8, 7, 1, 5), (64, 2, 0, 5), (64, 3, 1, 1), (0, 2, 1, 1)):
-        gpu.set_option("tail_park", park)
-        gpu.set_option("tail_lag", lag)
-        gpu.set_option("overlap", overlap)
-        gpu.resize(w, h)
-        gpu.reset_stats()
-        gpu.render_subframes(S.frame_params(sc.getCamera(), w, h, subframe_index=0, spp_total=spp, max_depth=depth), spp)
-        st = gpu.stats()
-        out.append((depth, gpu.read_accum(), gpu.read_aov(0), gpu.read_aov(1), st["rays_radiance"], st["rays_shadow"]))
-    gpu.set_option("tail_park", 64)
-    gpu.set_option("tail_lag", 2)
-    gpu.set_option("overlap", 1)
-    gpu.resize(w, h)
-    for other in out[1:]:
-        ref = next(o for o in out if o[0] == other[0])
-        for a, b in zip(ref[1:4], other[1:4]):
-            assert np.array_equal(a, b)
-        assert other[4] == ref[4] and other[5] == ref[5]
 
 
 def test_speculative_subframes_are_exact(gpu):

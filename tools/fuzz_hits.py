@@ -132,7 +132,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     ctx.set_option("curve_split", 1 + seed % 4); ctx.set_option("leaf_max_tris", 1 + seed % 4)
     ctx.set_option("leaf_lines", (seed // 5) % 2)  # triangle leaves laid out by 128-byte line: same records
     if (seed // 4) % 3 == 2:
-        ctx.set_option("wide", 8)  # the 8-wide node layout (octant-ordered slots) must give the same records
+        ctx.set_option("build_quality", 0)  # the Karras radix tree instead of PLOC must give the same records
     ctx.set_scene(arr); got = ctx.trace(rays, 0)
     sh = rays.copy(); sh["tmax"] = rs.uniform(0.5, 5.0)
     ws, gs = o.trace(sh, 1)["t"], ctx.trace(sh, 1)["t"]

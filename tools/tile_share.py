@@ -1,6 +1,6 @@
 """Strong-scaling emulation on ONE GPU: render the tile share of rank 3 of a 1-, 2-, 4-, 8-rank split of the 1080p frame and compare
 with 1/N of the full frame.  usage (GPU box): python tools/tile_share.py [option=value ...]   (skh_set_option names,
-e.g. tail_park=0 for the launches without tail passes)"""
+e.g. overlap=0 for one-stream passes)"""
 import sys, time, numpy as np, torch
 sys.path.insert(0, ".")
 import bench
