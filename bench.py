@@ -362,6 +362,7 @@ def other_workload_leg(name, W, H, spp, depth, device_ordinal, steps=2):
     dt = time.perf_counter() - t0
     st = ctx.stats()
     baked = ctx.baked(len(arr["instances"]))
+    binfo = _bvh_info(ctx)
     ctx.close()
     rays = st["rays_radiance"] + st["rays_shadow"]
     nr, ns = max(1, cst["rays_radiance"]), max(1, cst["rays_shadow"])
@@ -370,8 +371,16 @@ def other_workload_leg(name, W, H, spp, depth, device_ordinal, steps=2):
             "per_ray": {"nodes": round(cst["nodes_visited"][0] / nr, 2), "tris": round(cst["prims_tested"][0] / nr, 2)},
             "per_shadow_ray": {"nodes": round(cst["nodes_visited"][1] / ns, 2), "tris": round(cst["prims_tested"][1] / ns, 2)},
             "rays_per_frame": int(rays / steps),
-            "bvh_build_ms": round(st["ms_build"], 2), "bake_world": {"baked_instances": baked[1], "baked_triangles": baked[2]},
+            "bvh_build_ms": round(st["ms_build"], 2), "bvh": binfo, "bake_world": {"baked_instances": baked[1], "baked_triangles": baked[2]},
             "scene_load_s": round(load_s, 1)}
+
+
+def _bvh_info(ctx):
+    """the triangle hierarchy's build record (skh_get_build_info): reinsertion rounds / moves, SAH-style cost before and after"""
+    b = ctx.build_info()
+    return {"triangles": b["triangles"], "nodes": b["nodes"], "reinsert_rounds": b["reinsert_rounds"], "reinsert_moves": b["reinsert_moves"],
+            "reinsert_min_size": b["reinsert_min_size"], "reinsert_ms": round(b["ms_reinsert"], 2),
+            "cost_ratio": round(b["cost_after"] / b["cost_before"], 4) if b["cost_before"] > 0 else None}
 
 
 def roofline_fractions(algorithmic_bytes_per_launch, counter_bytes_per_launch, avg_launch_ms, peak_gbs=HBM_PEAK_GBS):
@@ -469,6 +478,7 @@ def main():
     ctx.set_tiles(args.tile, my_tiles if world > 1 else None)
     ctx.resize(W, H)
     build_ms = ctx.stats()["ms_build"]
+    bvh_info = _bvh_info(ctx)
     baked = ctx.baked(len(arr["instances"]))
     params = S.frame_params(cam, W, H, subframe_index=0, samples_this_launch=1, spp_total=args.spp, max_depth=args.depth)
 
@@ -706,7 +716,7 @@ def main():
             "config": {"workload": workload, "resolution": f"{W}x{H}", "bounces": args.depth, "spp": args.spp,
                        "step": f"one frame = {args.spp} sub-frames of 1 spp", "tile": args.tile, "world_size": world,
                        "parallelism": f"pixel tiles round-robin over {world} GPU(s), 1 gather/frame ({gather_kind})" if world > 1
-                       else "single GPU", "rays_per_frame": int(rays_total / K), "bvh_build_ms": round(build_ms, 2),
+                       else "single GPU", "rays_per_frame": int(rays_total / K), "bvh_build_ms": round(build_ms, 2), "bvh": bvh_info,
                        "bake_world": {"baked_instances": baked[1], "baked_triangles": baked[2]}, "scene_load_s": round(t_scene, 1)},
             "gather": gather_kind, "rccl_nranks": rccl_nranks,
             "roofline_replayed": bool(pmc and pmc.get("replayed")) or pmc is None,

@@ -191,6 +191,7 @@ static inline int sibling(const Tree& t, int x)
     return t.L[p] == x ? t.R[p] : t.L[p];
 }
 // best new position for subtree `in`.  Nodes whose subtree holds fewer than minSize primitives are not entered (and are not moved).
+static bool ancestors = false;
 static Move find_best(const Tree& t, int in, int minSize, long* visits)
 {
     const int n = t.n;
@@ -242,7 +243,13 @@ static Move find_best(const Tree& t, int in, int minSize, long* visits)
             break;
         pivotBox = merge(pivotBox, t.box[sk]);
         if (pivot != p0)
+        {
+            // `in` as the new sibling of its own ancestor a_k (which has shrunk to a_k' = pivotBox): the new node has a_k's old box
+            const float g = base - area(pivotBox);
+            if (ancestors && g > mv.gain)
+                mv.gain = g, mv.out = pivot, mv.pivot = up;
             base += area(t.box[pivot]) - area(pivotBox); // a_k shrinks to a_k' once the pivot has moved past it
+        }
         below = pivot;
         pivot = up;
     }
@@ -635,6 +642,7 @@ int main(int argc, char** argv)
             // handed out in proportion: splits_i = floor(priority_i / total * budget * n), each split halves the polygon's box along its longest
             // axis at the midpoint (Ganestam & Doggett 2016 style recursive clipping)
             std::vector<float> pr(nT);
+            const float splitExp = getf("splitexp", 1.0f / 3.0f);
             double tot = 0;
             for (int i = 0; i < nT; ++i)
             {
@@ -643,10 +651,20 @@ int main(int argc, char** argv)
                 const float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
                 // projected areas: the box half-area equals sum of |projections| only for a box-filling shape; priority as in the literature:
                 const float triA = std::fabs(cx) + std::fabs(cy) + std::fabs(cz); // 2 x the sum of the three axis projections of the triangle
-                pr[i] = std::cbrt(std::max(0.0f, area(tri_box(t)) - 0.5f * triA)); // X^(1/3) as in Fuetterling et al. / embree presplit heuristics
+                pr[i] = std::pow(std::max(0.0f, area(tri_box(t)) - 0.5f * triA), splitExp); // X^(1/3) as in Fuetterling et al. / embree presplit heuristics
                 tot += pr[i];
             }
-            const double scale = budget * nT / tot;
+            // scale such that the extra references come out at the budget (bisection on the floor sum)
+            double slo = 0, shi = budget * nT / tot * 64;
+            for (int it = 0; it < 40; ++it)
+            {
+                const double mid = 0.5 * (slo + shi);
+                double extra = 0;
+                for (int i = 0; i < nT; ++i)
+                    extra += std::floor(pr[i] * mid);
+                (extra > budget * nT ? shi : slo) = mid;
+            }
+            const double scale = slo;
             for (int i = 0; i < nT; ++i)
             {
                 const int pieces = 1 + (int)(pr[i] * scale);
@@ -711,6 +729,7 @@ int main(int argc, char** argv)
     refit(t);
     printf("PLOC: %.2f s, SAH(internal area / root area) = %.2f\n", now() - t0, sah_internal(t));
 
+    ancestors = geti("ancestors", 0) != 0;
     const int rounds = geti("reinsert", 0), minSize = geti("minsize", 1), stride = geti("stride", 1);
     for (int k = 0; k < rounds; ++k)
     {

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SKH_ABI_VERSION 3 /* 3 (round 4): + skh_unit_probe, skh_copy_aov; options tail_park, tail_lag */
+#define SKH_ABI_VERSION 4 /* 4 (round 5): + skh_get_build_info; options reinsert_rounds, reinsert_min_size; wide, tail_park, tail_lag removed.  3 (round 4): + skh_unit_probe, skh_copy_aov */
 
 /* mirrors oka::Result (include/render/common.h:30-35) */
 typedef enum skh_status
@@ -418,7 +418,10 @@ skh_status skh_unit_probe(skh_context* ctx, uint32_t unit, uint32_t param, const
  *                 triangles when that empties the top level, 3 = every mesh instance, 4 (default) = 3 while the instanced triangles stay
  *                 within bake_budget_mtris (64) million, else 2; 0 = every instance keeps its TLAS leaf), world_kernel 1|0 (scenes
  *                 with an empty top level run the world-only build of the traversal kernel)
- *   build         build_quality 1|0 (PLOC | Karras radix tree), morton_bits (10 per axis in the sort keys; 4..21), ploc_top (0: clusters left at which the triangle build widens PLOC's neighbour search from 12 to 96), leaf_max_tris (2), leaf_lines 0|1 (triangle leaves padded so that none
+ *   build         build_quality 1|0 (PLOC | Karras radix tree), reinsert_rounds (8; 0 = off: rounds of parallel reinsertion over the PLOC tree of the
+ *                 triangle build -- every subtree looks for the place in the tree where it costs least, the best non-conflicting moves are applied),
+ *                 reinsert_curve_rounds (4: the same over the curve sub-segment trees),
+ *                 reinsert_min_size (0 = auto: 1 up to 4 M triangles, 32 beyond: only the part of the tree above subtrees of this many primitives is optimised), morton_bits (10 per axis in the sort keys; 4..21), ploc_top (0: clusters left at which the triangle build widens PLOC's neighbour search from 12 to 96), leaf_max_tris (2), leaf_lines 0|1 (triangle leaves padded so that none
  *                 straddles a 128-byte line it need not: -11 % fetched lines, same time, more memory), curve_leaf (1), curve_split (4: parameter sub-ranges
  *                 per curve segment), tlas_build 1|0|2 (GPU PLOC over the instance boxes (default) | exact sweep SAH on the host: 5 % fewer instance
  *                 entries, single-threaded | the sweep up to 8192 instances, the GPU beyond), tlas_open (1: TLAS leaves per instance budget),
@@ -439,6 +442,22 @@ typedef struct skh_device_info
     char name[64];
 } skh_device_info;
 skh_status skh_get_device_info(skh_context* ctx, skh_device_info* out);
+/* what the last skh_build_accel did to the triangle hierarchy (the builder that replaces optixAccelBuild with PREFER_FAST_TRACE,
+ * OptixRender.cpp:318-386): PLOC over the Morton order, then rounds of parallel reinsertion (options reinsert_rounds / reinsert_min_size) */
+typedef struct skh_build_info
+{
+    uint32_t triangles; /* primitives of the triangle build (meshes + baked world-space groups) */
+    uint32_t nodes; /* 64-byte 4-wide nodes */
+    uint32_t reinsert_rounds; /* rounds that ran (a round without a move ends the pass) */
+    uint32_t reinsert_moves; /* subtrees moved, all rounds */
+    uint32_t reinsert_min_size; /* truncation used: only nodes whose parent holds at least this many primitives moved */
+    uint32_t reserved;
+    double cost_before; /* sum of the internal binary nodes' box half-areas after PLOC ... */
+    double cost_after; /* ... and after the reinsertion pass (== cost_before when it did not run) */
+    double ms_reinsert; /* wall time of the pass, inside ms_build */
+    double ms_build; /* == skh_stats.ms_build */
+} skh_build_info;
+skh_status skh_get_build_info(skh_context* ctx, skh_build_info* out);
 skh_status skh_get_stats(skh_context* ctx, skh_stats* out);
 skh_status skh_reset_stats(skh_context* ctx);
 skh_status skh_synchronize(skh_context* ctx);

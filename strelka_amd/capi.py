@@ -26,8 +26,11 @@ SYMBOLS = ["skh_create", "skh_destroy", "skh_last_error", "skh_abi_version", "sk
            "skh_render_subframe", "skh_render_subframes", "skh_tonemap", "skh_read_accum", "skh_read_aov",
            "skh_buffer_alloc", "skh_buffer_free", "skh_buffer_download", "skh_copy_accum", "skh_copy_accum_tiles", "skh_scatter_tiles", "skh_trace", "skh_trace_device",
            "skh_set_option", "skh_get_stats", "skh_reset_stats", "skh_synchronize", "skh_get_stream", "skh_bsdf_probe", "skh_get_device_info", "skh_comm_unique_id", "skh_comm_init",
-           "skh_comm_destroy", "skh_gather_tiles", "skh_host_register", "skh_host_unregister", "skh_get_baked", "skh_comm_info", "skh_probe_memory", "skh_unit_probe", "skh_copy_aov"]
+           "skh_comm_destroy", "skh_gather_tiles", "skh_host_register", "skh_host_unregister", "skh_get_baked", "skh_comm_info", "skh_probe_memory", "skh_unit_probe", "skh_copy_aov", "skh_get_build_info"]
 
+BUILD_INFO = np.dtype([("triangles", np.uint32), ("nodes", np.uint32), ("reinsert_rounds", np.uint32), ("reinsert_moves", np.uint32),
+                       ("reinsert_min_size", np.uint32), ("reserved", np.uint32), ("cost_before", np.float64), ("cost_after", np.float64),
+                       ("ms_reinsert", np.float64), ("ms_build", np.float64)])
 DEVICE_INFO = np.dtype([("compute_units", np.uint32), ("simds_per_cu", np.uint32), ("clock_khz", np.uint32), ("memory_clock_khz", np.uint32),
                         ("memory_bus_bits", np.uint32), ("wavefront_size", np.uint32), ("total_memory_bytes", np.uint64), ("name", "S64")])
 
@@ -88,6 +91,7 @@ def load():
     lib.skh_bsdf_probe.argtypes = [vp, vp, u32, vp]
     lib.skh_unit_probe.argtypes = [vp, u32, u32, vp, vp, u32, vp]
     lib.skh_get_device_info.argtypes = [vp, vp]
+    lib.skh_get_build_info.argtypes = [vp, vp]
     lib.skh_host_register.argtypes = [vp, vp, C.c_size_t]
     lib.skh_host_unregister.argtypes = [vp, vp]
     lib.skh_comm_unique_id.argtypes = [vp]
@@ -310,6 +314,12 @@ class Context:
         d = np.zeros((), DEVICE_INFO)
         self._ck(self.lib.skh_get_device_info(self.h, _p(d)), "skh_get_device_info")
         return {k: (d[k].item().decode() if k == "name" else int(d[k])) for k in DEVICE_INFO.names}
+
+    def build_info(self):
+        """what the last skh_build_accel did to the triangle hierarchy (reinsertion rounds / moves, cost before and after)"""
+        d = np.zeros((), BUILD_INFO)
+        self._ck(self.lib.skh_get_build_info(self.h, _p(d)), "skh_get_build_info")
+        return {k: (float(d[k]) if d[k].dtype.kind == "f" else int(d[k])) for k in BUILD_INFO.names if k != "reserved"}
 
     def baked(self, n_instances):
         """(per-instance flags, baked instances, baked triangles) of option bake_world after the build"""

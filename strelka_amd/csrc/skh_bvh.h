@@ -59,8 +59,10 @@ static_assert(sizeof(Node4) == 64, "node size");
 SKH_HD void encode_node4(Node4& nd, const float* nlo, const float* nhi, const float cloIn[4][3], const float chiIn[4][3],
                          const int* refsIn, int cnt)
 {
-    // Children go into the slots by ascending surface area.  The closest-hit traversal orders them by entry distance anyway; the
-    // any-hit traversal visits slot 3 first, i.e. the child most likely to hold an occluder.
+    // Children go into the slots by ascending surface area.  The closest-hit traversal orders them by entry distance (children entered at the
+    // same distance -- the ray starts inside both -- in slot order: smaller first; the reverse measured +3.5 % closest-hit time); the any-hit
+    // traversal visits slot 3 first, i.e. the child most likely to hold an occluder.  (Round 5 tried ordering by the number of primitives
+    // below instead: closest-hit -1.5 %, any-hit +4 ... +12 % on the three kitchens.  Area stays.)
     float clo[4][3], chi[4][3];
     int refs[4];
     {
@@ -851,22 +853,36 @@ __global__ void __launch_bounds__(SKH_PLOC_BLOCK) k_ploc_nn(const float4* __rest
 __global__ void k_ploc_merge(float4* __restrict__ cLo, float4* __restrict__ cHi, const uint32_t* __restrict__ nn, uint32_t m, int n,
                              int* __restrict__ childL, int* __restrict__ childR, int* __restrict__ nodeSize,
                              float4* __restrict__ nodeLo, float4* __restrict__ nodeHi, uint32_t* __restrict__ nodeCounter,
-                             uint32_t* __restrict__ flags)
+                             uint32_t* __restrict__ flags, int* __restrict__ parent /* 2n words preset to -1, or null */)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m)
         return;
     const uint32_t j = nn[i];
     uint32_t keep = 1;
-    if (j != 0xffffffffu && nn[j] == i)
+    const bool pair = j != 0xffffffffu && nn[j] == i;
+    // node ids: one returning atomic per wave (a 23 M-primitive build made 23 M of them on one word: 15 ms of its 38)
+    const bool makes = pair && i < j;
+    const unsigned long long mm = __ballot(makes);
+    uint32_t idBase = 0;
+    if (mm != 0ull)
+    {
+        const int leader = __ffsll((long long)mm) - 1;
+        if ((int)(threadIdx.x & 63u) == leader)
+            idBase = atomicAdd(nodeCounter, (uint32_t)__popcll(mm));
+        idBase = __shfl(idBase, leader);
+    }
+    if (pair)
     {
         if (i < j)
         {
             const float4 lo = cLo[i], hi = cHi[i], olo = cLo[j], ohi = cHi[j];
             const int a = __float_as_int(lo.w), b = __float_as_int(olo.w);
-            const int id = (int)atomicAdd(nodeCounter, 1u);
+            const int id = (int)(idBase + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u)));
             childL[id] = a;
             childR[id] = b;
+            if (parent)
+                parent[a] = id, parent[b] = id;
             nodeSize[id] = subtree_size(nodeSize, a, n) + subtree_size(nodeSize, b, n);
             const float4 mlo = make_float4(fminf(lo.x, olo.x), fminf(lo.y, olo.y), fminf(lo.z, olo.z), 0.0f);
             const float4 mhi = make_float4(fmaxf(hi.x, ohi.x), fmaxf(hi.y, ohi.y), fmaxf(hi.z, ohi.z), 0.0f);
@@ -902,6 +918,302 @@ __global__ void k_ploc_roots(const float4* __restrict__ cLo, const float4* __res
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m)
         groupRootBin[__float_as_uint(cHi[i].w)] = __float_as_int(cLo[i].w);
+}
+
+// ---- parallel reinsertion (after Meister & Bittner 2018, "Parallel reinsertion for bounding volume hierarchy optimization") ----------
+// PLOC decides every merge inside a window of the Morton order; what it gets wrong -- a long thin triangle merged early with small
+// neighbours, whose box then inflates every ancestor; objects that interleave in Morton order -- shows at the upper levels, the ones every
+// ray walks.  One round: every node x looks for the position in the tree where the subtree it roots would cost least (k_ri_search:
+// branch-and-bound over the sibling subtrees of its ancestors), the best non-conflicting moves are applied, boxes and subtree sizes are
+// recomputed (k_ri_refit).  Cost = sum of the internal nodes' box areas (the SAH with fixed leaves).
+//
+// Moving x from under p (sibling s, grandparent g) to become the sibling of `out`: p is re-used as the new parent of (x, out).  With the
+// ancestors of x called a0 = p, a1, ... and the pivot ak = the lowest common ancestor of x and out:
+//   gain = A(a0) + sum_{0<j<k} (A(aj) - A(aj')) - sum_{b on the path pivot -> out, exclusive} (A(b U x) - A(b)) - A(out U x)
+// aj' = aj without x (the union of the sibling subtrees below it).  The search walks the pivot upwards; under each pivot it walks the
+// subtree on the other side STACKLESSLY (parent pointers; the growth sum is added going down and subtracted coming back) and leaves a
+// subtree as soon as not even a zero-cost insertion below it could beat the best gain so far.
+// Conflicts: a move rewrites the child / parent words of six nodes -- x, p, s, g, out, parent(out) --, which it must own: atomicMax of
+// (gain bits, x) per node, the best move wins (k_ri_claim / k_ri_own; deterministic).  The nodes in between only get new boxes from the
+// refit; what they must not be is carried away by another move -- two moves that take each other's target subtree along would close a
+// cycle -- so an owner steps back when a node between `out` and the pivot is the x of a BETTER move (k_ri_check).  In every would-be
+// cycle the move before the best one steps back: no cycle survives.  Many moves may pass through the same upper nodes, which whole-path
+// locks forbid (lab: 52 k instead of 20 k moves in the first round on the 1.6 M-triangle architectural kitchen, experiments/bvhlab).
+// minSize > 1 truncates the tree: only nodes whose parent holds >= minSize primitives move, subtrees below that size are not entered --
+// the upper levels of a 23 M-triangle tree at 4 % of the search work (lab: 18.6 against 18.4 nodes per bounce ray; 20.9 untouched).
+SKH_DI float ri_area(const float4& lo, const float4& hi)
+{
+    const float ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z;
+    return ex * ey + ey * ez + ez * ex;
+}
+SKH_DI float ri_union_area(const float4& lo, const float4& hi, const float4& blo, const float4& bhi)
+{
+    const float ex = fmaxf(hi.x, bhi.x) - fminf(lo.x, blo.x), ey = fmaxf(hi.y, bhi.y) - fminf(lo.y, blo.y), ez = fmaxf(hi.z, bhi.z) - fminf(lo.z, blo.z);
+    return ex * ey + ey * ez + ez * ex;
+}
+SKH_DI unsigned long long ri_key(float gain, int x)
+{
+    return ((unsigned long long)__float_as_uint(gain) << 32) | (uint32_t)x; // (gain > 0: its bits order like the value)
+}
+// moves[x] = {out, pivot, gain bits, -} for the nodes that want to move, whose ids are appended to cand[]
+__global__ void __launch_bounds__(256) k_ri_search(const int* __restrict__ childL, const int* __restrict__ childR, const int* __restrict__ parent,
+                                                   const int* __restrict__ nodeSize, const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi,
+                                                   int n, int minSize, uint32_t stride, uint32_t phase, int4* __restrict__ moves,
+                                                   uint32_t* __restrict__ cand, uint32_t* __restrict__ nCand)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= 2 * n - 1)
+        return;
+    int4 result = make_int4(-1, -1, 0, -1);
+    const int p0 = parent[x];
+    const bool mine = stride <= 1u || ((uint32_t)x % stride) == phase;
+    if (mine && p0 >= 0 && parent[p0] >= 0 && nodeSize[p0] >= minSize)
+    {
+        const float4 ilo = nodeLo[x], ihi = nodeHi[x];
+        const float Ain = ri_area(ilo, ihi);
+        float base = ri_area(nodeLo[p0], nodeHi[p0]);
+        float bestGain = 0.0f;
+        float4 plo = make_float4(3e38f, 3e38f, 3e38f, 0.0f), phi = make_float4(-3e38f, -3e38f, -3e38f, 0.0f);
+        int pivot = p0, below = x;
+        for (;;)
+        {
+            const int l = childL[pivot];
+            const int sk = l == below ? childR[pivot] : l;
+            int node = sk;
+            float grow = 0.0f;
+            for (;;)
+            {
+                const float4 nlo = nodeLo[node], nhi = nodeHi[node];
+                const float An = ri_area(nlo, nhi), Au = ri_union_area(nlo, nhi, ilo, ihi);
+                const float g = base - grow - Au;
+                if (g > bestGain && !(pivot == p0 && node == sk))
+                {
+                    bestGain = g;
+                    result.x = node, result.y = pivot;
+                }
+                const float grow2 = grow + (Au - An);
+                if (node < n - 1 && base - grow2 - Ain > bestGain && nodeSize[node] >= minSize)
+                {
+                    grow = grow2;
+                    node = childL[node];
+                    continue;
+                }
+                bool done = false;
+                for (;;)
+                {
+                    if (node == sk)
+                    {
+                        done = true;
+                        break;
+                    }
+                    const int par = parent[node];
+                    if (childL[par] == node)
+                    {
+                        node = childR[par];
+                        break;
+                    }
+                    const float4 qlo = nodeLo[par], qhi = nodeHi[par];
+                    grow -= ri_union_area(qlo, qhi, ilo, ihi) - ri_area(qlo, qhi);
+                    node = par;
+                }
+                if (done)
+                    break;
+            }
+            const int up = parent[pivot];
+            if (up < 0)
+                break;
+            const float4 slo = nodeLo[sk], shi = nodeHi[sk];
+            plo = make_float4(fminf(plo.x, slo.x), fminf(plo.y, slo.y), fminf(plo.z, slo.z), 0.0f);
+            phi = make_float4(fmaxf(phi.x, shi.x), fmaxf(phi.y, shi.y), fmaxf(phi.z, shi.z), 0.0f);
+            if (pivot != p0)
+                base += ri_area(nodeLo[pivot], nodeHi[pivot]) - ri_area(plo, phi); // a_k shrinks to a_k' once the pivot has moved past it
+            below = pivot;
+            pivot = up;
+        }
+        result.z = __float_as_int(bestGain);
+    }
+    if (result.x >= 0)
+    {
+        // the nodes that want to move, as a list: the claim / own / check / apply / mark kernels run over it (a few per cent of the nodes)
+        moves[x] = result;
+        const unsigned long long m = __ballot(1);
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if ((int)(threadIdx.x & 63u) == leader)
+            base = atomicAdd(nCand, (uint32_t)__popcll(m));
+        base = __shfl(base, leader);
+        cand[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)x;
+    }
+}
+SKH_DI int ri_sibling(const int* __restrict__ childL, const int* __restrict__ childR, int p, int x)
+{
+    const int l = childL[p];
+    return l == x ? childR[p] : l;
+}
+__global__ void __launch_bounds__(256) k_ri_claim(const int4* __restrict__ moves, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ nCand,
+                                                  const int* __restrict__ childL, const int* __restrict__ childR,
+                                                  const int* __restrict__ parent, unsigned long long* __restrict__ lock)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *nCand)
+        return;
+    const int x = (int)cand[i];
+    const int4 m = moves[x];
+    const unsigned long long k = ri_key(__int_as_float(m.z), x);
+    const int p = parent[x];
+    atomicMax(&lock[x], k);
+    atomicMax(&lock[p], k);
+    atomicMax(&lock[ri_sibling(childL, childR, p, x)], k);
+    atomicMax(&lock[parent[p]], k);
+    atomicMax(&lock[m.x], k);
+    atomicMax(&lock[parent[m.x]], k);
+}
+// owners of all six announce the subtree they carry away: moving[x] = key
+// (moving[] is all zero between rounds: k_ri_mark's caller clears the winners' and losers' entries through the list again)
+__global__ void __launch_bounds__(256) k_ri_own(const int4* __restrict__ moves, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ nCand,
+                                                const int* __restrict__ childL, const int* __restrict__ childR,
+                                                const int* __restrict__ parent, const unsigned long long* __restrict__ lock,
+                                                unsigned long long* __restrict__ moving)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *nCand)
+        return;
+    const int x = (int)cand[i];
+    const int4 m = moves[x];
+    const unsigned long long k = ri_key(__int_as_float(m.z), x);
+    const int p = parent[x];
+    const bool mine = lock[x] == k && lock[p] == k && lock[ri_sibling(childL, childR, p, x)] == k && lock[parent[p]] == k && lock[m.x] == k && lock[parent[m.x]] == k;
+    moving[x] = mine ? k : 0ull;
+}
+__global__ void __launch_bounds__(256) k_ri_check(const int4* __restrict__ moves, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ nCand,
+                                                  const int* __restrict__ parent, const unsigned long long* __restrict__ moving, uint8_t* __restrict__ win,
+                                                  uint32_t* __restrict__ nWin)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *nCand)
+        return;
+    const int x = (int)cand[i];
+    const unsigned long long k = moving[x];
+    bool ok = k != 0ull;
+    if (ok)
+    {
+        const int4 m = moves[x];
+        for (int a = parent[m.x]; a != m.y; a = parent[a])
+            if (moving[a] > k)
+            {
+                ok = false;
+                break;
+            }
+    }
+    win[x] = ok ? 1 : 0;
+    if (ok)
+        atomicAdd(nWin, 1u);
+}
+// (every word written here belongs to a node the move owns: no two winners touch the same word)
+__global__ void __launch_bounds__(256) k_ri_apply(int4* __restrict__ moves, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ nCand,
+                                                  const uint8_t* __restrict__ win, int* __restrict__ childL, int* __restrict__ childR, int* __restrict__ parent)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *nCand)
+        return;
+    const int x = (int)cand[i];
+    if (!win[x])
+        return;
+    const int out = moves[x].x;
+    const int p = parent[x], g = parent[p];
+    moves[x].w = g; // (k_ri_mark stamps the old place's ancestors from here)
+    const int s = ri_sibling(childL, childR, p, x);
+    if (childL[g] == p) // s takes p's place under g
+        childL[g] = s;
+    else
+        childR[g] = s;
+    parent[s] = g;
+    const int po = parent[out]; // (read after the line above: out may be s)
+    if (childL[po] == out) // p goes in above `out`
+        childL[po] = p;
+    else
+        childR[po] = p;
+    parent[p] = po;
+    childL[p] = x;
+    childR[p] = out;
+    parent[out] = p;
+}
+// After the moves only the nodes between a moved subtree's old and new place and the root have new boxes / sizes: the winners stamp those
+// paths (k_ri_mark: from g and from p upwards, stopping at a node somebody else has stamped -- that somebody goes on to the root); only those
+// are recomputed.  (A full second-arriver refit of the 46 M nodes of the kitchen's tree took 147 ms per round -- its agent-scope fences, not the
+// arithmetic --; the stamped paths are 1-2 % of the nodes.)
+__global__ void __launch_bounds__(256) k_ri_mark(const int4* __restrict__ moves, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ nCand,
+                                                 const uint8_t* __restrict__ win, const int* __restrict__ parent, uint32_t* __restrict__ stamp, uint32_t round)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *nCand)
+        return;
+    const int x = (int)cand[i];
+    if (!win[x])
+        return;
+    const int p = parent[x]; // (after k_ri_apply: p sits above `out` now; its old grandparent is the parent of its old sibling)
+    for (int a = p; a >= 0; a = parent[a])
+        if (atomicExch(&stamp[a], round) == round)
+            break;
+    for (int a = moves[x].w /* g, recorded by k_ri_apply */; a >= 0; a = parent[a])
+        if (atomicExch(&stamp[a], round) == round)
+            break;
+}
+SKH_DI void ri_compute(int x, const int* __restrict__ childL, const int* __restrict__ childR, float4* nodeLo, float4* nodeHi, int* nodeSize, int n)
+{
+    const int a = childL[x], b = childR[x];
+    const float4 alo = nodeLo[a], ahi = nodeHi[a];
+    const float4 blo = nodeLo[b], bhi = nodeHi[b];
+    nodeLo[x] = make_float4(fminf(alo.x, blo.x), fminf(alo.y, blo.y), fminf(alo.z, blo.z), 0.0f);
+    nodeHi[x] = make_float4(fmaxf(ahi.x, bhi.x), fmaxf(ahi.y, bhi.y), fmaxf(ahi.z, bhi.z), 0.0f);
+    nodeSize[x] = (a >= n - 1 ? 1 : nodeSize[a]) + (b >= n - 1 ? 1 : nodeSize[b]);
+}
+// Refit of the stamped nodes, level by level: k_ri_pending counts every stamped node's stamped children and lists those that have none;
+// each k_ri_refit_level launch computes the nodes of its list and hands a parent on to the next launch's list when its last stamped child is
+// done.  Kernel boundaries order the launches' writes and reads, so no fence is needed (the single-launch version -- second arriver goes on,
+// agent-scope fences around the arrival counter -- spent 2.5-3 ms per round in ~50 dependent release / acquire pairs, each an L2 write-back).
+__global__ void __launch_bounds__(256) k_ri_pending(const int* __restrict__ childL, const int* __restrict__ childR, const uint32_t* __restrict__ stamp,
+                                                    uint32_t round, int n, uint32_t* __restrict__ pending, uint32_t* __restrict__ list, uint32_t* __restrict__ count)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n - 1 || stamp[x] != round)
+        return;
+    const int a = childL[x], b = childR[x];
+    const uint32_t c = ((a < n - 1 && stamp[a] == round) ? 1u : 0u) + ((b < n - 1 && stamp[b] == round) ? 1u : 0u);
+    pending[x] = c;
+    if (c == 0u)
+        list[atomicAdd(count, 1u)] = (uint32_t)x;
+}
+__global__ void __launch_bounds__(256) k_ri_refit_level(const uint32_t* __restrict__ listIn, const uint32_t* __restrict__ countIn, uint32_t* __restrict__ listOut,
+                                                        uint32_t* __restrict__ countOut, const int* __restrict__ parent, const int* __restrict__ childL,
+                                                        const int* __restrict__ childR, uint32_t* __restrict__ pending, float4* nodeLo, float4* nodeHi,
+                                                        int* nodeSize, int n)
+{
+    const uint32_t m = *countIn;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
+    {
+        const int x = (int)listIn[i];
+        ri_compute(x, childL, childR, nodeLo, nodeHi, nodeSize, n);
+        const int par = parent[x];
+        if (par >= 0 && atomicSub(&pending[par], 1u) == 1u) // (every ancestor of a stamped node is stamped)
+            listOut[atomicAdd(countOut, 1u)] = (uint32_t)par;
+    }
+}
+// sum of the internal nodes' half-areas -- reporting only (skh_build_info.cost_before / cost_after)
+__global__ void __launch_bounds__(256) k_ri_cost(const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi, int nInternal, double* __restrict__ out)
+{
+    __shared__ double s[4];
+    double v = 0.0;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < nInternal; x += gridDim.x * blockDim.x)
+        v += (double)ri_area(nodeLo[x], nodeHi[x]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0)
+        s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicAdd(out, (s[0] + s[1]) + (s[2] + s[3]));
 }
 
 // ---- multi-block exclusive scan (uint32): block scan -> scan of block totals -> add back ---------------------------

@@ -59,6 +59,7 @@ enum KernelClass
     KC_COUNT
 };
 
+#define SKH_RI_MAX_LEVELS 1024 // tree levels one reinsertion round may have to refit (a deeper tree fails the build)
 #define SKH_MAX_LAUNCH_ROUNDS 140 // MAX_BOUNCES (128) + slack
 
 struct TimedSpan
@@ -148,6 +149,10 @@ struct skh_context
     uint32_t wavesPerCUShadowWorld = 32; // ... its world-only build 8 (SKH_WORLD_ANYHIT_MIN_WAVES)
     uint32_t queueConstBits[2] = { 0, 0 }; // materialTmin / shadowTmin the constant planes of the ray queues hold (bit patterns)
     bool queueConstFilled = false; // ... and whether they hold them at all (alloc_frame resets it)
+    uint32_t reinsertRounds = 8; // option reinsert_rounds: rounds of parallel reinsertion over the PLOC tree of the triangle build (skh_bvh.h k_ri_*)
+    uint32_t reinsertCurveRounds = 4; // option reinsert_curve_rounds: the same pass over the curve sub-segment trees
+    uint32_t reinsertMinSize = 0; // option reinsert_min_size: 0 = auto (1 up to 4 M primitives, 32 beyond)
+    skh_build_info buildInfo = {};
     uint32_t plocTop = 0; // triangle build: clusters left at which PLOC switches to the wide neighbour search (option ploc_top; 0 = never)
     uint32_t wavesPerCUWorld = 32; // the world-only closest-hit build: 64 VGPRs, 8 per SIMD (SKH_WORLD_CLOSEST_MIN_WAVES)
     uint32_t smallWavesClosest = 16, smallWavesShadow = 16; // overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24
@@ -308,11 +313,15 @@ struct LbvhOut
     std::vector<int> hostGroupRoot;
     uint32_t numNodes = 0;
     uint32_t numSlots = 0; // entries of sortedVals: n, or more when the leaves were laid out by 128-byte line (0xffffffff = padding slot)
+    // the reinsertion pass (skh_bvh.h k_ri_*), when it ran: rounds done, moves applied, sum of the internal nodes' box areas before / after, time
+    uint32_t riRounds = 0, riMoves = 0, riMinSize = 0;
+    double riCostBefore = 0.0, riCostAfter = 0.0, riMs = 0.0;
 };
 
 static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const std::vector<uint32_t>& groupCount,
                              const float4* dBoxLo, const float4* dBoxHi, const uint32_t* dGrp, int leafMax, bool ploc, LbvhOut& out,
-                             int search = 0 /* PLOC search radius: 0 triangles, 1 TLAS, 2 curve sub-segments */, uint32_t lineRecBytes = 0 /* > 0: leaf records of this size, laid out by 128-byte line */)
+                             int search = 0 /* PLOC search radius: 0 triangles, 1 TLAS, 2 curve sub-segments */, uint32_t lineRecBytes = 0 /* > 0: leaf records of this size, laid out by 128-byte line */,
+                             uint32_t riRounds = 0 /* reinsertion rounds after PLOC */, uint32_t riMinSize = 1)
 {
     hipStream_t st = c->stream;
     skh_status s;
@@ -449,6 +458,11 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
                 nonEmpty += groupCount[g] ? 1u : 0u;
             uint32_t hc[4] = { 0, 0, 0, 0 }; // [2] PLOC node counter, [3] surviving cluster count
             he = hipMemcpyAsync(ctr.p, hc, sizeof(hc), hipMemcpyHostToDevice, st);
+            if (riRounds)
+            {
+                LB_ALLOC(parent, sizeof(int) * 2 * (size_t)n);
+                SKH_TRY(c, hipMemsetAsync(parent.p, 0xff, sizeof(int) * 2 * (size_t)n, st)); // -1: roots (and the ids PLOC never hands out) have no parent
+            }
             k_ploc_init<<<G1, B, 0, st>>>(valsA, sortedKeys, dBoxLo, dBoxHi, n, cLo[0].as<float4>(), cHi[0].as<float4>(),
                                           nodeLo.as<float4>(), nodeHi.as<float4>(), keyShift);
             uint32_t m = n;
@@ -467,7 +481,7 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
                     k_ploc_nn<SKH_PLOC_RADIUS><<<gm, SKH_PLOC_BLOCK, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), m, nn.as<uint32_t>());
                 k_ploc_merge<<<(m + B - 1) / B, B, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), nn.as<uint32_t>(), m, (int)n,
                                                             childL.as<int>(), childR.as<int>(), nodeSize.as<int>(), nodeLo.as<float4>(),
-                                                            nodeHi.as<float4>(), ctr.as<uint32_t>() + 2, pflags.as<uint32_t>());
+                                                            nodeHi.as<float4>(), ctr.as<uint32_t>() + 2, pflags.as<uint32_t>(), riRounds ? parent.as<int>() : nullptr);
                 he = hipMemcpyAsync(ppos.p, pflags.p, sizeof(uint32_t) * (size_t)m, hipMemcpyDeviceToDevice, st);
                 {
                     const uint32_t sb = (m + SKH_SCAN_BLOCK * SKH_SCAN_ITEMS - 1) / (SKH_SCAN_BLOCK * SKH_SCAN_ITEMS);
@@ -489,6 +503,117 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
             }
             if (he == hipSuccess)
                 k_ploc_roots<<<(m + B - 1) / B, B, 0, st>>>(cLo[cur].as<float4>(), cHi[cur].as<float4>(), m, out.groupRoot.as<int>());
+            if (he == hipSuccess && riRounds && n >= 8)
+            {
+                // ---- parallel reinsertion over the binary tree (skh_bvh.h): rounds of search / claim / own / check / apply / refit ----
+                DevBuf moves, lock, moving, win, rflags, cost, cand, stamp, refitList, refitCount;
+                auto cleanupR = [&]() {
+                    for (DevBuf* b : { &moves, &lock, &moving, &win, &rflags, &cost, &cand, &stamp, &refitList, &refitCount })
+                        dev_free(*b);
+                };
+                const size_t N2 = 2 * (size_t)n;
+                skh_status sr = SKH_OK;
+                if ((sr = dev_alloc(c, moves, sizeof(int4) * N2)) != SKH_OK || (sr = dev_alloc(c, lock, sizeof(unsigned long long) * N2)) != SKH_OK ||
+                    (sr = dev_alloc(c, moving, sizeof(unsigned long long) * N2)) != SKH_OK || (sr = dev_alloc(c, win, N2)) != SKH_OK ||
+                    (sr = dev_alloc(c, rflags, sizeof(uint32_t) * (size_t)n)) != SKH_OK || (sr = dev_alloc(c, cost, sizeof(double) * 2 + sizeof(uint32_t) * 2)) != SKH_OK ||
+                    (sr = dev_alloc(c, cand, sizeof(uint32_t) * N2)) != SKH_OK || (sr = dev_alloc(c, stamp, sizeof(uint32_t) * (size_t)n)) != SKH_OK ||
+                    (sr = dev_alloc(c, refitList, sizeof(uint32_t) * 2 * (size_t)n)) != SKH_OK || (sr = dev_alloc(c, refitCount, sizeof(uint32_t) * SKH_RI_MAX_LEVELS)) != SKH_OK)
+                {
+                    cleanupR();
+                    cleanup2();
+                    cleanup();
+                    return sr;
+                }
+                const auto t0 = std::chrono::steady_clock::now();
+                const uint32_t nInternal = hc[2]; // ids PLOC handed out
+                const uint32_t GN = (uint32_t)((N2 + B - 1) / B);
+                double* dCost = cost.as<double>();
+                uint32_t* dWin = reinterpret_cast<uint32_t*>(dCost + 2); // [0] moves applied this round, [1] candidates
+                he = hipMemsetAsync(cost.p, 0, sizeof(double) * 2 + sizeof(uint32_t) * 2, st);
+                if (he == hipSuccess)
+                    he = hipMemsetAsync(stamp.p, 0, sizeof(uint32_t) * (size_t)n, st);
+                k_ri_cost<<<1024, B, 0, st>>>(nodeLo.as<float4>(), nodeHi.as<float4>(), (int)nInternal, dCost);
+                out.riMinSize = riMinSize;
+                uint32_t nCandHost = (uint32_t)N2; // (upper bound for the first round's list kernels; afterwards the previous round's count, which only shrinks... not relied on: see below)
+                for (uint32_t r = 0; he == hipSuccess && r < riRounds; ++r)
+                {
+                    he = hipMemsetAsync(lock.p, 0, sizeof(unsigned long long) * N2, st);
+                    if (he == hipSuccess)
+                        he = hipMemsetAsync(moving.p, 0, sizeof(unsigned long long) * N2, st);
+                    if (he == hipSuccess)
+                        he = hipMemsetAsync(dWin, 0, sizeof(uint32_t) * 2, st);
+                    k_ri_search<<<GN, B, 0, st>>>(childL.as<int>(), childR.as<int>(), parent.as<int>(), nodeSize.as<int>(), nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n,
+                                                  (int)riMinSize, 1u, 0u, moves.as<int4>(), cand.as<uint32_t>(), dWin + 1);
+                    // the list kernels are sized by the candidate count, read back here (one small synchronisation per round; the search is the long kernel)
+                    if (he == hipSuccess)
+                        he = hipMemcpyAsync(&nCandHost, dWin + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+                    if (he == hipSuccess)
+                        he = hipStreamSynchronize(st);
+                    out.riRounds = r + 1;
+                    if (he != hipSuccess || nCandHost == 0)
+                        break;
+                    const uint32_t GC = (nCandHost + B - 1) / B;
+                    k_ri_claim<<<GC, B, 0, st>>>(moves.as<int4>(), cand.as<uint32_t>(), dWin + 1, childL.as<int>(), childR.as<int>(), parent.as<int>(), lock.as<unsigned long long>());
+                    k_ri_own<<<GC, B, 0, st>>>(moves.as<int4>(), cand.as<uint32_t>(), dWin + 1, childL.as<int>(), childR.as<int>(), parent.as<int>(), lock.as<unsigned long long>(),
+                                               moving.as<unsigned long long>());
+                    k_ri_check<<<GC, B, 0, st>>>(moves.as<int4>(), cand.as<uint32_t>(), dWin + 1, parent.as<int>(), moving.as<unsigned long long>(), win.as<uint8_t>(), dWin);
+                    k_ri_apply<<<GC, B, 0, st>>>(moves.as<int4>(), cand.as<uint32_t>(), dWin + 1, win.as<uint8_t>(), childL.as<int>(), childR.as<int>(), parent.as<int>());
+                    k_ri_mark<<<GC, B, 0, st>>>(moves.as<int4>(), cand.as<uint32_t>(), dWin + 1, win.as<uint8_t>(), parent.as<int>(), stamp.as<uint32_t>(), r + 1u);
+                    {
+                        // refit of the stamped paths, one tree level per launch (rflags = stamped children still to come; lists ping-pong in `refitList`)
+                        uint32_t* lv = refitCount.as<uint32_t>();
+                        if (he == hipSuccess)
+                            he = hipMemsetAsync(lv, 0, sizeof(uint32_t) * SKH_RI_MAX_LEVELS, st);
+                        uint32_t* lists[2] = { refitList.as<uint32_t>(), refitList.as<uint32_t>() + n };
+                        k_ri_pending<<<(n + B - 1) / B, B, 0, st>>>(childL.as<int>(), childR.as<int>(), stamp.as<uint32_t>(), r + 1u, (int)n, rflags.as<uint32_t>(), lists[0], lv);
+                        bool levelsDone = false;
+                        for (uint32_t k = 0; he == hipSuccess && k + 1 < SKH_RI_MAX_LEVELS; ++k)
+                        {
+                            k_ri_refit_level<<<256, B, 0, st>>>(lists[k & 1], lv + k, lists[(k + 1) & 1], lv + k + 1, parent.as<int>(), childL.as<int>(), childR.as<int>(),
+                                                                rflags.as<uint32_t>(), nodeLo.as<float4>(), nodeHi.as<float4>(), nodeSize.as<int>(), (int)n);
+                            if ((k & 15u) == 15u)
+                            {
+                                uint32_t next = 0;
+                                he = hipMemcpyAsync(&next, lv + k + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+                                if (he == hipSuccess)
+                                    he = hipStreamSynchronize(st);
+                                if (next == 0)
+                                {
+                                    levelsDone = true;
+                                    break;
+                                }
+                            }
+                        }
+                        if (he == hipSuccess && !levelsDone)
+                        {
+                            cleanupR();
+                            cleanup2();
+                            cleanup();
+                            c->err = "lbvh_build: the binary tree is deeper than SKH_RI_MAX_LEVELS (degenerate geometry?)";
+                            return SKH_FAIL;
+                        }
+                    }
+                    uint32_t moved = 0;
+                    if (he == hipSuccess)
+                        he = hipMemcpyAsync(&moved, dWin, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+                    if (he == hipSuccess)
+                        he = hipStreamSynchronize(st);
+                    out.riMoves += moved;
+                    if (moved == 0)
+                        break;
+                }
+                if (he == hipSuccess)
+                {
+                    double hcost[2] = { 0, 0 };
+                    k_ri_cost<<<1024, B, 0, st>>>(nodeLo.as<float4>(), nodeHi.as<float4>(), (int)nInternal, dCost + 1);
+                    he = hipMemcpyAsync(hcost, dCost, sizeof(hcost), hipMemcpyDeviceToHost, st);
+                    if (he == hipSuccess)
+                        he = hipStreamSynchronize(st);
+                    out.riCostBefore = hcost[0], out.riCostAfter = hcost[1];
+                }
+                out.riMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                cleanupR();
+            }
         }
         else
         {
@@ -1355,8 +1480,18 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
                                                              (uint32_t)wInst.size(), c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(),
                                                              c->dMeshes.as<uint4>(), nBaked, nMeshTris, nMeshes, nBakedG[0], dBoxLo.as<float4>(),
                                                              dBoxHi.as<float4>(), dGrp.as<uint32_t>());
+    const uint32_t riMin = c->reinsertMinSize ? c->reinsertMinSize : (nTris <= (4u << 20) ? 1u : 32u);
     BA(lbvh_build(c, nTris, nMeshes + 2u, meshTriCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), (int)c->leafMaxTris, usePloc, triOut,
-                  0, c->leafLines ? 48u : 0u));
+                  0, c->leafLines ? 48u : 0u, usePloc ? c->reinsertRounds : 0u, riMin));
+    memset(&c->buildInfo, 0, sizeof(c->buildInfo));
+    c->buildInfo.triangles = nTris;
+    c->buildInfo.nodes = triOut.numNodes;
+    c->buildInfo.reinsert_rounds = triOut.riRounds;
+    c->buildInfo.reinsert_moves = triOut.riMoves;
+    c->buildInfo.reinsert_min_size = triOut.riMinSize;
+    c->buildInfo.cost_before = triOut.riCostBefore;
+    c->buildInfo.cost_after = triOut.riRounds ? triOut.riCostAfter : triOut.riCostBefore;
+    c->buildInfo.ms_reinsert = triOut.riMs;
     const uint32_t nTriSlots = triOut.numSlots; // >= nTris: the line layout pads in front of leaves that would straddle a 128-byte line
     c->nTriSlots = nTriSlots;
     BA(dev_alloc(c, c->dTris, sizeof(float4) * 3 * (size_t)std::max(1u, nTriSlots)));
@@ -1441,7 +1576,8 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         k_seg_boxes<<<(nSub + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), c->dSegStartAll.as<uint32_t>(),
                                                       dSegCurve.as<uint32_t>(), nSub, K, dBoxLo.as<float4>(), dBoxHi.as<float4>(),
                                                       dGrp.as<uint32_t>());
-    BA(lbvh_build(c, nSub, nCurves, curveSubCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), (int)c->curveLeaf, usePloc, segOut, 2));
+    BA(lbvh_build(c, nSub, nCurves, curveSubCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), (int)c->curveLeaf, usePloc, segOut, 2, 0u,
+                  usePloc ? c->reinsertCurveRounds : 0u, c->reinsertMinSize ? c->reinsertMinSize : (nSub <= (8u << 20) ? 1u : 32u)));
     BA(dev_alloc(c, c->dSegs, sizeof(float4) * 4 * (size_t)std::max(1u, nSub)));
     BA(dev_alloc(c, c->dSegPrim, sizeof(uint32_t) * (size_t)std::max(1u, nSub)));
     BA(dev_alloc(c, c->dSegBound, sizeof(float4) * 2 * (size_t)std::max(1u, nSub)));
@@ -3340,6 +3476,13 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         c->buildQuality = value != 0;
         c->accelBuilt = false;
     }
+    else if (n == "reinsert_rounds" || n == "reinsert_curve_rounds" || n == "reinsert_min_size")
+    {
+        if (value < 0 || value > (n == "reinsert_min_size" ? (1 << 24) : 64))
+            return SKH_INVALID_ARGUMENT;
+        (n == "reinsert_rounds" ? c->reinsertRounds : (n == "reinsert_curve_rounds" ? c->reinsertCurveRounds : c->reinsertMinSize)) = (uint32_t)value;
+        c->accelBuilt = false;
+    }
     else if (n == "ploc_top")
     {
         if (value < 0)
@@ -3378,6 +3521,15 @@ skh_status skh_get_device_info(skh_context* c, skh_device_info* out)
     out->wavefront_size = (uint32_t)prop.warpSize;
     out->total_memory_bytes = (uint64_t)prop.totalGlobalMem;
     strncpy(out->name, prop.name, sizeof(out->name) - 1);
+    return SKH_OK;
+}
+
+skh_status skh_get_build_info(skh_context* c, skh_build_info* out)
+{
+    if (!c || !out)
+        return SKH_INVALID_ARGUMENT;
+    *out = c->buildInfo;
+    out->ms_build = c->msBuild;
     return SKH_OK;
 }
 
