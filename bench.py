@@ -368,8 +368,11 @@ def other_workload_leg(name, W, H, spp, depth, device_ordinal, steps=2):
     nr, ns = max(1, cst["rays_radiance"]), max(1, cst["rays_shadow"])
     return {"workload": workload, "value": round(rays / dt / 1e6, 1), "unit": "Mray/s", "ms_per_step": round(dt / steps * 1e3, 3),
             "kernel_ms_per_frame": {k: round(st[k] / steps, 3) for k in ("ms_trace_closest", "ms_trace_shadow", "ms_shade")},
-            "per_ray": {"nodes": round(cst["nodes_visited"][0] / nr, 2), "tris": round(cst["prims_tested"][0] / nr, 2)},
-            "per_shadow_ray": {"nodes": round(cst["nodes_visited"][1] / ns, 2), "tris": round(cst["prims_tested"][1] / ns, 2)},
+            "bounces": depth,
+            "per_ray": {"nodes": round(cst["nodes_visited"][0] / nr, 2), "tris": round(cst["prims_tested"][0] / nr, 2),
+                        "segs": round(cst["segs_tested"][0] / nr, 2), "instances": round(cst["instances_entered"][0] / nr, 2)},
+            "per_shadow_ray": {"nodes": round(cst["nodes_visited"][1] / ns, 2), "tris": round(cst["prims_tested"][1] / ns, 2),
+                               "segs": round(cst["segs_tested"][1] / ns, 2), "instances": round(cst["instances_entered"][1] / ns, 2)},
             "rays_per_frame": int(rays / steps),
             "bvh_build_ms": round(st["ms_build"], 2), "bvh": binfo, "bake_world": {"baked_instances": baked[1], "baked_triangles": baked[2]},
             "scene_load_s": round(load_s, 1)}
@@ -381,6 +384,33 @@ def _bvh_info(ctx):
     return {"triangles": b["triangles"], "nodes": b["nodes"], "reinsert_rounds": b["reinsert_rounds"], "reinsert_moves": b["reinsert_moves"],
             "reinsert_min_size": b["reinsert_min_size"], "reinsert_ms": round(b["ms_reinsert"], 2),
             "cost_ratio": round(b["cost_after"] / b["cost_before"], 4) if b["cost_before"] > 0 else None}
+
+
+def frac_of_copy(blk, ceilings):
+    """counter HBM bytes / time against what a plain copy reaches on THIS box (ceilings.stream_copy_GBps) instead of the 8 TB/s data-sheet peak"""
+    if not ceilings or not blk.get("achieved") or not ceilings.get("stream_copy_GBps"):
+        return None
+    return round(blk["achieved"] / ceilings["stream_copy_GBps"], 4)
+
+
+def derive_limiter(blk, ceilings):
+    """Names what the kernel is closest to, from the line's own fractions: HBM bytes (counter upper bound, against the 8 TB/s peak), the
+    measured random-line rate (L2-miss lines / s against roofline.ceilings), VALU issue (against SIMDs x clock / 2).  The largest one is
+    the limiter when it is above 0.6; below that no roof is reached and the kernel is latency / divergence bound -- the record says so
+    instead of naming a roof."""
+    cands = {"hbm_bytes": blk.get("frac") or 0.0,
+             "random_line_rate": (blk.get("l2_miss_lines") or {}).get("frac_of_measured_random_line_rate") or 0.0,
+             "valu_issue": (blk.get("valu") or {}).get("frac_valu_issue") or 0.0}
+    name, top = max(cands.items(), key=lambda kv: kv[1])
+    fr = {k: round(v, 3) for k, v in cands.items()}
+    if top <= 0.0:
+        return {"name": "unknown: no counters in this run", "fractions": fr}
+    if top < 0.6:
+        lanes = (blk.get("valu") or {}).get("lanes_per_valu_inst")
+        return {"name": "latency / divergence: none of %s above 0.6 (largest: %s %.2f%s)" % (" / ".join(cands), name, top,
+                                                                                             ", %.1f of 64 lanes per VALU instruction" % lanes if lanes else ""),
+                "fractions": fr}
+    return {"name": name, "fractions": fr}
 
 
 def roofline_fractions(algorithmic_bytes_per_launch, counter_bytes_per_launch, avg_launch_ms, peak_gbs=HBM_PEAK_GBS):
@@ -606,6 +636,8 @@ def main():
     extra = None
     if rank == 0 and world == 1 and args.scene == "kitchen" and not args.no_extra and not args.no_drop_in and not args.pmc_child:
         extra = {name: other_workload_leg(name, W, H, args.spp, args.depth, local_rank) for name in ("kitchen_unshared", "kitchen_arch")}
+        # C5 (BASELINE.json configs[4]): the basis-curves workload at ITS depth (3), 64 spp per pass like the headline
+        extra["hair"] = other_workload_leg("hair", W, H, args.spp, 3, local_rank)
     if rank == 0:
         K = max(1, args.steps)
         # ---- rooflines of the three hot kernels.  Per kernel, from this run's counters and hipEvent times:
@@ -689,6 +721,9 @@ def main():
                                             "frac_of_measured_random_line_rate": round(rate / line_rate, 4)}
         except Exception as e:  # a ceiling is context, not the measurement: say so and go on
             sys.stderr.write("[bench] memory ceilings not measured: %s\n" % e)
+        for blk in kern.values():
+            blk["limiter"] = derive_limiter(blk, ceilings)
+            blk["frac_of_measured_copy"] = frac_of_copy(blk, ceilings)
         nrs = max(1, cst["rays_shadow"])
         c0 = kern["closest"]
         roofline = {"kernel": "k_trace<closest>", "bound": "hbm", "achieved": c0["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": c0["frac"],
@@ -696,7 +731,7 @@ def main():
                     "algorithmic_frac": c0["algorithmic_frac"], "model_exceeds_peak": c0["model_exceeds_peak"], "l2_hit_share": c0["l2_hit_share"],
                     "algorithmic_frac_is": "SURVEY 8(d) no-reuse bytes / time / peak; above 1 = the caches serve part of the model's bytes",
                     "traffic": c0["traffic"], "traffic_source": pmc.get("source") if pmc else None,
-                    "limiter": "valu_issue (divergence): see valu", "valu": c0.get("valu"),
+                    "limiter": derive_limiter(c0, ceilings), "frac_of_measured_copy": frac_of_copy(c0, ceilings), "valu": c0.get("valu"),
                     "cached_bw": dict(c0["cached_bw"], note="SURVEY 8(d) bytes / time; served by L2 + Infinity Cache + HBM together, not an HBM fraction"),
                     "avg_launch_ms": c0["avg_launch_ms"], "rays_per_launch": c0["units_per_launch"],
                     "clock_ghz": round(clock_ghz, 3), "simds": simds,

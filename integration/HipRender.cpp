@@ -6,7 +6,12 @@
 #ifdef SKH_WITH_STRELKA_HEADERS
 #    include "SkhMaterials.h"
 
-#    include <stb_image.h> // the reference's texture loader (OptixRender.cpp:18,1191-1264); STB_IMAGE_IMPLEMENTATION lives in the render library
+// The reference's texture loader (OptixRender.cpp:18,1191-1264).  In the reference STB_IMAGE_STATIC + STB_IMAGE_IMPLEMENTATION sit in OptixRender.cpp:16-17, which
+// strelka_hip.cmake drops from the render target: this file fills that slot, so that targets which link `render` without the scene loader
+// (HdStrelka: render + scene + materialmanager) still resolve stbi_load / stbi_image_free.
+#    define STB_IMAGE_STATIC // (as OptixRender.cpp:16: the symbols stay file-local, gltfloader.cpp:5 has its own copy)
+#    define STB_IMAGE_IMPLEMENTATION
+#    include <stb_image.h>
 #    include <filesystem>
 #endif
 

@@ -1419,6 +1419,9 @@ __global__ void k_gather_tris(const uint8_t* __restrict__ verts, const uint32_t*
         const uint32_t inst = wInst[w], t = kk - wFirst[w];
         const float* m = reinterpret_cast<const float*>(instances + (size_t)inst * 64);
         const uint32_t geom = reinterpret_cast<const uint32_t*>(instances + (size_t)inst * 64)[13];
+        // (a baked LIGHT proxy keeps the plain primitive index: the `light` word of its shading record is the light's index, not a mesh base,
+        // and k_shade reads no triangle record for a light hit)
+        const bool isMesh = reinterpret_cast<const uint32_t*>(instances + (size_t)inst * 64)[12] == 0u;
         const uint32_t tvBase = reinterpret_cast<const uint32_t*>(shadeInstances + (size_t)inst * 64)[15];
         const uint4 me = meshes[geom];
 #pragma unroll
@@ -1431,7 +1434,7 @@ __global__ void k_gather_tris(const uint8_t* __restrict__ verts, const uint32_t*
             // record, build_shading_tables) with SKH_PRIM_DIRECT set: k_shade fetches the record straight from the hit, beside the instance
             // record instead of behind it; the traversal treats the word as opaque (within an instance it orders like t, so ties break alike),
             // the raw-query output turns it back into t (k_hits_soa_to_aos)
-            r[k] = make_float4(q.x, q.y, q.z, k == 0 ? __uint_as_float((tvBase + t) | SKH_PRIM_DIRECT) : (k == 1 ? __uint_as_float(inst) : 0.0f));
+            r[k] = make_float4(q.x, q.y, q.z, k == 0 ? __uint_as_float(isMesh ? ((tvBase + t) | SKH_PRIM_DIRECT) : t) : (k == 1 ? __uint_as_float(inst) : 0.0f));
         }
     }
     out[3 * (size_t)j + 0] = r[0];

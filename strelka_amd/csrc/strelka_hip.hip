@@ -1254,11 +1254,15 @@ static skh_status build_shading_tables(skh_context* c)
 {
     const uint32_t nMeshes = (uint32_t)c->meshes.size();
     std::vector<uint32_t> base(nMeshes + 1u, 0u);
+    uint64_t total = 0; // (summed wide and tested before narrowing: a 32-bit sum that wraps would pass the test below with aliased bases)
     for (uint32_t m = 0; m < nMeshes; ++m)
-        base[m + 1] = base[m] + c->meshes[m].index_count / 3u;
+    {
+        total += c->meshes[m].index_count / 3u;
+        base[m + 1] = (uint32_t)std::min<uint64_t>(total, 0xffffffffull);
+    }
     const uint32_t nTris = base[nMeshes];
     skh_status s;
-    if (nTris >= SKH_PRIM_DIRECT)
+    if (total >= SKH_PRIM_DIRECT)
     {
         c->err = "skh_build_accel: more than 2^31 - 1 triangles (the primitive word of a hit keeps its top bit for SKH_PRIM_DIRECT)";
         return SKH_INVALID_ARGUMENT;

@@ -172,3 +172,22 @@ def test_committed_round_profile_is_self_consistent():
     k = line["kernel_ms_per_frame"]
     assert abs(sum(k.values()) - line["ms_per_step"]) <= 0.02 * line["ms_per_step"]
     assert abs(line["value"] - line["config"]["rays_per_frame"] / line["ms_per_step"] / 1e3) <= 0.01 * line["value"]
+
+
+def test_limiter_is_derived_from_the_lines_own_fractions():
+    """roofline.limiter names the largest of the HBM-byte, random-line-rate and VALU-issue fractions when it is above 0.6 and says
+    "latency / divergence" otherwise (round 4 printed a string literal whatever the counters said); frac_of_measured_copy prices the
+    counter bytes against this box's measured copy rate instead of the 8 TB/s data-sheet peak."""
+    blk = {"frac": 0.53, "achieved": 4275.9, "l2_miss_lines": {"frac_of_measured_random_line_rate": 0.56},
+           "valu": {"frac_valu_issue": 0.54, "lanes_per_valu_inst": 37.9}}
+    lim = bench.derive_limiter(blk, None)
+    assert lim["name"].startswith("latency / divergence") and "random_line_rate 0.56" in lim["name"] and "37.9 of 64 lanes" in lim["name"]
+    assert lim["fractions"] == {"hbm_bytes": 0.53, "random_line_rate": 0.56, "valu_issue": 0.54}
+    assert bench.derive_limiter(dict(blk, frac=0.66), None)["name"] == "hbm_bytes"
+    assert bench.derive_limiter(dict(blk, valu={"frac_valu_issue": 0.9}), None)["name"] == "valu_issue"
+    assert bench.derive_limiter({}, None)["name"].startswith("unknown")
+    assert bench.frac_of_copy(blk, {"stream_copy_GBps": 4386.5}) == round(4275.9 / 4386.5, 4)
+    assert bench.frac_of_copy(blk, None) is None
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"limiter": "' not in src  # no literal limiter left
+    assert 'extra["hair"]' in src  # C5 is a leg of the default line
