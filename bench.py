@@ -555,6 +555,8 @@ def main():
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         if int(okt.item()) == 1:
             gather_kind = "skh_gather_tiles: RCCL send/recv below the C ABI"
+            if os.environ.get("SKH_RCCL_LIB"):  # (tests: tests/cpp/rccl_double.cpp stands in for librccl so that N ranks can share one GPU)
+                gather_kind += " (SKH_RCCL_LIB test double, not RCCL: %s)" % os.path.basename(os.environ["SKH_RCCL_LIB"])
             rccl_nranks = ctx.comm_info()[2]  # what RCCL itself reports (ncclCommCount)
         else:
             ctx.comm_destroy()

@@ -2662,6 +2662,7 @@ struct RcclApi
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr; // optional
     ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr; // optional
     std::string why;
+    bool overridden = false; // bound to SKH_RCCL_LIB instead of librccl (tests)
 };
 static bool rccl_load(RcclApi& api);
 RcclApi* rccl()
@@ -2675,9 +2676,20 @@ RcclApi* rccl()
 }
 static bool rccl_load(RcclApi& api)
 {
+    // SKH_RCCL_LIB (tests only): the library to bind instead -- tests/cpp/rccl_double.cpp, a stand-in for N ranks SHARING one GPU, so that the
+    // N > 1 branch of skh_gather_tiles runs on a 1-GPU box.  RTLD_LOCAL: its nccl* symbols must not shadow the real ones PyTorch has loaded.
+    if (const char* over = getenv("SKH_RCCL_LIB"))
+    {
+        if (!(api.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL)))
+        {
+            api.why = std::string("SKH_RCCL_LIB=") + over + ": " + dlerror();
+            return false;
+        }
+        api.overridden = true;
+    }
     // (a process that uses PyTorch has its librccl.so.1 loaded already: the same soname resolves to that copy)
     for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" })
-        if ((api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
+        if (api.lib || (api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
             break;
     if (!api.lib)
     {

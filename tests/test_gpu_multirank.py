@@ -66,3 +66,44 @@ def test_a_failed_communicator_is_recorded_with_its_error():
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-1500:]
     rec = json.loads(lines[0])
     assert rec["gather"] == "torch.distributed gather" and rec["rccl_nranks"] == 0 and "gather_error" in rec
+
+
+def _build_rccl_double(tmp_path):
+    """tests/cpp/rccl_double.cpp -> a shared library with the ten nccl* symbols the loader binds, for N processes sharing one GPU"""
+    out = str(tmp_path / "librccl_double.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", out,
+                           os.path.join(ROOT, "tests", "cpp", "rccl_double.cpp"), "-L/opt/rocm/lib", "-lamdhip64", "-lrt"])
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_the_rccl_branch_of_the_gather_runs_with_n_ranks(tmp_path, world):
+    """skh_gather_tiles with commWorld > 1 -- ncclGroupStart, N-1 ncclRecv into the root's chunk offsets, one ncclSend per other rank from its
+    zero-padded staging buffer, ncclGroupEnd -- executed for real, below the C ABI, by N ranks.  A 1-GPU box cannot form an RCCL communicator
+    of more than one rank, so SKH_RCCL_LIB binds tests/cpp/rccl_double.cpp instead (same call sequence, buffers and sizes; shared-memory
+    transport).  200 x 136 at tile 32 = 35 tiles: with 8 ranks three of them own 5 tiles and five own 4, so max_tiles padding is exercised.
+    The gathered image must be the 1-rank image bit for bit and the record must name N ranks and say that the double was used."""
+    lib = _build_rccl_double(tmp_path)
+    env = dict(os.environ, SKH_BENCH_CHECKSUM="1", SKH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, env)
+    env = dict(env, SKH_GATHER="rccl", SKH_RCCL_LIB=lib)
+    many = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                 "--master-port", str(29541 + world), "bench.py", "--gpus", str(world)] + ARGS, env)
+    assert many["n_gpus"] == world and many["rccl_nranks"] == world
+    assert many["gather"].startswith("skh_gather_tiles") and "test double" in many["gather"] and "gather_error" not in many
+    assert many["image_crc32"] == one["image_crc32"]
+    assert many["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
+    tiles = many["per_rank"]["tiles"]
+    assert sum(tiles) == 35 and (world != 8 or (max(tiles) == 5 and min(tiles) == 4))
+
+
+def test_the_real_rccl_stays_the_default(monkeypatch):
+    """SKH_RCCL_LIB is the only way to the double: without it the loader binds librccl.so.1, and bench.py still exits 3 when the real
+    communicator cannot form on the nccl backend (tests/test_bench_launch.py covers gather_fallback_allowed)."""
+    src = open(os.path.join(ROOT, "strelka_amd", "csrc", "strelka_hip.hip")).read()
+    assert 'getenv("SKH_RCCL_LIB")' in src and '"librccl.so.1"' in src
+    import bench
+
+    monkeypatch.delenv("SKH_ALLOW_GATHER_FALLBACK", raising=False)
+    assert not bench.gather_fallback_allowed("nccl", {})
