@@ -381,7 +381,10 @@ skh_status skh_bsdf_probe(skh_context* ctx, const skh_bsdf_query* queries, uint3
  *   SKH_UNIT_MIS            --                   f32 a, b                                 --                            f32 misWeightBalance(a, b)
  *   SKH_UNIT_ACCUMULATE     f32 exposure[3]      f32 value[3]  (a SEQUENCE: record k is   first sub-frame index         f32 accumulator[3] after record k
  *                                                folded into the result of 0..k-1)
- *   SKH_UNIT_TONEMAP        f32 exposure[3]      f32 color[3]                             --                            f32 tonemap[3], inverseTonemap[3] */
+ *   SKH_UNIT_TONEMAP        f32 exposure[3]      f32 color[3]                             --                            f32 tonemap[3], inverseTonemap[3]
+ *   SKH_UNIT_LIBM           --                   f32 x, y                                 --                            f32 sin x, cos x, acos x, asin x, atan2(y, x), exp x, log x,
+ *                                                                                                                       sinh x, pow(x, y), atan2(x, y): strelka_amd/csrc/skh_libm.h,
+ *                                                                                                                       the libm stand-ins both sides compile */
 typedef enum skh_unit
 {
     SKH_UNIT_SAMPLER = 0,
@@ -392,7 +395,8 @@ typedef enum skh_unit
     SKH_UNIT_MIS = 5,
     SKH_UNIT_ACCUMULATE = 6,
     SKH_UNIT_TONEMAP = 7,
-    SKH_UNIT_COUNT = 8
+    SKH_UNIT_LIBM = 8,
+    SKH_UNIT_COUNT = 9
 } skh_unit;
 skh_status skh_unit_probe(skh_context* ctx, uint32_t unit, uint32_t param, const void* consts, const void* in, uint32_t n, void* out);
 

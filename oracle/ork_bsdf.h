@@ -70,7 +70,7 @@ static inline f3 cosine_hemisphere(float u1, float u2, float& cosTheta)
     const float r = sqrtf(u1);
     const float phi = 2.0f * kPi * u2;
     cosTheta = sqrtf(fmaxf(0.0f, 1.0f - u1));
-    return f3{ r * cosf(phi), r * sinf(phi), cosTheta };
+    return f3{ r * skm::cosf_(phi), r * skm::sinf_(phi), cosTheta };
 }
 static inline float lum3(const f3& c)
 {
@@ -105,8 +105,8 @@ static inline f3 ggx_sample_vndf(const f3& Ve, float alpha, float u1, float u2)
     const f3 T2 = cross(Vh, T1);
     const float r = sqrtf(u1);
     const float phi = 2.0f * kPi * u2;
-    const float t1 = r * cosf(phi);
-    float t2 = r * sinf(phi);
+    const float t1 = r * skm::cosf_(phi);
+    float t2 = r * skm::sinf_(phi);
     const float s = 0.5f * (1.0f + Vh.z);
     t2 = (1.0f - s) * sqrtf(fmaxf(0.0f, 1.0f - t1 * t1)) + s * t2;
     const f3 Nh = t1 * T1 + t2 * T2 + sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2)) * Vh;
@@ -276,7 +276,7 @@ static inline float safe_sqrtf(float x)
 }
 static inline float safe_asinf(float x)
 {
-    return asinf(clampf(x, -1.0f, 1.0f));
+    return skm::asinf_(clampf(x, -1.0f, 1.0f));
 }
 static inline float hair_pow20(float x)
 {
@@ -307,25 +307,25 @@ static inline float hair_I0(float x)
 static inline float hair_logI0(float x)
 {
     if (x > 12.0f)
-        return x + 0.5f * ((-logf(2.0f * kPi) + logf(1.0f / x)) + 1.0f / (8.0f * x));
-    return logf(hair_I0(x));
+        return x + 0.5f * ((-skm::logf_(2.0f * kPi) + skm::logf_(1.0f / x)) + 1.0f / (8.0f * x));
+    return skm::logf_(hair_I0(x));
 }
 static inline float hair_Mp(float cosThetaI, float cosThetaO, float sinThetaI, float sinThetaO, float v)
 {
     const float a = cosThetaI * cosThetaO / v;
     const float b = sinThetaI * sinThetaO / v;
-    return v <= 0.1f ? expf((((hair_logI0(a) - b) - 1.0f / v) + 0.6931f) + logf(1.0f / (2.0f * v))) :
-                       (expf(-b) * hair_I0(a)) / (sinhf(1.0f / v) * 2.0f * v);
+    return v <= 0.1f ? skm::expf_((((hair_logI0(a) - b) - 1.0f / v) + 0.6931f) + skm::logf_(1.0f / (2.0f * v))) :
+                       (skm::expf_(-b) * hair_I0(a)) / (skm::sinhf_(1.0f / v) * 2.0f * v);
 }
 static inline float hair_logistic(float x, float s)
 {
     x = fabsf(x);
-    const float e = expf(-x / s);
+    const float e = skm::expf_(-x / s);
     return e / (s * sqrf(1.0f + e));
 }
 static inline float hair_logistic_cdf(float x, float s)
 {
-    return 1.0f / (1.0f + expf(-x / s));
+    return 1.0f / (1.0f + skm::expf_(-x / s));
 }
 static inline float hair_trimmed_logistic(float x, float s, float a, float b)
 {
@@ -334,7 +334,7 @@ static inline float hair_trimmed_logistic(float x, float s, float a, float b)
 static inline float hair_sample_trimmed_logistic(float u, float s, float a, float b)
 {
     const float k = hair_logistic_cdf(b, s) - hair_logistic_cdf(a, s);
-    const float x = -s * logf(1.0f / (u * k + hair_logistic_cdf(a, s)) - 1.0f);
+    const float x = -s * skm::logf_(1.0f / (u * k + hair_logistic_cdf(a, s)) - 1.0f);
     return clampf(x, a, b);
 }
 static inline float hair_Phi(int p, float gammaO, float gammaT)
@@ -376,7 +376,7 @@ static inline HairTerms hair_terms(const Material& m)
     t.v[3] = t.v[2];
     const float bn = fmaxf(m.reserved[3] > 0.0f ? m.reserved[3] : m.roughness, 0.02f);
     t.s = 0.626657069f * ((0.265f * bn + 1.194f * (bn * bn)) + 5.372f * hair_pow22(bn)); // sqrt(pi / 8) * (...)
-    t.sin2k[0] = sinf(m.reserved[4]);
+    t.sin2k[0] = skm::sinf_(m.reserved[4]);
     t.cos2k[0] = safe_sqrtf(1.0f - sqrf(t.sin2k[0]));
     for (int i = 1; i < 3; ++i)
     {
@@ -415,7 +415,7 @@ static inline HairGeom hair_geom(const HairTerms& t, const f3& wo)
     HairGeom g;
     g.sinThetaO = clampf(wo.x, -1.0f, 1.0f);
     g.cosThetaO = safe_sqrtf(1.0f - sqrf(g.sinThetaO));
-    g.phiO = atan2f(wo.z, wo.y);
+    g.phiO = skm::atan2f_(wo.z, wo.y);
     const float sinThetaT = g.sinThetaO / t.eta;
     const float cosThetaT = safe_sqrtf(1.0f - sqrf(sinThetaT));
     const float etap = sqrtf(t.eta * t.eta - sqrf(g.sinThetaO)) / fmaxf(g.cosThetaO, 1e-6f);
@@ -424,7 +424,7 @@ static inline HairGeom hair_geom(const HairTerms& t, const f3& wo)
     g.gammaT = safe_asinf(sinGammaT);
     g.gammaO = safe_asinf(t.h);
     const float l = 2.0f * cosGammaT / fmaxf(cosThetaT, 1e-6f);
-    g.T = f3{ expf(-t.sigma_a.x * l), expf(-t.sigma_a.y * l), expf(-t.sigma_a.z * l) };
+    g.T = f3{ skm::expf_(-t.sigma_a.x * l), skm::expf_(-t.sigma_a.y * l), skm::expf_(-t.sigma_a.z * l) };
     return g;
 }
 static inline void hair_tilt(const HairTerms& t, const HairGeom& g, int p, float& sinThetaOp, float& cosThetaOp)
@@ -458,7 +458,7 @@ static inline void hair_eval_local(const HairTerms& t, const f3& wo, const f3& w
     const HairGeom g = hair_geom(t, wo);
     const float sinThetaI = clampf(wi.x, -1.0f, 1.0f);
     const float cosThetaI = safe_sqrtf(1.0f - sqrf(sinThetaI));
-    const float phi = atan2f(wi.z, wi.y) - g.phiO;
+    const float phi = skm::atan2f_(wi.z, wi.y) - g.phiO;
     f3 ap[4];
     float apPdf[4];
     hair_Ap(t, g.cosThetaO, g.T, ap, apPdf);
@@ -493,14 +493,14 @@ static inline f3 hair_sample_local(const HairTerms& t, const f3& wo, float u0, f
     float so, co;
     hair_tilt(t, g, p, so, co);
     const float ua = fmaxf(u0, 1e-5f);
-    const float cosTheta = 1.0f + t.v[p] * logf(ua + (1.0f - ua) * expf(-2.0f / t.v[p]));
+    const float cosTheta = 1.0f + t.v[p] * skm::logf_(ua + (1.0f - ua) * skm::expf_(-2.0f / t.v[p]));
     const float sinTheta = safe_sqrtf(1.0f - sqrf(cosTheta));
-    const float cosPhi = cosf(2.0f * kPi * u1);
+    const float cosPhi = skm::cosf_(2.0f * kPi * u1);
     const float sinThetaI = -cosTheta * so + sinTheta * cosPhi * co;
     const float cosThetaI = safe_sqrtf(1.0f - sqrf(sinThetaI));
     const float dphi = p < 3 ? hair_Phi(p, g.gammaO, g.gammaT) + hair_sample_trimmed_logistic(u3, t.s, -kPi, kPi) : 2.0f * kPi * u3;
     const float phiI = g.phiO + dphi;
-    return f3{ sinThetaI, cosThetaI * cosf(phiI), cosThetaI * sinf(phiI) };
+    return f3{ sinThetaI, cosThetaI * skm::cosf_(phiI), cosThetaI * skm::sinf_(phiI) };
 }
 // hair frame from the MDL state: x = tangent_u, z = normal orthogonalised against it, y = z x x
 static inline bool hair_frame(const BsdfState& st, f3& X, f3& Y, f3& Z)

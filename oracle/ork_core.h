@@ -277,10 +277,10 @@ static inline SphQuad sph_quad_init(const UniformLight& l, const f3& o) // Light
     const f3 n1 = normalize(cross(v10, v11));
     const f3 n2 = normalize(cross(v11, v01));
     const f3 n3 = normalize(cross(v01, v00));
-    const float g0 = acosf(-dot(n0, n1));
-    const float g1 = acosf(-dot(n1, n2));
-    const float g2 = acosf(-dot(n2, n3));
-    const float g3 = acosf(-dot(n3, n0));
+    const float g0 = skm::acosf_(-dot(n0, n1));
+    const float g1 = skm::acosf_(-dot(n1, n2));
+    const float g2 = skm::acosf_(-dot(n2, n3));
+    const float g3 = skm::acosf_(-dot(n3, n0));
     q.b0 = n0.z;
     q.b1 = n2.z;
     q.b0sq = q.b0 * q.b0;
@@ -291,7 +291,7 @@ static inline SphQuad sph_quad_init(const UniformLight& l, const f3& o) // Light
 static inline f3 sph_quad_sample(const SphQuad& q, float u, float v) // Lights.h:155-189
 {
     const float au = u * q.S + q.k;
-    const float fu = (cosf(au) * q.b0 - q.b1) / sinf(au);
+    const float fu = (skm::cosf_(au) * q.b0 - q.b1) / skm::sinf_(au);
     float cu = 1.0f / sqrtf(fu * fu + q.b0sq) * (fu > 0.0f ? 1.0f : -1.0f);
     cu = clampf(cu, -1.0f, 1.0f);
     float xu = -(cu * q.z0) / sqrtf(1.0f - cu * cu);
@@ -323,7 +323,7 @@ static inline float get_rect_light_pdf(const UniformLight& l, const f3& lightHit
 }
 static inline float get_direct_light_pdf(float angle) // Lights.h:211-214: float * float(1 - cosf)
 {
-    return 1.0f / (2.0f * kPi * (1.0f - cosf(angle)));
+    return 1.0f / (2.0f * kPi * (1.0f - skm::cosf_(angle)));
 }
 static inline float get_sphere_light_pdf() // Lights.h:216-219
 {
@@ -405,12 +405,12 @@ static inline void create_coordinate_system(const f3& N, f3& Nt, f3& Nb) // Ligh
 static inline f3 sample_cone(float ux, float uy, float angle, const f3& direction, float& pdf)
 {
     const float phi = (float)(2.0 * (double)kPi * (double)ux);
-    const float cosTheta = (float)(1.0 - (double)uy * (1.0 - (double)cosf(angle)));
+    const float cosTheta = (float)(1.0 - (double)uy * (1.0 - (double)skm::cosf_(angle)));
     const float sinTheta = (float)sqrt(1.0 - (double)(cosTheta * cosTheta));
     f3 u, v;
     create_coordinate_system(direction, u, v);
-    const f3 sampledDir = normalize(cosf(phi) * sinTheta * u + sinf(phi) * sinTheta * v + cosTheta * direction);
-    pdf = (float)(1.0 / (2.0 * (double)kPi * (1.0 - (double)cosf(angle))));
+    const f3 sampledDir = normalize(skm::cosf_(phi) * sinTheta * u + skm::sinf_(phi) * sinTheta * v + cosTheta * direction);
+    pdf = (float)(1.0 / (2.0 * (double)kPi * (1.0 - (double)skm::cosf_(angle))));
     return sampledDir;
 }
 static inline LightSampleData sample_distant_light(const UniformLight& l, float ux, float uy,
@@ -436,7 +436,7 @@ static inline LightSampleData sample_sphere_light(const UniformLight& l, float u
     const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
     const float phi = 2.0f * kPi * uy;
     const float radius = l.points[0].x;
-    const f3 sphereDirection{ sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta };
+    const f3 sphereDirection{ sinTheta * skm::cosf_(phi), sinTheta * skm::sinf_(phi), cosTheta };
     const f3 lightPoint = mk3(l.points[1]) + radius * sphereDirection;
     d.L = normalize(lightPoint - hitPoint);
     d.distToLight = length(lightPoint - hitPoint);

@@ -9,6 +9,10 @@
 //   * lerp(a,b,t)      == a + t*(b-a)                       (sutil/vec_math.h:504-507)
 // Compile with -ffp-contract=off so no FMA contraction changes the rounding.
 #pragma once
+// sin / cos / acos / asin / atan2 / exp / log / sinh / pow: the SAME text the device code compiles (fixed polynomials in correctly rounded
+// operations: identical bits on both sides; accuracy against glibc: tests/test_libm.py).  The one include that points from the checker to the
+// product tree -- for libm stand-ins only; everything that restates the reference is written separately in oracle/.
+#include "../strelka_amd/csrc/skh_libm.h"
 #include <cmath>
 #include <cstdint>
 #include <cstring>

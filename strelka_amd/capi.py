@@ -264,7 +264,7 @@ class Context:
 
     # skh_unit: (words in, words out) per record
     UNITS = {"sampler": (0, 5, 3), "sobol": (1, 2, 1), "light_sample": (2, 5, 12), "light_pdf": (3, 6, 1), "light_normal": (4, 3, 4),
-             "mis": (5, 2, 1), "accumulate": (6, 3, 3), "tonemap": (7, 3, 6)}
+             "mis": (5, 2, 1), "accumulate": (6, 3, 3), "tonemap": (7, 3, 6), "libm": (8, 2, 10)}
 
     def unit_probe(self, unit, records, param=0, consts=None):
         """skh_unit_probe: one device call of the named function per record (include/strelka_hip.h lists the record layouts);

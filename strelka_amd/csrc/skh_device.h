@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "skh_libm.h"
 
 namespace skh
 {
@@ -431,10 +432,10 @@ SKH_DI SphQuad sph_quad_init(const Light& l, const v3& o) // Lights.h:97-153
     const v3 n1 = normalize(cross(v10, v11));
     const v3 n2 = normalize(cross(v11, v01));
     const v3 n3 = normalize(cross(v01, v00));
-    const float g0 = acosf(-dot(n0, n1));
-    const float g1 = acosf(-dot(n1, n2));
-    const float g2 = acosf(-dot(n2, n3));
-    const float g3 = acosf(-dot(n3, n0));
+    const float g0 = skm::acosf_(-dot(n0, n1));
+    const float g1 = skm::acosf_(-dot(n1, n2));
+    const float g2 = skm::acosf_(-dot(n2, n3));
+    const float g3 = skm::acosf_(-dot(n3, n0));
     q.b0 = n0.z;
     q.b1 = n2.z;
     q.b0sq = q.b0 * q.b0;
@@ -445,7 +446,7 @@ SKH_DI SphQuad sph_quad_init(const Light& l, const v3& o) // Lights.h:97-153
 SKH_DI v3 sph_quad_sample(const SphQuad& q, float u, float v) // Lights.h:155-189
 {
     const float au = u * q.S + q.k;
-    const float fu = (cosf(au) * q.b0 - q.b1) / sinf(au);
+    const float fu = (skm::cosf_(au) * q.b0 - q.b1) / skm::sinf_(au);
     float cu = 1.0f / sqrtf(fu * fu + q.b0sq) * (fu > 0.0f ? 1.0f : -1.0f);
     cu = clampf(cu, -1.0f, 1.0f);
     float xu = -(cu * q.z0) / sqrtf(1.0f - cu * cu);
@@ -472,7 +473,7 @@ SKH_DI float get_light_pdf(const Light& l, const v3& lightHitPoint, const v3& su
     case 2:
         return 1.0f / (4.0f * SKH_PI);
     case 3:
-        return 1.0f / (2.0f * SKH_PI * (1.0f - cosf(l.halfAngle)));
+        return 1.0f / (2.0f * SKH_PI * (1.0f - skm::cosf_(l.halfAngle)));
     default:
         break;
     }
@@ -531,12 +532,12 @@ SKH_DI void create_coordinate_system(const v3& N, v3& Nt, v3& Nb) // Lights.h:29
 SKH_DI v3 sample_cone(float ux, float uy, float angle, const v3& direction, float& pdf)
 {
     const float phi = (float)(2.0 * (double)SKH_PI * (double)ux);
-    const float cosTheta = (float)(1.0 - (double)uy * (1.0 - (double)cosf(angle)));
+    const float cosTheta = (float)(1.0 - (double)uy * (1.0 - (double)skm::cosf_(angle)));
     const float sinTheta = (float)sqrt(1.0 - (double)(cosTheta * cosTheta));
     v3 u, v;
     create_coordinate_system(direction, u, v);
-    const v3 sampledDir = normalize(cosf(phi) * sinTheta * u + sinf(phi) * sinTheta * v + cosTheta * direction);
-    pdf = (float)(1.0 / (2.0 * (double)SKH_PI * (1.0 - (double)cosf(angle))));
+    const v3 sampledDir = normalize(skm::cosf_(phi) * sinTheta * u + skm::sinf_(phi) * sinTheta * v + cosTheta * direction);
+    pdf = (float)(1.0 / (2.0 * (double)SKH_PI * (1.0 - (double)skm::cosf_(angle))));
     return sampledDir;
 }
 SKH_DI LightSample sample_distant_light(const Light& l, float ux, float uy) // Lights.h:319-333
@@ -559,7 +560,7 @@ SKH_DI LightSample sample_sphere_light(const Light& l, float ux, float uy, const
     const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
     const float phi = 2.0f * SKH_PI * uy;
     const float radius = l.points[0].x;
-    const v3 sphereDirection = mk3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+    const v3 sphereDirection = mk3(sinTheta * skm::cosf_(phi), sinTheta * skm::sinf_(phi), cosTheta);
     const v3 lightPoint = mk3(l.points[1]) + radius * sphereDirection;
     d.L = normalize(lightPoint - hitPoint);
     d.distToLight = length(lightPoint - hitPoint);
@@ -941,7 +942,7 @@ SKH_DI v3 cosine_hemisphere(float u1, float u2, float& cosTheta)
     const float r = sqrtf(u1);
     const float phi = 2.0f * SKH_PI * u2;
     cosTheta = sqrtf(fmaxf(0.0f, 1.0f - u1));
-    return mk3(r * cosf(phi), r * sinf(phi), cosTheta);
+    return mk3(r * skm::cosf_(phi), r * skm::sinf_(phi), cosTheta);
 }
 SKH_DI v3 schlick3(const v3& f0, float c)
 {
@@ -970,8 +971,8 @@ SKH_DI v3 ggx_sample_vndf(const v3& Ve, float alpha, float u1, float u2) // Heit
     const v3 T2 = cross(Vh, T1);
     const float r = sqrtf(u1);
     const float phi = 2.0f * SKH_PI * u2;
-    const float t1 = r * cosf(phi);
-    float t2 = r * sinf(phi);
+    const float t1 = r * skm::cosf_(phi);
+    float t2 = r * skm::sinf_(phi);
     const float s = 0.5f * (1.0f + Vh.z);
     t2 = (1.0f - s) * sqrtf(fmaxf(0.0f, 1.0f - t1 * t1)) + s * t2;
     const v3 Nh = t1 * T1 + t2 * T2 + sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2)) * Vh;
@@ -1117,7 +1118,7 @@ SKH_DI float safe_sqrtf_(float x)
 }
 SKH_DI float safe_asinf_(float x)
 {
-    return asinf(clampf(x, -1.0f, 1.0f));
+    return skm::asinf_(clampf(x, -1.0f, 1.0f));
 }
 SKH_DI float hair_pow20(float x)
 {
@@ -1147,25 +1148,25 @@ SKH_DI float hair_I0(float x)
 SKH_DI float hair_logI0(float x)
 {
     if (x > 12.0f)
-        return x + 0.5f * ((-logf(2.0f * SKH_PI) + logf(1.0f / x)) + 1.0f / (8.0f * x));
-    return logf(hair_I0(x));
+        return x + 0.5f * ((-skm::logf_(2.0f * SKH_PI) + skm::logf_(1.0f / x)) + 1.0f / (8.0f * x));
+    return skm::logf_(hair_I0(x));
 }
 SKH_DI float hair_Mp(float cosThetaI, float cosThetaO, float sinThetaI, float sinThetaO, float v)
 {
     const float a = cosThetaI * cosThetaO / v;
     const float b = sinThetaI * sinThetaO / v;
-    return v <= 0.1f ? expf((((hair_logI0(a) - b) - 1.0f / v) + 0.6931f) + logf(1.0f / (2.0f * v))) :
-                       (expf(-b) * hair_I0(a)) / (sinhf(1.0f / v) * 2.0f * v);
+    return v <= 0.1f ? skm::expf_((((hair_logI0(a) - b) - 1.0f / v) + 0.6931f) + skm::logf_(1.0f / (2.0f * v))) :
+                       (skm::expf_(-b) * hair_I0(a)) / (skm::sinhf_(1.0f / v) * 2.0f * v);
 }
 SKH_DI float hair_logistic(float x, float s)
 {
     x = fabsf(x);
-    const float e = expf(-x / s);
+    const float e = skm::expf_(-x / s);
     return e / (s * sqrf_(1.0f + e));
 }
 SKH_DI float hair_logistic_cdf(float x, float s)
 {
-    return 1.0f / (1.0f + expf(-x / s));
+    return 1.0f / (1.0f + skm::expf_(-x / s));
 }
 SKH_DI float hair_trimmed_logistic(float x, float s, float a, float b)
 {
@@ -1174,7 +1175,7 @@ SKH_DI float hair_trimmed_logistic(float x, float s, float a, float b)
 SKH_DI float hair_sample_trimmed_logistic(float u, float s, float a, float b)
 {
     const float k = hair_logistic_cdf(b, s) - hair_logistic_cdf(a, s);
-    const float x = -s * logf(1.0f / (u * k + hair_logistic_cdf(a, s)) - 1.0f);
+    const float x = -s * skm::logf_(1.0f / (u * k + hair_logistic_cdf(a, s)) - 1.0f);
     return clampf(x, a, b);
 }
 SKH_DI float hair_Phi(int p, float gammaO, float gammaT)
@@ -1216,7 +1217,7 @@ SKH_DI HairTerms hair_terms(const Material& m)
     t.v[3] = t.v[2];
     const float bn = fmaxf(m.reserved[3] > 0.0f ? m.reserved[3] : m.roughness, 0.02f);
     t.s = 0.626657069f * ((0.265f * bn + 1.194f * (bn * bn)) + 5.372f * hair_pow22(bn));
-    t.sin2k[0] = sinf(m.reserved[4]);
+    t.sin2k[0] = skm::sinf_(m.reserved[4]);
     t.cos2k[0] = safe_sqrtf_(1.0f - sqrf_(t.sin2k[0]));
 #pragma unroll
     for (int i = 1; i < 3; ++i)
@@ -1257,7 +1258,7 @@ SKH_DI HairGeom hair_geom(const HairTerms& t, const v3& wo)
     HairGeom g;
     g.sinThetaO = clampf(wo.x, -1.0f, 1.0f);
     g.cosThetaO = safe_sqrtf_(1.0f - sqrf_(g.sinThetaO));
-    g.phiO = atan2f(wo.z, wo.y);
+    g.phiO = skm::atan2f_(wo.z, wo.y);
     const float sinThetaT = g.sinThetaO / t.eta;
     const float cosThetaT = safe_sqrtf_(1.0f - sqrf_(sinThetaT));
     const float etap = sqrtf(t.eta * t.eta - sqrf_(g.sinThetaO)) / fmaxf(g.cosThetaO, 1e-6f);
@@ -1266,7 +1267,7 @@ SKH_DI HairGeom hair_geom(const HairTerms& t, const v3& wo)
     g.gammaT = safe_asinf_(sinGammaT);
     g.gammaO = safe_asinf_(t.h);
     const float l = 2.0f * cosGammaT / fmaxf(cosThetaT, 1e-6f);
-    g.T = mk3(expf(-t.sigma_a.x * l), expf(-t.sigma_a.y * l), expf(-t.sigma_a.z * l));
+    g.T = mk3(skm::expf_(-t.sigma_a.x * l), skm::expf_(-t.sigma_a.y * l), skm::expf_(-t.sigma_a.z * l));
     return g;
 }
 SKH_DI void hair_tilt(const HairTerms& t, const HairGeom& g, int p, float& sinThetaOp, float& cosThetaOp)
@@ -1298,7 +1299,7 @@ SKH_DI void hair_eval_local(const HairTerms& t, const v3& wo, const v3& wi, v3& 
     const HairGeom g = hair_geom(t, wo);
     const float sinThetaI = clampf(wi.x, -1.0f, 1.0f);
     const float cosThetaI = safe_sqrtf_(1.0f - sqrf_(sinThetaI));
-    const float phi = atan2f(wi.z, wi.y) - g.phiO;
+    const float phi = skm::atan2f_(wi.z, wi.y) - g.phiO;
     v3 ap[4];
     float apPdf[4];
     hair_Ap(t, g.cosThetaO, g.T, ap, apPdf);
@@ -1335,14 +1336,14 @@ SKH_DI v3 hair_sample_local(const HairTerms& t, const v3& wo, float u0, float u1
     hair_tilt(t, g, p, so, co);
     const float vp = p == 0 ? t.v[0] : (p == 1 ? t.v[1] : t.v[2]); // (v[3] == v[2])
     const float ua = fmaxf(u0, 1e-5f);
-    const float cosTheta = 1.0f + vp * logf(ua + (1.0f - ua) * expf(-2.0f / vp));
+    const float cosTheta = 1.0f + vp * skm::logf_(ua + (1.0f - ua) * skm::expf_(-2.0f / vp));
     const float sinTheta = safe_sqrtf_(1.0f - sqrf_(cosTheta));
-    const float cosPhi = cosf(2.0f * SKH_PI * u1);
+    const float cosPhi = skm::cosf_(2.0f * SKH_PI * u1);
     const float sinThetaI = -cosTheta * so + sinTheta * cosPhi * co;
     const float cosThetaI = safe_sqrtf_(1.0f - sqrf_(sinThetaI));
     const float dphi = p < 3 ? hair_Phi(p, g.gammaO, g.gammaT) + hair_sample_trimmed_logistic(u3, t.s, -SKH_PI, SKH_PI) : 2.0f * SKH_PI * u3;
     const float phiI = g.phiO + dphi;
-    return mk3(sinThetaI, cosThetaI * cosf(phiI), cosThetaI * sinf(phiI));
+    return mk3(sinThetaI, cosThetaI * skm::cosf_(phiI), cosThetaI * skm::sinf_(phiI));
 }
 SKH_DI bool hair_frame(const v3& normal, const v3& tangent_u, v3& X, v3& Y, v3& Z)
 {

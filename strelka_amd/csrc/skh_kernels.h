@@ -1998,7 +1998,7 @@ __global__ void __launch_bounds__(256) k_tonemap(float4* __restrict__ image, uin
     if (gamma > 0.0f)
     {
         const float g = 1.0f / gamma;
-        c = mk3(powf(c.x, g), powf(c.y, g), powf(c.z, g));
+        c = mk3(skm::powf_(c.x, g), skm::powf_(c.y, g), skm::powf_(c.z, g));
         px.w = 1.0f;
     }
     image[i] = make_float4(c.x, c.y, c.z, px.w);

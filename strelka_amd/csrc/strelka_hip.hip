@@ -3214,8 +3214,8 @@ skh_status skh_bsdf_probe(skh_context* c, const skh_bsdf_query* queries, uint32_
 
 // ---- unit probes (tests): the device functions of the sampler, the light samplers and the accumulator, one call per record, so that
 // GPU tests can hold the HIP code against the reference-generated fixtures of tests/golden/ directly ----
-static const uint32_t kUnitIn[SKH_UNIT_COUNT] = { 20, 8, 20, 24, 12, 8, 12, 12 }, kUnitOut[SKH_UNIT_COUNT] = { 12, 4, 48, 4, 16, 4, 12, 24 };
-static const uint32_t kUnitConst[SKH_UNIT_COUNT] = { 0, 0, 112, 112, 112, 0, 12, 12 };
+static const uint32_t kUnitIn[SKH_UNIT_COUNT] = { 20, 8, 20, 24, 12, 8, 12, 12, 8 }, kUnitOut[SKH_UNIT_COUNT] = { 12, 4, 48, 4, 16, 4, 12, 24, 40 };
+static const uint32_t kUnitConst[SKH_UNIT_COUNT] = { 0, 0, 112, 112, 112, 0, 12, 12, 0 };
 __global__ void __launch_bounds__(256) k_unit_probe(uint32_t unit, uint32_t param, const float* __restrict__ consts, const uint32_t* __restrict__ in, uint32_t n,
                                                     uint32_t* __restrict__ out)
 {
@@ -3296,6 +3296,14 @@ __global__ void __launch_bounds__(256) k_unit_probe(uint32_t unit, uint32_t para
         const v3 t = tonemap(c, e), iv = inverse_tonemap(c, e);
         float* o = fout + 6 * (size_t)i;
         o[0] = t.x, o[1] = t.y, o[2] = t.z, o[3] = iv.x, o[4] = iv.y, o[5] = iv.z;
+        break;
+    }
+    case SKH_UNIT_LIBM: {
+        // skh_libm.h on the device: the bits the CPU checker's copy of the same text must reproduce
+        const float x = fin[2 * (size_t)i], y = fin[2 * (size_t)i + 1];
+        float* o = fout + 10 * (size_t)i;
+        o[0] = skm::sinf_(x), o[1] = skm::cosf_(x), o[2] = skm::acosf_(x), o[3] = skm::asinf_(x), o[4] = skm::atan2f_(y, x);
+        o[5] = skm::expf_(x), o[6] = skm::logf_(x), o[7] = skm::sinhf_(x), o[8] = skm::powf_(x, y), o[9] = skm::atan2f_(x, y);
         break;
     }
     default:

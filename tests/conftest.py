@@ -21,7 +21,7 @@ def ork():
 
 
 def pytest_sessionfinish(session, exitstatus):
-    """measured image differences of every GPU-vs-oracle comparison (tests/test_gpu_parity.py::_image_close) -> gpurun_out/"""
+    """measured image differences of every GPU-vs-oracle comparison (tests/test_gpu_parity.py::_image_equal) -> gpurun_out/"""
     mod = sys.modules.get("tests.test_gpu_parity")
     log = getattr(mod, "PARITY_LOG", None)
     if log:

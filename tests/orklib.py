@@ -143,6 +143,8 @@ def load():
             lib.ork_set_num_threads(usable_cpus())
         lib.ork_create.restype = C.c_void_p
         lib.ork_destroy.argtypes = [C.c_void_p]
+        lib.ork_libm.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.ork_libm.restype = None
         lib.ork_mis_weight.restype = C.c_float
         lib.ork_mis_weight.argtypes = [C.c_float, C.c_float]
         for name in ("ork_set_geometry", "ork_set_curves", "ork_set_instances", "ork_set_lights", "ork_set_materials",

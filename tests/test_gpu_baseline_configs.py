@@ -4,7 +4,7 @@
   C4  kitchen stand-in, 3840x2160, 6 bounces, 8 tile sets -- Russian roulette (depth > 3) and the 8-rank tile split at 4K (16 spp);
       the whole 256-spp frame once through properties + an oracle band of its 64-sub-frame prefix
   C5  hair stand-in, 1920x1080, 3 bounces                 -- full-resolution properties (hit parity is in test_gpu_fullsize)
-Tolerances are the ones of tests/test_gpu_parity.py (_image_close); ray counts and tile-sharded images are exact."""
+Images are compared with tests/test_gpu_parity.py::_image_equal (bit for bit since round 5); ray counts and tile-sharded images are exact."""
 import numpy as np
 import pytest
 
@@ -48,7 +48,7 @@ def _gpu_frame(arr, cam, W, H, spp, depth, options=None, tile_xy=None, total=Non
 
 
 def test_c1_coffeemaker_512_whole_configuration_matches_oracle():
-    from tests.test_gpu_parity import _image_close
+    from tests.test_gpu_parity import _image_equal
 
     sc = scenes.coffeemaker_standin()
     arr = sc.arrays()
@@ -56,20 +56,20 @@ def test_c1_coffeemaker_512_whole_configuration_matches_oracle():
     W = H = 512
     want, so = _oracle_frame(arr, sc.getCamera(), W, H, 16, 2)
     got, st = _gpu_frame(arr, sc.getCamera(), W, H, 16, 2)
-    _image_close(got, want)
+    _image_equal(got, want)
     assert st["rays_radiance"] == so["rays_radiance"] and W * H * 16 <= st["rays_radiance"] <= W * H * 16 * 2
     assert want[..., :3].max() > 0
 
 
 def test_c2_cornell_1024_oracle_on_two_samples_and_256_spp_properties():
-    from tests.test_gpu_parity import _image_close
+    from tests.test_gpu_parity import _image_equal
 
     sc = scenes.cornell_box()
     arr = sc.arrays()
     W = H = 1024
     want, so = _oracle_frame(arr, sc.getCamera(), W, H, 2, 4, total=256)
     got, st = _gpu_frame(arr, sc.getCamera(), W, H, 2, 4, total=256)
-    _image_close(got, want)
+    _image_equal(got, want)
     assert st["rays_radiance"] == so["rays_radiance"]
     # the whole 256-spp frame: the same bits whatever the pass size, every pixel finite and non-negative
     full, stf = _gpu_frame(arr, sc.getCamera(), W, H, 256, 4)
@@ -82,7 +82,7 @@ def test_c2_cornell_1024_oracle_on_two_samples_and_256_spp_properties():
 
 
 def test_c4_kitchen_4k_depth6_roulette_and_eight_rank_tiles():
-    from tests.test_gpu_parity import _image_close
+    from tests.test_gpu_parity import _image_equal
 
     sc = scenes.kitchen_standin()
     arr = sc.arrays()
@@ -109,11 +109,9 @@ def test_c4_kitchen_4k_depth6_roulette_and_eight_rank_tiles():
     r0, r1 = 1024, 1056
     for i in range(SPP):
         o.render_subframe(S.frame_params(sc.getCamera(), W, H, subframe_index=i, samples_this_launch=1, spp_total=256, max_depth=DEPTH), rows=(r0, r1))
-    # measured at 2 spp: relative L2 2.1e-4, 0.0033 % of the band's 123 k pixels (4 of them) off at depth 6: flipped paths as in
-    # tests/test_gpu_fullsize.py, each worth a whole sample (their weight in the LDR-space average shrinks with more sub-frames)
-    # at 16 spp: 0.020 % of the band's pixels (24) hold one flipped path among their 16 samples -- about 1.3e-5 per path, the rate of
-    # the 1-spp frames -- so the pixel bar scales with the sample count here
-    _image_close(base[r0:r1], o.read_accum()[r0:r1], l2_tol=2e-3, frac_tol=6e-4)
+    # (round 4 held this band at L2 <= 2e-3 / 0.06 % of the pixels: ~1.3e-5 of the paths were flipped across an edge by libm differences;
+    # with the shared skh_libm.h the band is equal bit for bit)
+    _image_equal(base[r0:r1], o.read_accum()[r0:r1])
 
 
 def test_c4_kitchen_4k_full_256_spp_frame_properties():
@@ -124,7 +122,7 @@ def test_c4_kitchen_4k_full_256_spp_frame_properties():
     band of a 64-sub-frame prefix of the SAME frame (spp_total 256) against the oracle."""
     from strelka_amd import capi
     from tests import orklib
-    from tests.test_gpu_parity import _image_close
+    from tests.test_gpu_parity import _image_equal
 
     sc = scenes.kitchen_standin()
     arr = sc.arrays()
@@ -158,9 +156,7 @@ def test_c4_kitchen_4k_full_256_spp_frame_properties():
     o.resize(W, H)
     for i in range(64):
         o.render_subframe(S.frame_params(sc.getCamera(), W, H, subframe_index=i, samples_this_launch=1, spp_total=SPP, max_depth=DEPTH), rows=(1024, 1056))
-    # (flipped paths at ~1.3e-5 per path as in the 16-spp band above: with 64 samples per pixel ~0.08 % of the band's pixels hold one,
-    # each worth 1/64 of a pixel -- below the 2e-3 pixel bar for most of them)
-    _image_close(band64, o.read_accum()[1024:1056], l2_tol=2e-3, frac_tol=1e-3)
+    _image_equal(band64, o.read_accum()[1024:1056])
 
 
 def test_c5_hair_1080p_depth3_properties():

@@ -45,7 +45,7 @@ def test_architectural_kitchen_hits_and_image_match_oracle():
     the image bar -- long thin triangles and big flat walls are where a conservative-box / watertight-test mismatch would show first."""
     from strelka_amd import capi, scene as S
     from tests import orklib
-    from tests.test_gpu_parity import _image_close
+    from tests.test_gpu_parity import _image_equal
 
     sc = scenes.kitchen_architectural()
     arr = sc.arrays()
@@ -68,10 +68,8 @@ def test_architectural_kitchen_hits_and_image_match_oracle():
         p = S.frame_params(sc.getCamera(), W, H, subframe_index=i, spp_total=SPP, max_depth=4)
         ctx.render_subframe(p)
         o.render_subframe(p)
-    # measured (MI355X, four image sizes, 513 k paths): 13 pixels off = 2.5e-5 per path, twice the round blobs' rate -- the ordinary flipped
-    # paths (a BSDF sample's direction differs by an ulp between libm and the ROCm device library and lands on the other side of an
-    # edge), more of them because this scene has far more edges per pixel; radiance-ray counts equal in every run.  Here: 2 pixels of 14 400
-    _image_close(ctx.read_accum(), o.read_accum(), l2_tol=5e-3, frac_tol=5e-4)
+    # (round 4: 2 of 14 400 pixels held a path flipped across an edge by an ulp of libm difference; none since both sides share skh_libm.h)
+    _image_equal(ctx.read_accum(), o.read_accum())
     assert ctx.stats()["rays_radiance"] == o.stats()["rays_radiance"]
     ctx.close()
 
@@ -153,7 +151,7 @@ def test_kitchen_1080p_subframe_image_matches_oracle(kitchen):
     sub-frame on the host cores: same tolerance as the small-scene render tests, same number of radiance rays."""
     from strelka_amd import capi
     from tests import orklib
-    from tests.test_gpu_parity import _image_close
+    from tests.test_gpu_parity import _image_equal
 
     sc, arr = kitchen
     W, H = 1920, 1080
@@ -168,10 +166,9 @@ def test_kitchen_1080p_subframe_image_matches_oracle(kitchen):
     ctx.resize(W, H)
     ctx.render_subframe(p)
     got = ctx.read_accum()
-    # measured: relative L2 7.7e-4 with 0.0014 % of the 2.07 M pixels off -- about 30 paths of 2 M land on the other side of a
-    # triangle edge (1-ulp sin/cos differences); each is a whole 1-spp sample, some of them on a light worth 30 against an
-    # image mean of 0.1, so those few pixels ARE the L2 norm.  The pixel fraction is the meaningful bar here: <= 0.01 %.
-    _image_close(got, want, l2_tol=3e-3)
+    # (round 4: ~30 of these 2 M paths landed on the other side of a triangle edge -- 1-ulp sin / cos differences between the two libms --,
+    # relative L2 7.7e-4.  Equal bit for bit now.)
+    _image_equal(got, want)
     assert ctx.stats()["rays_radiance"] == o.stats()["rays_radiance"]
     ctx.close()
 

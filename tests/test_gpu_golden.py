@@ -75,7 +75,7 @@ def test_sobol_words_bit_exact_on_the_device(ctx):
     assert np.array_equal(out[:, 0], want)
 
 
-@pytest.mark.parametrize("method,fname,ulps", [(0, "lights_rect_uniform.f32", 0), (1, "lights_rect_sph.f32", 64),
+@pytest.mark.parametrize("method,fname,ulps", [(0, "lights_rect_uniform.f32", 0), (1, "lights_rect_sph.f32", -1),
                                                (2, "lights_sphere.f32", 4), (3, "lights_distant.f32", 4)])
 def test_light_sampling_on_the_device(ctx, method, fname, ulps):
     rect, sph, dist = _lights()
@@ -86,8 +86,11 @@ def test_light_sampling_on_the_device(ctx, method, fname, ulps):
     if ulps == 0:
         assert np.array_equal(out.view(np.uint32), want.view(np.uint32))  # SampleRectLightUniform: + - * / sqrt only
     elif method == 1:
-        # the spherical-rectangle sampler chains acos / cos / sin (the CPU test's bar)
-        assert np.allclose(out, want, rtol=2e-4, atol=2e-5, equal_nan=True)
+        # the spherical-rectangle sampler chains four acos, then cos / sin through a cancelling sum (Lights.h:97-189): a 1-ulp difference
+        # in one acos is amplified ~100x in the sampled point.  Against the fixtures (glibc) the shared skm:: functions measure <= 1.2e-5
+        # relative / 160 ulp on a near-zero coordinate; the bar is 3e-5 relative + 1e-6 absolute (was 2e-4 + 2e-5 with the ROCm device
+        # library).  Against the CPU restatement the device is exact: test_light_samplers_on_the_device_equal_the_checkers_bit_for_bit.
+        assert np.allclose(out, want, rtol=3e-5, atol=1e-6, equal_nan=True)
     else:
         assert _close_ulp(out, want, ulps).all()
 
@@ -146,3 +149,38 @@ def test_unit_probe_refuses_bad_arguments(ctx):
 
     with pytest.raises(capi.SkhError):
         ctx.unit_probe("light_sample", np.zeros((1, 5), np.float32), param=0, consts=None)  # a light sampler without a light
+
+
+def test_libm_is_bit_identical_on_the_device(ctx):
+    """strelka_amd/csrc/skh_libm.h compiled for gfx950 returns the bits the CPU checker's copy of the same text returns -- sin, cos, acos,
+    asin, atan2, exp, log, sinh, pow over 400 k arguments incl. infinities, NaN, zeros, subnormal results.  This is what lets the image
+    comparisons of this suite be array_equal: both sides now share every rounding of the render path."""
+    from tests import orklib
+    from tests.test_libm import cpu_libm, libm_inputs
+
+    rec = libm_inputs()
+    want = cpu_libm(rec)
+    got = ctx.unit_probe("libm", rec).view(np.float32)
+    both_nan = np.isnan(got) & np.isnan(want)
+    same = (got.view(np.uint32) == want.view(np.uint32)) | both_nan
+    assert same.all(), (int((~same).sum()), rec[np.argwhere(~same)[:5, 0]], np.argwhere(~same)[:5])
+
+
+@pytest.mark.parametrize("method", [0, 1, 2, 3])
+def test_light_samplers_on_the_device_equal_the_checkers_bit_for_bit(ctx, method):
+    """Beyond the fixtures' ulp bars: device and CPU restatement agree exactly on every light sample (they share skh_libm.h)."""
+    import ctypes as C
+
+    from tests import orklib
+
+    ork = orklib.load()
+    rect, sph, dist = _lights()
+    light = {0: rect, 1: rect, 2: sph, 3: dist}[method]
+    inp = g("lights_in.f32", np.float32).reshape(-1, 5)
+    P = np.ascontiguousarray(inp[:, :3])
+    u = np.ascontiguousarray(inp[:, 3:5])
+    want = np.zeros((len(inp), 12), np.float32)
+    ork.ork_sample_light(light.ctypes.data_as(C.c_void_p), method, u.ctypes.data_as(C.c_void_p), P.ctypes.data_as(C.c_void_p), len(inp), want.ctypes.data_as(C.c_void_p))
+    got = ctx.unit_probe("light_sample", inp, param=method, consts=light).view(np.float32)
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), int((~same).sum())

@@ -74,7 +74,7 @@ def _close_ulp(a, b, ulps):
     return ok
 
 
-@pytest.mark.parametrize("method,fname,ulps", [(0, "lights_rect_uniform.f32", 0), (1, "lights_rect_sph.f32", 64),
+@pytest.mark.parametrize("method,fname,ulps", [(0, "lights_rect_uniform.f32", 0), (1, "lights_rect_sph.f32", -1),
                                                (2, "lights_sphere.f32", 4), (3, "lights_distant.f32", 4)])
 def test_light_sampling(ork, method, fname, ulps):
     rect, sph, dist = _lights()
@@ -87,9 +87,10 @@ def test_light_sampling(ork, method, fname, ulps):
     if ulps == 0:
         assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
     else:
-        # the spherical-rectangle sampler chains acos/cos/sin; compare with an absolute+relative tolerance
+        # the spherical-rectangle sampler chains four acos, then cos / sin through a cancelling sum: a 1-ulp difference in one acos (the
+        # fixture: glibc; here: skm::acosf_, <= 1.3 ulp) is amplified ~100x.  Measured <= 1.2e-5 relative; bar 3e-5 + 1e-6 absolute.
         if method == 1:
-            assert np.allclose(out, want, rtol=2e-4, atol=2e-5, equal_nan=True)
+            assert np.allclose(out, want, rtol=3e-5, atol=1e-6, equal_nan=True)
         else:
             assert _close_ulp(out, want, ulps).all()
 
@@ -105,7 +106,13 @@ def test_light_pdfs_and_normals(ork):
     pdf = np.zeros(len(inp), np.float32); sa = np.zeros(len(inp), np.float32)
     ork.ork_light_pdf(p(rect), p(lp), p(P), len(inp), p(pdf), p(sa))
     assert np.array_equal(pdf.view(np.uint32), want[:, 0].copy().view(np.uint32))
-    assert np.allclose(sa, want[:, 1], rtol=2e-4, atol=1e-6)
+    # 1 / (solid angle), the angle being g0 + g1 + g2 + g3 - 2 pi with four acos terms near pi / 2 (Lights.h:131-138): whatever libm computes
+    # them, the sum carries an ABSOLUTE noise of a few ulp(pi / 2) = a few 1e-7 sr, which is all there is of the angle of a far, small light
+    # (the fixture's own 1 / 599186 sr is one such value).  The fixture came from glibc's acosf, the restatement uses the shared
+    # skm::acosf_ (<= 1.3 ulp, skh_libm.h): the angles must agree to 4e-7 sr absolute (measured 2.4e-7) or 2e-4 relative, whichever is larger.
+    with np.errstate(divide="ignore"):
+        ang, ang_want = 1.0 / sa.astype(np.float64), 1.0 / want[:, 1].astype(np.float64)
+    assert np.allclose(ang, ang_want, rtol=2e-4, atol=4e-7)
     ork.ork_light_pdf(p(sph), p(lp), p(P), len(inp), p(pdf), None)
     assert np.array_equal(pdf, want[:, 2])
     ork.ork_light_pdf(p(dist), p(lp), p(P), len(inp), p(pdf), None)
