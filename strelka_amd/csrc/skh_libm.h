@@ -55,6 +55,8 @@ SKH_LIBM_FN bool isnan_(float x)
 // x * 2^k, exact while the result is normal; two-step for results in the subnormal range
 SKH_LIBM_FN float scale2(float x, int k)
 {
+    if (k >= -126 && k <= 127)
+        return x * u2f((uint32_t)(k + 127) << 23);
     if (k > 127)
     {
         x = x * u2f(0x7f000000u); // 2^127
@@ -102,6 +104,9 @@ SKH_LIBM_FN float cos_poly(float r)
 }
 SKH_LIBM_FN float sinf_(float x)
 {
+#if defined(SKH_LIBM_NATIVE) && defined(__HIP_DEVICE_COMPILE__)
+    return __ocml_sin_f32(x);
+#endif
     if (!(fabs_(x) < 3.0e38f))
         return x - x; // inf, nan -> nan
     float r;
@@ -112,6 +117,9 @@ SKH_LIBM_FN float sinf_(float x)
 }
 SKH_LIBM_FN float cosf_(float x)
 {
+#if defined(SKH_LIBM_NATIVE) && defined(__HIP_DEVICE_COMPILE__)
+    return __ocml_cos_f32(x);
+#endif
     if (!(fabs_(x) < 3.0e38f))
         return x - x;
     float r;
@@ -134,6 +142,9 @@ SKH_LIBM_FN float asin_poly(float z)
 }
 SKH_LIBM_FN float asinf_(float x)
 {
+#if defined(SKH_LIBM_NATIVE) && defined(__HIP_DEVICE_COMPILE__)
+    return __ocml_asin_f32(x);
+#endif
     const float a = fabs_(x);
     if (!(a <= 1.0f))
         return (x - x) / (x - x); // nan
@@ -154,6 +165,9 @@ SKH_LIBM_FN float asinf_(float x)
 }
 SKH_LIBM_FN float acosf_(float x)
 {
+#if defined(SKH_LIBM_NATIVE) && defined(__HIP_DEVICE_COMPILE__)
+    return __ocml_acos_f32(x);
+#endif
     const float a = fabs_(x);
     if (!(a <= 1.0f))
         return (x - x) / (x - x);
@@ -198,6 +212,9 @@ SKH_LIBM_FN float atan_pos(float a) // a >= 0
 }
 SKH_LIBM_FN float atan2f_(float y, float x)
 {
+#if defined(SKH_LIBM_NATIVE) && defined(__HIP_DEVICE_COMPILE__)
+    return __ocml_atan2_f32(y, x);
+#endif
     if (isnan_(x) || isnan_(y))
         return x + y;
     const float ax = fabs_(x), ay = fabs_(y);
@@ -218,6 +235,9 @@ SKH_LIBM_FN float atan2f_(float y, float x)
 // ---- exp / log / sinh / pow -------------------------------------------------------------------------------------------------------
 SKH_LIBM_FN float expf_(float x)
 {
+#if defined(SKH_LIBM_NATIVE) && defined(__HIP_DEVICE_COMPILE__)
+    return __ocml_exp_f32(x);
+#endif
     if (isnan_(x))
         return x;
     if (x > 88.7228394f)
@@ -238,6 +258,9 @@ SKH_LIBM_FN float expf_(float x)
 }
 SKH_LIBM_FN float logf_(float x)
 {
+#if defined(SKH_LIBM_NATIVE) && defined(__HIP_DEVICE_COMPILE__)
+    return __ocml_log_f32(x);
+#endif
     if (isnan_(x))
         return x;
     if (x < 0.0f)
@@ -280,6 +303,9 @@ SKH_LIBM_FN float logf_(float x)
 }
 SKH_LIBM_FN float sinhf_(float x)
 {
+#if defined(SKH_LIBM_NATIVE) && defined(__HIP_DEVICE_COMPILE__)
+    return __ocml_sinh_f32(x);
+#endif
     const float a = fabs_(x);
     if (isnan_(x))
         return x;
@@ -303,6 +329,9 @@ SKH_LIBM_FN float sinhf_(float x)
 // the product y * log(x) carries log's low part along, so that the result stays within a few ulp for |y log x| up to ~50
 SKH_LIBM_FN float powf_(float x, float y)
 {
+#if defined(SKH_LIBM_NATIVE) && defined(__HIP_DEVICE_COMPILE__)
+    return __ocml_pow_f32(x, y);
+#endif
     if (isnan_(x) || isnan_(y))
         return x + y;
     if (y == 0.0f || x == 1.0f)
@@ -324,3 +353,9 @@ SKH_LIBM_FN float powf_(float x, float y)
 }
 
 } // namespace skm
+
+// A/B only (docs/LOG.md round 5, "what the shared libm costs"): -DSKH_LIBM_NATIVE makes the DEVICE side call the ROCm device library again --
+// faster where it leans on v_exp_f32 / v_log_f32 / v_sin_f32, but no longer the bits the CPU checker computes (the image tests then fail).
+#if defined(SKH_LIBM_NATIVE) && defined(__HIP_DEVICE_COMPILE__)
+#    define SKH_LIBM_NATIVE_ACTIVE 1
+#endif
