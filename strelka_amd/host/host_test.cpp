@@ -109,7 +109,7 @@ int main(int argc, char** argv)
         }
         if (!loaded.saveDump(dir + "/resaved.skscene"))
             return 7;
-        printf("host_test load ok: %zu vertices, %zu instances, %zu lights, %u cameras\n", loaded.getVertices().size(), loaded.getInstances().size(),
+        printf("host_test load ok: %zu vertices, %zu instances, %zu lights, %zu cameras\n", loaded.getVertices().size(), loaded.getInstances().size(),
                loaded.getLights().size(), loaded.getCameraCount());
         return 0;
     }

@@ -310,9 +310,9 @@ public:
     // flat binary dump of the arrays render() uploads (".skscene"; format in strelka_amd/scene_io.py)
     bool saveDump(const std::string& path) const;
     bool loadDump(const std::string& path); // replaces the scene's content; false (scene untouched) on a malformed file
-    uint32_t getCameraCount() const
+    size_t getCameraCount() // (scene.h:284-288: size_t, not const -- it takes the camera mutex there)
     {
-        return (uint32_t)mCameras.size();
+        return mCameras.size();
     }
 
     std::vector<Vertex>& getVertices()
