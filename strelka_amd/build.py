@@ -80,10 +80,30 @@ def build_host(force=False, verbose=False):
                       "-I" + os.path.join(ROOT, "include"), "-L" + libdir, "-lstrelka_hip", "-Wl,-rpath,$ORIGIN/.."],
             common + ["-o", HOST_TEST, os.path.join(HOST_DIR, "host_test.cpp"), "-L" + HOST_DIR, "-loka_hip", "-L" + libdir,
                       "-lstrelka_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/.."]]
-    for c in cmds:
-        if verbose:
-            print(" ".join(c))
-        subprocess.check_call(c)
+    # (pytest -n runs several workers: one builds, under the lock, into temporary files that are renamed into place; the others wait and find
+    # the files up to date -- a reader must never see a half-written liboka_hip.so)
+    import fcntl
+
+    def stale():
+        return force or not os.path.exists(HOST_TEST) or any(os.path.getmtime(s) > os.path.getmtime(HOST_TEST) for s in srcs)
+
+    with open(HOST_LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if stale():
+                tmp_lib, tmp_test = "%s.tmp.%d" % (HOST_LIB, os.getpid()), "%s.tmp.%d" % (HOST_TEST, os.getpid())
+                cmds[0][cmds[0].index(HOST_LIB)] = tmp_lib
+                cmds[1][cmds[1].index(HOST_TEST)] = tmp_test
+                if verbose:
+                    print(" ".join(cmds[0]))
+                subprocess.check_call(cmds[0])
+                os.replace(tmp_lib, HOST_LIB)
+                if verbose:
+                    print(" ".join(cmds[1]))
+                subprocess.check_call(cmds[1])
+                os.replace(tmp_test, HOST_TEST)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return HOST_TEST
 
 

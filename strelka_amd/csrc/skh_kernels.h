@@ -34,11 +34,16 @@ struct HostInstance // == skh_instance (64 B), as uploaded
     uint32_t type, geom, material, light;
 };
 
+#define SKH_WORLD_CURVES 16
+#define SKH_REF_CURVEROOT 0x40000000 // stack entry (world-only kernel with curves): (ref & 0xffff) indexes DevScene::worldCurveRoot / worldCurveInst
 struct DevScene
 {
     const Node4* tlasNodes;
     const uint32_t* tlasInst; // leaf order -> instance id
     int tlasRoot;
+    uint32_t numWorldCurves; // curve instances under identity transforms, walked from the world-only kernel (no TLAS leaf): their curve trees' roots ...
+    int worldCurveRoot[SKH_WORLD_CURVES];
+    uint32_t worldCurveInst[SKH_WORLD_CURVES]; // ... and instance ids
     uint32_t numInstances;
     const DevInstance* inst; // per instance (shading side: w2o)
     const DevInstance* tinst; // per TLAS leaf: (instance, BLAS subtree) after opening; pad = instance id
@@ -224,6 +229,9 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 #define SKH_CURVE_MIN_WAVES 6 // 80 VGPRs (29 dwords spilled) for the build with the inlined curve intersector: hair stand-in 425 / 455 / 478 / 480 Mray/s
                               // at 4 / 5 / 6 / 7 waves per SIMD (the build needs 104 VGPRs unconstrained)
 #endif
+#ifndef SKH_WORLD_CURVE_MIN_WAVES
+#define SKH_WORLD_CURVE_MIN_WAVES 6 // the world-only kernel with the curve block
+#endif
 #ifndef SKH_ANYHIT_MIN_WAVES
 #define SKH_ANYHIT_MIN_WAVES 7 // the any-hit build needs 71 VGPRs: 28 waves per CU (shadow 45.9 -> 43.4 ms over 24)
 #endif
@@ -274,14 +282,19 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 // (The measured-negative variants of round 4 -- pop-time culling, postponed leaves, the touch prefetch, packed node FMAs, 8-wide nodes, continuations --
 // live in experiments/skh_trace_r04_variants.h with their numbers; three builds ship: world-only, two-level, two-level + curves.)
 template <bool ANY_HIT, bool COUNT, bool CURVES, bool WORLD = false>
-__global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (ANY_HIT ? SKH_WORLD_ANYHIT_MIN_WAVES : SKH_WORLD_CLOSEST_MIN_WAVES) : (CURVES ? SKH_CURVE_MIN_WAVES : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES))) SKH_TRACE_ATTR
+__global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? SKH_WORLD_CURVE_MIN_WAVES : SKH_CURVE_MIN_WAVES) : (WORLD ? (ANY_HIT ? SKH_WORLD_ANYHIT_MIN_WAVES : SKH_WORLD_CLOSEST_MIN_WAVES) : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES))) SKH_TRACE_ATTR
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
             uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, 
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
             StatsDev* __restrict__ stats)
 {
-    static_assert(!WORLD || !CURVES, "the world-only build is a triangle kernel");
-    constexpr bool TRICOOP = SKH_TRI_COOP && WORLD; // (closest-hit and any-hit builds of the world-only kernel)
+    // WORLD && CURVES (round 5): the world-only kernel with the curve block in it -- scenes whose every mesh instance is baked and whose curve
+    // instances (at most SKH_WORLD_CURVES) sit under identity transforms.  Their curve trees' roots wait at the BOTTOM of every ray's stack as
+    // markers (SKH_REF_CURVEROOT | k): a ray walks the world-space triangles first, then each curve tree, with no top level, no instance entry
+    // block, no sentinel and no world-space copy of the ray (hair stand-in: an instance-entry pass in 98 % of the outer iterations before).
+    // Taking a marker applies the identity transform to the ray exactly as the instance path does (x * 1 + y * 0 + z * 0 can turn a -0 into
+    // +0): hit records are the instance path's, bit for bit.
+    constexpr bool TRICOOP = SKH_TRI_COOP && WORLD && !CURVES; // (closest-hit and any-hit builds of the world-only TRIANGLE kernel)
     // per-lane stack entries in LDS (the rest: SKH_STACK_OVF entries in global memory); TRICOOP gives one up for its two 64-byte lane tables
     // (LDS is handed out in 1280-byte granules here: 20 x 256 B = 4 granules exactly, 128 B more would cost a fifth = 25 instead of 28 waves per CU)
     constexpr int NLDS = TRICOOP ? SKH_STACK_LDS - 1 : SKH_STACK_LDS;
@@ -428,7 +441,22 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (ANY_HIT ? SKH_WORLD_
                 if (ANY_HIT && !WORLD)
                     invw = inv;
                 const int wr0 = sc.worldRoot, wr1 = ANY_HIT ? SKH_REF_INVALID : sc.lightRoot; // (kernel arguments: scalar branches)
-                if (wr0 != SKH_REF_INVALID || wr1 != SKH_REF_INVALID)
+                if (WORLD && CURVES)
+                {
+                    // stack, bottom to top: the curve trees' markers, the light proxies' root; current node: the world-space triangles' root
+                    sh = make_shear(dw);
+                    curInst = 0xffffffffu;
+                    curType = 0;
+                    sp = 0;
+                    for (uint32_t k = 0; k < sc.numWorldCurves; ++k)
+                        lds[(sp++) * SKH_TRACE_BLOCK] = (int)(SKH_REF_CURVEROOT | k);
+                    if (wr0 != SKH_REF_INVALID && wr1 != SKH_REF_INVALID)
+                        lds[(sp++) * SKH_TRACE_BLOCK] = wr1;
+                    cur = wr0 != SKH_REF_INVALID ? wr0 : wr1;
+                    if (cur == SKH_REF_INVALID)
+                        cur = lds[(--sp) * SKH_TRACE_BLOCK]; // (no triangles at all: the first marker; numWorldCurves >= 1 in this build)
+                }
+                else if (wr0 != SKH_REF_INVALID || wr1 != SKH_REF_INVALID)
                 {
                     // baked instances first: the ray starts INSIDE their world-space groups (identity entry: o = ow, d = dw), the top
                     // level waits under a sentinel on the stack
@@ -668,9 +696,27 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, WORLD ? (ANY_HIT ? SKH_WORLD_
             // ---- descend through internal nodes ----
             while ((!TRICOOP || hasRay) && cur >= 0 && cur != SKH_REF_INVALID)
             {
+                if constexpr (WORLD && CURVES)
+                {
+                    if (cur & SKH_REF_CURVEROOT)
+                    {
+                        // the next curve tree (the triangles and the trees before it are done): the ray goes through the identity transform as it
+                        // would through the instance's record, the instance id comes from the table
+                        const uint32_t k = (uint32_t)cur & 0xffffu;
+                        const float ident[12] = { 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f };
+                        o = xform_point_rel(ident, o);
+                        d = xform_vector(ident, d);
+                        inv = rcp3(d);
+                        curInst = sc.worldCurveInst[k];
+                        curType = 2;
+                        cur = sc.worldCurveRoot[k];
+                        if (cur < 0 || cur == SKH_REF_INVALID)
+                            break; // (a tree of one leaf)
+                    }
+                }
                 SKH_LP(itN++; rayNodes++;)
                 // one 64-byte fetch = four quantised child boxes
-                const float4* np = reinterpret_cast<const float4*>((WORLD ? sc.triNodes : nodes) + cur);
+                const float4* np = reinterpret_cast<const float4*>((WORLD ? (CURVES && curType == 2 ? sc.segNodes : sc.triNodes) : nodes) + cur);
                 const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
                 if (COUNT)
                     tc.nodes++;

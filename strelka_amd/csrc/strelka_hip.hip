@@ -141,6 +141,9 @@ struct skh_context
         dOvf, dOvf2, dStats, dScratchImage;
     uint32_t traceBlocks = 0;
     uint32_t curveSplitBuilt = 1;
+    uint32_t numWorldCurves = 0; // curve instances under identity transforms that the world-only kernel walks itself (skh_build_accel)
+    int worldCurveRoot[SKH_WORLD_CURVES];
+    uint32_t worldCurveInst[SKH_WORLD_CURVES];
     uint32_t numTlasLeaves = 0;
     bool countTraversal = false, timing = false;
     // scheduling of the persistent trace kernels, measured on MI355X (kitchen C3, 32 sub-frames per pass):
@@ -162,6 +165,7 @@ struct skh_context
     uint32_t nodeBreakClosest = 32, nodeBreakShadow = 28; // (closest: 24 -> 32 in round 3 for the world-only kernel: kitchen 86.6 -> 85.9 ms, unshared 74.7 -> 73.6, three runs each;
                                                           // shadow: 20 -> 28 in round 4, with the shared triangle pass: kitchen 34.85 -> 34.3 ms, unshared 29.3 -> 28.55, three runs each; 36: 34.35 / 28.7)
     // leave the node loop when fewer than x/64 of the wave's rays are still descending
+    uint32_t worldCurveMin = 32; // ... of the world-only kernel with the curve block (option curve_min sets both)
     uint32_t curveMin = 48; // (cooperative curve block) end-point runs queued by the parked lanes before the block runs, one run per lane (round 3, Mray/s on the hair
                             // stand-in: 16: 712, 32: 907, 40: 958, 48: 984, 56: 971, 64: 887; round 2 counted parked LANES whose owners ran their own runs: 48: 334)
     uint32_t leafMin = 16; // postpone the minority kind of leaf work unless it has this many lanes (0 = never postpone; measured +1.5 % at 16)
@@ -1338,6 +1342,8 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     // two world-space groups: [0] mesh instances (every ray), [1] light proxies (radiance rays only: shadow rays do not see lights,
     // RAY_MASK_SHADOW, closest_hit.cu:191) -- the ray mask stays a property of the group, not of the triangle
     std::vector<uint32_t> wInst, wFirst;
+    bool worldCurves = false;
+    std::vector<uint32_t> worldCurveInst;
     uint32_t nBakedG[2] = { 0, 0 };
     {
         uint64_t uniqueTris = 0;
@@ -1392,7 +1398,13 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         // Light proxies follow the meshes only when that EMPTIES the top level (then no ray ever leaves world space): beside a
         // populated TLAS their own group costs every radiance ray a root visit that the TLAS's distance-ordered culling mostly
         // avoided (kitchen stand-in, closest-hit 99.4 -> 102.4 ms), without a TLAS it saves the whole level (unshared variant: 89.7 -> 81.2 ms)
-        bool tlasStays = false;
+        // "World curves" (round 5): when every curve instance with segments sits under a bit-exact IDENTITY transform and there are at most
+        // SKH_WORLD_CURVES of them, their trees are walked straight from the world-only kernel -- no top level, no instance entry; the identity
+        // is still APPLIED to the ray (same bits as the instance path) --, so they do not keep the top level alive either.  An integer rule the
+        // CPU checker evaluates too (it decides which light proxies are baked).
+        bool meshStays = false, curvesIdentity = true;
+        std::vector<uint32_t> curveInst;
+        static const float kIdentity[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
         for (uint32_t i = 0; i < nInst; ++i)
         {
             const skh_instance& in = c->instances[i];
@@ -1402,11 +1414,23 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
                 if (in.geom_id < c->curves.size())
                     for (uint32_t k = 0; k < c->curves[in.geom_id].vertex_counts_count; ++k)
                         segs += std::max(3u, c->curveVertexCounts[c->curves[in.geom_id].vertex_counts_start + k]) - 3u;
-                tlasStays = tlasStays || (valid[i] && segs > 0);
+                if (valid[i] && segs > 0)
+                {
+                    curveInst.push_back(i);
+                    curvesIdentity = curvesIdentity && memcmp(in.transform, kIdentity, sizeof(kIdentity)) == 0;
+                }
             }
             else if (in.type == SKH_INSTANCE_MESH)
-                tlasStays = tlasStays || (valid[i] && !pick[i] && c->meshes[in.geom_id].index_count >= 3);
+                meshStays = meshStays || (valid[i] && !pick[i] && c->meshes[in.geom_id].index_count >= 3);
         }
+        bool lightsAllPicked = true; // (a light proxy the bake mode leaves behind keeps the top level alive as well)
+        for (uint32_t i = 0; i < nInst; ++i)
+            if (c->instances[i].type == SKH_INSTANCE_LIGHT && eligible(i) && !pick[i])
+                lightsAllPicked = false;
+        worldCurves = !meshStays && !curveInst.empty() && curveInst.size() <= SKH_WORLD_CURVES && curvesIdentity && lightsAllPicked;
+        if (worldCurves)
+            worldCurveInst = curveInst;
+        const bool tlasStays = meshStays || (!curveInst.empty() && !worldCurves);
         for (uint32_t i = 0; i < nInst; ++i)
         {
             const skh_instance& in = c->instances[i];
@@ -1605,6 +1629,25 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     if (nInst > 0 && c->tightInstanceBoxes)
         k_instance_tight_boxes<<<nInst, 256, 0, st>>>(c->dInstances.as<HostInstance>(), c->dDevInst.as<DevInstance>(), c->dMeshes.as<uint4>(),
                                                       c->dVerts.as<uint8_t>(), nMeshes, 1u << 22, dBoxLo.as<float4>(), dBoxHi.as<float4>());
+    // world curves: walked from the world-only kernel (option world_kernel; without it they keep their TLAS leaves: same hit records)
+    c->numWorldCurves = 0;
+    bool othersInTlas = false; // (by the rule above nothing else has a leaf when worldCurves holds; checked, not assumed: a curve instance without a leaf AND without the kernel would vanish)
+    for (uint32_t i = 0; i < nInst; ++i)
+        if (valid[i] && c->instances[i].type != SKH_INSTANCE_CURVE)
+        {
+            const std::vector<int>& roots = triOut.hostGroupRoot;
+            othersInTlas = othersInTlas || (c->instances[i].geom_id < roots.size() && roots[c->instances[i].geom_id] != SKH_REF_INVALID);
+        }
+    if (worldCurves && c->worldKernel && !othersInTlas)
+        for (uint32_t i : worldCurveInst)
+        {
+            const int root = c->instances[i].geom_id < segOut.hostGroupRoot.size() ? segOut.hostGroupRoot[c->instances[i].geom_id] : SKH_REF_INVALID;
+            if (root == SKH_REF_INVALID)
+                continue;
+            c->worldCurveRoot[c->numWorldCurves] = root;
+            c->worldCurveInst[c->numWorldCurves++] = i;
+            valid[i] = 0; // no TLAS leaf
+        }
     uint32_t nValidHost = 0;
     for (uint32_t i = 0; i < nInst; ++i)
         nValidHost += valid[i] ? 1u : 0u;
@@ -2057,6 +2100,9 @@ static DevScene make_dev_scene(const skh_context* c)
     sc.tlasNodes = c->dTlasNodes.as<Node4>();
     sc.tlasInst = c->dTlasInst.as<uint32_t>();
     sc.tlasRoot = c->tlasRoot;
+    sc.numWorldCurves = c->numWorldCurves;
+    for (uint32_t k = 0; k < SKH_WORLD_CURVES; ++k)
+        sc.worldCurveRoot[k] = k < c->numWorldCurves ? c->worldCurveRoot[k] : SKH_REF_INVALID, sc.worldCurveInst[k] = k < c->numWorldCurves ? c->worldCurveInst[k] : 0u;
     sc.numInstances = c->nInstances;
     sc.inst = c->dDevInst.as<DevInstance>();
     sc.tinst = c->dTravInst.as<DevInstance>();
@@ -2121,19 +2167,26 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
     const bool curveBuild = c->nSegs != 0;
     const uint32_t fetchMin = ANY ? (curveBuild ? c->curveFetchMinShadow : c->fetchMinShadow) : (curveBuild ? c->curveFetchMinClosest : c->fetchMinClosest);
     const uint32_t nodeBreak = ANY ? (curveBuild ? c->curveNodeBreakShadow : c->nodeBreakShadow) : (curveBuild ? c->curveNodeBreakClosest : c->nodeBreakClosest);
-    const uint32_t fm = fetchMin | (c->curveMin << 8) | (nodeBreak << 16) | (c->leafMin << 24);
+    // (the world-only kernel with the curve block -- curve instances under identity transforms -- wants the triangle kernels' node-loop exits and
+    // an earlier curve block: hair stand-in 1 862 -> 1 937 Mray/s with 32 / 28 / 32 against the two-level curve build's 20 / 20 / 48, gpurun_out/r5t)
+    const bool wcv = c->nSegs && c->tlasRoot == SKH_REF_INVALID && c->numWorldCurves > 0 && c->worldKernel;
+    const uint32_t nodeBreakW = wcv ? (ANY ? c->nodeBreakShadow : c->nodeBreakClosest) : nodeBreak;
+    const uint32_t fm = fetchMin | ((wcv ? c->worldCurveMin : c->curveMin) << 8) | (nodeBreakW << 16) | (c->leafMin << 24);
     if (!st)
         st = c->stream;
     int* ovf = st == c->stream ? c->dOvf.as<int>() : c->dOvf2.as<int>(); // (two trace kernels may be in flight)
     StatsDev* sd = c->dStats.as<StatsDev>();
     const bool worldOnly = !c->nSegs && c->tlasRoot == SKH_REF_INVALID && (c->worldRoot != SKH_REF_INVALID || c->lightRoot != SKH_REF_INVALID) && c->worldKernel;
-    // (the world-only builds run 8 waves per SIMD)
+    const bool worldCurves = c->nSegs && c->tlasRoot == SKH_REF_INVALID && c->numWorldCurves > 0 && c->worldKernel; // the world-only kernel with the curve block
+    // (the world-only triangle builds run 8 waves per SIMD)
     const uint32_t fullGrid = (ANY && !c->nSegs) ? (uint32_t)c->numCUs * (worldOnly ? c->wavesPerCUShadowWorld : c->wavesPerCUShadow)
                                                  : (worldOnly ? (uint32_t)c->numCUs * c->wavesPerCUWorld : c->traceBlocks);
     const uint32_t blocks = c->gridOverride ? std::min(c->gridOverride, fullGrid) : fullGrid;
     if (worldOnly)
         // every instance is baked: the world-only build of the kernel (no instance entry, no object-space copy of the ray)
         k_trace<ANY, COUNT, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
+    else if (worldCurves)
+        k_trace<ANY, COUNT, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
     else if (c->nSegs)
         k_trace<ANY, COUNT, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
     else
@@ -3369,7 +3422,7 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
     {
         if (value < 1 || value > 64)
             return SKH_INVALID_ARGUMENT;
-        c->curveMin = (uint32_t)value;
+        c->curveMin = c->worldCurveMin = (uint32_t)value;
     }
     else if (n == "leaf_min")
     {
