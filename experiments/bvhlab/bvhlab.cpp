@@ -258,6 +258,8 @@ static Move find_best(const Tree& t, int in, int minSize, long* visits)
     return mv;
 }
 
+static std::vector<char> g_active; // (sparse=1) nodes searched in this round: last round's candidates and the nodes next to last round's moves
+static bool g_sparse = false;
 static int reinsertion_batch(Tree& t, int minSize, int stride, int phase, double* gainSum, long* visitsOut, bool pathLocks, long* candOut)
 {
     const int n = t.n, N = 2 * n - 1;
@@ -267,6 +269,8 @@ static int reinsertion_batch(Tree& t, int minSize, int stride, int phase, double
     for (int x = 0; x < N; ++x)
     {
         if (stride > 1 && (x % stride) != phase)
+            continue;
+        if (g_sparse && !g_active.empty() && !g_active[x])
             continue;
         const int sz = x >= n - 1 ? 1 : t.size[x];
         if (sz < minSize && !(t.parent[x] >= 0 && t.size[t.parent[x]] >= minSize))
@@ -374,6 +378,29 @@ static int reinsertion_batch(Tree& t, int minSize, int stride, int phase, double
         t.parent[out] = p, t.parent[x] = p;
         gs += mv[x].gain;
     }
+    if (g_sparse)
+    {
+        std::vector<char> next(N, 0);
+        for (int x = 0; x < N; ++x)
+            if (mv[x].out >= 0)
+                next[x] = 1; // wanted to move (won or lost): look again
+        for (int x : winners)
+        {
+            // the nodes along the old and the new place's paths to the root got new boxes: they and their children may want to move now
+            for (int a = t.parent[x]; a >= 0; a = t.parent[a])
+            {
+                if (next[a] == 2)
+                    break;
+                next[a] = 2;
+                next[t.L[a]] = std::max<char>(next[t.L[a]], 1), next[t.R[a]] = std::max<char>(next[t.R[a]], 1);
+            }
+        }
+        long na = 0;
+        for (int x = 0; x < N; ++x)
+            na += next[x] ? 1 : 0;
+        printf("  next round searches %ld of %d nodes\n", na, N);
+        g_active.swap(next);
+    }
     refit(t);
     if (gainSum)
         *gainSum = gs;
@@ -394,6 +421,7 @@ struct Flat
     std::vector<Wide> nodes;
     std::vector<uint32_t> leafPrim;
 };
+static int quantMode = 0;
 static void collapse(const Tree& t, int leafMax, Flat& f, bool sahRule)
 {
     const int n = t.n;
@@ -463,6 +491,31 @@ static void collapse(const Tree& t, int leafMax, Flat& f, bool sahRule)
                 w.ref[k] = (int)f.nodes.size();
                 f.nodes.push_back(Wide());
                 q.push_back(Item{ c, w.ref[k] });
+            }
+        }
+        if (quantMode)
+        {
+            // the GPU node's 8-bit child boxes: origin = node box min, one cell size per axis covering the extent in 255 steps -- a power of two
+            // (quantMode 1, what encode_node4 stores) or the extent / 255 itself (quantMode 2)
+            const Box nb = t.box[it.bin];
+            for (int a = 0; a < 3; ++a)
+            {
+                const float ext = std::max(nb.hi[a] - nb.lo[a], 1e-30f);
+                float cell = ext / 255.0f;
+                if (quantMode == 1)
+                {
+                    int e;
+                    (void)std::frexp(cell, &e);
+                    cell = std::ldexp(1.0f, e); // 255 * 2^e > ext
+                }
+                else
+                    cell *= 1.000001f;
+                for (int k = 0; k < cnt; ++k)
+                {
+                    const float ql = std::floor((w.cb[k].lo[a] - nb.lo[a]) / cell), qh = std::ceil((w.cb[k].hi[a] - nb.lo[a]) / cell);
+                    w.cb[k].lo[a] = nb.lo[a] + std::min(std::max(ql, 0.0f), 255.0f) * cell;
+                    w.cb[k].hi[a] = nb.lo[a] + std::min(std::max(qh, 0.0f), 255.0f) * cell;
+                }
             }
         }
         f.nodes[it.out] = w;
@@ -730,6 +783,7 @@ int main(int argc, char** argv)
     printf("PLOC: %.2f s, SAH(internal area / root area) = %.2f\n", now() - t0, sah_internal(t));
 
     ancestors = geti("ancestors", 0) != 0;
+    g_sparse = geti("sparse", 0) != 0;
     const int rounds = geti("reinsert", 0), minSize = geti("minsize", 1), stride = geti("stride", 1);
     for (int k = 0; k < rounds; ++k)
     {
@@ -737,10 +791,13 @@ int main(int argc, char** argv)
         long visits = 0;
         t0 = now();
         long cand = 0;
+        if (geti("fullevery", 0) > 0 && (k % geti("fullevery", 0)) == 0)
+            g_active.clear(); // a full search again
         const int moved = reinsertion_batch(t, minSize, stride, k % stride, &gs, &visits, opt.count("lockmode") && opt["lockmode"] == "path", &cand);
         printf("reinsertion %d: %ld candidates, %d moved, %.1f M search visits, %.2f s, SAH = %.2f\n", k, cand, moved, visits * 1e-6, now() - t0, sah_internal(t));
     }
 
+    quantMode = geti("quant", 0);
     Flat f;
     collapse(t, geti("leaf", 2), f, opt.count("collapse") && opt["collapse"] == "sah");
     printf("4-wide: %zu nodes, %zu leaf slots\n", f.nodes.size(), f.leafPrim.size());

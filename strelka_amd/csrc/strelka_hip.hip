@@ -510,9 +510,9 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
             if (he == hipSuccess && riRounds && n >= 8)
             {
                 // ---- parallel reinsertion over the binary tree (skh_bvh.h): rounds of search / claim / own / check / apply / refit ----
-                DevBuf moves, lock, moving, win, rflags, cost, cand, stamp, refitList, refitCount;
+                DevBuf moves, lock, moving, win, rflags, cost, cand, stamp, refitList, refitCount, activeA, activeB;
                 auto cleanupR = [&]() {
-                    for (DevBuf* b : { &moves, &lock, &moving, &win, &rflags, &cost, &cand, &stamp, &refitList, &refitCount })
+                    for (DevBuf* b : { &moves, &lock, &moving, &win, &rflags, &cost, &cand, &stamp, &refitList, &refitCount, &activeA, &activeB })
                         dev_free(*b);
                 };
                 const size_t N2 = 2 * (size_t)n;
@@ -521,7 +521,8 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
                     (sr = dev_alloc(c, moving, sizeof(unsigned long long) * N2)) != SKH_OK || (sr = dev_alloc(c, win, N2)) != SKH_OK ||
                     (sr = dev_alloc(c, rflags, sizeof(uint32_t) * (size_t)n)) != SKH_OK || (sr = dev_alloc(c, cost, sizeof(double) * 2 + sizeof(uint32_t) * 2)) != SKH_OK ||
                     (sr = dev_alloc(c, cand, sizeof(uint32_t) * N2)) != SKH_OK || (sr = dev_alloc(c, stamp, sizeof(uint32_t) * (size_t)n)) != SKH_OK ||
-                    (sr = dev_alloc(c, refitList, sizeof(uint32_t) * 2 * (size_t)n)) != SKH_OK || (sr = dev_alloc(c, refitCount, sizeof(uint32_t) * SKH_RI_MAX_LEVELS)) != SKH_OK)
+                    (sr = dev_alloc(c, refitList, sizeof(uint32_t) * 2 * (size_t)n)) != SKH_OK || (sr = dev_alloc(c, refitCount, sizeof(uint32_t) * SKH_RI_MAX_LEVELS)) != SKH_OK ||
+                    (sr = dev_alloc(c, activeA, N2)) != SKH_OK || (sr = dev_alloc(c, activeB, N2)) != SKH_OK)
                 {
                     cleanupR();
                     cleanup2();
@@ -546,8 +547,13 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
                         he = hipMemsetAsync(moving.p, 0, sizeof(unsigned long long) * N2, st);
                     if (he == hipSuccess)
                         he = hipMemsetAsync(dWin, 0, sizeof(uint32_t) * 2, st);
+                    // every third round searches from every node; the rounds between from last round's candidates and the nodes next to its moves only
+                    uint8_t* activeCur = (r & 1u) ? activeB.as<uint8_t>() : activeA.as<uint8_t>();
+                    uint8_t* activeNext = (r & 1u) ? activeA.as<uint8_t>() : activeB.as<uint8_t>();
+                    if (he == hipSuccess)
+                        he = hipMemsetAsync(activeNext, 0, N2, st);
                     k_ri_search<<<GN, B, 0, st>>>(childL.as<int>(), childR.as<int>(), parent.as<int>(), nodeSize.as<int>(), nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n,
-                                                  (int)riMinSize, 1u, 0u, moves.as<int4>(), cand.as<uint32_t>(), dWin + 1);
+                                                  (int)riMinSize, (r % 3u) == 0u ? nullptr : activeCur, moves.as<int4>(), cand.as<uint32_t>(), dWin + 1);
                     // the list kernels are sized by the candidate count, read back here (one small synchronisation per round; the search is the long kernel)
                     if (he == hipSuccess)
                         he = hipMemcpyAsync(&nCandHost, dWin + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
@@ -557,12 +563,12 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
                     if (he != hipSuccess || nCandHost == 0)
                         break;
                     const uint32_t GC = (nCandHost + B - 1) / B;
-                    k_ri_claim<<<GC, B, 0, st>>>(moves.as<int4>(), cand.as<uint32_t>(), dWin + 1, childL.as<int>(), childR.as<int>(), parent.as<int>(), lock.as<unsigned long long>());
+                    k_ri_claim<<<GC, B, 0, st>>>(moves.as<int4>(), cand.as<uint32_t>(), dWin + 1, childL.as<int>(), childR.as<int>(), parent.as<int>(), lock.as<unsigned long long>(), activeNext);
                     k_ri_own<<<GC, B, 0, st>>>(moves.as<int4>(), cand.as<uint32_t>(), dWin + 1, childL.as<int>(), childR.as<int>(), parent.as<int>(), lock.as<unsigned long long>(),
                                                moving.as<unsigned long long>());
                     k_ri_check<<<GC, B, 0, st>>>(moves.as<int4>(), cand.as<uint32_t>(), dWin + 1, parent.as<int>(), moving.as<unsigned long long>(), win.as<uint8_t>(), dWin);
                     k_ri_apply<<<GC, B, 0, st>>>(moves.as<int4>(), cand.as<uint32_t>(), dWin + 1, win.as<uint8_t>(), childL.as<int>(), childR.as<int>(), parent.as<int>());
-                    k_ri_mark<<<GC, B, 0, st>>>(moves.as<int4>(), cand.as<uint32_t>(), dWin + 1, win.as<uint8_t>(), parent.as<int>(), stamp.as<uint32_t>(), r + 1u);
+                    k_ri_mark<<<GC, B, 0, st>>>(moves.as<int4>(), cand.as<uint32_t>(), dWin + 1, win.as<uint8_t>(), parent.as<int>(), childL.as<int>(), childR.as<int>(), stamp.as<uint32_t>(), r + 1u, activeNext);
                     {
                         // refit of the stamped paths, one tree level per launch (rflags = stamped children still to come; lists ping-pong in `refitList`)
                         uint32_t* lv = refitCount.as<uint32_t>();
