@@ -54,3 +54,31 @@ def test_copy_accum_is_the_accumulator():
     ctx.synchronize()
     ctx.close()
     assert (d.cpu().numpy().reshape(H, W, 4) == want.reshape(H, W, 4)).all()
+
+
+def test_build_info_reports_the_reinsertion_pass():
+    """skh_get_build_info: what the last skh_build_accel did to the triangle hierarchy -- rounds, moves, the sum of the internal nodes' box areas
+    before and after (the pass must lower it), its time inside ms_build; with the pass off, or on the radix-tree builder, the record says so."""
+    from strelka_amd import capi, scenes
+
+    sc = scenes.kitchen_standin(seed=5, n_meshes=12, n_instances=120, tri_lo=100, tri_hi=3000)
+    arr = sc.arrays()
+    ctx = capi.Context(0)
+    ctx.set_scene(arr)
+    b = ctx.build_info()
+    assert b["triangles"] > 10000 and b["nodes"] > 1000
+    assert 1 <= b["reinsert_rounds"] <= 8 and b["reinsert_moves"] > 100 and b["reinsert_min_size"] == 1
+    assert 0.5 * b["cost_before"] < b["cost_after"] < 0.99 * b["cost_before"]
+    assert 0.0 < b["ms_reinsert"] < b["ms_build"]
+    ctx.set_option("reinsert_rounds", 0)
+    ctx.set_scene(arr)
+    b0 = ctx.build_info()
+    assert b0["reinsert_rounds"] == 0 and b0["reinsert_moves"] == 0 and b0["triangles"] == b["triangles"]
+    ctx.set_option("reinsert_rounds", 8)
+    ctx.set_option("build_quality", 0)  # the Karras radix tree has no per-group parent chain: no reinsertion
+    ctx.set_scene(arr)
+    assert ctx.build_info()["reinsert_rounds"] == 0
+    for name, bad in (("reinsert_rounds", 65), ("reinsert_curve_rounds", -1), ("reinsert_min_size", -3)):
+        with pytest.raises(capi.SkhError):
+            ctx.set_option(name, bad)
+    ctx.close()
