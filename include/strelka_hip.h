@@ -421,9 +421,9 @@ skh_status skh_unit_probe(skh_context* ctx, uint32_t unit, uint32_t param, const
  *                 user -- what HdStrelka's per-instance meshes are --, 2 = also instances of meshes with <= bake_small_tris (64)
  *                 triangles when that empties the top level, 3 = every mesh instance, 4 (default) = 3 while the instanced triangles stay
  *                 within bake_budget_mtris (64) million, else 2; 0 = every instance keeps its TLAS leaf), world_kernel 1|0 (scenes
- *                 with an empty top level run the world-only build of the traversal kernel; curve instances under bit-exact identity
- *                 transforms -- at most 16, no unbaked mesh or light instance beside them -- do not need a top level either: their trees are walked
- *                 from the world-only kernel with the curve block, the identity still applied to the ray)
+ *                 with an empty top level run the world-only build of the traversal kernel; curve instances -- at most 16, no unbaked
+ *                 mesh or light instance beside them -- do not need a top level either: their trees are walked from the world-only kernel with the
+ *                 curve block, each instance's transform applied to the ray as at a TLAS leaf)
  *   build         build_quality 1|0 (PLOC | Karras radix tree), reinsert_rounds (8; 0 = off: rounds of parallel reinsertion over the PLOC tree of the
  *                 triangle build -- every subtree looks for the place in the tree where it costs least, the best non-conflicting moves are applied),
  *                 reinsert_curve_rounds (4: the same over the curve sub-segment trees),

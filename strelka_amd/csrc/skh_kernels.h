@@ -36,6 +36,7 @@ struct HostInstance // == skh_instance (64 B), as uploaded
 
 #define SKH_WORLD_CURVES 16
 #define SKH_REF_CURVEROOT 0x40000000 // stack entry (world-only kernel with curves): (ref & 0xffff) indexes DevScene::worldCurveRoot / worldCurveInst
+#define SKH_REF_CURVEROOT_IDENT 0x20000000 // ... of an instance under a bit-exact identity transform, which is only valid as the FIRST curve tree of a ray (o, d still the world ray)
 struct DevScene
 {
     const Node4* tlasNodes;
@@ -44,6 +45,7 @@ struct DevScene
     uint32_t numWorldCurves; // curve instances under identity transforms, walked from the world-only kernel (no TLAS leaf): their curve trees' roots ...
     int worldCurveRoot[SKH_WORLD_CURVES];
     uint32_t worldCurveInst[SKH_WORLD_CURVES]; // ... and instance ids
+    uint32_t worldCurveIdentLast; // 1: the LAST entry's instance sits under a bit-exact identity transform (the host puts such an instance last)
     uint32_t numInstances;
     const DevInstance* inst; // per instance (shading side: w2o)
     const DevInstance* tinst; // per TLAS leaf: (instance, BLAS subtree) after opening; pad = instance id
@@ -288,12 +290,12 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? SKH_WORLD_C
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
             StatsDev* __restrict__ stats)
 {
-    // WORLD && CURVES (round 5): the world-only kernel with the curve block in it -- scenes whose every mesh instance is baked and whose curve
-    // instances (at most SKH_WORLD_CURVES) sit under identity transforms.  Their curve trees' roots wait at the BOTTOM of every ray's stack as
-    // markers (SKH_REF_CURVEROOT | k): a ray walks the world-space triangles first, then each curve tree, with no top level, no instance entry
-    // block, no sentinel and no world-space copy of the ray (hair stand-in: an instance-entry pass in 98 % of the outer iterations before).
-    // Taking a marker applies the identity transform to the ray exactly as the instance path does (x * 1 + y * 0 + z * 0 can turn a -0 into
-    // +0): hit records are the instance path's, bit for bit.
+    // WORLD && CURVES (round 5): the world-only kernel with the curve block in it -- scenes whose every mesh instance is baked and that hold at
+    // most SKH_WORLD_CURVES curve instances.  Their curve trees' roots wait at the BOTTOM of every ray's stack as markers
+    // (SKH_REF_CURVEROOT | k): a ray walks the world-space triangles first, then each curve tree, with no top level, no instance entry block, no
+    // sentinel and no world-space copy of the ray in registers (hair stand-in: an instance-entry pass in 98 % of the outer iterations before).
+    // Taking a marker sends the world ray (re-read from the queue) through the instance's transform exactly as a TLAS leaf would: hit records are
+    // the two-level path's, bit for bit.
     constexpr bool TRICOOP = SKH_TRI_COOP && WORLD && !CURVES; // (closest-hit and any-hit builds of the world-only TRIANGLE kernel)
     // per-lane stack entries in LDS (the rest: SKH_STACK_OVF entries in global memory); TRICOOP gives one up for its two 64-byte lane tables
     // (LDS is handed out in 1280-byte granules here: 20 x 256 B = 4 granules exactly, 128 B more would cost a fifth = 25 instead of 28 waves per CU)
@@ -366,6 +368,33 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? SKH_WORLD_C
             dst = SKH_OVF_AT(sp - NLDS);                             \
         else                                                         \
             dst = SKH_REF_INVALID;                                   \
+    }
+
+#define SKH_TAKE_MARKER()                                                                                         \
+    {                                                                                                             \
+        const uint32_t k = (uint32_t)cur & 0xffffu;                                                               \
+        curInst = sc.worldCurveInst[k];                                                                           \
+        if ((uint32_t)cur & SKH_REF_CURVEROOT_IDENT)                                                              \
+        {                                                                                                         \
+            /* a bit-exact identity transform (the common bake): the world ray is still in (o, d); it goes through the identity as it would */ \
+            /* through the instance's record (x * 1 + y * 0 + z * 0 can turn a -0 into +0), without the nine loads below */ \
+            const float ident[12] = { 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f };    \
+            o = xform_point_rel(ident, o);                                                                        \
+            d = xform_vector(ident, d);                                                                           \
+        }                                                                                                         \
+        else                                                                                                      \
+        {                                                                                                         \
+            const float4* ip = reinterpret_cast<const float4*>(sc.inst + curInst);                                \
+            const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2];                                                      \
+            const v3 wo = mk3(rq.plane(0)[ridx], rq.plane(1)[ridx], rq.plane(2)[ridx]);                           \
+            const v3 wd = mk3(rq.plane(3)[ridx], rq.plane(4)[ridx], rq.plane(5)[ridx]);                           \
+            const float m[12] = { i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w };       \
+            o = xform_point_rel(m, wo);                                                                           \
+            d = xform_vector(m, wd);                                                                              \
+        }                                                                                                         \
+        inv = rcp3(d);                                                                                            \
+        curType = 2;                                                                                              \
+        cur = sc.worldCurveRoot[k];                                                                               \
     }
 
     for (;;)
@@ -448,8 +477,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? SKH_WORLD_C
                     curInst = 0xffffffffu;
                     curType = 0;
                     sp = 0;
+                    // (the marker popped FIRST -- the last one pushed -- may take the identity short cut: (o, d) still hold the world ray then)
                     for (uint32_t k = 0; k < sc.numWorldCurves; ++k)
-                        lds[(sp++) * SKH_TRACE_BLOCK] = (int)(SKH_REF_CURVEROOT | k);
+                        lds[(sp++) * SKH_TRACE_BLOCK] = (int)(SKH_REF_CURVEROOT | k | ((k + 1u == sc.numWorldCurves && sc.worldCurveIdentLast) ? SKH_REF_CURVEROOT_IDENT : 0u));
                     if (wr0 != SKH_REF_INVALID && wr1 != SKH_REF_INVALID)
                         lds[(sp++) * SKH_TRACE_BLOCK] = wr1;
                     cur = wr0 != SKH_REF_INVALID ? wr0 : wr1;
@@ -694,22 +724,18 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? SKH_WORLD_C
         if (hasRay || TRICOOP) // (TRICOOP: every lane comes along to the triangle pass; the node loop and the pop stay with the lanes that have a ray)
         {
             // ---- descend through internal nodes ----
-            while ((!TRICOOP || hasRay) && cur >= 0 && cur != SKH_REF_INVALID)
+            // (a curve tree's marker under a general transform ends the node loop -- its nine loads must not sit in every iteration of every wave:
+            // hair 1 937 -> 1 637 Mray/s --; the identity short cut is taken right here, so that a lane whose triangle walk ends on a missed box
+            // goes on into the curve tree without a pass of its own: closest-hit 76.8 -> 71.5 ms)
+            while ((!TRICOOP || hasRay) && cur >= 0 && cur != SKH_REF_INVALID &&
+                   !(WORLD && CURVES && ((uint32_t)cur & SKH_REF_CURVEROOT) != 0u && (ANY_HIT || ((uint32_t)cur & SKH_REF_CURVEROOT_IDENT) == 0u)))
             {
-                if constexpr (WORLD && CURVES)
+                // (the any-hit build takes every marker outside the loop: measured 49.9 against 53.8 ms; the closest-hit build the other way round)
+                if constexpr (WORLD && CURVES && !ANY_HIT)
                 {
-                    if (cur & SKH_REF_CURVEROOT)
+                    if ((uint32_t)cur & SKH_REF_CURVEROOT_IDENT)
                     {
-                        // the next curve tree (the triangles and the trees before it are done): the ray goes through the identity transform as it
-                        // would through the instance's record, the instance id comes from the table
-                        const uint32_t k = (uint32_t)cur & 0xffffu;
-                        const float ident[12] = { 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f };
-                        o = xform_point_rel(ident, o);
-                        d = xform_vector(ident, d);
-                        inv = rcp3(d);
-                        curInst = sc.worldCurveInst[k];
-                        curType = 2;
-                        cur = sc.worldCurveRoot[k];
+                        SKH_TAKE_MARKER()
                         if (cur < 0 || cur == SKH_REF_INVALID)
                             break; // (a tree of one leaf)
                     }
@@ -807,6 +833,19 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? SKH_WORLD_C
                 if ((uint32_t)__popcll(__ballot(cur >= 0 && cur != SKH_REF_INVALID)) < breakBelow)
                     break;
             }
+            bool tookMarker = false;
+            if constexpr (WORLD && CURVES)
+            {
+                if (hasRay && cur >= 0 && cur != SKH_REF_INVALID && (cur & SKH_REF_CURVEROOT))
+                {
+                    // the next curve tree (the triangles and the trees before it are done): the WORLD ray -- read back from the queue: once per
+                    // ray and curve instance, cheaper than six registers held through the whole traversal -- goes through the instance's
+                    // transform exactly as it would at a TLAS leaf (same record, same operations: same object-space ray, same hit records).
+                    // Outside the node loop: inside it the nine loads cost every iteration of every wave (hair 1 937 -> 1 637 Mray/s)
+                    SKH_TAKE_MARKER();
+                    tookMarker = true; // (like an instance entry: the lane keeps `cur` and descends in the next pass)
+                }
+            }
             if (!WORLD && cur == SKH_REF_SENTINEL)
             {
                 o = ow;
@@ -818,10 +857,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? SKH_WORLD_C
             }
             // ---- leaf ----
             SKH_LP({ const unsigned long long t = __builtin_readcyclecounter(); cy[1] += t - cyA; cyA = t; })
-            bool entered = false;
+            bool entered = tookMarker;
             // Two kinds of leaf work (instance entry, primitive tests) are two branches of the same wave.  When one of them has
             // only a few takers it is postponed: those lanes keep their leaf and meet the next pass's takers (leafMin = 0/1: off)
-            bool isLeaf = (!TRICOOP || hasRay) && cur < 0 && cur != SKH_REF_SENTINEL;
+            bool isLeaf = (!TRICOOP || hasRay) && cur < 0 && cur != SKH_REF_SENTINEL && !tookMarker;
             if (CURVES)
             {
                 // The iterative curve intersector costs ~1000 instructions; run for the one or two lanes that happen to need it, it
@@ -1063,6 +1102,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? SKH_WORLD_C
                         break;
                     }
                     SKH_POP(cur);
+                    if (WORLD && CURVES && cur >= 0 && cur != SKH_REF_INVALID && (cur & SKH_REF_CURVEROOT))
+                        SKH_TAKE_MARKER() // (popped right behind a leaf: the lane descends into the curve tree in the next pass, no pass of its own)
                     if (!WORLD && cur == SKH_REF_SENTINEL)
                     {
                         o = ow;
@@ -1110,6 +1151,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? SKH_WORLD_C
 #undef SKH_PUSH
 #undef SKH_POP
 #undef SKH_OVF_AT
+#undef SKH_TAKE_MARKER
     if (COUNT)
     {
         const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.prims), c2 = wave_sum(tc.segs), d2 = wave_sum(tc.insts);

@@ -144,6 +144,7 @@ struct skh_context
     uint32_t numWorldCurves = 0; // curve instances under identity transforms that the world-only kernel walks itself (skh_build_accel)
     int worldCurveRoot[SKH_WORLD_CURVES];
     uint32_t worldCurveInst[SKH_WORLD_CURVES];
+    uint32_t worldCurveIdentLast = 0;
     uint32_t numTlasLeaves = 0;
     bool countTraversal = false, timing = false;
     // scheduling of the persistent trace kernels, measured on MI355X (kitchen C3, 32 sub-frames per pass):
@@ -1404,13 +1405,12 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         // Light proxies follow the meshes only when that EMPTIES the top level (then no ray ever leaves world space): beside a
         // populated TLAS their own group costs every radiance ray a root visit that the TLAS's distance-ordered culling mostly
         // avoided (kitchen stand-in, closest-hit 99.4 -> 102.4 ms), without a TLAS it saves the whole level (unshared variant: 89.7 -> 81.2 ms)
-        // "World curves" (round 5): when every curve instance with segments sits under a bit-exact IDENTITY transform and there are at most
-        // SKH_WORLD_CURVES of them, their trees are walked straight from the world-only kernel -- no top level, no instance entry; the identity
-        // is still APPLIED to the ray (same bits as the instance path) --, so they do not keep the top level alive either.  An integer rule the
-        // CPU checker evaluates too (it decides which light proxies are baked).
-        bool meshStays = false, curvesIdentity = true;
+        // "World curves" (round 5): when a scene holds at most SKH_WORLD_CURVES curve instances with segments (and nothing else needs a top
+        // level), their trees are walked straight from the world-only kernel -- no TLAS, no instance-entry pass; the instance's transform is
+        // still applied to the ray, by the same operations --, so they do not keep the top level alive either.  An integer rule the CPU
+        // checker evaluates too (it decides which light proxies are baked).
+        bool meshStays = false;
         std::vector<uint32_t> curveInst;
-        static const float kIdentity[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
         for (uint32_t i = 0; i < nInst; ++i)
         {
             const skh_instance& in = c->instances[i];
@@ -1421,10 +1421,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
                     for (uint32_t k = 0; k < c->curves[in.geom_id].vertex_counts_count; ++k)
                         segs += std::max(3u, c->curveVertexCounts[c->curves[in.geom_id].vertex_counts_start + k]) - 3u;
                 if (valid[i] && segs > 0)
-                {
                     curveInst.push_back(i);
-                    curvesIdentity = curvesIdentity && memcmp(in.transform, kIdentity, sizeof(kIdentity)) == 0;
-                }
             }
             else if (in.type == SKH_INSTANCE_MESH)
                 meshStays = meshStays || (valid[i] && !pick[i] && c->meshes[in.geom_id].index_count >= 3);
@@ -1433,7 +1430,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         for (uint32_t i = 0; i < nInst; ++i)
             if (c->instances[i].type == SKH_INSTANCE_LIGHT && eligible(i) && !pick[i])
                 lightsAllPicked = false;
-        worldCurves = !meshStays && !curveInst.empty() && curveInst.size() <= SKH_WORLD_CURVES && curvesIdentity && lightsAllPicked;
+        worldCurves = !meshStays && !curveInst.empty() && curveInst.size() <= SKH_WORLD_CURVES && lightsAllPicked;
         if (worldCurves)
             worldCurveInst = curveInst;
         const bool tlasStays = meshStays || (!curveInst.empty() && !worldCurves);
@@ -1644,6 +1641,15 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
             const std::vector<int>& roots = triOut.hostGroupRoot;
             othersInTlas = othersInTlas || (c->instances[i].geom_id < roots.size() && roots[c->instances[i].geom_id] != SKH_REF_INVALID);
         }
+    // (an instance under a bit-exact identity transform goes LAST in the table = first off every ray's stack: the kernel skips its matrix fetch)
+    static const float kIdentity[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+    c->worldCurveIdentLast = 0;
+    for (size_t k = 0; k + 1 < worldCurveInst.size(); ++k)
+        if (memcmp(c->instances[worldCurveInst[k]].transform, kIdentity, sizeof(kIdentity)) == 0)
+        {
+            std::swap(worldCurveInst[k], worldCurveInst.back());
+            break;
+        }
     if (worldCurves && c->worldKernel && !othersInTlas)
         for (uint32_t i : worldCurveInst)
         {
@@ -1652,6 +1658,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
                 continue;
             c->worldCurveRoot[c->numWorldCurves] = root;
             c->worldCurveInst[c->numWorldCurves++] = i;
+            c->worldCurveIdentLast = memcmp(c->instances[i].transform, kIdentity, sizeof(kIdentity)) == 0 ? 1u : 0u; // (of the last one entered)
             valid[i] = 0; // no TLAS leaf
         }
     uint32_t nValidHost = 0;
@@ -2107,6 +2114,7 @@ static DevScene make_dev_scene(const skh_context* c)
     sc.tlasInst = c->dTlasInst.as<uint32_t>();
     sc.tlasRoot = c->tlasRoot;
     sc.numWorldCurves = c->numWorldCurves;
+    sc.worldCurveIdentLast = c->worldCurveIdentLast;
     for (uint32_t k = 0; k < SKH_WORLD_CURVES; ++k)
         sc.worldCurveRoot[k] = k < c->numWorldCurves ? c->worldCurveRoot[k] : SKH_REF_INVALID, sc.worldCurveInst[k] = k < c->numWorldCurves ? c->worldCurveInst[k] : 0u;
     sc.numInstances = c->nInstances;

@@ -449,11 +449,13 @@ def test_curve_intersector_finds_the_first_entry_into_the_swept_volume(ork):
 
 
 def test_world_curves_rule_decides_the_light_proxies():
-    """Round 5's "world curves": when every curve instance with segments sits under a bit-exact identity transform (at most 16 of them) and no
-    mesh or light instance is left unbaked, the curve sets need no top level -- the product walks their trees from the world-only kernel -- and the
-    light proxies follow the meshes into world space.  The rule is an integer rule both sides evaluate; here the checker's side: identity ->
-    lights baked; a rotated, a translated or a -0.0-carrying transform, a 17th curve instance or bake mode 1 (the shared light quad stays) -> not.
-    Hit records never depend on it for the curves themselves (the identity is still applied to the ray): closest hits equal the unbaked context's."""
+    """Round 5's "world curves": when a scene holds at most 16 curve instances with segments and no mesh or light instance is left unbaked, the
+    curve sets need no top level -- the product walks their trees from the world-only kernel, each instance's transform applied to the ray as
+    at a TLAS leaf -- and the light proxies follow the meshes into world space.  The rule is an integer rule both sides evaluate; here the
+    checker's side: one curve instance, under any transform -> lights baked; a 17th curve instance, or bake mode 1 (the shared light quad
+    stays behind) -> not.  The curves' own hit records never depend on it: closest hits equal the unbaked context's."""
+    from tests.test_gpu_parity import camera_rays
+
     sc = scenes.hair_standin(seed=5, n_strands=4000, n_cp=7)
     arr = dict(sc.arrays())
     inst = arr["instances"]
@@ -469,37 +471,30 @@ def test_world_curves_rule_decides_the_light_proxies():
 
     o_id, b = baked_lights(arr)
     assert b == [1, 1]
-    for change in ("rotate", "translate", "negzero", "mode1", "many"):
+    rays = np.concatenate([camera_rays(sc, 48, 48, 20000, 3), scenes.random_rays(20000, 4, -1.5, 1.5)])
+    for change, want in (("rotate", [1, 1]), ("mode1", [0, 0]), ("many", [0, 0]), ("sixteen", [1, 1])):
         a2 = dict(arr)
         i2 = inst.copy()
         mode = 4
         if change == "rotate":
             m = np.eye(4)
             m[:3] = i2["transform"][curves[0]].reshape(3, 4)
-            i2["transform"][curves[0]] = (m @ S.rotate((0, 1, 0), 0.3))[:3].astype(np.float32).reshape(12)
-        elif change == "translate":
-            i2["transform"][curves[0]][3] = 0.25
-        elif change == "negzero":
-            i2["transform"][curves[0]][1] = -0.0  # equal to the identity as a number, not as bits: x * -0 rounds differently from x * +0
+            i2["transform"][curves[0]] = (S.translate((0.1, -0.2, 0.05)) @ m @ S.rotate((0, 1, 0), 0.3) @ S.scale((1.0, 0.7, 1.3)))[:3].astype(np.float32).reshape(12)
         elif change == "mode1":
             mode = 1
         else:
-            extra = np.repeat(i2[curves[:1]], 16)
-            i2 = np.concatenate([i2, extra])
+            i2 = np.concatenate([i2, np.repeat(i2[curves[:1]], 16 if change == "many" else 15)])
         a2["instances"] = i2
-        _, b2 = baked_lights(a2, mode)
-        assert b2 == [0, 0], change
-    # the curves' hit records are the same with and without the rule's consequences
-    from tests.test_gpu_parity import camera_rays
-
-    rays = np.concatenate([camera_rays(sc, 48, 48, 20000, 3), scenes.random_rays(20000, 4, -1.5, 1.5)])
-    ref = orklib.new_context()
-    ref.set_bake(0)
-    ref.set_scene(arr)
-    a, r0 = o_id.trace(rays, 0), ref.trace(rays, 0)
-    on_curves = np.isin(r0["instance_id"], curves)
-    assert on_curves.sum() > 200
-    for f in ("instance_id", "prim_id"):
-        assert np.array_equal(a[f][on_curves], r0[f][on_curves])
-    for f in ("t", "u", "v"):
-        assert np.array_equal(a[f][on_curves].view(np.uint32), r0[f][on_curves].view(np.uint32))
+        o2, b2 = baked_lights(a2, mode)
+        assert b2 == want, change
+        if change == "rotate":  # the transformed curve set's hit records with and without the rule's consequences
+            ref = orklib.new_context()
+            ref.set_bake(0)
+            ref.set_scene(a2)
+            a, r0 = o2.trace(rays, 0), ref.trace(rays, 0)
+            on_curves = np.isin(r0["instance_id"], curves)
+            assert on_curves.sum() > 200
+            for f in ("instance_id", "prim_id"):
+                assert np.array_equal(a[f][on_curves], r0[f][on_curves])
+            for f in ("t", "u", "v"):
+                assert np.array_equal(a[f][on_curves].view(np.uint32), r0[f][on_curves].view(np.uint32))
