@@ -473,7 +473,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? SKH_WORLD_C
                 if (WORLD && CURVES)
                 {
                     // stack, bottom to top: the curve trees' markers, the light proxies' root; current node: the world-space triangles' root
-                    sh = make_shear(dw);
+                    if (!CURVES) // (the curve builds are short of registers and meet few triangles: they recompute the shear at every triangle leaf)
+                        sh = make_shear(dw);
                     curInst = 0xffffffffu;
                     curType = 0;
                     sp = 0;
@@ -490,7 +491,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? SKH_WORLD_C
                 {
                     // baked instances first: the ray starts INSIDE their world-space groups (identity entry: o = ow, d = dw), the top
                     // level waits under a sentinel on the stack
-                    sh = make_shear(dw);
+                    if (!CURVES) // (the curve builds are short of registers and meet few triangles: they recompute the shear at every triangle leaf)
+                        sh = make_shear(dw);
                     nodes = sc.triNodes;
                     inBlas = true;
                     curInst = 0xffffffffu; // = "the instance id is in the triangle record"
@@ -1024,7 +1026,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? SKH_WORLD_C
                         o = xform_point_rel(m, ow);
                         d = xform_vector(m, dw);
                         inv = rcp3(d);
-                        sh = make_shear(d);
+                        if (!CURVES)
+                            sh = make_shear(d);
                         curInst = __float_as_uint(i3.w); // the instance this leaf belongs to
                         curType = __float_as_uint(i3.z);
                         nodes = (CURVES && curType == 2) ? sc.segNodes : sc.triNodes;
@@ -1054,6 +1057,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? SKH_WORLD_C
                 }
                 else
                 {
+                    if (CURVES)
+                        sh = make_shear(d); // (same function of the same direction: same bits as the value the other builds keep)
                     for (uint32_t k = (TRICOOP ? kStart : 0u); k < count; ++k)
                     {
                         const float4* tp = sc.tris + 3 * (size_t)(first + k);
