@@ -1432,15 +1432,18 @@ SKH_DI SurfaceHit fill_curve(const DevScene& sc, const HostInstance& hi, const f
 // k_shade: __miss__ms (OptixRender.cu:250-257), __closesthit__light (:315-341), __closesthit__radiance
 // (closest_hit.cu:456-606) and the tail of the raygen bounce loop (OptixRender.cu:131-153) for one bounce.
 // ------------------------------------------------------------------------------------------------------------
-#ifndef SKH_SHADE_ATTR
-#define SKH_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(4, 4))) // 128 VGPRs (4 spilled dwords): four 256-thread blocks per CU
+#ifndef SKH_SHADE_WAVES
+#define SKH_SHADE_WAVES(HAIR) ((HAIR) ? 4 : 5) // waves per SIMD: the triangle-material build fits 96 VGPRs without a spill since round 5 (the path's radiance stays in memory, the
+                                                // continuation code is gone): kitchen k_shade 30.7 -> 27.8 ms, Cornell 8.97 -> 8.20; six waves spill 27 dwords (30.2 ms); the hair build
+                                                // (Chiang BSDF) spills 27 at five (16.7 -> 18.2 ms) and stays at four
 #endif
+#define SKH_SHADE_ATTR(HAIR) __attribute__((amdgpu_waves_per_eu(SKH_SHADE_WAVES(HAIR), SKH_SHADE_WAVES(HAIR))))
 #ifndef SKH_SHADE_BLOCK
 #define SKH_SHADE_BLOCK 256 // 132 VGPRs = 3 waves/SIMD: 256-thread blocks (1 wave per SIMD) fill all three, 512-thread blocks only two
 #endif
 // HAIR: the build with df::chiang_hair_bsdf in it (launched when the material list holds a hair material)
 template <bool HAIR>
-__global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
+__global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
     k_shade(DevScene sc, FrameP fp, uint32_t sampleOffset, uint32_t depth /* bounce index */, const uint32_t* __restrict__ tileXY, RayQ rq,
             const uint32_t* __restrict__ countPtr, HitQ hq, PathS ps, RayQ nextQ, uint32_t* __restrict__ nextCount, RayQ shadowQ,
             float* __restrict__ contrib, uint32_t* __restrict__ shadowCount)
@@ -1470,6 +1473,10 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
 #else
 #define SKH_SP(k)
 #endif
+    bool valid = il < n;
+    uint32_t pid = 0;
+    v3 rayO = mk3(0.0f), rayD = mk3(0.0f);
+    float4 hr0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), hr1 = hr0;
     {
         // 20 KB table -> LDS: the block's five fetches go out together (a rolled loop waited for each in turn)
         constexpr int passes = ((SKH_SOBOL_LUT_WORDS / 4) + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK; // (256 threads: five whole passes; 512: the third is half one)
@@ -1496,17 +1503,15 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR
 #endif
     }
     __syncthreads();
-    bool valid = il < n;
     bool emitNext = false, emitShadow = false;
     v3 nextO = mk3(0.0f), nextD = mk3(0.0f), shO = mk3(0.0f), shD = mk3(0.0f), shC = mk3(0.0f);
     float shTmax = 0.0f;
-    uint32_t pid = 0;
     if (valid)
     {
         pid = rq.ids()[i];
-        const v3 rayO = mk3(rq.plane(0)[i], rq.plane(1)[i], rq.plane(2)[i]);
-        const v3 rayD = mk3(rq.plane(3)[i], rq.plane(4)[i], rq.plane(5)[i]);
-        const float4 hr0 = hq.rec(i)[0], hr1 = hq.rec(i)[1];
+        rayO = mk3(rq.plane(0)[i], rq.plane(1)[i], rq.plane(2)[i]);
+        rayD = mk3(rq.plane(3)[i], rq.plane(4)[i], rq.plane(5)[i]);
+        hr0 = hq.rec(i)[0], hr1 = hq.rec(i)[1];
         const float ht = hr0.x, hu = hr0.y, hv = hr0.z;
         const uint32_t hinst = __float_as_uint(hr1.x), hprim = __float_as_uint(hr1.y);
         float* P = ps.base;
