@@ -231,6 +231,9 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 #define SKH_CURVE_MIN_WAVES 6 // 80 VGPRs (29 dwords spilled) for the build with the inlined curve intersector: hair stand-in 425 / 455 / 478 / 480 Mray/s
                               // at 4 / 5 / 6 / 7 waves per SIMD (the build needs 104 VGPRs unconstrained)
 #endif
+#ifndef SKH_WORLD_CURVE_ANYHIT_MIN_WAVES
+#define SKH_WORLD_CURVE_ANYHIT_MIN_WAVES 6
+#endif
 #ifndef SKH_WORLD_CURVE_MIN_WAVES
 #define SKH_WORLD_CURVE_MIN_WAVES 6 // the world-only kernel with the curve block
 #endif
@@ -284,7 +287,7 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 // (The measured-negative variants of round 4 -- pop-time culling, postponed leaves, the touch prefetch, packed node FMAs, 8-wide nodes, continuations --
 // live in experiments/skh_trace_r04_variants.h with their numbers; three builds ship: world-only, two-level, two-level + curves.)
 template <bool ANY_HIT, bool COUNT, bool CURVES, bool WORLD = false>
-__global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? SKH_WORLD_CURVE_MIN_WAVES : SKH_CURVE_MIN_WAVES) : (WORLD ? (ANY_HIT ? SKH_WORLD_ANYHIT_MIN_WAVES : SKH_WORLD_CLOSEST_MIN_WAVES) : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES))) SKH_TRACE_ATTR
+__global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? SKH_WORLD_CURVE_ANYHIT_MIN_WAVES : SKH_WORLD_CURVE_MIN_WAVES) : SKH_CURVE_MIN_WAVES) : (WORLD ? (ANY_HIT ? SKH_WORLD_ANYHIT_MIN_WAVES : SKH_WORLD_CLOSEST_MIN_WAVES) : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES))) SKH_TRACE_ATTR
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
             uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, 
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
