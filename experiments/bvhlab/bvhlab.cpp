@@ -522,6 +522,125 @@ static void collapse(const Tree& t, int leafMax, Flat& f, bool sahRule)
     }
 }
 
+// ---- cost-optimal collapse (after Ylitie, Karras & Laine 2017, section 4.1, for 4-wide nodes) ----
+// C(x, i) = cheapest way to represent x's subtree by at most i wide-node children (i = 1 .. 3): a leaf (<= leafMax primitives), one wide node whose
+// four slots are dealt between x's two children, or -- for i > 1 -- x dissolved and the i slots dealt between its children.  cn / ct price a wide-node visit
+// and a primitive test per unit of box area.  The top-down pass follows the argmins.
+static void collapse_dp(const Tree& t, int leafMax, Flat& f, float cn, float ct)
+{
+    const int n = t.n, total = 2 * n - 1;
+    std::vector<std::array<float, 3>> C(total);
+    std::vector<int> order; // internal nodes, parents before children
+    order.reserve(n);
+    order.push_back(t.root);
+    for (size_t i = 0; i < order.size(); ++i)
+    {
+        const int x = order[i];
+        if (t.L[x] < n - 1)
+            order.push_back(t.L[x]);
+        if (t.R[x] < n - 1)
+            order.push_back(t.R[x]);
+    }
+    for (int x = n - 1; x < total; ++x)
+        C[x] = { area(t.box[x]) * ct, area(t.box[x]) * ct, area(t.box[x]) * ct };
+    auto deal = [&](int x, int j) { // j slots between the children of x
+        float best = 3e38f;
+        for (int k = 1; k < j; ++k)
+            best = std::min(best, C[t.L[x]][k - 1] + C[t.R[x]][j - k - 1]);
+        return best;
+    };
+    for (size_t i = order.size(); i-- > 0;)
+    {
+        const int x = order[i];
+        const float A = area(t.box[x]);
+        const float leaf = t.size[x] <= leafMax ? A * t.size[x] * ct : 3e38f;
+        const float inner = A * cn + deal(x, 4);
+        C[x][0] = std::min(leaf, inner);
+        C[x][1] = std::min(C[x][0], deal(x, 2));
+        C[x][2] = std::min(C[x][1], deal(x, 3));
+    }
+    f.nodes.clear();
+    f.leafPrim.clear();
+    struct Item
+    {
+        int bin, out;
+    };
+    std::vector<Item> q{ Item{ t.root, 0 } };
+    f.nodes.push_back(Wide());
+    long nLeaf = 0, nLeafPrims = 0, slotsUsed = 0;
+    for (size_t qi = 0; qi < q.size(); ++qi)
+    {
+        const Item it = q[qi];
+        int slot[4], cnt = 0;
+        // expand (x, budget) pairs into the wide node's children
+        struct E
+        {
+            int x, b;
+        };
+        std::vector<E> st;
+        auto push_deal = [&](int x, int j) {
+            int bk = 1;
+            float best = 3e38f;
+            for (int k = 1; k < j; ++k)
+            {
+                const float c = C[t.L[x]][k - 1] + C[t.R[x]][j - k - 1];
+                if (c < best)
+                    best = c, bk = k;
+            }
+            st.push_back(E{ t.R[x], j - bk }), st.push_back(E{ t.L[x], bk });
+        };
+        push_deal(it.bin, 4);
+        while (!st.empty())
+        {
+            E e = st.back();
+            st.pop_back();
+            while (e.b > 1 && (e.x >= n - 1 || C[e.x][e.b - 1] == C[e.x][e.b - 2]))
+                --e.b;
+            if (e.b == 1)
+                slot[cnt++] = e.x;
+            else
+                push_deal(e.x, e.b);
+        }
+        Wide w;
+        w.cnt = cnt;
+        slotsUsed += cnt;
+        for (int k = 0; k < 4; ++k)
+            w.ref[k] = INT32_MIN, w.cb[k] = empty_box();
+        for (int k = 0; k < cnt; ++k)
+        {
+            const int c = slot[k];
+            w.cb[k] = t.box[c];
+            const int csz = c >= n - 1 ? 1 : t.size[c];
+            const bool isLeaf = c >= n - 1 || (csz <= leafMax && area(t.box[c]) * csz * ct <= area(t.box[c]) * cn + deal(c, 4));
+            if (isLeaf)
+            {
+                const int first = (int)f.leafPrim.size();
+                std::vector<int> s2{ c };
+                while (!s2.empty())
+                {
+                    const int x = s2.back();
+                    s2.pop_back();
+                    if (x >= n - 1)
+                        f.leafPrim.push_back(t.prim[x - (n - 1)]);
+                    else
+                        s2.push_back(t.R[x]), s2.push_back(t.L[x]);
+                }
+                w.ref[k] = ~((first << 3) | (csz - 1));
+                ++nLeaf, nLeafPrims += csz;
+            }
+            else
+            {
+                w.ref[k] = (int)f.nodes.size();
+                f.nodes.push_back(Wide());
+                q.push_back(Item{ c, w.ref[k] });
+            }
+        }
+        f.nodes[it.out] = w;
+    }
+    printf("dp collapse: cost %.4g, %.2f children per node, %.2f primitives per leaf\n", (double)C[t.root][0] / area(t.box[t.root]), (double)slotsUsed / f.nodes.size(),
+           (double)nLeafPrims / nLeaf);
+}
+
 // ---- traversal simulator ----
 struct Ray
 {
@@ -799,7 +918,10 @@ int main(int argc, char** argv)
 
     quantMode = geti("quant", 0);
     Flat f;
-    collapse(t, geti("leaf", 2), f, opt.count("collapse") && opt["collapse"] == "sah");
+    if (opt.count("collapse") && opt["collapse"] == "dp")
+        collapse_dp(t, geti("leaf", 2), f, getf("cn", 1.0f), getf("ct", 1.0f));
+    else
+        collapse(t, geti("leaf", 2), f, opt.count("collapse") && opt["collapse"] == "sah");
     printf("4-wide: %zu nodes, %zu leaf slots\n", f.nodes.size(), f.leafPrim.size());
 
     // ---- rays: camera, one diffuse bounce from the camera hits, shadow rays from those hits towards a point under the ceiling ----
