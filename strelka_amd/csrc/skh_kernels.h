@@ -286,6 +286,16 @@ SKH_DI uint32_t wave_sum(uint32_t v)
 // HdStrelka's per-instance meshes): one world-space tree, no instance entry / exit, no object-space copy of the ray, no sentinel.
 // (The measured-negative variants of round 4 -- pop-time culling, postponed leaves, the touch prefetch, packed node FMAs, 8-wide nodes, continuations --
 // live in experiments/skh_trace_r04_variants.h with their numbers; three builds ship: world-only, two-level, two-level + curves.)
+// (keeps a loop-invariant address out of the hoister's hands: the overflow column's 64-bit address is built where it is used -- branches that
+// never run unless a stack passes its LDS entries -- instead of living in two registers, or in scratch, through the traversal loops)
+SKH_DI uint32_t skh_opaque(uint32_t v)
+{
+    asm volatile("" : "+s"(v)); // (a wave-uniform value: stays scalar)
+    return v;
+}
+#ifndef SKH_BEST_LDS
+#define SKH_BEST_LDS 1
+#endif
 template <bool ANY_HIT, bool COUNT, bool CURVES, bool WORLD = false>
 __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? SKH_WORLD_CURVE_ANYHIT_MIN_WAVES : SKH_WORLD_CURVE_MIN_WAVES) : SKH_CURVE_MIN_WAVES) : (WORLD ? (ANY_HIT ? SKH_WORLD_ANYHIT_MIN_WAVES : SKH_WORLD_CLOSEST_MIN_WAVES) : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES))) SKH_TRACE_ATTR
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
@@ -302,8 +312,13 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
     constexpr bool TRICOOP = SKH_TRI_COOP && WORLD && !CURVES; // (closest-hit and any-hit builds of the world-only TRIANGLE kernel)
     // per-lane stack entries in LDS (the rest: SKH_STACK_OVF entries in global memory); TRICOOP gives one up for its two 64-byte lane tables
     // (LDS is handed out in 1280-byte granules here: 20 x 256 B = 4 granules exactly, 128 B more would cost a fifth = 25 instead of 28 waves per CU)
-    constexpr int NLDS = TRICOOP ? SKH_STACK_LDS - 1 : SKH_STACK_LDS;
+    // The closest-hit CURVE builds keep the attributes of the best hit so far -- instance, primitive, u, v: written when a hit is accepted, read on a tie
+    // and once per ray for the result -- in LDS instead of four registers (they are the builds that spill, and their scratch traffic goes to HBM:
+    // docs/LOG.md, round 5); one stack entry pays for the 1 KB (19 x 256 + 512 (s_runs) + 1024 = 5 granules, as before).
+    constexpr bool BESTLDS = CURVES && !ANY_HIT && SKH_BEST_LDS;
+    constexpr int NLDS = (TRICOOP || BESTLDS) ? SKH_STACK_LDS - 1 : SKH_STACK_LDS;
     __shared__ int s_stack[NLDS * SKH_TRACE_BLOCK];
+    __shared__ uint32_t s_best[BESTLDS ? 4 * SKH_TRACE_BLOCK : 1];
     __shared__ unsigned char s_tab[TRICOOP ? 128 : 1]; // [0..63] owner lanes by rank, [64..127] helper lanes by rank
     const uint32_t fetchMin = fetchArg & 0xffu, curveMin = (fetchArg >> 8) & 0xffu, nodeBreak = (fetchArg >> 16) & 0xffu, leafMin = fetchArg >> 24;
     const uint32_t lane = threadIdx.x;
@@ -319,7 +334,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
     bool exhausted = false;
     int* lds = s_stack + lane;
     // (the overflow area is addressed from ovfBase where it is used -- rare paths -- instead of through a per-lane 64-bit pointer held across the loops)
-#define SKH_OVF_AT(e) ovfBase[(size_t)(e) * ovfStride + (blockIdx.x * SKH_TRACE_BLOCK + threadIdx.x)]
+#define SKH_OVF_AT(e) ovfBase[(size_t)(e) * ovfStride + (skh_opaque(blockIdx.x * SKH_TRACE_BLOCK) + threadIdx.x)]
     const uint32_t ovfStride = gridDim.x * SKH_TRACE_BLOCK;
     const uint32_t rayMask = CURVES ? (ANY_HIT ? 3u : 255u) : (ANY_HIT ? 1u : 253u);
     TraceCounters tc = { 0, 0, 0, 0 };
@@ -352,6 +367,18 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
     HitRec best;
     best.t = 0.0f, best.inst = best.prim = 0xffffffffu, best.u = best.v = 0.0f, best.found = false;
 
+#define SKH_BEST_INST() (BESTLDS ? s_best[lane] : best.inst)
+#define SKH_BEST_PRIM() (BESTLDS ? s_best[SKH_TRACE_BLOCK + lane] : best.prim)
+#define SKH_BEST_SET(INST, PRIM, U, V)                                                                \
+    {                                                                                                 \
+        if (BESTLDS)                                                                                  \
+        {                                                                                             \
+            s_best[lane] = (INST), s_best[SKH_TRACE_BLOCK + lane] = (PRIM);                           \
+            s_best[2 * SKH_TRACE_BLOCK + lane] = __float_as_uint(U), s_best[3 * SKH_TRACE_BLOCK + lane] = __float_as_uint(V); \
+        }                                                                                             \
+        else                                                                                          \
+            best.inst = (INST), best.prim = (PRIM), best.u = (U), best.v = (V);                       \
+    }
 #define SKH_PUSH(v)                                                  \
     {                                                                \
         if (sp < NLDS)                                               \
@@ -429,8 +456,19 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                 else
                 {
                     float4* hr = hq.rec(i);
-                    hr[0] = make_float4(best.found ? best.t : -1.0f, best.u, best.v, 0.0f);
-                    hr[1] = make_float4(__uint_as_float(best.inst), __uint_as_float(best.prim), 0.0f, 0.0f);
+                    if (BESTLDS)
+                    {
+                        // (a miss reports what a fresh record holds: u = v = 0, instance = primitive = ~0)
+                        const bool f = best.found;
+                        hr[0] = make_float4(f ? best.t : -1.0f, f ? __uint_as_float(s_best[2 * SKH_TRACE_BLOCK + lane]) : 0.0f,
+                                            f ? __uint_as_float(s_best[3 * SKH_TRACE_BLOCK + lane]) : 0.0f, 0.0f);
+                        hr[1] = make_float4(__uint_as_float(f ? s_best[lane] : 0xffffffffu), __uint_as_float(f ? s_best[SKH_TRACE_BLOCK + lane] : 0xffffffffu), 0.0f, 0.0f);
+                    }
+                    else
+                    {
+                        hr[0] = make_float4(best.found ? best.t : -1.0f, best.u, best.v, 0.0f);
+                        hr[1] = make_float4(__uint_as_float(best.inst), __uint_as_float(best.prim), 0.0f, 0.0f);
+                    }
                 }
             }
         }
@@ -700,13 +738,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                                 const uint32_t prim = spw & 0x0fffffffu;
                                 // a sub-range leaf keeps the hit only if u is its own (the leaf that owns u reports the same bits)
                                 if (min((uint32_t)(u * (float)sc.curveSplit), sc.curveSplit - 1u) == (spw >> 28) &&
-                                    (!best.found || t < best.t || curInst < best.inst || (curInst == best.inst && prim < best.prim)))
+                                    (!best.found || t < best.t || curInst < SKH_BEST_INST() || (curInst == SKH_BEST_INST() && prim < SKH_BEST_PRIM())))
                                 {
                                     best.t = t;
-                                    best.inst = curInst;
-                                    best.prim = prim;
-                                    best.u = u;
-                                    best.v = 0.0f;
+                                    SKH_BEST_SET(curInst, prim, u, 0.0f)
                                     best.found = true;
                                 }
                             }
@@ -719,6 +754,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                     if (pend == 0u)
                         cur = SKH_REF_INVALID; // leaf done: the lane pops its next entry below
                 }
+                // the reciprocal direction is not needed inside the block: recomputed here (same operation on the same d: same bits) instead of
+                // being held -- or spilled -- across the Newton runs
+                inv = rcp3(d);
                 __builtin_amdgcn_wave_barrier(); // (s_runs is rewritten by the next block)
             }
         }
@@ -1083,13 +1121,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                         {
                             const uint32_t prim = __float_as_uint(a.w);
                             const uint32_t hinst = (WORLD || curInst == 0xffffffffu) ? __float_as_uint(b.w) : curInst; // (baked group: the record names its instance)
-                            if (!best.found || t < best.t || hinst < best.inst || (hinst == best.inst && prim < best.prim))
+                            if (!best.found || t < best.t || hinst < SKH_BEST_INST() || (hinst == SKH_BEST_INST() && prim < SKH_BEST_PRIM()))
                             {
                                 best.t = t;
-                                best.inst = hinst;
-                                best.prim = prim;
-                                best.u = u;
-                                best.v = v;
+                                SKH_BEST_SET(hinst, prim, u, v)
                                 best.found = true;
                             }
                         }
