@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
             uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, 
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
-            StatsDev* __restrict__ stats)
+            StatsDev* __restrict__ stats, uint32_t fetchChunk /* world-only triangle builds: queue positions reserved per atomic, 0 = what each refill needs */)
 {
     // WORLD && CURVES (round 5): the world-only kernel with the curve block in it -- scenes whose every mesh instance is baked and that hold at
     // most SKH_WORLD_CURVES curve instances.  Their curve trees' roots wait at the BOTTOM of every ray's stack as markers
@@ -332,6 +332,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
     const uint32_t group = blockIdx.x & 7u;
     uint32_t tries = 0;
     bool exhausted = false;
+    uint32_t resBase = 0, resLeft = 0; // the wave's reservation in the ray queue (fetchChunk): wave-uniform
     int* lds = s_stack + lane;
     // (the overflow area is addressed from ovfBase where it is used -- rare paths -- instead of through a per-lane 64-bit pointer held across the loops)
 #define SKH_OVF_AT(e) ovfBase[(size_t)(e) * ovfStride + (skh_opaque(blockIdx.x * SKH_TRACE_BLOCK) + threadIdx.x)]
@@ -475,33 +476,76 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
         if (!exhausted && (want >= fetchMin || want == 64u))
         {
             SKH_LP(wv[4]++; wv[5] += want;)
-            uint32_t base = 0, count = 0;
-            const int leader = __ffsll((long long)needMask) - 1;
-            while (tries < 8u)
+            uint32_t base = 0, count = 0, base2 = 0, count1 = 0;
+            if constexpr (WORLD && !CURVES)
             {
-                const uint32_t g = (group + tries) & 7u;
-                uint32_t b = 0;
-                if ((int)lane == leader)
-                    b = atomicAdd(&fetch[g * SKH_FETCH_STRIDE], want);
-                b = __shfl(b, leader);
-                const uint32_t lo = g * perGroup;
-                const uint32_t hi = lo + min(countPtr[g * SKH_COUNT_STRIDE], perGroup);
-                if (lo < hi && b < hi - lo)
+                // The wave takes `want` positions from its shard's cursor -- or, for hierarchies small enough that the launch would be bound by the cursors'
+                // atomics (fetchChunk: Cornell), reserves a chunk per atomic and serves its next refills from the reservation; a refill that finds the
+                // reservation short takes what is left and the start of the next chunk.  (Which wave traces which ray does not show in any result.)
+                const uint32_t chunk = fetchChunk;
+                count1 = min(want, resLeft); // (0 without chunks)
+                base = resBase, count = count1;
+                resBase += count1, resLeft -= count1;
+                if (count1 < want)
                 {
-                    base = lo + b;
-                    count = min(want, hi - base);
-                    if (count < want)
-                        ++tries; // this range is now empty
-                    break;
+                    const uint32_t ask = chunk ? chunk : want;
+                    const int leader = __ffsll((long long)needMask) - 1;
+                    while (tries < 8u)
+                    {
+                        const uint32_t g = (group + tries) & 7u;
+                        uint32_t b = 0;
+                        if ((int)lane == leader)
+                            b = atomicAdd(&fetch[g * SKH_FETCH_STRIDE], ask);
+                        b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader); // (a scalar: the reservation lives in SGPRs)
+                        const uint32_t lo = g * perGroup;
+                        const uint32_t hi = lo + min(countPtr[g * SKH_COUNT_STRIDE], perGroup);
+                        if (lo < hi && b < hi - lo)
+                        {
+                            const uint32_t got = min(ask, hi - (lo + b));
+                            if (got < ask)
+                                ++tries; // this range is now empty
+                            const uint32_t count2 = min(want - count1, got);
+                            base2 = lo + b;
+                            if (chunk)
+                                resBase = base2 + count2, resLeft = got - count2;
+                            count = count1 + count2;
+                            break;
+                        }
+                        ++tries;
+                    }
+                    if (tries >= 8u && count == 0)
+                        exhausted = true;
                 }
-                ++tries;
             }
-            if (tries >= 8u && count == 0)
-                exhausted = true;
+            else
+            {
+                const int leader = __ffsll((long long)needMask) - 1;
+                while (tries < 8u)
+                {
+                    const uint32_t g = (group + tries) & 7u;
+                    uint32_t b = 0;
+                    if ((int)lane == leader)
+                        b = atomicAdd(&fetch[g * SKH_FETCH_STRIDE], want);
+                    b = __shfl(b, leader);
+                    const uint32_t lo = g * perGroup;
+                    const uint32_t hi = lo + min(countPtr[g * SKH_COUNT_STRIDE], perGroup);
+                    if (lo < hi && b < hi - lo)
+                    {
+                        base = lo + b;
+                        count = min(want, hi - base);
+                        if (count < want)
+                            ++tries; // this range is now empty
+                        break;
+                    }
+                    ++tries;
+                }
+                if (tries >= 8u && count == 0)
+                    exhausted = true;
+            }
             const uint32_t rank = rank_below(needMask);
             if (!hasRay && rank < count)
             {
-                ridx = base + rank;
+                ridx = (WORLD && !CURVES) ? (rank < count1 ? base + rank : base2 + (rank - count1)) : base + rank;
                 ow = mk3(rq.plane(0)[ridx], rq.plane(1)[ridx], rq.plane(2)[ridx]);
                 dw = mk3(rq.plane(3)[ridx], rq.plane(4)[ridx], rq.plane(5)[ridx]);
                 tmin = rq.plane(6)[ridx];

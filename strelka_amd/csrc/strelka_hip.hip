@@ -145,6 +145,8 @@ struct skh_context
     int worldCurveRoot[SKH_WORLD_CURVES];
     uint32_t worldCurveInst[SKH_WORLD_CURVES];
     uint32_t worldCurveIdentLast = 0;
+    uint32_t hierNodes = 0;  // 4-wide nodes of the triangle and curve trees (skh_build_accel): decides the automatic fetch_chunk
+    int32_t fetchChunk = -1; // option fetch_chunk: queue positions a trace wave reserves per atomic; 0 = one atomic per refill; -1 = automatic
     uint32_t numTlasLeaves = 0;
     bool countTraversal = false, timing = false;
     // scheduling of the persistent trace kernels, measured on MI355X (kitchen C3, 32 sub-frames per pass):
@@ -1517,6 +1519,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     memset(&c->buildInfo, 0, sizeof(c->buildInfo));
     c->buildInfo.triangles = nTris;
     c->buildInfo.nodes = triOut.numNodes;
+    c->hierNodes = triOut.numNodes;
     c->buildInfo.reinsert_rounds = triOut.riRounds;
     c->buildInfo.reinsert_moves = triOut.riMoves;
     c->buildInfo.reinsert_min_size = triOut.riMinSize;
@@ -1619,6 +1622,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     c->curveSplitBuilt = K;
     dev_free(c->dSegNodes);
     c->dSegNodes = segOut.nodes;
+    c->hierNodes += segOut.numNodes;
     // ---- instances -> TLAS (baked instances were marked invalid above: they get a record for shading, no leaf) ----
     BA(dev_upload(c, dW2o, w2o.data(), sizeof(float) * w2o.size()));
     BA(dev_upload(c, dValid, valid.data(), valid.size()));
@@ -2196,15 +2200,20 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
     const uint32_t fullGrid = (ANY && !c->nSegs) ? (uint32_t)c->numCUs * (worldOnly ? c->wavesPerCUShadowWorld : c->wavesPerCUShadow)
                                                  : (worldOnly ? (uint32_t)c->numCUs * c->wavesPerCUWorld : c->traceBlocks);
     const uint32_t blocks = c->gridOverride ? std::min(c->gridOverride, fullGrid) : fullGrid;
+    // A hierarchy that fits the L2 many times over (Cornell: 30 triangles) makes rays so cheap that the launch is bound by the eight queue cursors'
+    // atomics (~88 M per second and address): such scenes reserve 128 positions per atomic (Cornell 13.5 -> 14.8 Gray/s).  Larger scenes lose by it
+    // (neighbouring rays are then traced at different times by one wave instead of together by neighbouring waves: kitchen -1 %, hair -2 %;
+    // docs/LOG.md, round 5); only the world-only triangle builds carry the code.
+    const uint32_t chunk = c->fetchChunk >= 0 ? (uint32_t)c->fetchChunk : (c->hierNodes <= 16384u ? 128u : 0u);
     if (worldOnly)
         // every instance is baked: the world-only build of the kernel (no instance entry, no object-space copy of the ray)
-        k_trace<ANY, COUNT, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
+        k_trace<ANY, COUNT, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, chunk);
     else if (worldCurves)
-        k_trace<ANY, COUNT, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
+        k_trace<ANY, COUNT, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, chunk);
     else if (c->nSegs)
-        k_trace<ANY, COUNT, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
+        k_trace<ANY, COUNT, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, chunk);
     else
-        k_trace<ANY, COUNT, false><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd);
+        k_trace<ANY, COUNT, false><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, chunk);
 }
 
 // After a synchronisation: did any traversal of the calls since the last check drop a stack entry (its result may miss hits)?
@@ -3431,6 +3440,12 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
             return SKH_INVALID_ARGUMENT;
         (n == "fetch_min_closest" ? c->fetchMinClosest : c->fetchMinShadow) = (uint32_t)value; // (an explicit value applies to both builds)
         (n == "fetch_min_closest" ? c->curveFetchMinClosest : c->curveFetchMinShadow) = (uint32_t)value;
+    }
+    else if (n == "fetch_chunk")
+    {
+        if (value < -1 || value > 4096)
+            return SKH_INVALID_ARGUMENT;
+        c->fetchChunk = (int32_t)value;
     }
     else if (n == "curve_min")
     {
