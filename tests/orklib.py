@@ -137,8 +137,12 @@ def usable_cpus():
 def load():
     global _lib
     if _lib is None:
-        build()
-        lib = C.CDLL(LIB)
+        # ORK_LIB: another build of the same source (tools/oracle_sanitize.sh loads an ASan / UBSan build)
+        if os.environ.get("ORK_LIB"):
+            lib = C.CDLL(os.environ["ORK_LIB"])
+        else:
+            build()
+            lib = C.CDLL(LIB)
         if not os.environ.get("OMP_NUM_THREADS"):
             lib.ork_set_num_threads(usable_cpus())
         lib.ork_create.restype = C.c_void_p
