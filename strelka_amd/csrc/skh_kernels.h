@@ -293,6 +293,10 @@ SKH_DI uint32_t skh_opaque(uint32_t v)
     asm volatile("" : "+s"(v)); // (a wave-uniform value: stays scalar)
     return v;
 }
+struct LightBox
+{
+    float lo[3], hi[3];
+};
 #ifndef SKH_BEST_LDS
 #define SKH_BEST_LDS 1
 #endif
@@ -301,7 +305,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
             uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, 
             HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
-            StatsDev* __restrict__ stats, uint32_t fetchChunk /* world-only triangle builds: queue positions reserved per atomic, 0 = what each refill needs */)
+            StatsDev* __restrict__ stats, LightBox lightBox /* around the baked light proxies (closest-hit builds) */, uint32_t fetchChunk /* world-only triangle builds: queue positions reserved per atomic, 0 = what each refill needs */)
 {
     // WORLD && CURVES (round 5): the world-only kernel with the curve block in it -- scenes whose every mesh instance is baked and that hold at
     // most SKH_WORLD_CURVES curve instances.  Their curve trees' roots wait at the BOTTOM of every ray's stack as markers
@@ -380,6 +384,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
         else                                                                                          \
             best.inst = (INST), best.prim = (PRIM), best.u = (U), best.v = (V);                       \
     }
+// a baked light proxy's triangle in the world-space group (merge_light_proxies): any-hit queries do not see lights (the proxies that stay instances
+// are masked at their TLAS leaf); in a world-space group -- the only place where the instance id comes with the triangle -- a primitive word
+// without SKH_PRIM_DIRECT is a light proxy's
+#define SKH_HIDDEN_LIGHT(A) (ANY_HIT && (WORLD || curInst == 0xffffffffu) && (__float_as_uint((A).w) & SKH_PRIM_DIRECT) == 0u)
 #define SKH_PUSH(v)                                                  \
     {                                                                \
         if (sp < NLDS)                                               \
@@ -554,7 +562,20 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                 inv = rcp3(d);
                 if (ANY_HIT && !WORLD)
                     invw = inv;
-                const int wr0 = sc.worldRoot, wr1 = ANY_HIT ? SKH_REF_INVALID : sc.lightRoot; // (kernel arguments: scalar branches)
+                const int wr0 = sc.worldRoot; // (kernel arguments: scalar branches)
+                int wr1 = ANY_HIT ? SKH_REF_INVALID : sc.lightRoot;
+                if (!ANY_HIT && wr1 != SKH_REF_INVALID)
+                {
+                    // The baked light proxies' tree is every radiance ray's LAST stop (one node visit per ray at least: 4 % of the kitchen's): a ray that
+                    // misses the box around ALL of them (lightBox: the group's bounds plus the node encoder's margin; the node test's own slab
+                    // arithmetic and slack, so whatever a visit of the root could find lies inside) does not go there at all.
+                    const float lnx = ((inv.x >= 0.0f ? lightBox.lo[0] : lightBox.hi[0]) - o.x) * inv.x, lfx = ((inv.x >= 0.0f ? lightBox.hi[0] : lightBox.lo[0]) - o.x) * inv.x;
+                    const float lny = ((inv.y >= 0.0f ? lightBox.lo[1] : lightBox.hi[1]) - o.y) * inv.y, lfy = ((inv.y >= 0.0f ? lightBox.hi[1] : lightBox.lo[1]) - o.y) * inv.y;
+                    const float lnz = ((inv.z >= 0.0f ? lightBox.lo[2] : lightBox.hi[2]) - o.z) * inv.z, lfz = ((inv.z >= 0.0f ? lightBox.hi[2] : lightBox.lo[2]) - o.z) * inv.z;
+                    const float ltn = fmaxf(fmaxf(lnx, lny), fmaxf(lnz, tmin)), ltf = fminf(fminf(lfx, lfy), fminf(lfz, rq.plane(7)[ridx] /* the ray's tmax */));
+                    if (!(ltn <= ltf * SKH_SLAB_SLACK))
+                        wr1 = SKH_REF_INVALID;
+                }
                 if (WORLD && CURVES)
                 {
                     // stack, bottom to top: the curve trees' markers, the light proxies' root; current node: the world-space triangles' root
@@ -1062,6 +1083,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                     else
                         ih = intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), ht, hu, hv);
                     hprim = __float_as_uint(a.w), hinst = __float_as_uint(b.w);
+                    // (a baked light proxy in the world-space group -- merge_light_proxies --: any-hit queries do not see lights; its primitive word lacks SKH_PRIM_DIRECT)
+                    if (ANY_HIT && (hprim & SKH_PRIM_DIRECT) == 0u)
+                        ih = false;
                 }
                 if (!COOP_REGS && helper)
                 {
@@ -1158,9 +1182,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                         wv[6] += __any(pf & 1u) ? 1u : 0u; // triangle passes in which some lane took the fp64 edge-function fallback
                         wv[7] += __any(pf & 4u) ? 1u : 0u; // ... in which some lane got as far as the division
                         wv[8] += __any(pf & 2u) ? 1u : 0u; // ... passed the sign test
-                        if (ih && (best.found || t < best.t))
+                        if (ih && (best.found || t < best.t) && !SKH_HIDDEN_LIGHT(a))
 #else
-                        if (intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), t, u, v) && (best.found || t < best.t))
+                        if (intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), t, u, v) && (best.found || t < best.t) && !SKH_HIDDEN_LIGHT(a))
 #endif
                         {
                             const uint32_t prim = __float_as_uint(a.w);
@@ -1236,6 +1260,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
         SKH_LP(cy[4] += __builtin_readcyclecounter() - cyA;)
     }
 #undef SKH_PUSH
+#undef SKH_HIDDEN_LIGHT
 #undef SKH_POP
 #undef SKH_OVF_AT
 #undef SKH_TAKE_MARKER

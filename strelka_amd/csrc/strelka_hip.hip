@@ -200,6 +200,8 @@ struct skh_context
     uint32_t mortonBits = 10; // per axis, in the builders' sort keys (option morton_bits 4..21: 10 / 13 / 16 / 20 measured within the +-1.5 % the tree's shape varies by anyway)
     uint32_t leafLines = 0;   // 1: triangle leaves laid out by 128-byte line (skh_bvh.h: k_leaf_place): -11 % fetched lines, same time (docs/LOG.md)
     uint32_t nTriSlots = 0;
+    LightBox lightBox = { { -INFINITY, -INFINITY, -INFINITY }, { INFINITY, INFINITY, INFINITY } }; // around the baked light proxies' group (skh_build_accel), with the node encoder's margin
+    uint32_t mergeLightProxies = 0; // option merge_light_proxies: baked light proxies share the world-space mesh triangles' tree (any-hit queries skip their triangles) instead of a tree of their own that every radiance ray visits
     uint32_t leafMaxTris = 2; // measured on MI355X: 2 beats 1, 3, 4, 6, 8 (the kernel is ALU bound, wasted triangle tests cost more than extra nodes)
     uint32_t buildQuality = 1; // 0: Karras radix tree (fastest build), 1: PLOC clustering (SAH-class quality)
     float sceneLo[3] = { 0, 0, 0 }, sceneHi[3] = { 1, 1, 1 };
@@ -1478,8 +1480,12 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
             triLocal.push_back(t);
         }
     }
-    meshTriCount[nMeshes] = nBakedG[0];
-    meshTriCount[nMeshes + 1u] = nBakedG[1];
+    // (merge_light_proxies: one world-space group for both kinds -- a light proxy is told from a mesh triangle by its primitive word, which
+    // lacks SKH_PRIM_DIRECT (k_gather_tris); any-hit queries, which must not see lights (RAY_MASK_SHADOW, closest_hit.cu:191), skip those triangles)
+    const bool mergeLights = c->mergeLightProxies != 0u && nBakedG[0] != 0u && nBakedG[1] != 0u;
+    const uint32_t nGroup0 = mergeLights ? nBakedG[0] + nBakedG[1] : nBakedG[0], nGroup1 = mergeLights ? 0u : nBakedG[1];
+    meshTriCount[nMeshes] = nGroup0;
+    meshTriCount[nMeshes + 1u] = nGroup1;
     const uint32_t nMeshTris = (uint32_t)triMesh.size();
     const uint32_t nTris = nMeshTris + nBaked;
     c->nTris = nTris;
@@ -1511,7 +1517,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     if (nBaked)
         k_baked_tri_boxes<<<(nBaked + B - 1) / B, B, 0, st>>>(c->dInstances.as<uint8_t>(), dWInst.as<uint32_t>(), dWFirst.as<uint32_t>(),
                                                              (uint32_t)wInst.size(), c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(),
-                                                             c->dMeshes.as<uint4>(), nBaked, nMeshTris, nMeshes, nBakedG[0], dBoxLo.as<float4>(),
+                                                             c->dMeshes.as<uint4>(), nBaked, nMeshTris, nMeshes, nGroup0, dBoxLo.as<float4>(),
                                                              dBoxHi.as<float4>(), dGrp.as<uint32_t>());
     const uint32_t riMin = c->reinsertMinSize ? c->reinsertMinSize : (nTris <= (4u << 20) ? 1u : 32u);
     BA(lbvh_build(c, nTris, nMeshes + 2u, meshTriCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), (int)c->leafMaxTris, usePloc, triOut,
@@ -1537,9 +1543,11 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
                                                               c->dTris.as<float4>());
     dev_free(c->dTriNodes);
     c->dTriNodes = triOut.nodes;
-    c->worldRoot = nBakedG[0] ? triOut.hostGroupRoot[nMeshes] : SKH_REF_INVALID;
-    c->lightRoot = nBakedG[1] ? triOut.hostGroupRoot[nMeshes + 1u] : SKH_REF_INVALID;
+    c->worldRoot = nGroup0 ? triOut.hostGroupRoot[nMeshes] : SKH_REF_INVALID;
+    c->lightRoot = nGroup1 ? triOut.hostGroupRoot[nMeshes + 1u] : SKH_REF_INVALID;
     float worldBounds[6] = { INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY };
+    for (int k = 0; k < 3; ++k)
+        c->lightBox.lo[k] = -INFINITY, c->lightBox.hi[k] = INFINITY;
     if (nBaked)
     {
         float gb[12];
@@ -1550,8 +1558,15 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
             cleanup();
             return SKH_FAIL;
         }
+        for (int k = 0; k < 3; ++k)
+        {
+            // (the margin encode_node4 puts around a node's box: what a visit of the group's root could find lies inside)
+            const float m = nGroup1 ? std::max(std::fabs(gb[6 + k]), std::fabs(gb[9 + k])) * 0x1p-20f + 1e-30f : 0.0f;
+            c->lightBox.lo[k] = nGroup1 ? gb[6 + k] - m : -INFINITY;
+            c->lightBox.hi[k] = nGroup1 ? gb[9 + k] + m : INFINITY;
+        }
         for (uint32_t g = 0; g < 2; ++g)
-            if (nBakedG[g])
+            if (g == 0 ? nGroup0 : nGroup1)
                 for (int k = 0; k < 3; ++k)
                 {
                     worldBounds[k] = std::min(worldBounds[k], gb[6 * g + k]);
@@ -2207,13 +2222,13 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
     const uint32_t chunk = c->fetchChunk >= 0 ? (uint32_t)c->fetchChunk : (c->hierNodes <= 16384u ? 128u : 0u);
     if (worldOnly)
         // every instance is baked: the world-only build of the kernel (no instance entry, no object-space copy of the ray)
-        k_trace<ANY, COUNT, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, chunk);
+        k_trace<ANY, COUNT, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, c->lightBox, chunk);
     else if (worldCurves)
-        k_trace<ANY, COUNT, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, chunk);
+        k_trace<ANY, COUNT, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, c->lightBox, chunk);
     else if (c->nSegs)
-        k_trace<ANY, COUNT, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, chunk);
+        k_trace<ANY, COUNT, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, c->lightBox, chunk);
     else
-        k_trace<ANY, COUNT, false><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, chunk);
+        k_trace<ANY, COUNT, false><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, c->lightBox, chunk);
 }
 
 // After a synchronisation: did any traversal of the calls since the last check drop a stack entry (its result may miss hits)?
@@ -3440,6 +3455,13 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
             return SKH_INVALID_ARGUMENT;
         (n == "fetch_min_closest" ? c->fetchMinClosest : c->fetchMinShadow) = (uint32_t)value; // (an explicit value applies to both builds)
         (n == "fetch_min_closest" ? c->curveFetchMinClosest : c->curveFetchMinShadow) = (uint32_t)value;
+    }
+    else if (n == "merge_light_proxies")
+    {
+        if (value != 0 && value != 1)
+            return SKH_INVALID_ARGUMENT;
+        c->mergeLightProxies = (uint32_t)value;
+        c->accelBuilt = false;
     }
     else if (n == "fetch_chunk")
     {
