@@ -108,9 +108,17 @@ struct HitQ
 {
     float* base;
     uint32_t stride; // rays the buffer holds
+    // primBits = B > 0 (render passes of world-only triangle scenes whose instance count and shading-record count share 32 bits: option compact_hits):
+    // ONE 16-byte record per ray {t, u, v, instance << B | shading record (or a light proxy's primitive index)}, ~0 in the last word = a miss --
+    // 16 B less written per ray by the closest-hit launches and read back by k_shade
+    uint32_t primBits;
     __device__ float4* rec(uint32_t i) const
     {
         return reinterpret_cast<float4*>(base) + 2 * (size_t)i;
+    }
+    __device__ float4* rec16(uint32_t i) const
+    {
+        return reinterpret_cast<float4*>(base) + (size_t)i;
     }
 };
 struct PathS // per path slot: throughput rgb, radiance rgb, lastBsdfPdf, flags
@@ -473,6 +481,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                                             f ? __uint_as_float(s_best[3 * SKH_TRACE_BLOCK + lane]) : 0.0f, 0.0f);
                         hr[1] = make_float4(__uint_as_float(f ? s_best[lane] : 0xffffffffu), __uint_as_float(f ? s_best[SKH_TRACE_BLOCK + lane] : 0xffffffffu), 0.0f, 0.0f);
                     }
+                    else if (!CURVES && hq.primBits != 0u)
+                        *hq.rec16(i) = make_float4(best.found ? best.t : -1.0f, best.u, best.v,
+                                                   __uint_as_float(best.found ? (best.inst << hq.primBits) | (best.prim & ((1u << hq.primBits) - 1u)) : 0xffffffffu));
                     else
                     {
                         hr[0] = make_float4(best.found ? best.t : -1.0f, best.u, best.v, 0.0f);
@@ -1618,7 +1629,17 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
         pid = rq.ids()[i];
         rayO = mk3(rq.plane(0)[i], rq.plane(1)[i], rq.plane(2)[i]);
         rayD = mk3(rq.plane(3)[i], rq.plane(4)[i], rq.plane(5)[i]);
-        hr0 = hq.rec(i)[0], hr1 = hq.rec(i)[1];
+        if (hq.primBits != 0u)
+        {
+            // the 16-byte record of a world-only triangle scene: every mesh hit there names its shading record (SKH_PRIM_DIRECT); a light proxy's
+            // primitive index is not looked at by its hit program
+            hr0 = *hq.rec16(i);
+            const uint32_t w = __float_as_uint(hr0.w);
+            hr1.x = __uint_as_float(w == 0xffffffffu ? w : w >> hq.primBits);
+            hr1.y = __uint_as_float(w == 0xffffffffu ? w : ((w & ((1u << hq.primBits) - 1u)) | SKH_PRIM_DIRECT));
+        }
+        else
+            hr0 = hq.rec(i)[0], hr1 = hq.rec(i)[1];
         const float ht = hr0.x, hu = hr0.y, hv = hr0.z;
         const uint32_t hinst = __float_as_uint(hr1.x), hprim = __float_as_uint(hr1.y);
         float* P = ps.base;

@@ -201,7 +201,9 @@ struct skh_context
     uint32_t leafLines = 0;   // 1: triangle leaves laid out by 128-byte line (skh_bvh.h: k_leaf_place): -11 % fetched lines, same time (docs/LOG.md)
     uint32_t nTriSlots = 0;
     LightBox lightBox = { { -INFINITY, -INFINITY, -INFINITY }, { INFINITY, INFINITY, INFINITY } }; // around the baked light proxies' group (skh_build_accel), with the node encoder's margin
-    uint32_t mergeLightProxies = 0; // option merge_light_proxies: baked light proxies share the world-space mesh triangles' tree (any-hit queries skip their triangles) instead of a tree of their own that every radiance ray visits
+    uint32_t mergeLightProxies = 0;
+    uint32_t nShadeRecords = 0; // de-indexed shading triangle records (build_shading_tables)
+    uint32_t compactHits = 1;   // option compact_hits: 16-byte hit records in the render passes of world-only triangle scenes that fit (HitQ::primBits) // option merge_light_proxies: baked light proxies share the world-space mesh triangles' tree (any-hit queries skip their triangles) instead of a tree of their own that every radiance ray visits
     uint32_t leafMaxTris = 2; // measured on MI355X: 2 beats 1, 3, 4, 6, 8 (the kernel is ALU bound, wasted triangle tests cost more than extra nodes)
     uint32_t buildQuality = 1; // 0: Karras radix tree (fastest build), 1: PLOC clustering (SAH-class quality)
     float sceneLo[3] = { 0, 0, 0 }, sceneHi[3] = { 1, 1, 1 };
@@ -1276,6 +1278,7 @@ static skh_status build_shading_tables(skh_context* c)
         base[m + 1] = (uint32_t)std::min<uint64_t>(total, 0xffffffffull);
     }
     const uint32_t nTris = base[nMeshes];
+    c->nShadeRecords = nTris;
     skh_status s;
     if (total >= SKH_PRIM_DIRECT)
     {
@@ -2289,6 +2292,15 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     RayQ rq[2] = { RayQ{ c->dRayQ[0].as<float>(), NQ, c->queueRegion }, RayQ{ c->dRayQ[1].as<float>(), NQ, c->queueRegion } };
     RayQ shq{ c->dShadowQ.as<float>(), NQ, c->queueRegion };
     HitQ hq{ c->dHits.as<float>(), NQ };
+    {
+        // 16-byte hit records where they are possible: the world-only triangle kernels (every mesh hit names its shading record) and an instance
+        // count and a record count that share 32 bits with the all-ones word left for a miss
+        const bool worldTris = !c->nSegs && c->tlasRoot == SKH_REF_INVALID && (c->worldRoot != SKH_REF_INVALID || c->lightRoot != SKH_REF_INVALID) && c->worldKernel;
+        uint32_t B = 1;
+        while (B < 31u && (1u << B) < c->nShadeRecords)
+            ++B;
+        hq.primBits = (c->compactHits && worldTris && (uint64_t)c->nInstances <= (1ull << (32u - B)) - 1ull && (1ull << B) >= c->nShadeRecords) ? B : 0u;
+    }
     HitQ nohq{ nullptr, 0 };
     {
         // tmin / tmax of every radiance ray and tmin of every shadow ray are constants of the frame parameters (OptixRender.cu:121-122, closest_hit.cu):
@@ -3455,6 +3467,12 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
             return SKH_INVALID_ARGUMENT;
         (n == "fetch_min_closest" ? c->fetchMinClosest : c->fetchMinShadow) = (uint32_t)value; // (an explicit value applies to both builds)
         (n == "fetch_min_closest" ? c->curveFetchMinClosest : c->curveFetchMinShadow) = (uint32_t)value;
+    }
+    else if (n == "compact_hits")
+    {
+        if (value != 0 && value != 1)
+            return SKH_INVALID_ARGUMENT;
+        c->compactHits = (uint32_t)value;
     }
     else if (n == "merge_light_proxies")
     {
