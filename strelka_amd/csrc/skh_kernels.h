@@ -121,11 +121,18 @@ struct HitQ
         return reinterpret_cast<float4*>(base) + (size_t)i;
     }
 };
-struct PathS // per path slot: throughput rgb, radiance rgb, lastBsdfPdf, flags
+struct PathS // per path slot: planes 0-2 throughput rgb, 6 lastBsdfPdf, 7 flags (3-5 unused); behind them prd.radiance as ONE float4 per path
 {
     float* base;
     uint32_t stride;
+    // A path's radiance is read-modify-written from scattered lanes (the any-hit launches add an unoccluded light sample's contribution, a light hit its
+    // emission): one 16-byte access per path instead of three 4-byte ones in three planes (a scattered access costs by the instruction: docs/LOG.md, round 5).
+    __device__ float4* rad() const
+    {
+        return reinterpret_cast<float4*>(base + 8 * (size_t)stride);
+    }
 };
+#define SKH_PATH_FLOATS 12 // floats per path the buffer holds: 8 planes + the float4
 enum
 {
     PF_INSIDE = 1,
@@ -464,10 +471,12 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                     else if (!best.found)
                     {
                         const uint32_t pid = rq.ids()[i];
-                        float* rad = ps.base + (size_t)3 * ps.stride;
-                        rad[pid] += contrib[i];
-                        rad[pid + ps.stride] += contrib[i + contribStride];
-                        rad[pid + 2 * (size_t)ps.stride] += contrib[i + 2 * (size_t)contribStride];
+                        float4* rad = ps.rad() + pid;
+                        float4 r = *rad;
+                        r.x += contrib[i];
+                        r.y += contrib[i + contribStride];
+                        r.z += contrib[i + 2 * (size_t)contribStride];
+                        *rad = r;
                     }
                 }
                 else
@@ -1409,9 +1418,7 @@ __global__ void __launch_bounds__(512) k_raygen(FrameP fp, const uint32_t* __res
                             sampler_random(s, DIM_PIXEL_Y), o, d);
         // PerRayData init: OptixRender.cu:96-109.  Throughput = 1 and lastBsdfPdf = 0 are not stored: k_shade ASSUMES the initial
         // values at depth 0 instead of reading them, and writes its own for every path of that bounce, misses included
-        ps.base[path + 3 * (size_t)ps.stride] = 0.0f;
-        ps.base[path + 4 * (size_t)ps.stride] = 0.0f;
-        ps.base[path + 5 * (size_t)ps.stride] = 0.0f;
+        ps.rad()[path] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         reinterpret_cast<uint32_t*>(ps.base)[path + 7 * (size_t)ps.stride] = 0u; // flags: outside, eUndef (k_collect reads them even when max_depth = 0 launches no k_shade)
     }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1651,7 +1658,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
         // bounces leave it alone, and 12 B read + 12 B written per path were a tenth of this kernel's traffic.  Same values in the same order.
         v3 radiance = mk3(0.0f);
         bool radianceDirty = false;
-#define SKH_RADIANCE_LOAD() radiance = mk3(P[pid + 3 * S], P[pid + 4 * S], P[pid + 5 * S]), radianceDirty = true
+#define SKH_RADIANCE_LOAD() radiance = mk3(ps.rad()[pid]), radianceDirty = true
         float lastBsdfPdf = depth == 0u ? 0.0f : P[pid + 6 * S];
         uint32_t flags = depth == 0u ? 0u : reinterpret_cast<uint32_t*>(P)[pid + 7 * S];
         bool inside = (flags & PF_INSIDE) != 0;
@@ -1935,9 +1942,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
         P[pid + 2 * S] = throughput.z;
         if (radianceDirty)
         {
-            P[pid + 3 * S] = radiance.x;
-            P[pid + 4 * S] = radiance.y;
-            P[pid + 5 * S] = radiance.z;
+            ps.rad()[pid] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
         }
 #undef SKH_RADIANCE_LOAD
         P[pid + 6 * S] = lastBsdfPdf;
@@ -2008,7 +2013,7 @@ __global__ void __launch_bounds__(256) k_collect(FrameP fp, const uint32_t* __re
     if (slot >= fp.numSlots || !slot_to_pixel(fp, tileXY, slot, px, py))
         return;
     const size_t S = ps.stride, N = fp.numSlots;
-    const v3 rad = mk3(ps.base[slot + 3 * S], ps.base[slot + 4 * S], ps.base[slot + 5 * S]);
+    const v3 rad = mk3(ps.rad()[slot]);
     const uint32_t fe = (reinterpret_cast<const uint32_t*>(ps.base)[slot + 7 * S] >> PF_EVENT_SHIFT) & 3u;
     float v[11];
     if (sampleOffset == 0)
@@ -2138,7 +2143,7 @@ __global__ void __launch_bounds__(256)
     for (uint32_t sub = fp.finalFirst; sub < fp.finalFirst + fp.finalCount; ++sub)
     {
         const size_t p = (size_t)sub * fp.numSlots + slot;
-        const v3 rad = mk3(ps.base[p + 3 * S], ps.base[p + 4 * S], ps.base[p + 5 * S]);
+        const v3 rad = mk3(ps.rad()[p]);
         const uint32_t fe = (reinterpret_cast<const uint32_t*>(ps.base)[p + 7 * S] >> PF_EVENT_SHIFT) & 3u;
         // `result += prd.radiance` starts from 0.0f in the reference (OptixRender.cu:83,154): keep that addition
         const v3 result = mk3(0.0f) + rad;

@@ -2027,7 +2027,7 @@ static skh_status alloc_frame(skh_context* c)
     AF(dev_alloc(c, c->dDiffCnt, sizeof(uint16_t) * N1));
     AF(dev_alloc(c, c->dSpecCnt, sizeof(uint16_t) * N1));
     AF(dev_alloc(c, c->dSums, sizeof(float) * 11 * N1));
-    AF(dev_alloc(c, c->dPath, sizeof(float) * 8 * N));
+    AF(dev_alloc(c, c->dPath, sizeof(float) * SKH_PATH_FLOATS * N));
     AF(dev_alloc(c, c->dRayQ[0], sizeof(float) * 9 * NQ));
     AF(dev_alloc(c, c->dRayQ[1], sizeof(float) * 9 * NQ));
     AF(dev_alloc(c, c->dHits, sizeof(float) * 8 * NQ));
@@ -2485,7 +2485,7 @@ static skh_status spec_launch_next(skh_context* c)
     if (other == 1u)
     {
         const uint32_t stride = c->numSlots * cap;
-        skh_status s = dev_alloc(c, c->dPathB, sizeof(float) * 8 * (size_t)stride);
+        skh_status s = dev_alloc(c, c->dPathB, sizeof(float) * SKH_PATH_FLOATS * (size_t)stride);
         if (s != SKH_OK)
             return s;
         c->pathBStride = stride;
