@@ -319,7 +319,7 @@ template <bool ANY_HIT, bool COUNT, bool CURVES, bool WORLD = false>
 __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? SKH_WORLD_CURVE_ANYHIT_MIN_WAVES : SKH_WORLD_CURVE_MIN_WAVES) : SKH_CURVE_MIN_WAVES) : (WORLD ? (ANY_HIT ? SKH_WORLD_ANYHIT_MIN_WAVES : SKH_WORLD_CLOSEST_MIN_WAVES) : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES))) SKH_TRACE_ATTR
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
             uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, 
-            HitQ hq, PathS ps, const float* __restrict__ contrib, uint32_t contribStride, int* __restrict__ ovfBase,
+            HitQ hq, PathS ps, const float4* __restrict__ contrib /* per shadow-queue position: {contribution rgb, path id} */, int* __restrict__ ovfBase,
             StatsDev* __restrict__ stats, LightBox lightBox /* around the baked light proxies (closest-hit builds) */, uint32_t fetchChunk /* world-only triangle builds: queue positions reserved per atomic, 0 = what each refill needs */)
 {
     // WORLD && CURVES (round 5): the world-only kernel with the curve block in it -- scenes whose every mesh instance is baked and that hold at
@@ -470,12 +470,13 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                         hq.base[i] = best.found ? 1.0f : -1.0f;
                     else if (!best.found)
                     {
-                        const uint32_t pid = rq.ids()[i];
-                        float4* rad = ps.rad() + pid;
+                        // (one scattered 16-byte load: the light sample's contribution and the path it goes to, as k_shade wrote them)
+                        const float4 cw = contrib[i];
+                        float4* rad = ps.rad() + __float_as_uint(cw.w);
                         float4 r = *rad;
-                        r.x += contrib[i];
-                        r.y += contrib[i + contribStride];
-                        r.z += contrib[i + 2 * (size_t)contribStride];
+                        r.x += cw.x;
+                        r.y += cw.y;
+                        r.z += cw.z;
                         *rad = r;
                     }
                 }
@@ -1571,7 +1572,7 @@ template <bool HAIR>
 __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
     k_shade(DevScene sc, FrameP fp, uint32_t sampleOffset, uint32_t depth /* bounce index */, const uint32_t* __restrict__ tileXY, RayQ rq,
             const uint32_t* __restrict__ countPtr, HitQ hq, PathS ps, RayQ nextQ, uint32_t* __restrict__ nextCount, RayQ shadowQ,
-            float* __restrict__ contrib, uint32_t* __restrict__ shadowCount)
+            float4* __restrict__ contrib, uint32_t* __restrict__ shadowCount)
 {
     __shared__ uint32_t s_wave[2 * (SKH_COMPACT_MAX_WAVES + 1)];
     __shared__ uint32_t s_sobol[SKH_SOBOL_LUT_WORDS];
@@ -1976,10 +1977,8 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
         shadowQ.plane(5)[si] = shD.z;
         // (plane 6 = shadowTmin: filled once by the host)
         shadowQ.plane(7)[si] = shTmax;
-        shadowQ.ids()[si] = pid;
-        contrib[si] = shC.x;
-        contrib[si + shadowQ.stride] = shC.y;
-        contrib[si + 2 * (size_t)shadowQ.stride] = shC.z;
+        // (the path id travels with the contribution -- one 16-byte record the any-hit launch reads back with ONE scattered load -- not in the queue's id plane)
+        contrib[si] = make_float4(shC.x, shC.y, shC.z, __uint_as_float(pid));
     }
 #ifdef SKH_LANE_PROFILE
     SKH_SP(7) // compaction + queue writes

@@ -2032,7 +2032,7 @@ static skh_status alloc_frame(skh_context* c)
     AF(dev_alloc(c, c->dRayQ[1], sizeof(float) * 9 * NQ));
     AF(dev_alloc(c, c->dHits, sizeof(float) * 8 * NQ));
     AF(dev_alloc(c, c->dShadowQ, sizeof(float) * 9 * NQ));
-    AF(dev_alloc(c, c->dContrib, sizeof(float) * 3 * NQ));
+    AF(dev_alloc(c, c->dContrib, sizeof(float4) * NQ));
     c->queueConstFilled = false;
     AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * (SKH_COUNT_STRIDE * SKH_SHARDS * 2 * SKH_MAX_LAUNCH_ROUNDS + 16 * SKH_FETCH_STRIDE * SKH_MAX_LAUNCH_ROUNDS)));
     c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
@@ -2197,7 +2197,7 @@ static skh_status ensure_ready(skh_context* c)
 // one launch of the persistent trace kernel over a sharded queue: picks the build (world-only / two-level / two-level + curves) and the grid
 template <bool ANY, bool COUNT>
 static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint32_t* countPtr, uint32_t* fetch,
-                         HitQ hq, PathS ps, const float* contrib, uint32_t contribStride, hipStream_t st = nullptr)
+                         HitQ hq, PathS ps, const float4* contrib, hipStream_t st = nullptr)
 {
     // scenes without curve instances run the build of the kernel that has no curve intersector in it (fewer VGPRs)
     const bool curveBuild = c->nSegs != 0;
@@ -2225,13 +2225,13 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
     const uint32_t chunk = c->fetchChunk >= 0 ? (uint32_t)c->fetchChunk : (c->hierNodes <= 16384u ? 128u : 0u);
     if (worldOnly)
         // every instance is baked: the world-only build of the kernel (no instance entry, no object-space copy of the ray)
-        k_trace<ANY, COUNT, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, c->lightBox, chunk);
+        k_trace<ANY, COUNT, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, ovf, sd, c->lightBox, chunk);
     else if (worldCurves)
-        k_trace<ANY, COUNT, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, c->lightBox, chunk);
+        k_trace<ANY, COUNT, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, ovf, sd, c->lightBox, chunk);
     else if (c->nSegs)
-        k_trace<ANY, COUNT, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, c->lightBox, chunk);
+        k_trace<ANY, COUNT, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, ovf, sd, c->lightBox, chunk);
     else
-        k_trace<ANY, COUNT, false><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, contribStride, ovf, sd, c->lightBox, chunk);
+        k_trace<ANY, COUNT, false><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, ovf, sd, c->lightBox, chunk);
 }
 
 // After a synchronisation: did any traversal of the calls since the last check drop a stack entry (its result may miss hits)?
@@ -2351,9 +2351,9 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                 SpanGuard g(c, KC_TRACE_CLOSEST);
                 c->gridOverride = (useOverlap && smallPass) ? c->smallWavesClosest * (uint32_t)c->numCUs : 0u;
                 if (c->countTraversal)
-                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, hq, ps, nullptr, 0);
+                    launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, hq, ps, nullptr);
                 else
-                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, hq, ps, nullptr, 0);
+                    launch_trace<false, false>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, hq, ps, nullptr);
             }
             if (useOverlap && b > 0)
                 (void)hipStreamWaitEvent(st, c->evShadow, 0); // shade[b] reads the radiance shadow[b-1] adds to and reuses its queue
@@ -2365,7 +2365,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                 const dim3 sg(SKH_SHARDS * ((perShard + SKH_SHADE_BLOCK - 1) / SKH_SHADE_BLOCK));
 #define SKH_SHADE_LAUNCH(HAIRB)                                                                                                                      \
     k_shade<HAIRB><<<sg, SKH_SHADE_BLOCK, 0, st>>>(sc, fp, s, b, tiles, rq[b & 1], counts + 2 * b * QW, hq, ps, rq[(b + 1) & 1], counts + 2 * (b + 1) * QW, \
-                                                   shq, c->dContrib.as<float>(), counts + (2 * b + 1) * QW)
+                                                   shq, c->dContrib.as<float4>(), counts + (2 * b + 1) * QW)
                 if (c->hasHairMaterial)
                     SKH_SHADE_LAUNCH(true);
                 else
@@ -2383,9 +2383,9 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                     SpanGuard g(c, KC_TRACE_SHADOW, sst);
                     c->gridOverride = (useOverlap && smallPass) ? c->smallWavesShadow * (uint32_t)c->numCUs : 0u;
                     if (c->countTraversal)
-                        launch_trace<true, true>(c, sc, shq, counts + (2 * b + 1) * QW, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, nohq, ps, c->dContrib.as<float>(), NQ, sst);
+                        launch_trace<true, true>(c, sc, shq, counts + (2 * b + 1) * QW, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, nohq, ps, c->dContrib.as<float4>(), sst);
                     else
-                        launch_trace<true, false>(c, sc, shq, counts + (2 * b + 1) * QW, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, nohq, ps, c->dContrib.as<float>(), NQ, sst);
+                        launch_trace<true, false>(c, sc, shq, counts + (2 * b + 1) * QW, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, nohq, ps, c->dContrib.as<float4>(), sst);
                 }
                 c->gridOverride = 0;
                 if (useOverlap)
@@ -3197,16 +3197,16 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
         if (mode == SKH_TRACE_SHADOW)
         {
             if (c->countTraversal)
-                launch_trace<true, true>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
+                launch_trace<true, true>(c, sc, rq, dcount, dfetch, hq, ps, nullptr);
             else
-                launch_trace<true, false>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
+                launch_trace<true, false>(c, sc, rq, dcount, dfetch, hq, ps, nullptr);
         }
         else
         {
             if (c->countTraversal)
-                launch_trace<false, true>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
+                launch_trace<false, true>(c, sc, rq, dcount, dfetch, hq, ps, nullptr);
             else
-                launch_trace<false, false>(c, sc, rq, dcount, dfetch, hq, ps, nullptr, 0);
+                launch_trace<false, false>(c, sc, rq, dcount, dfetch, hq, ps, nullptr);
         }
     }
     k_hits_soa_to_aos<<<(n_rays + 255) / 256, 256, 0, c->stream>>>(hq, n_rays, per, per, mode, reinterpret_cast<skh_hit*>(d_hits), c->dShadeInst.as<skh_instance>());
