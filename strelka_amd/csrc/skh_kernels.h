@@ -108,10 +108,11 @@ struct HitQ
 {
     float* base;
     uint32_t stride; // rays the buffer holds
-    // primBits = B > 0 (render passes of world-only triangle scenes whose instance count and shading-record count share 32 bits: option compact_hits):
-    // ONE 16-byte record per ray {t, u, v, instance << B | shading record (or a light proxy's primitive index)}, ~0 in the last word = a miss --
+    // primBits = B > 0 (render passes of scenes the world-only kernels trace -- every mesh hit there names its shading record -- whose instance count and primitive range share 32 bits: option compact_hits):
+    // ONE 16-byte record per ray {t, u, v, instance << B | shading record (a light proxy's primitive index, a curve segment's)}, ~0 in the last word = a miss --
     // 16 B less written per ray by the closest-hit launches and read back by k_shade
     uint32_t primBits;
+    uint32_t recClamp; // (primBits > 0) the last shading record: k_shade's early fetch must stay inside the table when the word is a curve segment's index
     __device__ float4* rec(uint32_t i) const
     {
         return reinterpret_cast<float4*>(base) + 2 * (size_t)i;
@@ -483,7 +484,13 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                 else
                 {
                     float4* hr = hq.rec(i);
-                    if (BESTLDS)
+                    if (BESTLDS && hq.primBits != 0u)
+                    {
+                        const bool f = best.found;
+                        *hq.rec16(i) = make_float4(f ? best.t : -1.0f, f ? __uint_as_float(s_best[2 * SKH_TRACE_BLOCK + lane]) : 0.0f, f ? __uint_as_float(s_best[3 * SKH_TRACE_BLOCK + lane]) : 0.0f,
+                                                   __uint_as_float(f ? (s_best[lane] << hq.primBits) | (s_best[SKH_TRACE_BLOCK + lane] & ((1u << hq.primBits) - 1u)) : 0xffffffffu));
+                    }
+                    else if (BESTLDS)
                     {
                         // (a miss reports what a fresh record holds: u = v = 0, instance = primitive = ~0)
                         const bool f = best.found;
@@ -491,7 +498,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                                             f ? __uint_as_float(s_best[3 * SKH_TRACE_BLOCK + lane]) : 0.0f, 0.0f);
                         hr[1] = make_float4(__uint_as_float(f ? s_best[lane] : 0xffffffffu), __uint_as_float(f ? s_best[SKH_TRACE_BLOCK + lane] : 0xffffffffu), 0.0f, 0.0f);
                     }
-                    else if (!CURVES && hq.primBits != 0u)
+                    else if (hq.primBits != 0u)
                         *hq.rec16(i) = make_float4(best.found ? best.t : -1.0f, best.u, best.v,
                                                    __uint_as_float(best.found ? (best.inst << hq.primBits) | (best.prim & ((1u << hq.primBits) - 1u)) : 0xffffffffu));
                     else
@@ -1696,7 +1703,9 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
             const bool directTv = (hprim & SKH_PRIM_DIRECT) != 0u;
             float4 tv[6];
             {
-                const float4* tp = sc.shadeTris + 6 * (size_t)(directTv ? (hprim & ~SKH_PRIM_DIRECT) : 0u);
+                // (a 16-byte record -- HitQ::primBits -- marks every hit as direct: a curve segment's index must not leave the table)
+                const uint32_t recIdx = directTv ? (hprim & ~SKH_PRIM_DIRECT) : 0u;
+                const float4* tp = sc.shadeTris + 6 * (size_t)(hq.primBits ? min(recIdx, hq.recClamp) : recIdx);
 #pragma unroll
                 for (int k = 0; k < 6; ++k)
                     tv[k] = tp[k];
@@ -1763,7 +1772,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
                 v3 stT = mk3(0.0f);
                 // (a hair material on a triangle mesh reads state.tangent_u too: the vertex tangent, closest_hit.cu:399-400)
                 const bool hairOnMesh = HAIR && mat.type == 3u && hi.type != 2;
-                SurfaceHit sh = hi.type == 2 ? fill_curve(sc, hi, w2o, hprim, hu, ht, rayO, rayD, inside, HAIR ? &stT : nullptr) :
+                SurfaceHit sh = hi.type == 2 ? fill_curve(sc, hi, w2o, hprim & ~SKH_PRIM_DIRECT /* (a segment index never has the bit; a 16-byte record sets it for every hit) */, hu, ht, rayO, rayD, inside, HAIR ? &stT : nullptr) :
                                                fill_triangle(hi, w2o, tv, hu, hv, inside, (textured || hairOnMesh) ? &st : nullptr);
                 if (hairOnMesh)
                     stT = st.tangent_u;

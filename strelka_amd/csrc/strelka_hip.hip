@@ -2295,11 +2295,14 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     {
         // 16-byte hit records where they are possible: the world-only triangle kernels (every mesh hit names its shading record) and an instance
         // count and a record count that share 32 bits with the all-ones word left for a miss
-        const bool worldTris = !c->nSegs && c->tlasRoot == SKH_REF_INVALID && (c->worldRoot != SKH_REF_INVALID || c->lightRoot != SKH_REF_INVALID) && c->worldKernel;
+        const bool worldKernels = c->tlasRoot == SKH_REF_INVALID && c->worldKernel &&
+                                  (c->nSegs ? c->numWorldCurves != 0u : (c->worldRoot != SKH_REF_INVALID || c->lightRoot != SKH_REF_INVALID));
+        const uint32_t range = std::max(c->nShadeRecords, c->nSegs); // shading records, light proxies' triangles (records too), curve segments
         uint32_t B = 1;
-        while (B < 31u && (1u << B) < c->nShadeRecords)
+        while (B < 31u && (1u << B) < range)
             ++B;
-        hq.primBits = (c->compactHits && worldTris && (uint64_t)c->nInstances <= (1ull << (32u - B)) - 1ull && (1ull << B) >= c->nShadeRecords) ? B : 0u;
+        hq.primBits = (c->compactHits && worldKernels && c->nShadeRecords != 0u && (uint64_t)c->nInstances <= (1ull << (32u - B)) - 1ull && (1ull << B) >= range) ? B : 0u;
+        hq.recClamp = c->nShadeRecords ? c->nShadeRecords - 1u : 0u;
     }
     HitQ nohq{ nullptr, 0 };
     {
