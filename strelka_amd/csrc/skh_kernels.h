@@ -61,7 +61,7 @@ struct DevScene
     uint32_t curveSplit; // parameter sub-ranges per segment (sub-range in segPrim >> 28)
     // shading side
     const HostInstance* instances; // shading copy: for mesh instances `light` holds the mesh's first record in shadeTris
-    const float4* shadeTris; // de-indexed shading vertices, 3 x 32 B per triangle, meshes back to back
+    const float4* shadeTris; // de-indexed shading records, 96 B per triangle (k_gather_shade_tris), meshes back to back
     const uint8_t* verts;
     const uint32_t* indices;
     const uint4* meshes;
@@ -1479,14 +1479,23 @@ __global__ void __launch_bounds__(256) k_gather_shade_tris(const uint8_t* __rest
     }
     const uint4 me = meshes[lo];
     const uint32_t t = g - meshTriBase[lo];
+    // record: {p0, normal0} {p1, normal1} {p2, normal2} | {tangent0, tangent1, tangent2, uv0} {uv1, uv2, 0, 0} | unused: what every hit needs sits in the first
+    // three float4 -- three scattered loads per hit instead of six --, what only textured (or hair-on-mesh) hits need in the next two
+    float4 v0[3], v1[3];
 #pragma unroll
     for (uint32_t k = 0; k < 3u; ++k)
     {
         const uint32_t idx = indices[me.x + 3u * t + k];
         const float4* v = reinterpret_cast<const float4*>(verts + (size_t)(me.z + idx) * 32);
-        out[6 * (size_t)g + 2 * k] = v[0];
-        out[6 * (size_t)g + 2 * k + 1] = v[1];
+        v0[k] = v[0], v1[k] = v[1];
     }
+    float4* o = out + 6 * (size_t)g;
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k)
+        o[k] = make_float4(v0[k].x, v0[k].y, v0[k].z, v1[k].x);
+    o[3] = make_float4(v0[0].w, v0[1].w, v0[2].w, v1[0].y);
+    o[4] = make_float4(v1[1].y, v1[2].y, 0.0f, 0.0f);
+    o[5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 struct SurfaceHit
@@ -1503,12 +1512,11 @@ struct SurfaceTex // state.text_coords[0], tangent_u[0], tangent_v[0]: only text
 // The reference walks mesh -> 3 indices -> 3 vertices (closest_hit.cu:365-376); here the three vertices of every triangle sit
 // de-indexed in one 96-byte record (k_gather_shade_tris) whose mesh base came with the instance record -- one dependent fetch
 // instead of three -- and k_shade issues that fetch together with the material's (`tv` = the record).
-SKH_DI SurfaceHit fill_triangle(const HostInstance& hi, const float* w2o, const float4* tv, float bu, float bv, bool inside, SurfaceTex* tex)
+SKH_DI SurfaceHit fill_triangle(const HostInstance& hi, const float* w2o, const float4* tv /* {p, normal} x 3 */, const float4* tx /* {tangent x 3, uv0} {uv1, uv2} */, float bu, float bv, bool inside, SurfaceTex* tex)
 {
-    const float4 a0 = tv[0], a1 = tv[1], b0 = tv[2], b1 = tv[3], c0 = tv[4], c1 = tv[5];
-    const v3 p0 = mk3(a0), p1 = mk3(b0), p2 = mk3(c0);
-    const v3 n0 = unpack_normal(__float_as_uint(a1.x)), n1 = unpack_normal(__float_as_uint(b1.x)),
-             n2 = unpack_normal(__float_as_uint(c1.x));
+    const v3 p0 = mk3(tv[0]), p1 = mk3(tv[1]), p2 = mk3(tv[2]);
+    const v3 n0 = unpack_normal(__float_as_uint(tv[0].w)), n1 = unpack_normal(__float_as_uint(tv[1].w)),
+             n2 = unpack_normal(__float_as_uint(tv[2].w));
     SurfaceHit s;
     s.position = xform_point(hi.o2w, interpolate_attrib(p0, p1, p2, bu, bv));
     const v3 object_normal = interpolate_attrib(n0, n1, n2, bu, bv);
@@ -1521,13 +1529,13 @@ SKH_DI SurfaceHit fill_triangle(const HostInstance& hi, const float* w2o, const 
     if (tex)
     {
         float u0, v0u, u1, v1u, u2, v2u;
-        unpack_uv(__float_as_uint(a1.y), u0, v0u);
-        unpack_uv(__float_as_uint(b1.y), u1, v1u);
-        unpack_uv(__float_as_uint(c1.y), u2, v2u);
+        unpack_uv(__float_as_uint(tx[0].w), u0, v0u);
+        unpack_uv(__float_as_uint(tx[1].x), u1, v1u);
+        unpack_uv(__float_as_uint(tx[1].y), u2, v2u);
         const float bw = 1.0f - bu - bv;
         tex->u = (u0 * bw + u1 * bu) + u2 * bv;
         tex->v = (v0u * bw + v1u * bu) + v2u * bv;
-        const v3 t0 = unpack_normal(__float_as_uint(a0.w)), t1 = unpack_normal(__float_as_uint(b0.w)), t2 = unpack_normal(__float_as_uint(c0.w));
+        const v3 t0 = unpack_normal(__float_as_uint(tx[0].x)), t1 = unpack_normal(__float_as_uint(tx[0].y)), t2 = unpack_normal(__float_as_uint(tx[0].z));
         // the tangent goes through the NORMAL transform in the reference (closest_hit.cu:399-400)
         tex->tangent_u = normalize(xform_normal(w2o, interpolate_attrib(t0, t1, t2, bu, bv)));
         tex->tangent_v = cross(s.normal, tex->tangent_u); // worldBinormal, with the already flipped normal (:404)
@@ -1701,14 +1709,19 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
             // misses the caches -- goes out BESIDE the instance record's instead of behind it (chain: queue -> {instance, triangle} -> material,
             // was queue -> instance -> {triangle, material}).  Other hits read record 0 here for nothing and theirs below.
             const bool directTv = (hprim & SKH_PRIM_DIRECT) != 0u;
-            float4 tv[6];
+            float4 tv[3], tx[2];
+            // (tangents / UVs: only a textured material or a hair material on a mesh reads them -- scenes without either do not fetch them)
+            const bool txWanted = HAIR || sc.numTextures != 0u;
+            tx[0] = tx[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             {
                 // (a 16-byte record -- HitQ::primBits -- marks every hit as direct: a curve segment's index must not leave the table)
                 const uint32_t recIdx = directTv ? (hprim & ~SKH_PRIM_DIRECT) : 0u;
                 const float4* tp = sc.shadeTris + 6 * (size_t)(hq.primBits ? min(recIdx, hq.recClamp) : recIdx);
 #pragma unroll
-                for (int k = 0; k < 6; ++k)
+                for (int k = 0; k < 3; ++k)
                     tv[k] = tp[k];
+                if (txWanted)
+                    tx[0] = tp[3], tx[1] = tp[4];
             }
             // (the whole record now: the compiler sinks the loads of `material` / `light` below the type test = one more round trip)
             asm volatile("" ::"v"(hi.type), "v"(hi.material), "v"(hi.light));
@@ -1758,10 +1771,12 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
                 {
                     const float4* tp = sc.shadeTris + 6 * (size_t)(hi.light + hprim);
 #pragma unroll
-                    for (int k = 0; k < 6; ++k)
+                    for (int k = 0; k < 3; ++k)
                         tv[k] = tp[k];
+                    if (txWanted)
+                        tx[0] = tp[3], tx[1] = tp[4];
                 }
-                asm volatile("" ::"v"(mat.type), "v"(tv[0].x), "v"(tv[2].x), "v"(tv[4].x));
+                asm volatile("" ::"v"(mat.type), "v"(tv[0].x), "v"(tv[1].x), "v"(tv[2].x));
                 // mdlcode_init (closest_hit.cu:507): texture lookups of the material, triangle hits only.  OmniPBR: a valid
                 // diffuse_texture replaces the constant colour; a valid normalmap_texture replaces state.normal by
                 // normalize(tu x + tv y + n z), (x, y, z) = 2 rgb - 1 (base::tangent_space_normal_texture, factor 1)
@@ -1773,7 +1788,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
                 // (a hair material on a triangle mesh reads state.tangent_u too: the vertex tangent, closest_hit.cu:399-400)
                 const bool hairOnMesh = HAIR && mat.type == 3u && hi.type != 2;
                 SurfaceHit sh = hi.type == 2 ? fill_curve(sc, hi, w2o, hprim & ~SKH_PRIM_DIRECT /* (a segment index never has the bit; a 16-byte record sets it for every hit) */, hu, ht, rayO, rayD, inside, HAIR ? &stT : nullptr) :
-                                               fill_triangle(hi, w2o, tv, hu, hv, inside, (textured || hairOnMesh) ? &st : nullptr);
+                                               fill_triangle(hi, w2o, tv, tx, hu, hv, inside, (textured || hairOnMesh) ? &st : nullptr);
                 if (hairOnMesh)
                     stT = st.tangent_u;
                 if (textured)
