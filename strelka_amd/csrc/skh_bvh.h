@@ -1402,7 +1402,7 @@ __global__ void k_gather_tris(const uint8_t* __restrict__ verts, const uint32_t*
                                     const uint32_t* __restrict__ triLocal, const uint32_t* __restrict__ sortedVals, uint32_t n,
                                     uint32_t nMeshTris, const uint8_t* __restrict__ instances, const uint8_t* __restrict__ shadeInstances /* the copy whose
                                     light word holds a mesh instance's first shading record */, const uint32_t* __restrict__ wInst,
-                                    const uint32_t* __restrict__ wFirst, uint32_t nW, float4* __restrict__ out)
+                                    const uint32_t* __restrict__ wFirst, uint32_t nW, uint32_t direct /* 0: baked mesh triangles keep the plain primitive index too */, float4* __restrict__ out)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n)
@@ -1445,7 +1445,8 @@ __global__ void k_gather_tris(const uint8_t* __restrict__ verts, const uint32_t*
             // record, build_shading_tables) with SKH_PRIM_DIRECT set: k_shade fetches the record straight from the hit, beside the instance
             // record instead of behind it; the traversal treats the word as opaque (within an instance it orders like t, so ties break alike),
             // the raw-query output turns it back into t (k_hits_soa_to_aos)
-            r[k] = make_float4(q.x, q.y, q.z, k == 0 ? __uint_as_float(isMesh ? ((tvBase + t) | SKH_PRIM_DIRECT) : t) : (k == 1 ? __uint_as_float(inst) : 0.0f));
+            // (word 2: 1 = a light proxy's triangle -- any-hit queries do not see lights, merge_light_proxies)
+            r[k] = make_float4(q.x, q.y, q.z, k == 0 ? __uint_as_float((isMesh && direct) ? ((tvBase + t) | SKH_PRIM_DIRECT) : t) : (k == 1 ? __uint_as_float(inst) : __uint_as_float(isMesh ? 0u : 1u)));
         }
     }
     out[3 * (size_t)j + 0] = r[0];

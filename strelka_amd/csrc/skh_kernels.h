@@ -112,6 +112,7 @@ struct HitQ
     // ONE 16-byte record per ray {t, u, v, instance << B | shading record (a light proxy's primitive index, a curve segment's)}, ~0 in the last word = a miss --
     // 16 B less written per ray by the closest-hit launches and read back by k_shade
     uint32_t primBits;
+    uint32_t direct;   // (primBits > 0) 1: the word of a mesh hit is its shading record's index (SKH_PRIM_DIRECT implied); 0: the mesh-local primitive index
     uint32_t recClamp; // (primBits > 0) the last shading record: k_shade's early fetch must stay inside the table when the word is a curve segment's index
     __device__ float4* rec(uint32_t i) const
     {
@@ -401,9 +402,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
             best.inst = (INST), best.prim = (PRIM), best.u = (U), best.v = (V);                       \
     }
 // a baked light proxy's triangle in the world-space group (merge_light_proxies): any-hit queries do not see lights (the proxies that stay instances
-// are masked at their TLAS leaf); in a world-space group -- the only place where the instance id comes with the triangle -- a primitive word
-// without SKH_PRIM_DIRECT is a light proxy's
-#define SKH_HIDDEN_LIGHT(A) (ANY_HIT && (WORLD || curInst == 0xffffffffu) && (__float_as_uint((A).w) & SKH_PRIM_DIRECT) == 0u)
+// are masked at their TLAS leaf); k_gather_tris marks a baked proxy's triangles in the last word of the record (0 everywhere else)
+#define SKH_HIDDEN_LIGHT(C) (ANY_HIT && __float_as_uint((C).w) != 0u)
 #define SKH_PUSH(v)                                                  \
     {                                                                \
         if (sp < NLDS)                                               \
@@ -1111,8 +1111,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                     else
                         ih = intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), ht, hu, hv);
                     hprim = __float_as_uint(a.w), hinst = __float_as_uint(b.w);
-                    // (a baked light proxy in the world-space group -- merge_light_proxies --: any-hit queries do not see lights; its primitive word lacks SKH_PRIM_DIRECT)
-                    if (ANY_HIT && (hprim & SKH_PRIM_DIRECT) == 0u)
+                    // (a baked light proxy in the world-space group -- merge_light_proxies --: any-hit queries do not see lights; k_gather_tris marks its triangles in the record's last word)
+                    if (ANY_HIT && __float_as_uint(c.w) != 0u)
                         ih = false;
                 }
                 if (!COOP_REGS && helper)
@@ -1210,9 +1210,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                         wv[6] += __any(pf & 1u) ? 1u : 0u; // triangle passes in which some lane took the fp64 edge-function fallback
                         wv[7] += __any(pf & 4u) ? 1u : 0u; // ... in which some lane got as far as the division
                         wv[8] += __any(pf & 2u) ? 1u : 0u; // ... passed the sign test
-                        if (ih && (best.found || t < best.t) && !SKH_HIDDEN_LIGHT(a))
+                        if (ih && (best.found || t < best.t) && !SKH_HIDDEN_LIGHT(c))
 #else
-                        if (intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), t, u, v) && (best.found || t < best.t) && !SKH_HIDDEN_LIGHT(a))
+                        if (intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), t, u, v) && (best.found || t < best.t) && !SKH_HIDDEN_LIGHT(c))
 #endif
                         {
                             const uint32_t prim = __float_as_uint(a.w);
@@ -1659,7 +1659,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
             hr0 = *hq.rec16(i);
             const uint32_t w = __float_as_uint(hr0.w);
             hr1.x = __uint_as_float(w == 0xffffffffu ? w : w >> hq.primBits);
-            hr1.y = __uint_as_float(w == 0xffffffffu ? w : ((w & ((1u << hq.primBits) - 1u)) | SKH_PRIM_DIRECT));
+            hr1.y = __uint_as_float(w == 0xffffffffu ? w : ((w & ((1u << hq.primBits) - 1u)) | (hq.direct ? SKH_PRIM_DIRECT : 0u)));
         }
         else
             hr0 = hq.rec(i)[0], hr1 = hq.rec(i)[1];

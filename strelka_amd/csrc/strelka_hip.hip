@@ -203,6 +203,9 @@ struct skh_context
     LightBox lightBox = { { -INFINITY, -INFINITY, -INFINITY }, { INFINITY, INFINITY, INFINITY } }; // around the baked light proxies' group (skh_build_accel), with the node encoder's margin
     uint32_t mergeLightProxies = 0;
     uint32_t nShadeRecords = 0; // de-indexed shading triangle records (build_shading_tables)
+    int32_t directRecordsOpt = -1; // option direct_records: -1 = by the counts (below), 0 / 1 forced
+    uint32_t directRecords = 1; // baked mesh triangles name their shading record (SKH_PRIM_DIRECT); 0 when only (instance, mesh-local primitive) fits a 16-byte hit record
+    uint32_t hitPrimRange = 0;  // primitive words of this scene's hits stay below it (records, or mesh-local indices; curve segments)
     uint32_t compactHits = 1;   // option compact_hits: 16-byte hit records in the render passes of world-only triangle scenes that fit (HitQ::primBits) // option merge_light_proxies: baked light proxies share the world-space mesh triangles' tree (any-hit queries skip their triangles) instead of a tree of their own that every radiance ray visits
     uint32_t leafMaxTris = 2; // measured on MI355X: 2 beats 1, 3, 4, 6, 8 (the kernel is ALU bound, wasted triangle tests cost more than extra nodes)
     uint32_t buildQuality = 1; // 0: Karras radix tree (fastest build), 1: PLOC clustering (SAH-class quality)
@@ -1536,13 +1539,31 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     c->buildInfo.cost_after = triOut.riRounds ? triOut.riCostAfter : triOut.riCostBefore;
     c->buildInfo.ms_reinsert = triOut.riMs;
     const uint32_t nTriSlots = triOut.numSlots; // >= nTris: the line layout pads in front of leaves that would straddle a 128-byte line
+    {
+        // Which word a baked mesh triangle's hit carries.  The index of its shading record (k_shade fetches the record beside the instance's: one short
+        // step less) -- unless a 16-byte hit record {t, u, v, instance << B | primitive} (compact_hits) has room for the mesh-local index only:
+        // a closest-hit lane's second scattered store costs more than that step (kitchen closest-hit -4 %).
+        uint32_t maxMeshTris = 1;
+        for (uint32_t m = 0; m < nMeshes; ++m)
+            maxMeshTris = std::max(maxMeshTris, c->meshes[m].index_count / 3u);
+        auto fits = [&](uint32_t range) {
+            uint32_t B = 1;
+            while (B < 31u && (1u << B) < range)
+                ++B;
+            return (1ull << B) >= range && (uint64_t)nInst <= (1ull << (32u - B)) - 1ull;
+        };
+        const uint32_t nSegAll = (uint32_t)std::min<uint64_t>(0x7fffffffull, [&]() { uint64_t n = 0; for (const skh_curve& cu : c->curves) for (uint32_t k = 0; k < cu.vertex_counts_count; ++k) { const uint32_t ncp = c->curveVertexCounts[cu.vertex_counts_start + k]; n += ncp > 3u ? ncp - 3u : 0u; } return n; }());
+        const uint32_t rangeDirect = std::max(c->nShadeRecords, nSegAll), rangeLocal = std::max(maxMeshTris, nSegAll);
+        c->directRecords = c->directRecordsOpt >= 0 ? (uint32_t)c->directRecordsOpt : ((c->compactHits && !fits(rangeDirect) && fits(rangeLocal)) ? 0u : 1u);
+        c->hitPrimRange = c->directRecords ? rangeDirect : rangeLocal;
+    }
     c->nTriSlots = nTriSlots;
     BA(dev_alloc(c, c->dTris, sizeof(float4) * 3 * (size_t)std::max(1u, nTriSlots)));
     if (nTriSlots)
         k_gather_tris<<<(nTriSlots + B - 1) / B, B, 0, st>>>(c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(), c->dMeshes.as<uint4>(),
                                                               dTriMesh.as<uint32_t>(), dTriLocal.as<uint32_t>(),
                                                               triOut.sortedVals.as<uint32_t>(), nTriSlots, nMeshTris, c->dInstances.as<uint8_t>(), c->dShadeInst.as<uint8_t>(),
-                                                              dWInst.as<uint32_t>(), dWFirst.as<uint32_t>(), (uint32_t)wInst.size(),
+                                                              dWInst.as<uint32_t>(), dWFirst.as<uint32_t>(), (uint32_t)wInst.size(), c->directRecords,
                                                               c->dTris.as<float4>());
     dev_free(c->dTriNodes);
     c->dTriNodes = triOut.nodes;
@@ -2297,11 +2318,12 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
         // count and a record count that share 32 bits with the all-ones word left for a miss
         const bool worldKernels = c->tlasRoot == SKH_REF_INVALID && c->worldKernel &&
                                   (c->nSegs ? c->numWorldCurves != 0u : (c->worldRoot != SKH_REF_INVALID || c->lightRoot != SKH_REF_INVALID));
-        const uint32_t range = std::max(c->nShadeRecords, c->nSegs); // shading records, light proxies' triangles (records too), curve segments
+        const uint32_t range = std::max(1u, c->hitPrimRange); // shading records (or mesh-local indices), light proxies' triangles, curve segments: skh_build_accel
         uint32_t B = 1;
         while (B < 31u && (1u << B) < range)
             ++B;
         hq.primBits = (c->compactHits && worldKernels && c->nShadeRecords != 0u && (uint64_t)c->nInstances <= (1ull << (32u - B)) - 1ull && (1ull << B) >= range) ? B : 0u;
+        hq.direct = c->directRecords;
         hq.recClamp = c->nShadeRecords ? c->nShadeRecords - 1u : 0u;
     }
     HitQ nohq{ nullptr, 0 };
@@ -3476,6 +3498,14 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value != 0 && value != 1)
             return SKH_INVALID_ARGUMENT;
         c->compactHits = (uint32_t)value;
+        c->accelBuilt = false; // (skh_build_accel decides with it which word a baked triangle's hit carries)
+    }
+    else if (n == "direct_records")
+    {
+        if (value < -1 || value > 1)
+            return SKH_INVALID_ARGUMENT;
+        c->directRecordsOpt = (int32_t)value;
+        c->accelBuilt = false;
     }
     else if (n == "merge_light_proxies")
     {

@@ -460,7 +460,7 @@ def test_tonemap_kernels_match_oracle(gpu, ork):
                                   {"fetch_min_closest": 1, "fetch_min_shadow": 64, "waves_per_cu": 8},
                                   {"waves_per_cu_world": 5, "waves_per_cu_shadow_world": 17, "waves_per_cu_shadow": 3},
                                   {"node_break_closest": 0, "node_break_shadow": 48, "leaf_min": 0}, {"leaf_min": 40}, {"tlas_open": 8}, {"tlas_build": 0}, {"tlas_build": 1}, {"curve_split": 1}, {"curve_split": 5, "curve_min": 1}, {"reinsert_rounds": 0, "reinsert_curve_rounds": 0}, {"reinsert_rounds": 3, "reinsert_min_size": 4}, {"reinsert_rounds": 13, "reinsert_curve_rounds": 9, "reinsert_min_size": 1}, {"world_kernel": 0}, {"curve_min": 64}, {"tight_instance_boxes": 0}, {"overlap": 2}, {"overlap": 0}, {"leaf_lines": 1}, {"leaf_lines": 1, "leaf_max_tris": 4},
-                                  {"leaf_lines": 1, "leaf_max_tris": 7, "build_quality": 0}, {"morton_bits": 18}, {"morton_bits": 21, "build_quality": 0}, {"morton_bits": 5}, {"ploc_top": 4096}, {"merge_light_proxies": 1}, {"compact_hits": 0}, {"fetch_chunk": 0}, {"fetch_chunk": 7, "fetch_min_closest": 64}, {"fetch_chunk": 1000}])
+                                  {"leaf_lines": 1, "leaf_max_tris": 7, "build_quality": 0}, {"morton_bits": 18}, {"morton_bits": 21, "build_quality": 0}, {"morton_bits": 5}, {"ploc_top": 4096}, {"merge_light_proxies": 1}, {"compact_hits": 0}, {"direct_records": 0}, {"direct_records": 0, "compact_hits": 0}, {"fetch_chunk": 0}, {"fetch_chunk": 7, "fetch_min_closest": 64}, {"fetch_chunk": 1000}])
 def test_results_do_not_depend_on_the_acceleration_structure_or_scheduling(opts):
     """Closest hit = min t with (instance, primitive) tie-break and conservative boxes, any-hit = existence: builder
     (PLOC / radix tree), the reinsertion pass (rounds, truncation), the world-only kernels (with and without the curve block) against the two-level

@@ -133,6 +133,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     ctx.set_option("leaf_lines", (seed // 5) % 2)  # triangle leaves laid out by 128-byte line: same records
     ctx.set_option("merge_light_proxies", 0 if seed % 7 == 3 else 1)  # light proxies in the mesh triangles' world-space tree (any-hit skips them) or in their own
     ctx.set_option("fetch_chunk", (-1, 0, 5, 300)[(seed // 3) % 4])
+    ctx.set_option("direct_records", (-1, 0, 1)[(seed // 2) % 3])  # which word a baked triangle's hit carries (raw queries always report the mesh-local primitive)
     if (seed // 4) % 3 == 2:
         ctx.set_option("build_quality", 0)  # the Karras radix tree instead of PLOC must give the same records
     ctx.set_scene(arr); got = ctx.trace(rays, 0)
