@@ -52,6 +52,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     ctx = capi.Context(0)
     gpu_opts = {"subframe_batch": int(rs.choice([0, 1, 2])), "overlap": 1, "speculate": 8}
     ctx.set_option("subframe_batch", gpu_opts["subframe_batch"])
+    ctx.set_option("direct_records", (-1, 0, 1)[seed % 3])  # which word a baked triangle's hit carries: the image does not depend on it
+    ctx.set_option("compact_hits", 0 if seed % 5 == 4 else 1)
     crc_g = crc()  # ... and as the GPU receives them
     ctx.set_scene(arr)
     ctx.set_tiles(int(rs.choice([8, 16, 32, 64])), None)
