@@ -676,6 +676,9 @@ struct Counts
     long rays = 0, hits = 0;
 };
 // closest-hit (children sorted by entry distance) or any-hit (stored order, first hit ends the ray)
+// (study, `hist=1`: node visits by the number of children the ray enters -- 0 = the visit was a dead end -- and whether the ray starts INSIDE the node's box)
+static long g_hitHist[2][5];
+static bool g_hist = false;
 static bool trace(const Flat& f, const std::vector<Tri>& tris, const Ray& r, bool anyHit, float& tHit, uint32_t& primHit, long& nNodes, long& nTris)
 {
     float inv[3];
@@ -703,6 +706,17 @@ static bool trace(const Flat& f, const std::vector<Tri>& tris, const Ray& r, boo
                 }
                 if (t0 <= t1)
                     tn[c] = t0, rf[c] = w.ref[k], ++c;
+            }
+            if (g_hist)
+            {
+                bool inside = true; // the union of the children's boxes around the origin?
+                Box u = empty_box();
+                for (int k = 0; k < w.cnt; ++k)
+                    u = merge(u, w.cb[k]);
+                for (int a = 0; a < 3; ++a)
+                    inside = inside && r.o[a] >= u.lo[a] && r.o[a] <= u.hi[a];
+#pragma omp atomic
+                g_hitHist[inside ? 1 : 0][c]++;
             }
             if (!anyHit)
                 for (int i = 1; i < c; ++i) // insertion sort, nearest first
@@ -916,6 +930,7 @@ int main(int argc, char** argv)
         printf("reinsertion %d: %ld candidates, %d moved, %.1f M search visits, %.2f s, SAH = %.2f\n", k, cand, moved, visits * 1e-6, now() - t0, sah_internal(t));
     }
 
+    g_hist = geti("hist", 0) != 0;
     quantMode = geti("quant", 0);
     Flat f;
     if (opt.count("collapse") && opt["collapse"] == "dp")
@@ -991,6 +1006,15 @@ int main(int argc, char** argv)
             socc += trace(f, tris, shadow[i], true, th, ph, a, b) ? 1 : 0;
             sn += a, stt += b;
             ++nb;
+        }
+    if (g_hist)
+        for (int in = 0; in < 2; ++in)
+        {
+            long tot = 0;
+            for (int k = 0; k < 5; ++k)
+                tot += g_hitHist[0][k] + g_hitHist[1][k];
+            printf("node visits with the origin %s the node: children entered 0 / 1 / 2 / 3 / 4 = %.1f / %.1f / %.1f / %.1f / %.1f %% of all visits\n", in ? "INSIDE " : "outside",
+                   100.0 * g_hitHist[in][0] / tot, 100.0 * g_hitHist[in][1] / tot, 100.0 * g_hitHist[in][2] / tot, 100.0 * g_hitHist[in][3] / tot, 100.0 * g_hitHist[in][4] / tot);
         }
     printf("camera  %8d rays: %6.2f nodes %5.2f tris per ray (%.1f %% hit)\n", nr, cn / nr, ct / nr, 100.0 * hits / nr);
     printf("bounce  %8ld rays: %6.2f nodes %5.2f tris per ray (%.1f %% hit)\n", nb, bn / nb, bt / nb, 100.0 * bhits / nb);
