@@ -164,7 +164,7 @@ struct skh_context
     uint32_t smallWavesClosest = 16, smallWavesShadow = 16; // overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24
     uint32_t gridOverride = 0; // set by render_one around its launches
     uint32_t fetchMinClosest = 32 /* 24 until round 5: on the reinserted trees 32 is 0.4 ... 0.9 % ahead on all three kitchens, gpurun_out/r6c */, fetchMinShadow = 48; // idle lanes before a wave pulls new rays from the queue (round 3, world-space hierarchy: any-hit 32 -> 48: 39.7 -> 36.2 ms, 56: 37.5, 64: 51; closest 12..40 within 1 %)
-    uint32_t curveFetchMinClosest = 16, curveFetchMinShadow = 24, curveNodeBreakClosest = 20, curveNodeBreakShadow = 20; // the same four for the curve build (6 waves/SIMD): hair 482 vs 465 Mray/s
+    uint32_t curveFetchMinClosest = 16, curveFetchMinShadow = 16 /* 24 until the result writes got cheaper (round 5, late): hair any-hit 47.5-47.8 -> 46.5-47.0 ms with 12 ... 20, gpurun_out/r7v */, curveNodeBreakClosest = 20, curveNodeBreakShadow = 20; // the same four for the curve build (6 waves/SIMD): hair 482 vs 465 Mray/s
     uint32_t nodeBreakClosest = 32, nodeBreakShadow = 28; // (closest: 24 -> 32 in round 3 for the world-only kernel: kitchen 86.6 -> 85.9 ms, unshared 74.7 -> 73.6, three runs each;
                                                           // shadow: 20 -> 28 in round 4, with the shared triangle pass: kitchen 34.85 -> 34.3 ms, unshared 29.3 -> 28.55, three runs each; 36: 34.35 / 28.7)
     // leave the node loop when fewer than x/64 of the wave's rays are still descending
