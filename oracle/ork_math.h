@@ -17,6 +17,26 @@
 #include <cstdint>
 #include <cstring>
 
+// -DORK_LIBM_GLIBC (oracle/Makefile target liboracle_glibc.so): a SECOND build of the checker whose transcendentals are glibc's, not the
+// shared text -- the second opinion on skh_libm.h inside whole renders (tests/test_oracle_render.py, tests/test_gpu_parity.py hold the
+// default build and the GPU against it at round 4's image tolerances: an error in a shared polynomial would show there as more than
+// last-ulp path flips).  Every `skm::` below this line then names these wrappers.
+#ifdef ORK_LIBM_GLIBC
+namespace skm_glibc
+{
+static inline float sinf_(float x) { return ::sinf(x); }
+static inline float cosf_(float x) { return ::cosf(x); }
+static inline float asinf_(float x) { return ::asinf(x); }
+static inline float acosf_(float x) { return ::acosf(x); }
+static inline float atan2f_(float y, float x) { return ::atan2f(y, x); }
+static inline float expf_(float x) { return ::expf(x); }
+static inline float logf_(float x) { return ::logf(x); }
+static inline float sinhf_(float x) { return ::sinhf(x); }
+static inline float powf_(float x, float y) { return ::powf(x, y); }
+} // namespace skm_glibc
+#define skm skm_glibc
+#endif
+
 namespace ork
 {
 

@@ -15,6 +15,7 @@ _lib = None
 
 def build(force=False):
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle.cpp", "ork_math.h", "ork_core.h", "ork_trace.h", "ork_bsdf.h")]
+    srcs.append(os.path.join(ROOT, "strelka_amd", "csrc", "skh_libm.h"))  # ork_math.h includes it: a libm edit must rebuild the checker
     if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
 
@@ -134,6 +135,91 @@ def usable_cpus():
     return usable
 
 
+def _bind(lib):
+    """argtypes / restypes of the ork_* C API, for whichever build of oracle.cpp `lib` is"""
+    if not os.environ.get("OMP_NUM_THREADS"):
+        lib.ork_set_num_threads(usable_cpus())
+    lib.ork_create.restype = C.c_void_p
+    lib.ork_destroy.argtypes = [C.c_void_p]
+    lib.ork_libm.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.ork_libm.restype = None
+    lib.ork_mis_weight.restype = C.c_float
+    lib.ork_mis_weight.argtypes = [C.c_float, C.c_float]
+    for name in ("ork_set_geometry", "ork_set_curves", "ork_set_instances", "ork_set_lights", "ork_set_materials",
+                 "ork_build_accel", "ork_resize", "ork_render_subframe", "ork_render_subframe_rows",
+                 "ork_read_accum", "ork_read_image", "ork_read_aov", "ork_get_stats", "ork_reset_stats",
+                 "ork_trace", "ork_set_count_traversal"):
+        getattr(lib, name).restype = C.c_int
+    lib.ork_set_geometry.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    lib.ork_set_curves.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                   C.c_void_p, C.c_uint32]
+    for name in ("ork_set_instances", "ork_set_lights", "ork_set_materials"):
+        getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.ork_build_accel.argtypes = [C.c_void_p]
+    lib.ork_debug_path.restype = C.c_int
+    lib.ork_debug_path.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.ork_set_bake.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.ork_get_baked.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.ork_resize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.ork_render_subframe.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ork_render_subframe_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.ork_read_accum.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ork_read_image.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ork_read_aov.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.ork_get_stats.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ork_reset_stats.argtypes = [C.c_void_p]
+    lib.ork_set_count_traversal.argtypes = [C.c_void_p, C.c_int]
+    lib.ork_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    lib.ork_sample_index.restype = C.c_uint32
+    lib.ork_sample_index.argtypes = [C.c_uint32] * 4
+    lib.ork_sampler_values.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                       C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.ork_sobol_matrix.argtypes = [C.c_void_p]
+    lib.ork_sample_light.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.ork_light_pdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    lib.ork_curve_eval.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    lib.ork_accumulate_seq.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.ork_tonemap_pair.argtypes = [C.c_void_p] * 4
+    lib.ork_exposure.argtypes = [C.c_float] * 4 + [C.c_void_p]
+    lib.ork_pack_normal.restype = C.c_uint32
+    lib.ork_pack_normal.argtypes = [C.c_void_p]
+    lib.ork_pack_uv.restype = C.c_uint32
+    lib.ork_pack_uv.argtypes = [C.c_float, C.c_float]
+    lib.ork_unpack_normal.argtypes = [C.c_uint32, C.c_void_p]
+    lib.ork_unpack_uv.argtypes = [C.c_uint32, C.c_void_p]
+    lib.ork_offset_ray.argtypes = [C.c_void_p] * 3
+    lib.ork_camera_ray.argtypes = [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    lib.ork_clip_to_view.argtypes = [C.c_float] * 4 + [C.c_void_p]
+    lib.ork_invert_affine.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ork_tonemap_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_float]
+    lib.ork_bsdf_sample.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
+    lib.ork_bsdf_evaluate.argtypes = [C.c_void_p] * 6
+    lib.ork_bsdf_evaluate_side.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
+    lib.ork_bsdf_set_tangent.argtypes = [C.c_void_p]
+    lib.ork_intersect_triangle.restype = C.c_int
+    lib.ork_intersect_triangle.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    lib.ork_intersect_curve.restype = C.c_int
+    lib.ork_intersect_curve.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    lib.ork_sizeof.restype = C.c_uint32
+    lib.ork_sizeof.argtypes = [C.c_int]
+    lib.ork_num_threads.restype = C.c_int
+    return lib
+
+
+_glibc = None
+
+
+def load_glibc():
+    """The SAME checker source built with glibc's sin / cos / acos / asin / atan2 / exp / log / sinh / pow instead of the text it shares with the
+    product (oracle/ork_math.h, -DORK_LIBM_GLIBC; oracle/Makefile target liboracle_glibc.so): a second opinion on strelka_amd/csrc/skh_libm.h
+    inside whole renders.  Images from it are compared at round 4's tolerances, never bit for bit."""
+    global _glibc
+    if _glibc is None:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle_glibc.so"], stdout=subprocess.DEVNULL)
+        _glibc = _bind(C.CDLL(os.path.join(ORACLE_DIR, "liboracle_glibc.so")))
+    return _glibc
+
+
 def load():
     global _lib
     if _lib is None:
@@ -143,73 +229,7 @@ def load():
         else:
             build()
             lib = C.CDLL(LIB)
-        if not os.environ.get("OMP_NUM_THREADS"):
-            lib.ork_set_num_threads(usable_cpus())
-        lib.ork_create.restype = C.c_void_p
-        lib.ork_destroy.argtypes = [C.c_void_p]
-        lib.ork_libm.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
-        lib.ork_libm.restype = None
-        lib.ork_mis_weight.restype = C.c_float
-        lib.ork_mis_weight.argtypes = [C.c_float, C.c_float]
-        for name in ("ork_set_geometry", "ork_set_curves", "ork_set_instances", "ork_set_lights", "ork_set_materials",
-                     "ork_build_accel", "ork_resize", "ork_render_subframe", "ork_render_subframe_rows",
-                     "ork_read_accum", "ork_read_image", "ork_read_aov", "ork_get_stats", "ork_reset_stats",
-                     "ork_trace", "ork_set_count_traversal"):
-            getattr(lib, name).restype = C.c_int
-        lib.ork_set_geometry.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
-        lib.ork_set_curves.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
-                                       C.c_void_p, C.c_uint32]
-        for name in ("ork_set_instances", "ork_set_lights", "ork_set_materials"):
-            getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
-        lib.ork_build_accel.argtypes = [C.c_void_p]
-        lib.ork_debug_path.restype = C.c_int
-        lib.ork_debug_path.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
-        lib.ork_set_bake.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
-        lib.ork_get_baked.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
-        lib.ork_resize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
-        lib.ork_render_subframe.argtypes = [C.c_void_p, C.c_void_p]
-        lib.ork_render_subframe_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
-        lib.ork_read_accum.argtypes = [C.c_void_p, C.c_void_p]
-        lib.ork_read_image.argtypes = [C.c_void_p, C.c_void_p]
-        lib.ork_read_aov.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
-        lib.ork_get_stats.argtypes = [C.c_void_p, C.c_void_p]
-        lib.ork_reset_stats.argtypes = [C.c_void_p]
-        lib.ork_set_count_traversal.argtypes = [C.c_void_p, C.c_int]
-        lib.ork_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
-        lib.ork_sample_index.restype = C.c_uint32
-        lib.ork_sample_index.argtypes = [C.c_uint32] * 4
-        lib.ork_sampler_values.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
-                                           C.c_uint32, C.c_uint32, C.c_void_p]
-        lib.ork_sobol_matrix.argtypes = [C.c_void_p]
-        lib.ork_sample_light.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
-        lib.ork_light_pdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
-        lib.ork_curve_eval.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
-        lib.ork_accumulate_seq.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
-        lib.ork_tonemap_pair.argtypes = [C.c_void_p] * 4
-        lib.ork_exposure.argtypes = [C.c_float] * 4 + [C.c_void_p]
-        lib.ork_pack_normal.restype = C.c_uint32
-        lib.ork_pack_normal.argtypes = [C.c_void_p]
-        lib.ork_pack_uv.restype = C.c_uint32
-        lib.ork_pack_uv.argtypes = [C.c_float, C.c_float]
-        lib.ork_unpack_normal.argtypes = [C.c_uint32, C.c_void_p]
-        lib.ork_unpack_uv.argtypes = [C.c_uint32, C.c_void_p]
-        lib.ork_offset_ray.argtypes = [C.c_void_p] * 3
-        lib.ork_camera_ray.argtypes = [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
-        lib.ork_clip_to_view.argtypes = [C.c_float] * 4 + [C.c_void_p]
-        lib.ork_invert_affine.argtypes = [C.c_void_p, C.c_void_p]
-        lib.ork_tonemap_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_float]
-        lib.ork_bsdf_sample.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
-        lib.ork_bsdf_evaluate.argtypes = [C.c_void_p] * 6
-        lib.ork_bsdf_evaluate_side.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
-        lib.ork_bsdf_set_tangent.argtypes = [C.c_void_p]
-        lib.ork_intersect_triangle.restype = C.c_int
-        lib.ork_intersect_triangle.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
-        lib.ork_intersect_curve.restype = C.c_int
-        lib.ork_intersect_curve.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
-        lib.ork_sizeof.restype = C.c_uint32
-        lib.ork_sizeof.argtypes = [C.c_int]
-        lib.ork_num_threads.restype = C.c_int
-        _lib = lib
+        _lib = _bind(lib)
     return _lib
 
 

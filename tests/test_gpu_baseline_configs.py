@@ -3,7 +3,8 @@
   C2  Cornell box, 1024x1024, 4 bounces, 256 spp          -- oracle on 2 spp at full resolution; 256 spp through properties
   C4  kitchen stand-in, 3840x2160, 6 bounces, 8 tile sets -- Russian roulette (depth > 3) and the 8-rank tile split at 4K (16 spp);
       the whole 256-spp frame once through properties + an oracle band of its 64-sub-frame prefix
-  C5  hair stand-in, 1920x1080, 3 bounces                 -- full-resolution properties (hit parity is in test_gpu_fullsize)
+  C5  hair stand-in, 1920x1080, 3 bounces                 -- full-resolution properties (hit parity is in test_gpu_fullsize) + a 32-row
+      band through the hair, sub-frames 0..3 of 1024, against the oracle: image equal, ray counts equal (round 6)
 Images are compared with tests/test_gpu_parity.py::_image_equal (bit for bit since round 5); ray counts and tile-sharded images are exact."""
 import numpy as np
 import pytest
@@ -173,6 +174,39 @@ def test_c5_hair_1080p_depth3_properties():
     part = detile_numpy(tacc, t, 32, W, H)
     mask = detile_numpy(np.ones_like(tacc), t, 32, W, H)[..., 0] > 0
     assert part[mask].tobytes() == a[mask].tobytes()
+
+
+def test_c5_hair_1080p_band_matches_oracle():
+    """C5 at its own size against the checker (the 1080p C5 tests were property-only while C3 and C4 each had an
+    oracle band): 1920x1080, depth 3, sub-frames 0..3 of spp_total 1024, the 32 rows 512..543 -- through the middle of the hair --
+    `_image_equal` (zero differing pixels), and the same band rendered as a tile set (the row of 60 32x32 tiles) has the checker's
+    radiance- and shadow-ray counts exactly (the GPU skips zero-contribution shadow rays: <=).  Exercises the world-only curve kernel,
+    its light-proxy rule, the 16-byte curve hit record and the hair build of k_shade at the configuration's resolution."""
+    from tests import orklib
+    from tests.test_gpu_parity import _image_equal
+
+    sc = scenes.hair_standin()
+    arr = sc.arrays()
+    W, H, DEPTH, SPP, TOTAL = 1920, 1080, 3, 4, 1024
+    r0, r1 = 512, 544
+    full, _ = _gpu_frame(arr, sc.getCamera(), W, H, SPP, DEPTH, total=TOTAL)
+    o = orklib.new_context()
+    o.set_scene(arr)
+    o.resize(W, H)
+    for i in range(SPP):
+        o.render_subframe(S.frame_params(sc.getCamera(), W, H, subframe_index=i, samples_this_launch=1, spp_total=TOTAL, max_depth=DEPTH), rows=(r0, r1))
+    want = o.read_accum()[r0:r1]
+    so = o.stats()
+    assert (want[..., :3].sum(-1) > 0).mean() > 0.2  # the band is not background
+    _image_equal(full[r0:r1], want)
+    grid = tiles.tile_grid(W, H, 32)
+    band_tiles = np.ascontiguousarray(grid[grid[:, 1] == r0])
+    assert len(band_tiles) == W // 32
+    tacc, st = _gpu_frame(arr, sc.getCamera(), W, H, SPP, DEPTH, tile_xy=band_tiles, total=TOTAL)
+    part = detile_numpy(tacc, band_tiles, 32, W, H)
+    assert part[r0:r1].tobytes() == full[r0:r1].tobytes()
+    assert st["rays_radiance"] == so["rays_radiance"], (st["rays_radiance"], so["rays_radiance"])
+    assert 0.9 * so["rays_shadow"] <= st["rays_shadow"] <= so["rays_shadow"]
 
 
 def test_c5_hair_full_1024_spp_frame_properties():

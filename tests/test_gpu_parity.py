@@ -1,10 +1,11 @@
 """GPU parity tests proper (-m gpu): the HIP path, called through the C ABI (strelka_amd.capi -> libstrelka_hip.so),
 against the CPU oracle on the same seeded inputs.
 
-Bar (north_star): bit-exact hit indices (and t/u/v, since the intersection arithmetic is + - * / sqrt only);
-radiance within a stated per-pixel tolerance (transcendentals differ by a few ulp between glibc and the ROCm
-device library, and a 1-ulp direction change can flip a hit on an edge, so a tiny fraction of pixels may differ
-in one sample).
+Bar: bit-exact hit records (indices AND t/u/v: the intersection arithmetic is + - * / sqrt only, in one order on both sides);
+radiance EQUAL, pixel for pixel (`_image_equal`: zero differing pixels, no tolerance argument).  Until round 4 images were held at a
+per-pixel L2 tolerance because glibc and the ROCm device library round sin / cos / acos / exp / log differently; since round 5 both sides
+compile strelka_amd/csrc/skh_libm.h, whose accuracy is pinned separately against float64 (tests/test_libm.py on the CPU build,
+tests/test_gpu_golden.py::test_libm_on_the_device_against_float64 on the device's own outputs).
 """
 import os
 
@@ -174,6 +175,30 @@ def test_render_cornell_matches_oracle(gpu):
     st, so = gpu.stats(), o.stats()
     assert st["rays_radiance"] == so["rays_radiance"]  # same paths, bounce for bounce
     assert st["rays_shadow"] <= so["rays_shadow"]  # the GPU skips shadow rays whose contribution is exactly zero
+
+
+def test_render_against_the_glibc_build_of_the_checker(gpu):
+    """GPU vs the checker built with GLIBC's transcendentals (tests/orklib.py::load_glibc): the one comparison of this file in which the two
+    sides do NOT share skh_libm.h, at round 4's image tolerance (relative L2 <= 2e-5, <= 0.5 % of the pixels further than 1e-4 apart).  An
+    error in one of the shared polynomials -- invisible to `_image_equal` everywhere else -- would show here."""
+    from tests import orklib
+    from tests.test_oracle_render import _l2_and_outliers
+
+    glibc = orklib.load_glibc()
+    for sc, w, h, spp, depth in [(scenes.cornell_box(), 64, 64, 8, 4), (small_kitchen(), 96, 64, 4, 5),
+                                 (scenes.hair_standin(n_strands=2000), 96, 64, 4, 3), (scenes.light_zoo(), 64, 64, 4, 4)]:
+        arr = sc.arrays()
+        o = orklib.Oracle(glibc)
+        o.set_scene(arr)
+        o.resize(w, h)
+        gpu.set_scene(arr)
+        gpu.resize(w, h)
+        for i in range(spp):
+            p = S.frame_params(sc.getCamera(), w, h, subframe_index=i, spp_total=spp, max_depth=depth)
+            o.render_subframe(p)
+            gpu.render_subframe(p)
+        l2, off = _l2_and_outliers(gpu.read_accum(), o.read_accum())
+        assert l2 <= 2e-5 and off <= 0.005, (l2, off)
 
 
 def test_render_mixed_materials_matches_oracle(gpu):

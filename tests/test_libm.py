@@ -1,7 +1,8 @@
 """strelka_amd/csrc/skh_libm.h: the sin / cos / acos / asin / atan2 / exp / log / sinh / pow both sides compile (fixed polynomials in correctly
 rounded operations).  Here, on the CPU: how far they are from the correctly rounded values (float64 numpy as the reference), at the bars
 the header states -- the same <= 4 ulp class at which the reference-generated light fixtures are held.  That the DEVICE returns the same bits
-is tests/test_gpu_golden.py::test_libm_is_bit_identical_on_the_device."""
+is tests/test_gpu_golden.py::test_libm_is_bit_identical_on_the_device; that the device's OWN outputs meet the same float64 bars -- without the CPU
+compile of the shared text in between -- is test_libm_on_the_device_against_float64 there."""
 import numpy as np
 import pytest
 
@@ -33,29 +34,40 @@ def ulp_err(got, ref64):
         return np.abs(got.astype(np.float64) - ref64) / sp
 
 
-@pytest.mark.parametrize("col,fn,dom,bar", [
+ACCURACY_BARS = [
+    # (output column, float64 reference, domain, bar in ulp of the correctly rounded float32 value)
     (0, np.sin, lambda x, y: np.abs(x) <= 400, 1.7), (1, np.cos, lambda x, y: np.abs(x) <= 400, 1.7),
     (2, np.arccos, lambda x, y: np.abs(x) <= 1, 1.3), (3, np.arcsin, lambda x, y: np.abs(x) <= 1, 2.5),
     (5, np.exp, lambda x, y: (x > -87) & (x < 88), 1.2), (6, np.log, lambda x, y: (x > 1e-37) & (x < 1e38), 1.0),
-    (7, np.sinh, lambda x, y: np.abs(x) <= 20, 1.8)])
-def test_accuracy_against_the_correctly_rounded_value(col, fn, dom, bar):
-    rec = libm_inputs()
-    out = cpu_libm(rec)
+    (7, np.sinh, lambda x, y: np.abs(x) <= 20, 1.8)]
+
+
+def check_accuracy(rec, out, col, fn, dom, bar):
+    """`out` = the ten columns of SKH_UNIT_LIBM / ork_libm for the records `rec`, from WHICHEVER side computed them"""
     x, y = rec[:, 0].astype(np.float64), rec[:, 1].astype(np.float64)
     m = dom(x, y) & np.isfinite(x)
     err = ulp_err(out[m, col], fn(x[m]))
     assert m.sum() > 10000 and err.max() <= bar, (err.max(), x[m][err.argmax()])
 
 
-def test_atan2_and_pow_accuracy():
-    rec = libm_inputs()
-    out = cpu_libm(rec)
+def check_atan2_and_pow(rec, out):
     x, y = rec[:, 0].astype(np.float64), rec[:, 1].astype(np.float64)
     m = np.isfinite(x) & np.isfinite(y) & (x != 0) & (y != 0)
     assert ulp_err(out[m, 4], np.arctan2(y[m], x[m])).max() <= 3.5
     assert ulp_err(out[m, 9], np.arctan2(x[m], y[m])).max() <= 3.5
     g = m & (x >= 1e-6) & (x <= 1e4) & ((rec[:, 1] == np.float32(1.0 / 2.2)) | (rec[:, 1] == np.float32(2.2)))
     assert g.sum() > 10000 and ulp_err(out[g, 8], np.power(x[g], y[g])).max() <= 4.0
+
+
+@pytest.mark.parametrize("col,fn,dom,bar", ACCURACY_BARS)
+def test_accuracy_against_the_correctly_rounded_value(col, fn, dom, bar):
+    rec = libm_inputs()
+    check_accuracy(rec, cpu_libm(rec), col, fn, dom, bar)
+
+
+def test_atan2_and_pow_accuracy():
+    rec = libm_inputs()
+    check_atan2_and_pow(rec, cpu_libm(rec))
 
 
 def test_special_values():

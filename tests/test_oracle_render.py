@@ -131,3 +131,40 @@ def floor_under_rect_light():
     X, Z = np.meshgrid(xs, zs, indexing="ij")
     r2 = X * X + Z * Z + H * H
     return sc, rho * L / math.pi * float((H ** 3 / r2 ** 2.5).sum() * (a / n) * (b / n))
+
+
+def _l2_and_outliers(x, y):
+    x, y = x[..., :3].astype(np.float64), y[..., :3].astype(np.float64)
+    l2 = np.sqrt(((x - y) ** 2).sum()) / np.sqrt((y ** 2).sum())
+    rel = np.abs(x - y).max(-1) / np.maximum(y.max(-1), 1e-6)
+    return l2, float((rel > 1e-4).mean())
+
+
+def test_shared_libm_against_a_glibc_build_of_the_checker():
+    """The default checker compiles the product's skh_libm.h (so that GPU and checker agree bit for bit); that makes an error in one of its
+    polynomials invisible to every GPU-vs-checker comparison.  Second opinion: the SAME checker source built with glibc's transcendentals
+    (oracle/Makefile: liboracle_glibc.so, -DORK_LIBM_GLIBC) renders the same scenes -- Lambert (cosine sampling: sin / cos), the mixed-material
+    kitchen (GGX / glass), every light type (sphere: sin / cos / acos; distant: cos; spherical rectangle: acos chains) and hair (Chiang: exp /
+    log / atan2 / asin / sinh) -- and the images agree at round 4's bar, relative L2 <= 2e-5, with <= 0.5 % of the pixels further than 1e-4 apart
+    (a last-ulp difference in a direction may move single paths across an edge; measured: L2 2e-8 ... 1.3e-6, 0 ... 0.11 % of the pixels)."""
+    a, b = orklib.load(), orklib.load_glibc()
+
+    def render_with(lib, sc, w, h, spp, depth, **kw):
+        o = orklib.Oracle(lib)
+        o.set_scene(sc.arrays())
+        o.resize(w, h)
+        for i in range(spp):
+            o.render_subframe(S.frame_params(sc.getCamera(), w, h, subframe_index=i, spp_total=spp, max_depth=depth, **kw))
+        return o.read_accum()
+
+    differ = 0
+    for sc, w, h, spp, depth, kw in [(scenes.cornell_box(), 64, 64, 8, 4, {}),
+                                     (scenes.kitchen_standin(seed=7, n_meshes=12, n_instances=60, tri_lo=100, tri_hi=1500), 96, 64, 4, 5, {}),
+                                     (scenes.hair_standin(n_strands=2000), 96, 64, 4, 3, {}),
+                                     (scenes.light_zoo(), 64, 64, 4, 4, {}),
+                                     (scenes.light_zoo(), 64, 64, 4, 4, {"rect_light_sampling_method": 1})]:
+        x, y = render_with(a, sc, w, h, spp, depth, **kw), render_with(b, sc, w, h, spp, depth, **kw)
+        l2, off = _l2_and_outliers(x, y)
+        assert l2 <= 2e-5 and off <= 0.005, (l2, off)
+        differ += not np.array_equal(x, y)
+    assert differ >= 3  # the two builds really are different arithmetic (else this test compares a library with itself)
