@@ -274,6 +274,12 @@ SCENE_RECIPES = {
                      "architectural kitchen stand-in: %d unique triangles, %d instances of %d meshes (no sharing), "
                      "4 rect + 1 distant light, 60/25/10/5 %% diffuse/glossy/metal/glass"),
     "hair": (lambda scenes: scenes.hair_standin(), "hair stand-in (SURVEY 8d C5): %d scalp triangles, %d instances of %d meshes + 100 k strands"),
+    # the same strands as 8 / 16 / 17 curve prims (one instance each, identity transforms), and 17 prims under small translations: where the
+    # world-only curve kernel's table of per-instance trees ends (skh_kernels.h SKH_WORLD_CURVES) -- `also.hair_multi`
+    "hair_8": (lambda scenes: scenes.hair_standin(n_prims=8), "hair stand-in as 8 curve prims: %d scalp triangles, %d instances of %d meshes + 100 k strands"),
+    "hair_16": (lambda scenes: scenes.hair_standin(n_prims=16), "hair stand-in as 16 curve prims: %d scalp triangles, %d instances of %d meshes + 100 k strands"),
+    "hair_17": (lambda scenes: scenes.hair_standin(n_prims=17), "hair stand-in as 17 curve prims: %d scalp triangles, %d instances of %d meshes + 100 k strands"),
+    "hair_17_moved": (lambda scenes: scenes.hair_standin(n_prims=17, prim_offset=1e-3), "hair stand-in as 17 curve prims under translations: %d scalp triangles, %d instances of %d meshes + 100 k strands"),
     "cornell": (lambda scenes: scenes.cornell_box(), "cornell box (C2): %d triangles, %d instances of %d meshes"),
 }
 
@@ -446,7 +452,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--tile", type=int, default=32)
-    ap.add_argument("--scene", default="kitchen", help="kitchen | kitchen_unshared | kitchen_arch | cornell | hair | path to a .skscene dump or a .gltf file")
+    ap.add_argument("--scene", default="kitchen", help="kitchen | kitchen_unshared | kitchen_arch | cornell | hair | hair_8 | hair_16 | hair_17 | hair_17_moved | path to a .skscene dump or a .gltf file")
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to skh_set_option")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -640,6 +646,10 @@ def main():
         extra = {name: other_workload_leg(name, W, H, args.spp, args.depth, local_rank) for name in ("kitchen_unshared", "kitchen_arch")}
         # C5 (BASELINE.json configs[4]): the basis-curves workload at ITS depth (3), 64 spp per pass like the headline
         extra["hair"] = other_workload_leg("hair", W, H, args.spp, 3, local_rank)
+        # the same groom split into several curve prims: Mray/s and what each ray costs
+        extra["hair_multi"] = {name: {k: v for k, v in other_workload_leg(name, W, H, args.spp, 3, local_rank).items()
+                                      if k in ("workload", "value", "unit", "ms_per_step", "kernel_ms_per_frame", "per_ray", "per_shadow_ray", "bvh_build_ms")}
+                               for name in ("hair_8", "hair_16", "hair_17", "hair_17_moved")}
     if rank == 0:
         K = max(1, args.steps)
         # ---- rooflines of the three hot kernels.  Per kernel, from this run's counters and hipEvent times:

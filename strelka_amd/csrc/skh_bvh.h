@@ -224,17 +224,27 @@ SKH_DI void subseg_range(uint32_t sub, uint32_t K, float& u0, float& u1)
     u0 = K > 1u ? fmaxf((float)sub / (float)K - SKH_SUBSEG_PAD, 0.0f) : 0.0f;
     u1 = K > 1u ? fminf((float)(sub + 1u) / (float)K + SKH_SUBSEG_PAD, 1.0f) : 1.0f;
 }
-__global__ void k_seg_boxes(const float* __restrict__ points, const float* __restrict__ radii,
-                            const uint32_t* __restrict__ segStart, const uint32_t* __restrict__ segCurve, uint32_t n /*segments x K*/,
-                            uint32_t K, float4* __restrict__ boxLo, float4* __restrict__ boxHi, uint32_t* __restrict__ grp)
+// box of sub-range `sub` of K of the segment with control points q (xyz, radius): hull of the (padded) sub-curve's Bezier points, grown (see above)
+SKH_DI void subseg_box(const float4* q, uint32_t sub, uint32_t K, float rmax, float cmax, v3& lo, v3& hi)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
-        return;
-    const uint32_t seg = i / K, sub = i - seg * K;
-    const uint32_t s = segStart[seg];
-    float4 q[4], c[4];
-    float rmax = 0.0f, cmax = 0.0f;
+    float4 c[4];
+    float u0, u1;
+    subseg_range(sub, K, u0, u1);
+    subcurve_bezier(q, u0, u1, c);
+    lo = mk3(INFINITY), hi = mk3(-INFINITY);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+        lo = mk3(fminf(lo.x, c[k].x), fminf(lo.y, c[k].y), fminf(lo.z, c[k].z));
+        hi = mk3(fmaxf(hi.x, c[k].x), fmaxf(hi.y, c[k].y), fmaxf(hi.z, c[k].z));
+    }
+    const float m = (K > 1u ? 2.0f : 1.0f) * rmax * 1.01f + cmax * 4e-6f;
+    lo = mk3(lo.x - m, lo.y - m, lo.z - m);
+    hi = mk3(hi.x + m, hi.y + m, hi.z + m);
+}
+SKH_DI void load_segment(const float* __restrict__ points, const float* __restrict__ radii, uint32_t s, float4* q, float& rmax, float& cmax)
+{
+    rmax = 0.0f, cmax = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
@@ -243,20 +253,101 @@ __global__ void k_seg_boxes(const float* __restrict__ points, const float* __res
         rmax = fmaxf(rmax, fabsf(q[k].w));
         cmax = fmaxf(cmax, fmaxf(fabsf(p[0]), fmaxf(fabsf(p[1]), fabsf(p[2]))));
     }
-    float u0, u1;
-    subseg_range(sub, K, u0, u1);
-    subcurve_bezier(q, u0, u1, c);
-    v3 lo = mk3(INFINITY), hi = mk3(-INFINITY);
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-    {
-        lo = mk3(fminf(lo.x, c[k].x), fminf(lo.y, c[k].y), fminf(lo.z, c[k].z));
-        hi = mk3(fmaxf(hi.x, c[k].x), fmaxf(hi.y, c[k].y), fmaxf(hi.z, c[k].z));
-    }
-    const float m = (K > 1u ? 2.0f : 1.0f) * rmax * 1.01f + cmax * 4e-6f;
-    boxLo[i] = make_float4(lo.x - m, lo.y - m, lo.z - m, 0.0f);
-    boxHi[i] = make_float4(hi.x + m, hi.y + m, hi.z + m, 0.0f);
+}
+__global__ void k_seg_boxes(const float* __restrict__ points, const float* __restrict__ radii,
+                            const uint32_t* __restrict__ segStart, const uint32_t* __restrict__ segCurve, uint32_t n /*segments x K*/,
+                            uint32_t K, float4* __restrict__ boxLo, float4* __restrict__ boxHi, uint32_t* __restrict__ grp)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint32_t seg = i / K, sub = i - seg * K;
+    float4 q[4];
+    float rmax, cmax;
+    load_segment(points, radii, segStart[seg], q, rmax, cmax);
+    v3 lo, hi;
+    subseg_box(q, sub, K, rmax, cmax, lo, hi);
+    boxLo[i] = make_float4(lo.x, lo.y, lo.z, 0.0f);
+    boxHi[i] = make_float4(hi.x, hi.y, hi.z, 0.0f);
     grp[i] = segCurve[seg];
+}
+
+// ---- segment nodes (round 6) -----------------------------------------------------------------------------------------------------
+// The curve tree is built over whole SEGMENTS (one per leaf); under every leaf sits a *segment node*: a Node4 whose four child boxes are the
+// segment's SKH_SEGNODE_K parameter sub-ranges and whose four child references all name the segment's one leaf record.  The traversal's node
+// loop visits it like any node (same fetch, same four slab tests, same instructions -- no divergent code for the last level); if the ray meets
+// ANY of the sub-range boxes the lane goes to the leaf pass with ONE candidate for the segment (one bounding-cylinder test, then the
+// cooperative Newton block), otherwise it pops.  Against sub-ranges as primitives (curve_split = 4: 5.2 M leaves, the same segment a
+// candidate once per sub-range leaf the ray enters) the tree has a quarter of the leaves, a segment is tested at most once per ray, and the
+// sub-range rule of the Newton block (a sub-range leaf keeps a hit only if u is its own) is gone.  Boxes stay conservative, intersect_curve_segment
+// decides: same hit records.  A reference with SKH_REF_SEGNODE set indexes the node array like any other (low 28 bits).
+#define SKH_REF_SEGNODE 0x10000000
+#define SKH_SEGNODE_K 4u
+// box of a whole segment for the tree above the segment nodes = the union of its sub-range boxes (so a segment node's children lie inside what its parent stores for it)
+__global__ void k_seg_union_boxes(const float* __restrict__ points, const float* __restrict__ radii, const uint32_t* __restrict__ segStart,
+                                  const uint32_t* __restrict__ segCurve, uint32_t nSegs, float4* __restrict__ boxLo, float4* __restrict__ boxHi,
+                                  uint32_t* __restrict__ grp)
+{
+    const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seg >= nSegs)
+        return;
+    float4 q[4];
+    float rmax, cmax;
+    load_segment(points, radii, segStart[seg], q, rmax, cmax);
+    v3 lo = mk3(INFINITY), hi = mk3(-INFINITY);
+    for (uint32_t sub = 0; sub < SKH_SEGNODE_K; ++sub)
+    {
+        v3 l, h;
+        subseg_box(q, sub, SKH_SEGNODE_K, rmax, cmax, l, h);
+        lo = mk3(fminf(lo.x, l.x), fminf(lo.y, l.y), fminf(lo.z, l.z));
+        hi = mk3(fmaxf(hi.x, h.x), fmaxf(hi.y, h.y), fmaxf(hi.z, h.z));
+    }
+    boxLo[seg] = make_float4(lo.x, lo.y, lo.z, 0.0f);
+    boxHi[seg] = make_float4(hi.x, hi.y, hi.z, 0.0f);
+    grp[seg] = segCurve[seg];
+}
+// segment node of the segment at leaf position j (record position pos = j, or the segment's own index when the records are kept strand-major)
+__global__ void k_segnode_emit(const float* __restrict__ points, const float* __restrict__ radii, const uint32_t* __restrict__ segStart,
+                               const uint32_t* __restrict__ sortedVals, uint32_t nSegs, uint32_t strandMajor, Node4* __restrict__ segNodes /* nSegs, behind the tree's nodes */)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nSegs)
+        return;
+    const uint32_t seg = sortedVals[j];
+    const uint32_t pos = strandMajor ? seg : j;
+    float4 q[4];
+    float rmax, cmax;
+    load_segment(points, radii, segStart[seg], q, rmax, cmax);
+    float clo[4][3], chi[4][3], nlo[3] = { INFINITY, INFINITY, INFINITY }, nhi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    int refs[4];
+    for (uint32_t sub = 0; sub < SKH_SEGNODE_K; ++sub)
+    {
+        v3 l, h;
+        subseg_box(q, sub, SKH_SEGNODE_K, rmax, cmax, l, h);
+        clo[sub][0] = l.x, clo[sub][1] = l.y, clo[sub][2] = l.z;
+        chi[sub][0] = h.x, chi[sub][1] = h.y, chi[sub][2] = h.z;
+        for (int a = 0; a < 3; ++a)
+            nlo[a] = fminf(nlo[a], clo[sub][a]), nhi[a] = fmaxf(nhi[a], chi[sub][a]);
+        refs[sub] = make_leaf_ref(pos, 1u);
+    }
+    Node4 nd;
+    encode_node4(nd, nlo, nhi, clo, chi, refs, (int)SKH_SEGNODE_K);
+    segNodes[pos] = nd;
+}
+// child references of the tree's internal nodes (and the per-curve-set roots): a one-segment leaf -> the segment node in front of it
+__global__ void k_segnode_patch(int* __restrict__ refs, uint32_t nRefs, uint32_t stride, uint32_t perBlock, const uint32_t* __restrict__ sortedVals,
+                                uint32_t strandMajor, uint32_t firstSegNode)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nRefs)
+        return;
+    int* r = refs + (size_t)(i / perBlock) * stride + (i % perBlock);
+    const int v = *r;
+    if (v >= 0 || v == SKH_REF_SENTINEL)
+        return; // an internal node, an empty slot (SKH_REF_INVALID is positive)
+    const uint32_t e = (uint32_t)~v;
+    const uint32_t j = e >> 3; // (leaves hold exactly one segment in this build)
+    *r = (int)(SKH_REF_SEGNODE | (firstSegNode + (strandMajor ? sortedVals[j] : j)));
 }
 
 __global__ void k_init_group_bounds(uint32_t* __restrict__ gb, uint32_t nGroups)
@@ -1462,14 +1553,15 @@ __global__ void k_gather_tris(const uint8_t* __restrict__ verts, const uint32_t*
 // line L through the part's end points (r_max for the unsplit segment, see k_seg_boxes); a degenerate chord gives axis = 0,
 // which switches the test off.
 __global__ void k_gather_segs(const float* __restrict__ points, const float* __restrict__ radii,
-                              const uint32_t* __restrict__ segStart, const uint32_t* __restrict__ segLocal,
+                              const uint32_t* __restrict__ segStart, const uint32_t* __restrict__ segLocal, const uint32_t* __restrict__ segInstOf /* per build primitive: the instance of a merged segment, ~0 otherwise */,
                               const uint32_t* __restrict__ sortedVals, uint32_t n /*segments x K*/, uint32_t K, float4* __restrict__ out,
-                              uint32_t* __restrict__ outPrim, float4* __restrict__ outBound)
+                              uint32_t* __restrict__ outPrim, float4* __restrict__ outBound, uint32_t* __restrict__ outInst, uint32_t strandMajor /* (segment-node build, K = 1) records at the segment's own index: consecutive segments of a strand adjacent in memory */)
 {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n)
+    const uint32_t jj = blockIdx.x * blockDim.x + threadIdx.x;
+    if (jj >= n)
         return;
-    const uint32_t i = sortedVals[j];
+    const uint32_t i = sortedVals[jj];
+    const uint32_t j = strandMajor ? i : jj;
     const uint32_t seg = i / K, sub = i - seg * K;
     const uint32_t s = segStart[seg];
     float4 q[4], c[4];
@@ -1484,6 +1576,7 @@ __global__ void k_gather_segs(const float* __restrict__ points, const float* __r
         cmax = fmaxf(cmax, fmaxf(fabsf(p[0]), fmaxf(fabsf(p[1]), fabsf(p[2]))));
     }
     outPrim[j] = segLocal[seg] | (sub << 28);
+    outInst[j] = segInstOf[seg];
     float u0, u1;
     subseg_range(sub, K, u0, u1);
     subcurve_bezier(q, u0, u1, c);

@@ -58,6 +58,7 @@ struct DevScene
     const float4* segs; // 4 x float4 per segment, leaf order
     const uint32_t* segPrim; // leaf order -> segment index inside its curve set
     const float4* segBound; // 2 x float4 per leaf record: bounding cylinder {A, R}, {unit axis, 0}
+    const uint32_t* segInst; // leaf order -> the instance a MERGED segment belongs to (curve instances under identity transforms share one world-space tree: curInst == ~0 there)
     uint32_t curveSplit; // parameter sub-ranges per segment (sub-range in segPrim >> 28)
     // shading side
     const HostInstance* instances; // shading copy: for mesh instances `light` holds the mesh's first record in shadeTris
@@ -218,7 +219,8 @@ struct StatsDev
     unsigned long long shade[8]; // k_shade cycle split (SKH_SP marks)
     unsigned int slowCount, slowPad; // rays that took more than SKH_SLOW_RAY node steps: the first 16 are recorded
     float slow[16][12]; // steps, tris, insts, kernel, o xyz, d xyz, tmin, tmax
-    unsigned long long cyc[2][8]; // summed over waves: [0] refill [1] node loop [2] leaf [3] pop [4] result write [5] whole kernel
+    unsigned long long runHist[2][42], blockHist[2][42]; // Newton steps per run / of the longest run of a block (curve builds)
+    unsigned long long cyc[2][10]; // summed over waves: [0] refill [1] node loop [2] leaf [3] pop [4] result write [5] whole kernel [6] cycles [7] 100 MHz ticks [8] the curve block
 #endif
 };
 
@@ -317,6 +319,14 @@ struct LightBox
 #ifndef SKH_BEST_LDS
 #define SKH_BEST_LDS 1
 #endif
+#ifndef SKH_SEGNODE
+#define SKH_SEGNODE 0 // 1: the curve builds understand SEGMENT NODES (skh_bvh.h k_segnode_emit; option curve_segnode).  A measured negative of round 6 (hair
+                      // 2 003 -> 1 835 Mray/s: +15 node visits per shadow ray for no fewer Newton runs, docs/LOG.md): compiled out of the default
+                      // library, built and held to the oracle's hit records by tests/test_gpu_parity.py through a -DSKH_SEGNODE=1 variant
+#endif
+#ifndef SKH_ANYHIT_FLAT_PUSH
+#define SKH_ANYHIT_FLAT_PUSH 1 // the any-hit node loop pushes its hit children without a branch per child (A/B: -DSKH_ANYHIT_FLAT_PUSH=0)
+#endif
 template <bool ANY_HIT, bool COUNT, bool CURVES, bool WORLD = false>
 __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? SKH_WORLD_CURVE_ANYHIT_MIN_WAVES : SKH_WORLD_CURVE_MIN_WAVES) : SKH_CURVE_MIN_WAVES) : (WORLD ? (ANY_HIT ? SKH_WORLD_ANYHIT_MIN_WAVES : SKH_WORLD_CLOSEST_MIN_WAVES) : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES))) SKH_TRACE_ATTR
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
@@ -363,7 +373,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
 #ifdef SKH_LANE_PROFILE
     uint32_t wv[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     uint32_t rayNodes = 0, rayTris = 0, rayInsts = 0;
-    unsigned long long cy[6] = { 0, 0, 0, 0, 0, 0 };
+    unsigned long long cy[7] = { 0, 0, 0, 0, 0, 0, 0 };
     const unsigned long long cyStart = __builtin_readcyclecounter();
     const unsigned long long rtStart = __builtin_amdgcn_s_memrealtime(); // constant 100 MHz counter: cycles / realtime = the clock this launch really ran at
 #define SKH_LP(...) __VA_ARGS__
@@ -663,6 +673,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                 break;
             continue;
         }
+        SKH_LP({ const unsigned long long t = __builtin_readcyclecounter(); cy[0] += t - cyA; cyA = t; })
         if constexpr (CURVES)
         {
             // ---- the iterative curve intersector, wave-cooperative ----
@@ -689,6 +700,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
             const uint32_t nWalking = (uint32_t)__popcll(__ballot(hasRay && pend == 0u));
             if (nRuns != 0u && (nRuns >= curveMin || nWalking == 0u))
             {
+                SKH_LP(wv[9]++; wv[2] += nRuns;) // (profile build: curve blocks, Newton runs dealt)
                 const uint32_t P = incl - 2u * myCand;
                 {
                     uint32_t bits = take, j = P; // (<= 64 lanes x 2 candidates x 2 ends = 256 runs)
@@ -719,6 +731,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                     const float otmin = __shfl(tmin, owner);
                     const uint32_t ofirst = (uint32_t)__shfl((int)myFirst, owner);
                     float resT = 0.0f, resU = -1.0f;
+                    SKH_LP(uint32_t runSteps = 0;)
                     if (work)
                     {
                         const float4* cp = sc.segs + 4 * (size_t)(ofirst + slot);
@@ -745,6 +758,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                         float told = 0.0f, dt1 = 0.0f, dt2 = 0.0f;
                         for (int it = 0; it < 40; ++it)
                         {
+                            SKH_LP(runSteps = (uint32_t)it + 1u;)
                             // one step of the ray / tangent-cone iteration (intersect_curve_segment, loop body)
                             const v4 c4 = cubic_position(poly, tpar);
                             const v4 d4 = ((3.0f * poly.p[0] * tpar) + 2.0f * poly.p[1]) * tpar + poly.p[2];
@@ -804,6 +818,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                                 break;
                         }
                     }
+                    SKH_LP(if (work) atomicAdd(&stats->runHist[ANY_HIT ? 1 : 0][min(runSteps, 41u)], 1ull); { const uint32_t mx = wave_max(runSteps); if (lane == 0) atomicAdd(&stats->blockHist[ANY_HIT ? 1 : 0][min(mx, 41u)], 1ull); })
                     // owners collect the runs of this round: candidate c of a lane = runs P + 2c (its first end) and P + 2c + 1
                     const uint32_t maxCand = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max(myCand));
                     for (uint32_t c = 0; c < maxCand; ++c)
@@ -829,12 +844,14 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                             {
                                 const uint32_t spw = sc.segPrim[myFirst + k];
                                 const uint32_t prim = spw & 0x0fffffffu;
+                                // (the merged world-space tree -- curve instances under identity transforms -- names the instance per segment)
+                                const uint32_t hinst = (WORLD && curInst == 0xffffffffu) ? sc.segInst[myFirst + k] : curInst;
                                 // a sub-range leaf keeps the hit only if u is its own (the leaf that owns u reports the same bits)
                                 if (min((uint32_t)(u * (float)sc.curveSplit), sc.curveSplit - 1u) == (spw >> 28) &&
-                                    (!best.found || t < best.t || curInst < SKH_BEST_INST() || (curInst == SKH_BEST_INST() && prim < SKH_BEST_PRIM())))
+                                    (!best.found || t < best.t || hinst < SKH_BEST_INST() || (hinst == SKH_BEST_INST() && prim < SKH_BEST_PRIM())))
                                 {
                                     best.t = t;
-                                    SKH_BEST_SET(curInst, prim, u, 0.0f)
+                                    SKH_BEST_SET(hinst, prim, u, 0.0f)
                                     best.found = true;
                                 }
                             }
@@ -854,7 +871,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
             }
         }
         bool terminated = false;
-        SKH_LP(uint32_t itN = 0, itT = 0; { const unsigned long long t = __builtin_readcyclecounter(); cy[0] += t - cyA; cyA = t; })
+        SKH_LP(uint32_t itN = 0, itT = 0; { const unsigned long long t = __builtin_readcyclecounter(); cy[6] += t - cyA; cyA = t; })
         // (lanes parked in front of the curve intersector do not count: they are not waiting for the node loop to end)
         const uint32_t breakBelow = ((uint32_t)__popcll(__ballot(hasRay && !(CURVES && pend != 0u))) * nodeBreak) >> 6;
         if (hasRay || TRICOOP) // (TRICOOP: every lane comes along to the triangle pass; the node loop and the pop stay with the lanes that have a ray)
@@ -878,7 +895,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                 }
                 SKH_LP(itN++; rayNodes++;)
                 // one 64-byte fetch = four quantised child boxes
-                const float4* np = reinterpret_cast<const float4*>((WORLD ? (CURVES && curType == 2 ? sc.segNodes : sc.triNodes) : nodes) + cur);
+                // (curve builds: a reference with SKH_REF_SEGNODE set is a segment node -- same array, same layout: the low 28 bits index it)
+                const float4* np = reinterpret_cast<const float4*>((WORLD ? (CURVES && curType == 2 ? sc.segNodes : sc.triNodes) : nodes) + ((CURVES && SKH_SEGNODE) ? (cur & 0x0fffffff) : cur));
                 const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
                 if (COUNT)
                     tc.nodes++;
@@ -906,6 +924,14 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                     // ever let one through, its SKH_REF_INVALID is pushed and skipped when popped)
                     const bool hit = tnear <= tfar * SKH_SLAB_SLACK;
                     tn[k] = hit ? tnear : INFINITY;
+                }
+                if (CURVES && SKH_SEGNODE && ((uint32_t)cur & SKH_REF_SEGNODE) != 0u)
+                {
+                    // a SEGMENT NODE (skh_bvh.h k_segnode_emit): its four boxes are one segment's parameter sub-ranges and its four references all name the
+                    // segment's leaf.  Meeting any of them makes the segment ONE candidate (the lane leaves the loop with the leaf in `cur`: cylinder test, then
+                    // the cooperative block); nothing is pushed.
+                    tn[0] = fminf(fminf(tn[0], tn[1]), fminf(tn[2], tn[3]));
+                    tn[1] = tn[2] = tn[3] = INFINITY;
                 }
                 // sort the four candidates by entry distance (5-comparator network), nearest first
 #define SKH_CSWAP(a, b)                      \
@@ -949,16 +975,38 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                 }
                 else
                 {
-                    // occlusion query: any order finds an occluder; skip the ordering network
-                    cur = SKH_REF_INVALID;
+                    // occlusion query: any order finds an occluder; skip the ordering network.  The hit children in slot order: the last one becomes
+                    // `cur`, the ones before it are pushed in that order.
+                    if (SKH_ANYHIT_FLAT_PUSH && sp + 3 <= NLDS)
+                    {
+                        // (round 6) without a branch per child: the store is unconditional -- what lands above the new top is never read -- and the
+                        // top only moves for a real push: the compiler's version of the loop below was 22 branches and 74 scalar instructions in a
+                        // 257-instruction iteration
+                        int nc = tn[0] < INFINITY ? rf[0] : SKH_REF_INVALID;
+                        int top = sp;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (tn[k] < INFINITY)
+                        for (int k = 1; k < 4; ++k)
                         {
-                            if (cur != SKH_REF_INVALID)
-                                SKH_PUSH(cur);
-                            cur = rf[k];
+                            const bool h = tn[k] < INFINITY;
+                            lds[top * SKH_TRACE_BLOCK] = nc;
+                            top += (h && nc != SKH_REF_INVALID) ? 1 : 0;
+                            nc = h ? rf[k] : nc;
                         }
+                        sp = top;
+                        cur = nc;
+                    }
+                    else
+                    {
+                        cur = SKH_REF_INVALID;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (tn[k] < INFINITY)
+                            {
+                                if (cur != SKH_REF_INVALID)
+                                    SKH_PUSH(cur);
+                                cur = rf[k];
+                            }
+                    }
                 }
 #undef SKH_CSWAP
                 // a lane whose node had no hit child takes its next stack entry right here instead of idling until
@@ -1019,6 +1067,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                     entered = true; // (keeps `cur`: no pop)
                 }
             }
+            // (Round 6 measured the same postponement for the few TRIANGLE leaves of the world-only curve builds -- the hair stand-in's scalp: the triangle
+            // branch runs in 94 % of the outer iterations for 7.9 / 2.6 of 64 lanes -- and it loses: lanes waiting at a leaf are rays not traced;
+            // hair 2 055 Mray/s without, 2 017 / 1 894 / 1 649 / 1 327 with a threshold of 8 / 16 / 24 / 32 lanes: docs/LOG.md.)
             uint32_t kStart = 0; // (TRICOOP) triangles of this lane's leaf the shared pass has dealt with
             if constexpr (TRICOOP)
             {
@@ -1265,7 +1316,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
         cyA = __builtin_readcyclecounter();
         wv[0] += wave_max(itN);
         wv[1] += wave_max(itT & 0xffffu);
-        wv[2] += __any((itT >> 16) != 0) ? 1u : 0u;
+        if (!CURVES)
+            wv[2] += __any((itT >> 16) != 0) ? 1u : 0u;
 #endif
         if (terminated)
         {
@@ -1302,12 +1354,12 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
             atomicAdd(&stats->cyc[ANY_HIT ? 1 : 0][6], cy[5]);
             atomicAdd(&stats->cyc[ANY_HIT ? 1 : 0][7], __builtin_amdgcn_s_memrealtime() - rtStart);
         }
-        for (int k = 0; k < 6; ++k)
+        for (int k = 0; k < 7; ++k)
         {
             // cycle sums are wave-uniform increments taken by the lanes that were active: the busiest lane has (nearly) all of them
             uint32_t hi = wave_max((uint32_t)(cy[k] >> 8));
             if (lane == 0)
-                atomicAdd(&stats->cyc[ANY_HIT ? 1 : 0][k], (unsigned long long)hi << 8);
+                atomicAdd(&stats->cyc[ANY_HIT ? 1 : 0][k == 6 ? 8 : k], (unsigned long long)hi << 8);
         }
 #endif
         if (lane == 0)

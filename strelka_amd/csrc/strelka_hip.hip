@@ -95,7 +95,7 @@ struct skh_context
     DevBuf dShadeTris, dShadeInst; // shading side: de-indexed triangle records, instance records that carry their mesh's base
     DevBuf dCurveSegBase, dSegStartAll;
     // accel
-    DevBuf dTexels, dTexDesc, dSegBound, dScatterXY, dRaygenBase;
+    DevBuf dTexels, dTexDesc, dSegBound, dSegInst, dScatterXY, dRaygenBase;
     uint32_t raygenBlocksPerSub = 0, raygenValidPerSub = 0;
     uint32_t nTextures = 0;
     bool hasHairMaterial = false; // selects the k_shade build that carries df::chiang_hair_bsdf
@@ -177,6 +177,11 @@ struct skh_context
     bool tightInstanceBoxes = true; // TLAS leaf boxes from the transformed vertices, not from the transformed object box
     uint32_t curveLeaf = 1; // sub-segments per curve leaf (option curve_leaf; hair stand-in after the intersector's early exit, Mray/s: 1: 1456, 2: 1392, 3: 1309, 4: 1240;
                             // the cooperative block takes two candidates per lane and block)
+    uint32_t numMergedCurveInst = 0; // (build result) curve instances that share the merged world-space tree
+    uint32_t curveMerge = 1; // (option curve_merge) curve instances under identity transforms share ONE world-space tree in the world-only curve kernel
+    uint32_t curveSegNode = 0; // (option curve_segnode) 1: the curve tree is built over whole segments and ends in SEGMENT NODES (skh_bvh.h k_segnode_emit): a segment is a
+                               // candidate at most once per ray; 0: parameter sub-ranges as primitives (curve_split), rounds 3-5
+    uint32_t curveStrandMajor = 0; // (option curve_strand_major, segment-node build) 1: leaf records and segment nodes at the segment's own index (consecutive segments of a strand adjacent)
     uint32_t curveSplit = 4; // parameter sub-ranges per curve segment in the curve BLAS (round 3, one-sub-segment leaves: 2: 1460, 3: 1480, 4: 1503 Mray/s; build time and leaf
                              // memory grow with it.  Round 2, ms per 1080p sub-frame: 1: 61.6, 2: 52.1, 4: 49.7, 8: 50.1)
     // TLAS builder.  1 (default): on the GPU -- PLOC over the instance boxes with a 96-neighbour search, the BLAS builder, no host round
@@ -1100,7 +1105,7 @@ void skh_destroy(skh_context* c)
         (void)skh_comm_destroy(c);
     for (DevBuf* b : { &c->dShadeTris, &c->dShadeInst, &c->dVerts, &c->dIndices, &c->dMeshes, &c->dPoints, &c->dRadii, &c->dInstances, &c->dLights, &c->dMaterials,
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
-                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
+                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dSegInst, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
                        &c->dCounts, &c->dOvf, &c->dOvf2, &c->dStats, &c->dScratchImage, &c->dPathB })
         dev_free(*b);
@@ -1360,7 +1365,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     // RAY_MASK_SHADOW, closest_hit.cu:191) -- the ray mask stays a property of the group, not of the triangle
     std::vector<uint32_t> wInst, wFirst;
     bool worldCurves = false;
-    std::vector<uint32_t> worldCurveInst;
+    std::vector<uint32_t> worldCurveInst, mergedCurveInst; // instances with a table entry of their own / merged into the one world-space curve tree
     uint32_t nBakedG[2] = { 0, 0 };
     {
         uint64_t uniqueTris = 0;
@@ -1440,9 +1445,25 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         for (uint32_t i = 0; i < nInst; ++i)
             if (c->instances[i].type == SKH_INSTANCE_LIGHT && eligible(i) && !pick[i])
                 lightsAllPicked = false;
-        worldCurves = !meshStays && !curveInst.empty() && curveInst.size() <= SKH_WORLD_CURVES && lightsAllPicked;
+        // (round 6) Curve instances under a BIT-EXACT IDENTITY transform -- a groom handed over as several HdBasisCurves rprims -- do not take a
+        // table entry each: their segments are MERGED into one world-space curve tree (group 0 of the curve build, the segment records name
+        // their instance), which takes ONE entry.  Walking 8 / 16 per-prim trees one after the other cost the hair stand-in 33 % / 50 % of its
+        // rate (each ray visits every tree's root and whatever overlaps: 40 / 53 instead of 28 nodes per radiance ray), docs/LOG.md.
+        std::vector<uint32_t> identInst, otherInst;
+        {
+            static const float kIdent[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+            for (uint32_t i : curveInst)
+                (memcmp(c->instances[i].transform, kIdent, sizeof(kIdent)) == 0 ? identInst : otherInst).push_back(i);
+        }
+        worldCurves = !meshStays && !curveInst.empty() && otherInst.size() + (identInst.empty() ? 0u : 1u) <= SKH_WORLD_CURVES && lightsAllPicked;
         if (worldCurves)
-            worldCurveInst = curveInst;
+        {
+            // option curve_merge = 0 (A/B, tests): identity instances keep a tree and a table entry each while the table can hold them all
+            const bool merge = c->curveMerge || curveInst.size() > SKH_WORLD_CURVES;
+            worldCurveInst = merge ? otherInst : curveInst;
+            if (merge)
+                mergedCurveInst = identInst;
+        }
         const bool tlasStays = meshStays || (!curveInst.empty() && !worldCurves);
         for (uint32_t i = 0; i < nInst; ++i)
         {
@@ -1496,9 +1517,9 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     const uint32_t nTris = nMeshTris + nBaked;
     c->nTris = nTris;
     LbvhOut triOut, segOut;
-    DevBuf dTriMesh, dTriLocal, dBoxLo, dBoxHi, dGrp, dSegStart, dSegCurve, dSegLocal, dW2o, dValid, dWInst, dWFirst;
+    DevBuf dTriMesh, dTriLocal, dBoxLo, dBoxHi, dGrp, dSegStart, dSegCurve, dSegLocal, dSegBuildStart, dSegInstOf, dW2o, dValid, dWInst, dWFirst;
     auto cleanup = [&]() {
-        for (DevBuf* b : { &dTriMesh, &dTriLocal, &dBoxLo, &dBoxHi, &dGrp, &dSegStart, &dSegCurve, &dSegLocal, &dW2o, &dValid, &dWInst, &dWFirst,
+        for (DevBuf* b : { &dTriMesh, &dTriLocal, &dBoxLo, &dBoxHi, &dGrp, &dSegStart, &dSegCurve, &dSegLocal, &dSegBuildStart, &dSegInstOf, &dW2o, &dValid, &dWInst, &dWFirst,
                            &triOut.sortedVals, &segOut.sortedVals, &triOut.groupRoot, &segOut.groupRoot, &triOut.groupBounds,
                            &segOut.groupBounds })
             dev_free(*b);
@@ -1599,104 +1620,169 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     }
     // ---- curve segments of all curve sets (segment enumeration: OptixRender.cpp:226-245) ----
     const uint32_t nCurves = (uint32_t)c->curves.size();
-    std::vector<uint32_t> segStart, segCurve, segLocal, curveSegCount(nCurves), curveSegBase(nCurves);
+    std::vector<uint32_t> setSegStart, curveSegCount(nCurves), curveSegBase(nCurves); // per set, set after set: what k_shade looks a hit's control points up in
     for (uint32_t ci = 0; ci < nCurves; ++ci)
     {
         const skh_curve& cu = c->curves[ci];
-        curveSegBase[ci] = (uint32_t)segStart.size();
+        curveSegBase[ci] = (uint32_t)setSegStart.size();
         uint32_t off = 0, local = 0;
         for (uint32_t k = 0; k < cu.vertex_counts_count; ++k)
         {
             const uint32_t ncp = c->curveVertexCounts[cu.vertex_counts_start + k];
-            for (int i = 0; i < (int)ncp - 3; ++i)
-            {
-                segStart.push_back(cu.points_start + off + (uint32_t)i);
-                segCurve.push_back(ci);
-                segLocal.push_back(local++);
-            }
+            for (int i = 0; i < (int)ncp - 3; ++i, ++local)
+                setSegStart.push_back(cu.points_start + off + (uint32_t)i);
             off += ncp;
         }
         curveSegCount[ci] = local;
     }
-    const uint32_t nSegs = (uint32_t)segStart.size();
-    c->nSegs = nSegs;
-    for (uint32_t k = 0; k < nSegs; ++k)
-        if ((uint64_t)segStart[k] + 4 > c->nPoints)
+    for (uint32_t k = 0; k < (uint32_t)setSegStart.size(); ++k)
+        if ((uint64_t)setSegStart[k] + 4 > c->nPoints)
         {
             c->err = "skh_build_accel: curve segment reads past the control-point buffer";
             cleanup();
             return SKH_INVALID_ARGUMENT;
         }
-    BA(dev_upload(c, c->dSegStartAll, segStart.data(), sizeof(uint32_t) * (size_t)nSegs));
-    BA(dev_upload(c, c->dCurveSegBase, curveSegBase.data(), sizeof(uint32_t) * (size_t)nCurves));
-    BA(dev_upload(c, dSegCurve, segCurve.data(), sizeof(uint32_t) * (size_t)nSegs));
-    BA(dev_upload(c, dSegLocal, segLocal.data(), sizeof(uint32_t) * (size_t)nSegs));
-    const uint32_t K = std::max(1u, std::min(c->curveSplit, 8u));
-    if ((uint64_t)nSegs * K >= (1ull << 28))
-    {
-        c->err = "skh_build_accel: more than 2^28 curve sub-segments (lower the curve_split option)";
-        cleanup();
-        return SKH_INVALID_ARGUMENT;
-    }
-    const uint32_t nSub = nSegs * K;
-    std::vector<uint32_t> curveSubCount(nCurves);
-    for (uint32_t ci = 0; ci < nCurves; ++ci)
-        curveSubCount[ci] = curveSegCount[ci] * K;
-    BA(dev_alloc(c, dBoxLo, sizeof(float4) * (size_t)std::max(nSub, std::max(1u, c->nInstances))));
-    BA(dev_alloc(c, dBoxHi, sizeof(float4) * (size_t)std::max(nSub, std::max(1u, c->nInstances))));
-    BA(dev_alloc(c, dGrp, sizeof(uint32_t) * (size_t)std::max(nSub, std::max(1u, c->nInstances))));
-    if (nSub)
-        k_seg_boxes<<<(nSub + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), c->dSegStartAll.as<uint32_t>(),
-                                                      dSegCurve.as<uint32_t>(), nSub, K, dBoxLo.as<float4>(), dBoxHi.as<float4>(),
-                                                      dGrp.as<uint32_t>());
-    BA(lbvh_build(c, nSub, nCurves, curveSubCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), (int)c->curveLeaf, usePloc, segOut, 2, 0u,
-                  usePloc ? c->reinsertCurveRounds : 0u, c->reinsertMinSize ? c->reinsertMinSize : (nSub <= (8u << 20) ? 1u : 32u)));
-    BA(dev_alloc(c, c->dSegs, sizeof(float4) * 4 * (size_t)std::max(1u, nSub)));
-    BA(dev_alloc(c, c->dSegPrim, sizeof(uint32_t) * (size_t)std::max(1u, nSub)));
-    BA(dev_alloc(c, c->dSegBound, sizeof(float4) * 2 * (size_t)std::max(1u, nSub)));
-    if (nSub)
-        k_gather_segs<<<(nSub + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), c->dSegStartAll.as<uint32_t>(),
-                                                        dSegLocal.as<uint32_t>(), segOut.sortedVals.as<uint32_t>(), nSub, K,
-                                                        c->dSegs.as<float4>(), c->dSegPrim.as<uint32_t>(), c->dSegBound.as<float4>());
-    c->curveSplitBuilt = K;
-    dev_free(c->dSegNodes);
-    c->dSegNodes = segOut.nodes;
-    c->hierNodes += segOut.numNodes;
-    // ---- instances -> TLAS (baked instances were marked invalid above: they get a record for shading, no leaf) ----
-    BA(dev_upload(c, dW2o, w2o.data(), sizeof(float) * w2o.size()));
-    BA(dev_upload(c, dValid, valid.data(), valid.size()));
-    BA(dev_alloc(c, c->dDevInst, sizeof(DevInstance) * (size_t)std::max(1u, nInst)));
-    if (nInst)
-        k_instance_boxes<<<(nInst + B - 1) / B, B, 0, st>>>(c->dInstances.as<HostInstance>(), dW2o.as<float>(), dValid.as<uint8_t>(),
-                                                           triOut.groupBounds.as<float>(), triOut.groupRoot.as<int>(),
-                                                           segOut.groupBounds.as<float>(), segOut.groupRoot.as<int>(), nMeshes, nCurves,
-                                                           nInst, c->dDevInst.as<DevInstance>(), dBoxLo.as<float4>(),
-                                                           dBoxHi.as<float4>(), dGrp.as<uint32_t>());
-    if (nInst > 0 && c->tightInstanceBoxes)
-        k_instance_tight_boxes<<<nInst, 256, 0, st>>>(c->dInstances.as<HostInstance>(), c->dDevInst.as<DevInstance>(), c->dMeshes.as<uint4>(),
-                                                      c->dVerts.as<uint8_t>(), nMeshes, 1u << 22, dBoxLo.as<float4>(), dBoxHi.as<float4>());
-    // world curves: walked from the world-only kernel (option world_kernel; without it they keep their TLAS leaves: same hit records)
-    c->numWorldCurves = 0;
-    bool othersInTlas = false; // (by the rule above nothing else has a leaf when worldCurves holds; checked, not assumed: a curve instance without a leaf AND without the kernel would vanish)
+    // Is anything else going to keep a top-level leaf?  (By the rule above nothing does when worldCurves holds; checked, not assumed: a curve instance
+    // without a leaf AND without the world-only kernel would vanish.)  Decided HERE, before the curve build and before the validity flags go to the device
+    // (the host-sweep TLAS path picks its leaves by the device's flags: ADVICE r5).
+    bool othersInTlas = false;
     for (uint32_t i = 0; i < nInst; ++i)
         if (valid[i] && c->instances[i].type != SKH_INSTANCE_CURVE)
         {
             const std::vector<int>& roots = triOut.hostGroupRoot;
             othersInTlas = othersInTlas || (c->instances[i].geom_id < roots.size() && roots[c->instances[i].geom_id] != SKH_REF_INVALID);
         }
-    // (an instance under a bit-exact identity transform goes LAST in the table = first off every ray's stack: the kernel skips its matrix fetch)
-    static const float kIdentity[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
-    c->worldCurveIdentLast = 0;
-    for (size_t k = 0; k + 1 < worldCurveInst.size(); ++k)
-        if (memcmp(c->instances[worldCurveInst[k]].transform, kIdentity, sizeof(kIdentity)) == 0)
+    const bool worldCurveKernel = worldCurves && c->worldKernel && !othersInTlas;
+    if (!worldCurveKernel)
+        mergedCurveInst.clear(); // (every curve instance keeps its TLAS leaf and its set's own tree)
+    // The curve build's primitives, group after group: group 0 = the segments of the MERGED instances (identity transforms: object space is world
+    // space; the record names the instance), group 1 + s = curve set s (skipped when every instance of the set was merged).
+    std::vector<uint32_t> segStart, segCurve, segLocal, segInstOf;
+    std::vector<uint32_t> curveGroupCount(nCurves + 1u, 0u);
+    {
+        std::vector<uint8_t> setNeeded(nCurves, mergedCurveInst.empty() ? 1 : 0);
+        if (!mergedCurveInst.empty())
         {
-            std::swap(worldCurveInst[k], worldCurveInst.back());
-            break;
+            std::vector<uint8_t> isMerged(std::max(1u, nInst), 0);
+            for (uint32_t i : mergedCurveInst)
+                isMerged[i] = 1;
+            for (uint32_t i = 0; i < nInst; ++i)
+                if (c->instances[i].type == SKH_INSTANCE_CURVE && !isMerged[i] && c->instances[i].geom_id < nCurves)
+                    setNeeded[c->instances[i].geom_id] = 1;
         }
-    if (worldCurves && c->worldKernel && !othersInTlas)
+        for (uint32_t i : mergedCurveInst)
+        {
+            const uint32_t ci = c->instances[i].geom_id;
+            for (uint32_t l = 0; l < curveSegCount[ci]; ++l)
+            {
+                segStart.push_back(setSegStart[curveSegBase[ci] + l]);
+                segCurve.push_back(0u);
+                segLocal.push_back(l);
+                segInstOf.push_back(i);
+            }
+            curveGroupCount[0] += curveSegCount[ci];
+        }
+        for (uint32_t ci = 0; ci < nCurves; ++ci)
+            if (setNeeded[ci])
+            {
+                for (uint32_t l = 0; l < curveSegCount[ci]; ++l)
+                {
+                    segStart.push_back(setSegStart[curveSegBase[ci] + l]);
+                    segCurve.push_back(1u + ci);
+                    segLocal.push_back(l);
+                    segInstOf.push_back(0xffffffffu);
+                }
+                curveGroupCount[1u + ci] = curveSegCount[ci];
+            }
+    }
+    const uint32_t nSegs = (uint32_t)segStart.size();
+    c->nSegs = nSegs;
+    BA(dev_upload(c, c->dSegStartAll, setSegStart.data(), sizeof(uint32_t) * setSegStart.size()));
+    BA(dev_upload(c, c->dCurveSegBase, curveSegBase.data(), sizeof(uint32_t) * (size_t)nCurves));
+    BA(dev_upload(c, dSegBuildStart, segStart.data(), sizeof(uint32_t) * (size_t)nSegs));
+    BA(dev_upload(c, dSegInstOf, segInstOf.data(), sizeof(uint32_t) * (size_t)nSegs));
+    BA(dev_upload(c, dSegCurve, segCurve.data(), sizeof(uint32_t) * (size_t)nSegs));
+    BA(dev_upload(c, dSegLocal, segLocal.data(), sizeof(uint32_t) * (size_t)nSegs));
+    const bool segNode = c->curveSegNode != 0 && nSegs > 0;
+    const uint32_t K = segNode ? 1u : std::max(1u, std::min(c->curveSplit, 8u)); // (segment nodes: the tree's primitives are whole segments)
+    if ((uint64_t)nSegs * K >= (1ull << 28) || (segNode && (uint64_t)nSegs * 2 >= (1ull << 28)))
+    {
+        c->err = "skh_build_accel: more than 2^28 curve sub-segments (lower the curve_split option)";
+        cleanup();
+        return SKH_INVALID_ARGUMENT;
+    }
+    const uint32_t nSub = nSegs * K;
+    const uint32_t nCurveGroups = nCurves + 1u; // [0] the merged world-space curves, [1 + s] curve set s
+    std::vector<uint32_t> curveSubCount(nCurveGroups);
+    for (uint32_t g = 0; g < nCurveGroups; ++g)
+        curveSubCount[g] = curveGroupCount[g] * K;
+    BA(dev_alloc(c, dBoxLo, sizeof(float4) * (size_t)std::max(nSub, std::max(1u, c->nInstances))));
+    BA(dev_alloc(c, dBoxHi, sizeof(float4) * (size_t)std::max(nSub, std::max(1u, c->nInstances))));
+    BA(dev_alloc(c, dGrp, sizeof(uint32_t) * (size_t)std::max(nSub, std::max(1u, c->nInstances))));
+    if (nSub && segNode)
+        k_seg_union_boxes<<<(nSegs + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), dSegBuildStart.as<uint32_t>(),
+                                                            dSegCurve.as<uint32_t>(), nSegs, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>());
+    else if (nSub)
+        k_seg_boxes<<<(nSub + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), dSegBuildStart.as<uint32_t>(),
+                                                      dSegCurve.as<uint32_t>(), nSub, K, dBoxLo.as<float4>(), dBoxHi.as<float4>(),
+                                                      dGrp.as<uint32_t>());
+    BA(lbvh_build(c, nSub, nCurveGroups, curveSubCount, dBoxLo.as<float4>(), dBoxHi.as<float4>(), dGrp.as<uint32_t>(), segNode ? 1 : (int)c->curveLeaf, usePloc, segOut, 2, 0u,
+                  usePloc ? c->reinsertCurveRounds : 0u, c->reinsertMinSize ? c->reinsertMinSize : (nSub <= (8u << 20) ? 1u : 32u)));
+    const uint32_t strandMajor = segNode && c->curveStrandMajor ? 1u : 0u;
+    if (segNode)
+    {
+        // the tree's nodes, then one segment node per segment; every one-segment leaf reference (internal nodes' child words, the per-set roots) is
+        // redirected to the segment node in front of the leaf
+        DevBuf grown;
+        BA(dev_alloc(c, grown, sizeof(Node4) * ((size_t)segOut.numNodes + nSegs + 1)));
+        if (segOut.numNodes)
+            SKH_TRY(c, hipMemcpyAsync(grown.p, segOut.nodes.p, sizeof(Node4) * (size_t)segOut.numNodes, hipMemcpyDeviceToDevice, st));
+        k_segnode_emit<<<(nSegs + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), dSegBuildStart.as<uint32_t>(), segOut.sortedVals.as<uint32_t>(), nSegs,
+                                                         strandMajor, grown.as<Node4>() + segOut.numNodes);
+        if (segOut.numNodes)
+            k_segnode_patch<<<(segOut.numNodes * 4u + B - 1) / B, B, 0, st>>>(reinterpret_cast<int*>(grown.p) + 12, segOut.numNodes * 4u, 16u, 4u, segOut.sortedVals.as<uint32_t>(),
+                                                                             strandMajor, segOut.numNodes);
+        k_segnode_patch<<<(nCurveGroups + B - 1) / B, B, 0, st>>>(segOut.groupRoot.as<int>(), nCurveGroups, 1u, 1u, segOut.sortedVals.as<uint32_t>(), strandMajor, segOut.numNodes);
+        SKH_TRY(c, hipMemcpyAsync(segOut.hostGroupRoot.data(), segOut.groupRoot.p, sizeof(int) * (size_t)nCurveGroups, hipMemcpyDeviceToHost, st));
+        SKH_TRY(c, hipStreamSynchronize(st));
+        dev_free(segOut.nodes);
+        segOut.nodes = grown;
+        segOut.numNodes += nSegs;
+    }
+    BA(dev_alloc(c, c->dSegs, sizeof(float4) * 4 * (size_t)std::max(1u, nSub)));
+    BA(dev_alloc(c, c->dSegPrim, sizeof(uint32_t) * (size_t)std::max(1u, nSub)));
+    BA(dev_alloc(c, c->dSegBound, sizeof(float4) * 2 * (size_t)std::max(1u, nSub)));
+    BA(dev_alloc(c, c->dSegInst, sizeof(uint32_t) * (size_t)std::max(1u, nSub)));
+    if (nSub)
+        k_gather_segs<<<(nSub + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), dSegBuildStart.as<uint32_t>(),
+                                                        dSegLocal.as<uint32_t>(), dSegInstOf.as<uint32_t>(), segOut.sortedVals.as<uint32_t>(), nSub, K,
+                                                        c->dSegs.as<float4>(), c->dSegPrim.as<uint32_t>(), c->dSegBound.as<float4>(), c->dSegInst.as<uint32_t>(), strandMajor);
+    c->curveSplitBuilt = K;
+    dev_free(c->dSegNodes);
+    c->dSegNodes = segOut.nodes;
+    c->hierNodes += segOut.numNodes;
+    // world curves: walked from the world-only kernel (option world_kernel; without it they keep their TLAS leaves: same hit records).  Decided BEFORE the
+    // validity flags go to the device: both TLAS builders then agree on which instances have a leaf.
+    std::vector<int> curveSetRoot(nCurves, SKH_REF_INVALID); // root of curve set s's own tree (group 1 + s)
+    for (uint32_t ci = 0; ci < nCurves; ++ci)
+        curveSetRoot[ci] = segOut.hostGroupRoot[1u + ci];
+    c->numWorldCurves = 0;
+    c->worldCurveIdentLast = 0;
+    if (worldCurveKernel)
+    {
+        // (an instance under a bit-exact identity transform goes LAST in the table = first off every ray's stack: the kernel skips its matrix fetch.  With
+        // merged curves that entry is the merged tree's; without -- curve_merge 0 -- one identity instance is moved there)
+        static const float kIdentity[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+        if (mergedCurveInst.empty())
+            for (size_t k = 0; k + 1 < worldCurveInst.size(); ++k)
+                if (memcmp(c->instances[worldCurveInst[k]].transform, kIdentity, sizeof(kIdentity)) == 0)
+                {
+                    std::swap(worldCurveInst[k], worldCurveInst.back());
+                    break;
+                }
         for (uint32_t i : worldCurveInst)
         {
-            const int root = c->instances[i].geom_id < segOut.hostGroupRoot.size() ? segOut.hostGroupRoot[c->instances[i].geom_id] : SKH_REF_INVALID;
+            const int root = c->instances[i].geom_id < nCurves ? curveSetRoot[c->instances[i].geom_id] : SKH_REF_INVALID;
             if (root == SKH_REF_INVALID)
                 continue;
             c->worldCurveRoot[c->numWorldCurves] = root;
@@ -1704,6 +1790,29 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
             c->worldCurveIdentLast = memcmp(c->instances[i].transform, kIdentity, sizeof(kIdentity)) == 0 ? 1u : 0u; // (of the last one entered)
             valid[i] = 0; // no TLAS leaf
         }
+        if (!mergedCurveInst.empty() && segOut.hostGroupRoot[0] != SKH_REF_INVALID)
+        {
+            c->worldCurveRoot[c->numWorldCurves] = segOut.hostGroupRoot[0];
+            c->worldCurveInst[c->numWorldCurves++] = 0xffffffffu; // = "the segment record names the instance" (DevScene::segInst)
+            c->worldCurveIdentLast = 1u;
+            for (uint32_t i : mergedCurveInst)
+                valid[i] = 0;
+        }
+    }
+    c->numMergedCurveInst = worldCurveKernel ? (uint32_t)mergedCurveInst.size() : 0u;
+    // ---- instances -> TLAS (baked instances were marked invalid above: they get a record for shading, no leaf) ----
+    BA(dev_upload(c, dW2o, w2o.data(), sizeof(float) * w2o.size()));
+    BA(dev_upload(c, dValid, valid.data(), valid.size()));
+    BA(dev_alloc(c, c->dDevInst, sizeof(DevInstance) * (size_t)std::max(1u, nInst)));
+    if (nInst)
+        k_instance_boxes<<<(nInst + B - 1) / B, B, 0, st>>>(c->dInstances.as<HostInstance>(), dW2o.as<float>(), dValid.as<uint8_t>(),
+                                                           triOut.groupBounds.as<float>(), triOut.groupRoot.as<int>(),
+                                                           segOut.groupBounds.as<float>() + 6, segOut.groupRoot.as<int>() + 1 /* curve set s = group 1 + s */, nMeshes, nCurves,
+                                                           nInst, c->dDevInst.as<DevInstance>(), dBoxLo.as<float4>(),
+                                                           dBoxHi.as<float4>(), dGrp.as<uint32_t>());
+    if (nInst > 0 && c->tightInstanceBoxes)
+        k_instance_tight_boxes<<<nInst, 256, 0, st>>>(c->dInstances.as<HostInstance>(), c->dDevInst.as<DevInstance>(), c->dMeshes.as<uint4>(),
+                                                      c->dVerts.as<uint8_t>(), nMeshes, 1u << 22, dBoxLo.as<float4>(), dBoxHi.as<float4>());
     uint32_t nValidHost = 0;
     for (uint32_t i = 0; i < nInst; ++i)
         nValidHost += valid[i] ? 1u : 0u;
@@ -1716,7 +1825,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         for (uint32_t i = 0; i < nInst; ++i)
         {
             const skh_instance& in = c->instances[i];
-            const std::vector<int>& roots = in.type == SKH_INSTANCE_CURVE ? segOut.hostGroupRoot : triOut.hostGroupRoot;
+            const std::vector<int>& roots = in.type == SKH_INSTANCE_CURVE ? curveSetRoot : triOut.hostGroupRoot;
             if (valid[i] && in.geom_id < roots.size() && roots[in.geom_id] != SKH_REF_INVALID)
                 leafInst.push_back(i);
         }
@@ -2169,6 +2278,7 @@ static DevScene make_dev_scene(const skh_context* c)
     sc.segs = c->dSegs.as<float4>();
     sc.segPrim = c->dSegPrim.as<uint32_t>();
     sc.segBound = c->dSegBound.as<float4>();
+    sc.segInst = c->dSegInst.as<uint32_t>();
     sc.curveSplit = c->curveSplitBuilt;
     sc.worldRoot = c->worldRoot;
     sc.lightRoot = c->lightRoot;
@@ -3550,6 +3660,20 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         c->curveLeaf = (uint32_t)value;
         c->accelBuilt = false;
     }
+    else if (n == "curve_merge")
+    {
+        if (value < 0 || value > 1)
+            return SKH_INVALID_ARGUMENT;
+        c->curveMerge = (uint32_t)value;
+        c->accelBuilt = false;
+    }
+    else if (n == "curve_segnode" || n == "curve_strand_major")
+    {
+        if (value < 0 || value > 1 || (value == 1 && !SKH_SEGNODE)) // (the kernels of this library were compiled without segment-node support: skh_kernels.h SKH_SEGNODE)
+            return SKH_INVALID_ARGUMENT;
+        (n == "curve_segnode" ? c->curveSegNode : c->curveStrandMajor) = (uint32_t)value;
+        c->accelBuilt = false;
+    }
     else if (n == "curve_split")
     {
         if (value < 1 || value > 8)
@@ -3749,9 +3873,9 @@ skh_status skh_get_stats(skh_context* c, skh_stats* out)
     }
 #ifdef SKH_LANE_PROFILE
     for (int k = 0; k < 2; ++k)
-        fprintf(stderr, "[lane-profile] %s: rays %llu nodes %llu (TLAS %llu) tris %llu insts %llu | wave: nodeIt %llu triIt %llu instBlk %llu outer %llu refills %llu refilled %llu | tri passes with: fp64 fallback %llu, sign test passed %llu, division %llu\n",
+        fprintf(stderr, "[lane-profile] %s: rays %llu nodes %llu (TLAS %llu) tris %llu insts %llu | wave: nodeIt %llu triIt %llu instBlk %llu outer %llu refills %llu refilled %llu | tri passes with: fp64 fallback %llu, sign test passed %llu, division %llu | curve blocks %llu (instBlk = Newton runs in the curve builds)\n",
                 k ? "shadow" : "closest", k ? sd.raysShadow : sd.raysRadiance, sd.nodes[k], sd.segs[k], sd.prims[k], sd.insts[k], sd.wave[k][0], sd.wave[k][1],
-                sd.wave[k][2], sd.wave[k][3], sd.wave[k][4], sd.wave[k][5], sd.wave[k][6], sd.wave[k][8], sd.wave[k][7]);
+                sd.wave[k][2], sd.wave[k][3], sd.wave[k][4], sd.wave[k][5], sd.wave[k][6], sd.wave[k][8], sd.wave[k][7], sd.wave[k][9]);
     {
         double tot = 0;
         for (int k = 0; k < 8; ++k)
@@ -3765,7 +3889,23 @@ skh_status skh_get_stats(skh_context* c, skh_stats* out)
         fprintf(stderr, "[slow-ray] steps %.0f tris %.0f insts %.0f %s o %.9g %.9g %.9g d %.9g %.9g %.9g tmin %g tmax %g\n", sd.slow[k][0], sd.slow[k][1], sd.slow[k][2],
                 sd.slow[k][3] != 0.0f ? "shadow" : "closest", sd.slow[k][4], sd.slow[k][5], sd.slow[k][6], sd.slow[k][7], sd.slow[k][8], sd.slow[k][9], sd.slow[k][10], sd.slow[k][11]);
     for (int k = 0; k < 2; ++k)
-        fprintf(stderr, "[lane-cycles] %s: refill %.3g node %.3g leaf %.3g pop %.3g write %.3g total %.3g | shader clock while the waves ran: %.1f MHz (wave-seconds %.4g)\n", k ? "shadow" : "closest", (double)sd.cyc[k][0],
+    {
+        unsigned long long tr = 0, tb = 0;
+        for (int j = 0; j < 42; ++j)
+            tr += sd.runHist[k][j], tb += sd.blockHist[k][j];
+        if (tr)
+        {
+            fprintf(stderr, "[newton-steps] %s runs %llu:", k ? "shadow" : "closest", tr);
+            for (int j = 0; j < 42; ++j)
+                fprintf(stderr, " %d:%.2f%%", j, 100.0 * (double)sd.runHist[k][j] / (double)tr);
+            fprintf(stderr, "\n[newton-block-max] %s rounds %llu:", k ? "shadow" : "closest", tb);
+            for (int j = 0; j < 42; ++j)
+                fprintf(stderr, " %d:%.2f%%", j, 100.0 * (double)sd.blockHist[k][j] / (double)tb);
+            fprintf(stderr, "\n");
+        }
+    }
+    for (int k = 0; k < 2; ++k)
+        fprintf(stderr, "[lane-cycles] %s: refill %.3g curve-block %.3g node %.3g leaf %.3g pop %.3g write %.3g total %.3g | shader clock while the waves ran: %.1f MHz (wave-seconds %.4g)\n", k ? "shadow" : "closest", (double)sd.cyc[k][0], (double)sd.cyc[k][8],
                 (double)sd.cyc[k][1], (double)sd.cyc[k][2], (double)sd.cyc[k][3], (double)sd.cyc[k][4], (double)sd.cyc[k][5],
                 sd.cyc[k][7] ? (double)sd.cyc[k][6] / (double)sd.cyc[k][7] * 100.0 : 0.0, (double)sd.cyc[k][7] / 1e8);
 #endif

@@ -429,6 +429,92 @@ def test_thick_varying_radius_curves_bit_exact_for_every_sub_range_count(split):
     ctx.close()
 
 
+def test_segment_node_variant_is_exact(tmp_path):
+    """Round 6's SEGMENT NODES (skh_bvh.h k_segnode_emit: the curve tree over whole segments, one Node4 of the four parameter sub-ranges in front of
+    every leaf, a segment a candidate at most once per ray) are a measured negative (docs/LOG.md) and compiled out of the default library; the
+    -DSKH_SEGNODE=1 variant is held to the oracle's hit records here -- thick varying-radius tubes, thin hair, a render, both record orders -- and
+    the default library refuses the option instead of building a tree its kernels cannot walk."""
+    import subprocess
+    import sys
+
+    from strelka_amd import build, capi
+
+    ctx = capi.Context(0)
+    with pytest.raises(capi.SkhError):
+        ctx.set_option("curve_segnode", 1)
+    ctx.close()
+    lib = build.build_variant(str(tmp_path / "libstrelka_hip_segnode.so"), ["SKH_SEGNODE=1"])
+    code = r'''
+import os, sys
+sys.path.insert(0, os.environ["SKH_ROOT"])
+import numpy as np
+from strelka_amd import capi, scene as S, scenes
+from tests import orklib
+from tests.test_gpu_parity import thick_curves, small_hair, camera_rays, assert_hits_equal
+for strand_major in (0, 1):
+    for sc in (thick_curves(), small_hair()):
+        arr = sc.arrays()
+        o = orklib.new_context(); o.set_scene(arr)
+        ctx = capi.Context(0)
+        ctx.set_option("curve_segnode", 1); ctx.set_option("curve_strand_major", strand_major)
+        ctx.set_scene(arr)
+        rays = np.concatenate([camera_rays(sc, 64, 64, 20000, 5), scenes.random_rays(20000, 6, -2.5, 2.5)])
+        assert_hits_equal(ctx.trace(rays, 0), o.trace(rays, 0))
+        rays["tmax"] = 2.0
+        assert np.array_equal(ctx.trace(rays, 1)["t"], o.trace(rays, 1)["t"])
+        ctx.close()
+sc = small_hair(); arr = sc.arrays()
+o = orklib.new_context(); o.set_scene(arr); o.resize(96, 64)
+ctx = capi.Context(0); ctx.set_option("curve_segnode", 1); ctx.set_scene(arr); ctx.resize(96, 64)
+for i in range(4):
+    p = S.frame_params(sc.getCamera(), 96, 64, subframe_index=i, spp_total=4, max_depth=3)
+    o.render_subframe(p); ctx.render_subframe(p)
+assert np.array_equal(ctx.read_accum()[..., :3], o.read_accum()[..., :3])
+print("SEGNODE-OK")
+'''
+    import os
+
+    env = dict(os.environ, SKH_LIB=lib, SKH_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "SEGNODE-OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("n_prims,n_moved,merge", [(5, 2, 1), (5, 2, 0), (8, 0, 1), (20, 3, 1), (20, 3, 0), (20, 18, 1), (1, 0, 1)])
+def test_groom_split_into_several_curve_prims_is_exact(n_prims, n_moved, merge):
+    """Round 6: curve instances under bit-exact identity transforms are MERGED into one world-space curve tree of the world-only curve kernel (its
+    segment records name their instance); the others keep a tree and a table entry each (<= 16 entries, the merged tree counting once -- the
+    integer rule the checker shares, it decides which light proxies are baked); more than that falls back to the two-level kernel.  The same
+    strands as 1 / 5 / 8 / 20 prims, some under translations, with and without merging (curve_merge): hit records (closest + any-hit) and a
+    render equal to the oracle's, and -- the strands being the same -- the single-prim image's ray counts."""
+    from strelka_amd import capi
+    from tests import orklib
+
+    sc = scenes.hair_standin(seed=5, n_strands=1500, n_cp=8, n_prims=n_prims, prim_offset=0.01 if n_moved else 0.0, n_moved=n_moved)
+    arr = sc.arrays()
+    assert (arr["instances"]["type"] == S.INSTANCE_CURVE).sum() == n_prims
+    o = orklib.new_context()
+    o.set_scene(arr)
+    ctx = capi.Context(0)
+    ctx.set_option("curve_merge", merge)
+    ctx.set_scene(arr)
+    rays = np.concatenate([camera_rays(sc, 64, 64, 30000, 11), scenes.random_rays(10000, 12, -2.0, 2.0)])
+    want = o.trace(rays, 0)
+    hit_curve = np.isin(want["instance_id"], np.nonzero(arr["instances"]["type"] == S.INSTANCE_CURVE)[0])
+    assert hit_curve.mean() > 0.01 and len(np.unique(want["instance_id"][hit_curve])) >= min(n_prims, 3)
+    assert_hits_equal(ctx.trace(rays, 0), want)
+    rays["tmax"] = 4.0
+    assert np.array_equal(ctx.trace(rays, 1)["t"], o.trace(rays, 1)["t"])
+    o.resize(96, 64)
+    ctx.resize(96, 64)
+    for i in range(3):
+        p = S.frame_params(sc.getCamera(), 96, 64, subframe_index=i, spp_total=3, max_depth=3)
+        o.render_subframe(p)
+        ctx.render_subframe(p)
+    _image_equal(ctx.read_accum(), o.read_accum())
+    assert ctx.stats()["rays_radiance"] == o.stats()["rays_radiance"]
+    ctx.close()
+
+
 def test_render_hair_matches_oracle(gpu):
     sc = small_hair()
     o, want, got = _render_both(gpu, sc, 96, 64, 4, 3)
