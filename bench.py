@@ -279,6 +279,9 @@ SCENE_RECIPES = {
     "hair_8": (lambda scenes: scenes.hair_standin(n_prims=8), "hair stand-in as 8 curve prims: %d scalp triangles, %d instances of %d meshes + 100 k strands"),
     "hair_16": (lambda scenes: scenes.hair_standin(n_prims=16), "hair stand-in as 16 curve prims: %d scalp triangles, %d instances of %d meshes + 100 k strands"),
     "hair_17": (lambda scenes: scenes.hair_standin(n_prims=17), "hair stand-in as 17 curve prims: %d scalp triangles, %d instances of %d meshes + 100 k strands"),
+    "hair_2_moved": (lambda scenes: scenes.hair_standin(n_prims=2, prim_offset=1e-3), "hair stand-in as 2 curve prims under translations: %d scalp triangles, %d instances of %d meshes + 100 k strands"),
+    "hair_4_moved": (lambda scenes: scenes.hair_standin(n_prims=4, prim_offset=1e-3), "hair stand-in as 4 curve prims under translations: %d scalp triangles, %d instances of %d meshes + 100 k strands"),
+    "hair_8_moved": (lambda scenes: scenes.hair_standin(n_prims=8, prim_offset=1e-3), "hair stand-in as 8 curve prims under translations: %d scalp triangles, %d instances of %d meshes + 100 k strands"),
     "hair_17_moved": (lambda scenes: scenes.hair_standin(n_prims=17, prim_offset=1e-3), "hair stand-in as 17 curve prims under translations: %d scalp triangles, %d instances of %d meshes + 100 k strands"),
     "cornell": (lambda scenes: scenes.cornell_box(), "cornell box (C2): %d triangles, %d instances of %d meshes"),
 }

@@ -34,7 +34,10 @@ struct HostInstance // == skh_instance (64 B), as uploaded
     uint32_t type, geom, material, light;
 };
 
-#define SKH_WORLD_CURVES 16
+// Curve trees the world-only curve kernel walks one after the other (table entries; the MERGED tree of all identity-transform instances is one).  Round 5 allowed
+// 16; measured in round 6 against the two-level kernel on the hair stand-in cut into N prims under translations (gpurun_out/r6j): N = 2 -4 %, 4 -11 %, 8 -20 % --
+// every ray visits every tree, nothing culls an instance the ray misses.  Two entries keep "the merged groom + one moved prim" and "one prim under a transform".
+#define SKH_WORLD_CURVES 2
 #define SKH_REF_CURVEROOT 0x40000000 // stack entry (world-only kernel with curves): (ref & 0xffff) indexes DevScene::worldCurveRoot / worldCurveInst
 #define SKH_REF_CURVEROOT_IDENT 0x20000000 // ... of an instance under a bit-exact identity transform, which is only valid as the FIRST curve tree of a ray (o, d still the world ray)
 struct DevScene
@@ -348,6 +351,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
     // docs/LOG.md, round 5); one stack entry pays for the 1 KB (19 x 256 + 512 (s_runs) + 1024 = 5 granules, as before).
     constexpr bool BESTLDS = CURVES && !ANY_HIT && SKH_BEST_LDS;
     constexpr int NLDS = (TRICOOP || BESTLDS) ? SKH_STACK_LDS - 1 : SKH_STACK_LDS;
+    static_assert(!(WORLD && CURVES) || SKH_WORLD_CURVES + 4 <= NLDS, "the curve trees' markers and the light root are written to the LDS stack unchecked at refill (ADVICE r5): they must leave room for the walk");
     __shared__ int s_stack[NLDS * SKH_TRACE_BLOCK];
     __shared__ uint32_t s_best[BESTLDS ? 4 * SKH_TRACE_BLOCK : 1];
     __shared__ unsigned char s_tab[TRICOOP ? 128 : 1]; // [0..63] owner lanes by rank, [64..127] helper lanes by rank
@@ -1276,6 +1280,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                             }
                         }
                     }
+                    // (curve builds: the reciprocal direction is not needed by the triangle test -- recomputed here, same operation on the same d: same bits,
+                    // instead of being held, or spilled, across it: the two-level curve builds 19 -> 17 / 27 -> 21 spilled dwords; the world-only builds keep their 3 / 17)
+                    if (CURVES)
+                        inv = rcp3(d);
                 }
             }
             SKH_LP(if (entered) itT |= 0x10000u; { const unsigned long long t = __builtin_readcyclecounter(); cy[2] += t - cyA; cyA = t; })

@@ -479,13 +479,14 @@ print("SEGNODE-OK")
     assert out.returncode == 0 and "SEGNODE-OK" in out.stdout, out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("n_prims,n_moved,merge", [(5, 2, 1), (5, 2, 0), (8, 0, 1), (20, 3, 1), (20, 3, 0), (20, 18, 1), (1, 0, 1)])
+@pytest.mark.parametrize("n_prims,n_moved,merge", [(5, 1, 1), (5, 1, 0), (2, 0, 0), (2, 2, 1), (3, 2, 1), (8, 0, 1), (20, 0, 1), (20, 3, 1), (20, 18, 1), (1, 0, 1)])
 def test_groom_split_into_several_curve_prims_is_exact(n_prims, n_moved, merge):
     """Round 6: curve instances under bit-exact identity transforms are MERGED into one world-space curve tree of the world-only curve kernel (its
-    segment records name their instance); the others keep a tree and a table entry each (<= 16 entries, the merged tree counting once -- the
+    segment records name their instance); the others keep a tree and a table entry each (<= 2 entries, the merged tree counting once -- the
     integer rule the checker shares, it decides which light proxies are baked); more than that falls back to the two-level kernel.  The same
-    strands as 1 / 5 / 8 / 20 prims, some under translations, with and without merging (curve_merge): hit records (closest + any-hit) and a
-    render equal to the oracle's, and -- the strands being the same -- the single-prim image's ray counts."""
+    strands as 1 / 2 / 3 / 5 / 8 / 20 prims, some under translations, with and without merging (curve_merge): merged + one marker, two identity markers,
+    two moved markers, the two-level fallback (3 entries; 20 prims with 3 / 18 moved), 8 and 20 merged prims, one prim -- hit records (closest + any-hit)
+    and a render equal to the oracle's."""
     from strelka_amd import capi
     from tests import orklib
 
