@@ -191,3 +191,29 @@ def test_limiter_is_derived_from_the_lines_own_fractions():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert '"limiter": "' not in src  # no literal limiter left
     assert 'extra["hair"]' in src  # C5 is a leg of the default line
+
+
+def test_measured_clock_from_the_counter_pass(tmp_path):
+    """Round 6: the VALU-issue roof is priced against the clock the launches really ran at.  `_pmc_per_launch` turns the
+    GRBM_GUI_ACTIVE pass into GHz -- busy cycles / dispatch duration, per engine instance whether rocprofv3 writes one row per XCD or one row with
+    the sum of the eight -- and `pmc_figures` hands it on; the record carries `value_drop_in`, `interactive` and a `config.step` that says what the
+    headline's step is."""
+    head = "Kernel_Name,Counter_Name,Counter_Value,Dispatch_Id,Start_Timestamp,End_Timestamp\n"
+    k = '"void skh::k_trace<false, false, false, true>(skh::DevScene)"'
+    d = tmp_path / "perxcd"
+    d.mkdir()
+    # one row per XCD: 8 rows x 2.3e7 busy cycles over 10 ms -> 2.3 GHz; two dispatches
+    (d / "1_counter_collection.csv").write_text(head + "".join(f"{k},GRBM_GUI_ACTIVE,{2.3e7 if disp == 1 else 2.2e7},{disp},1000,{1000 + 10_000_000}\n"
+                                                                 for disp in (1, 2) for _ in range(8)))
+    got = bench._pmc_per_launch(str(d), bench.CLOSEST)
+    assert abs(got["__clock_ghz"] - 2.25) < 1e-6
+    d2 = tmp_path / "summed"
+    d2.mkdir()
+    (d2 / "1_counter_collection.csv").write_text(head + f"{k},GRBM_GUI_ACTIVE,{8 * 2.31e7},7,0,10000000\n")
+    assert abs(bench._pmc_per_launch(str(d2), bench.CLOSEST)["__clock_ghz"] - 2.31) < 1e-6
+    fig = bench.pmc_figures({"__clock_ghz": 2.31, "SQ_INSTS_VALU": 1e9}, 1000)
+    assert fig["clock_ghz_measured"] == 2.31
+    assert ("GRBM_GUI_ACTIVE",) in bench.PMC_PASSES
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for needle in ('out["value_drop_in"]', 'out["interactive"]', "one skh_render_subframes(", "frac_valu_issue_at_max_clock", 'extra["hair_multi"]'):
+        assert needle in src, needle
