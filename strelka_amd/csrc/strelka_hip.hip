@@ -206,12 +206,12 @@ struct skh_context
     uint32_t leafLines = 0;   // 1: triangle leaves laid out by 128-byte line (skh_bvh.h: k_leaf_place): -11 % fetched lines, same time (docs/LOG.md)
     uint32_t nTriSlots = 0;
     LightBox lightBox = { { -INFINITY, -INFINITY, -INFINITY }, { INFINITY, INFINITY, INFINITY } }; // around the baked light proxies' group (skh_build_accel), with the node encoder's margin
-    uint32_t mergeLightProxies = 0;
+    uint32_t mergeLightProxies = 0; // option merge_light_proxies: baked light proxies share the world-space mesh triangles' tree (any-hit queries skip their triangles) instead of a tree of their own that every radiance ray visits (a measured loss: docs/LOG.md round 5)
     uint32_t nShadeRecords = 0; // de-indexed shading triangle records (build_shading_tables)
     int32_t directRecordsOpt = -1; // option direct_records: -1 = by the counts (below), 0 / 1 forced
     uint32_t directRecords = 1; // baked mesh triangles name their shading record (SKH_PRIM_DIRECT); 0 when only (instance, mesh-local primitive) fits a 16-byte hit record
     uint32_t hitPrimRange = 0;  // primitive words of this scene's hits stay below it (records, or mesh-local indices; curve segments)
-    uint32_t compactHits = 1;   // option compact_hits: 16-byte hit records in the render passes of world-only triangle scenes that fit (HitQ::primBits) // option merge_light_proxies: baked light proxies share the world-space mesh triangles' tree (any-hit queries skip their triangles) instead of a tree of their own that every radiance ray visits
+    uint32_t compactHits = 1;   // option compact_hits: 16-byte hit records in the render passes of world-only triangle scenes that fit (HitQ::primBits)
     uint32_t leafMaxTris = 2; // measured on MI355X: 2 beats 1, 3, 4, 6, 8 (the kernel is ALU bound, wasted triangle tests cost more than extra nodes)
     uint32_t buildQuality = 1; // 0: Karras radix tree (fastest build), 1: PLOC clustering (SAH-class quality)
     float sceneLo[3] = { 0, 0, 0 }, sceneHi[3] = { 1, 1, 1 };
