@@ -1151,12 +1151,21 @@ SKH_DI float hair_logI0(float x)
         return x + 0.5f * ((-skm::logf_(2.0f * SKH_PI) + skm::logf_(1.0f / x)) + 1.0f / (8.0f * x));
     return skm::logf_(hair_I0(x));
 }
-SKH_DI float hair_Mp(float cosThetaI, float cosThetaO, float sinThetaI, float sinThetaO, float v)
+// What of M_p / N_p / the sampler depends on the MATERIAL only -- computed once per material (k_hair_consts: the same expressions, operation for operation,
+// that the per-call code of rounds 2-5 and the checker evaluate: same bits) instead of per BSDF call: per lobe 1 / v, log(1 / (2 v)), sinh(1 / v) 2 v and
+// exp(-2 / v); the trimmed logistic's normalisation and its lower CDF value.  (Round 6: the hair build of k_shade paid 15 % for the shared polynomial
+// exp / log, 13 of them per evaluation in terms that never change.)
+struct HairConst // 24 floats per material in DevScene::hairConst; lobes R, TT, TRT (the residual lobe uses TRT's)
+{
+    float v[3], invV[3], log1over2v[3], sinhDen[3], expm2overV[3];
+    float s, logisticDen, cdfA;
+    float sin2k[3], cos2k[3];
+};
+SKH_DI float hair_Mp(float cosThetaI, float cosThetaO, float sinThetaI, float sinThetaO, float v, float invV, float log1over2v, float sinhDen)
 {
     const float a = cosThetaI * cosThetaO / v;
     const float b = sinThetaI * sinThetaO / v;
-    return v <= 0.1f ? skm::expf_((((hair_logI0(a) - b) - 1.0f / v) + 0.6931f) + skm::logf_(1.0f / (2.0f * v))) :
-                       (skm::expf_(-b) * hair_I0(a)) / (skm::sinhf_(1.0f / v) * 2.0f * v);
+    return v <= 0.1f ? skm::expf_((((hair_logI0(a) - b) - invV) + 0.6931f) + log1over2v) : (skm::expf_(-b) * hair_I0(a)) / sinhDen;
 }
 SKH_DI float hair_logistic(float x, float s)
 {
@@ -1168,42 +1177,70 @@ SKH_DI float hair_logistic_cdf(float x, float s)
 {
     return 1.0f / (1.0f + skm::expf_(-x / s));
 }
-SKH_DI float hair_trimmed_logistic(float x, float s, float a, float b)
+SKH_DI float hair_trimmed_logistic(float x, const HairConst& hc) // over [-pi, pi]
 {
-    return hair_logistic(x, s) / (hair_logistic_cdf(b, s) - hair_logistic_cdf(a, s));
+    return hair_logistic(x, hc.s) / hc.logisticDen;
 }
-SKH_DI float hair_sample_trimmed_logistic(float u, float s, float a, float b)
+SKH_DI float hair_sample_trimmed_logistic(float u, const HairConst& hc, float a, float b)
 {
-    const float k = hair_logistic_cdf(b, s) - hair_logistic_cdf(a, s);
-    const float x = -s * skm::logf_(1.0f / (u * k + hair_logistic_cdf(a, s)) - 1.0f);
+    const float x = -hc.s * skm::logf_(1.0f / (u * hc.logisticDen + hc.cdfA) - 1.0f);
     return clampf(x, a, b);
 }
 SKH_DI float hair_Phi(int p, float gammaO, float gammaT)
 {
     return (2.0f * (float)p * gammaT - 2.0f * gammaO) + (float)p * SKH_PI;
 }
-SKH_DI float hair_Np(float phi, int p, float s, float gammaO, float gammaT)
+SKH_DI float hair_Np(float phi, int p, const HairConst& hc, float gammaO, float gammaT)
 {
     float dphi = phi - hair_Phi(p, gammaO, gammaT);
     while (dphi > SKH_PI)
         dphi -= 2.0f * SKH_PI;
     while (dphi < -SKH_PI)
         dphi += 2.0f * SKH_PI;
-    return hair_trimmed_logistic(dphi, s, -SKH_PI, SKH_PI);
+    return hair_trimmed_logistic(dphi, hc);
 }
 SKH_DI float hair_variance(float roughness)
 {
     const float r = fmaxf(roughness, 0.02f);
     return sqrf_((0.726f * r + 0.812f * (r * r)) + 3.7f * hair_pow20(r));
 }
+SKH_DI void hair_lobe(HairConst& c, int p, float v)
+{
+    c.v[p] = v;
+    c.invV[p] = 1.0f / v;
+    c.log1over2v[p] = skm::logf_(1.0f / (2.0f * v));
+    c.sinhDen[p] = skm::sinhf_(1.0f / v) * 2.0f * v;
+    c.expm2overV[p] = skm::expf_(-2.0f / v);
+}
+// the material-only part (one thread per material: k_hair_consts; the BSDF probe computes it in place)
+SKH_DI HairConst hair_const(const Material& m)
+{
+    HairConst c;
+    const float v0 = hair_variance(m.roughness);
+    hair_lobe(c, 0, v0);
+    hair_lobe(c, 1, m.metallic > 0.0f ? hair_variance(m.metallic) : 0.25f * v0);
+    hair_lobe(c, 2, m.specular > 0.0f ? hair_variance(m.specular) : 4.0f * v0);
+    const float bn = fmaxf(m.reserved[3] > 0.0f ? m.reserved[3] : m.roughness, 0.02f);
+    c.s = 0.626657069f * ((0.265f * bn + 1.194f * (bn * bn)) + 5.372f * hair_pow22(bn));
+    c.logisticDen = hair_logistic_cdf(SKH_PI, c.s) - hair_logistic_cdf(-SKH_PI, c.s);
+    c.cdfA = hair_logistic_cdf(-SKH_PI, c.s);
+    c.sin2k[0] = skm::sinf_(m.reserved[4]);
+    c.cos2k[0] = safe_sqrtf_(1.0f - sqrf_(c.sin2k[0]));
+#pragma unroll
+    for (int i = 1; i < 3; ++i)
+    {
+        c.sin2k[i] = 2.0f * c.cos2k[i - 1] * c.sin2k[i - 1];
+        c.cos2k[i] = sqrf_(c.cos2k[i - 1]) - sqrf_(c.sin2k[i - 1]);
+    }
+    return c;
+}
 struct HairTerms
 {
-    float h, eta, s, diffuse_w;
+    float h, eta, diffuse_w;
     v3 sigma_a, tint;
-    float v[4];
-    float sin2k[3], cos2k[3];
+    const HairConst* c; // (read where it is used: 24 per-material values the kernel does not have to hold in registers across the BSDF)
 };
-SKH_DI HairTerms hair_terms(const Material& m)
+SKH_DI HairTerms hair_terms(const Material& m, const HairConst& hc)
 {
     HairTerms t;
     t.h = 2.0f * SKH_HAIR_TEXCOORD_Y - 1.0f;
@@ -1211,20 +1248,7 @@ SKH_DI HairTerms hair_terms(const Material& m)
     t.sigma_a = mk3(fmaxf(m.reserved[0], 0.0f), fmaxf(m.reserved[1], 0.0f), fmaxf(m.reserved[2], 0.0f));
     t.tint = mk3(m.base_color[0], m.base_color[1], m.base_color[2]);
     t.diffuse_w = clampf(m.reserved[5], 0.0f, 1.0f);
-    t.v[0] = hair_variance(m.roughness);
-    t.v[1] = m.metallic > 0.0f ? hair_variance(m.metallic) : 0.25f * t.v[0];
-    t.v[2] = m.specular > 0.0f ? hair_variance(m.specular) : 4.0f * t.v[0];
-    t.v[3] = t.v[2];
-    const float bn = fmaxf(m.reserved[3] > 0.0f ? m.reserved[3] : m.roughness, 0.02f);
-    t.s = 0.626657069f * ((0.265f * bn + 1.194f * (bn * bn)) + 5.372f * hair_pow22(bn));
-    t.sin2k[0] = skm::sinf_(m.reserved[4]);
-    t.cos2k[0] = safe_sqrtf_(1.0f - sqrf_(t.sin2k[0]));
-#pragma unroll
-    for (int i = 1; i < 3; ++i)
-    {
-        t.sin2k[i] = 2.0f * t.cos2k[i - 1] * t.sin2k[i - 1];
-        t.cos2k[i] = sqrf_(t.cos2k[i - 1]) - sqrf_(t.sin2k[i - 1]);
-    }
+    t.c = &hc;
     return t;
 }
 SKH_DI void hair_Ap(const HairTerms& t, float cosThetaO, const v3& T, v3 ap[4], float apPdf[4])
@@ -1274,18 +1298,18 @@ SKH_DI void hair_tilt(const HairTerms& t, const HairGeom& g, int p, float& sinTh
 {
     if (p == 0)
     {
-        sinThetaOp = g.sinThetaO * t.cos2k[1] - g.cosThetaO * t.sin2k[1];
-        cosThetaOp = g.cosThetaO * t.cos2k[1] + g.sinThetaO * t.sin2k[1];
+        sinThetaOp = g.sinThetaO * t.c->cos2k[1] - g.cosThetaO * t.c->sin2k[1];
+        cosThetaOp = g.cosThetaO * t.c->cos2k[1] + g.sinThetaO * t.c->sin2k[1];
     }
     else if (p == 1)
     {
-        sinThetaOp = g.sinThetaO * t.cos2k[0] + g.cosThetaO * t.sin2k[0];
-        cosThetaOp = g.cosThetaO * t.cos2k[0] - g.sinThetaO * t.sin2k[0];
+        sinThetaOp = g.sinThetaO * t.c->cos2k[0] + g.cosThetaO * t.c->sin2k[0];
+        cosThetaOp = g.cosThetaO * t.c->cos2k[0] - g.sinThetaO * t.c->sin2k[0];
     }
     else if (p == 2)
     {
-        sinThetaOp = g.sinThetaO * t.cos2k[2] + g.cosThetaO * t.sin2k[2];
-        cosThetaOp = g.cosThetaO * t.cos2k[2] - g.sinThetaO * t.sin2k[2];
+        sinThetaOp = g.sinThetaO * t.c->cos2k[2] + g.cosThetaO * t.c->sin2k[2];
+        cosThetaOp = g.cosThetaO * t.c->cos2k[2] - g.sinThetaO * t.c->sin2k[2];
     }
     else
     {
@@ -1310,11 +1334,11 @@ SKH_DI void hair_eval_local(const HairTerms& t, const v3& wo, const v3& wi, v3& 
     {
         float so, co;
         hair_tilt(t, g, p, so, co);
-        const float mn = hair_Mp(cosThetaI, co, sinThetaI, so, t.v[p]) * hair_Np(phi, p, t.s, g.gammaO, g.gammaT);
+        const float mn = hair_Mp(cosThetaI, co, sinThetaI, so, t.c->v[p], t.c->invV[p], t.c->log1over2v[p], t.c->sinhDen[p]) * hair_Np(phi, p, *t.c, g.gammaO, g.gammaT);
         f_cos = f_cos + ap[p] * mn;
         pdf += apPdf[p] * mn;
     }
-    const float mr = hair_Mp(cosThetaI, g.cosThetaO, sinThetaI, g.sinThetaO, t.v[3]) * (1.0f / (2.0f * SKH_PI));
+    const float mr = hair_Mp(cosThetaI, g.cosThetaO, sinThetaI, g.sinThetaO, t.c->v[2], t.c->invV[2], t.c->log1over2v[2], t.c->sinhDen[2]) * (1.0f / (2.0f * SKH_PI));
     f_cos = f_cos + ap[3] * mr;
     pdf += apPdf[3] * mr;
 }
@@ -1334,14 +1358,15 @@ SKH_DI v3 hair_sample_local(const HairTerms& t, const v3& wo, float u0, float u1
     }
     float so, co;
     hair_tilt(t, g, p, so, co);
-    const float vp = p == 0 ? t.v[0] : (p == 1 ? t.v[1] : t.v[2]); // (v[3] == v[2])
+    const float vp = p == 0 ? t.c->v[0] : (p == 1 ? t.c->v[1] : t.c->v[2]); // (the residual lobe uses TRT's)
+    const float em = p == 0 ? t.c->expm2overV[0] : (p == 1 ? t.c->expm2overV[1] : t.c->expm2overV[2]);
     const float ua = fmaxf(u0, 1e-5f);
-    const float cosTheta = 1.0f + vp * skm::logf_(ua + (1.0f - ua) * skm::expf_(-2.0f / vp));
+    const float cosTheta = 1.0f + vp * skm::logf_(ua + (1.0f - ua) * em);
     const float sinTheta = safe_sqrtf_(1.0f - sqrf_(cosTheta));
     const float cosPhi = skm::cosf_(2.0f * SKH_PI * u1);
     const float sinThetaI = -cosTheta * so + sinTheta * cosPhi * co;
     const float cosThetaI = safe_sqrtf_(1.0f - sqrf_(sinThetaI));
-    const float dphi = p < 3 ? hair_Phi(p, g.gammaO, g.gammaT) + hair_sample_trimmed_logistic(u3, t.s, -SKH_PI, SKH_PI) : 2.0f * SKH_PI * u3;
+    const float dphi = p < 3 ? hair_Phi(p, g.gammaO, g.gammaT) + hair_sample_trimmed_logistic(u3, *t.c, -SKH_PI, SKH_PI) : 2.0f * SKH_PI * u3;
     const float phiI = g.phiO + dphi;
     return mk3(sinThetaI, cosThetaI * skm::cosf_(phiI), cosThetaI * skm::sinf_(phiI));
 }
@@ -1364,7 +1389,7 @@ SKH_DI bool hair_frame(const v3& normal, const v3& tangent_u, v3& X, v3& Y, v3& 
 // distribution function (scenes without a hair material run the build without it: fewer registers).
 template <bool HAIR>
 SKH_DI void bsdf_sample(const Material& m, const v3& stN, const v3& stNg, const v3& stT, const v3& k1, float xi0, float xi1, float xi2,
-                        float xi3, bool inside, BsdfSample& out)
+                        float xi3, bool inside, BsdfSample& out, const HairConst* hc = nullptr /* (HAIR) the material's constants: DevScene::hairConst */)
 {
     v3 N = stN, Ng = stNg;
     if (dot(Ng, k1) < 0.0f)
@@ -1398,7 +1423,7 @@ SKH_DI void bsdf_sample(const Material& m, const v3& stN, const v3& stNg, const 
         v3 X, Y, Z;
         if (!hair_frame(stN, stT, X, Y, Z))
             return;
-        const HairTerms t = hair_terms(m);
+        const HairTerms t = hair_terms(m, *hc);
         const v3 ho = mk3(dot(k1, X), dot(k1, Y), dot(k1, Z));
         float u2 = xi2;
         if (u2 < t.diffuse_w)
@@ -1514,7 +1539,8 @@ SKH_DI void bsdf_sample(const Material& m, const v3& stN, const v3& stNg, const 
 }
 // mdlcode_evaluate equivalent
 template <bool HAIR>
-SKH_DI void bsdf_evaluate(const Material& m, const v3& stN, const v3& stNg, const v3& stT, const v3& k1, const v3& k2, bool inside, BsdfEval& out)
+SKH_DI void bsdf_evaluate(const Material& m, const v3& stN, const v3& stNg, const v3& stT, const v3& k1, const v3& k2, bool inside, BsdfEval& out,
+                          const HairConst* hc = nullptr)
 {
     v3 N = stN, Ng = stNg;
     if (dot(Ng, k1) < 0.0f)
@@ -1540,7 +1566,7 @@ SKH_DI void bsdf_evaluate(const Material& m, const v3& stN, const v3& stNg, cons
         v3 X, Y, Z;
         if (!hair_frame(stN, stT, X, Y, Z))
             return;
-        const HairTerms t = hair_terms(m);
+        const HairTerms t = hair_terms(m, *hc);
         const v3 ho = mk3(dot(k1, X), dot(k1, Y), dot(k1, Z));
         const v3 hi = mk3(dot(k2, X), dot(k2, Y), dot(k2, Z));
         v3 fh;

@@ -77,6 +77,7 @@ struct DevScene
     uint32_t numLights;
     const Material* materials;
     uint32_t numMaterials;
+    const HairConst* hairConst; // per material: what of df::chiang_hair_bsdf depends on the material only (k_hair_consts), read by the hair build of k_shade
     const uint32_t* texels; // RGBA8 texels of all textures
     const uint4* texDesc; // per texture: {offset in texels, width, height, 0}
     uint32_t numTextures;
@@ -1385,6 +1386,14 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
 #undef SKH_LP
 }
 
+// what of the hair BSDF depends on the material only, one thread per material (skh_device.h hair_const; skh_set_materials)
+__global__ void k_hair_consts(const Material* __restrict__ mats, uint32_t n, HairConst* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[i] = hair_const(mats[i]);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // slot <-> pixel: slot = tile * T^2 + morton(xl, yl): a wave's 64 lanes cover an 8x8 pixel block
 // ------------------------------------------------------------------------------------------------------------
@@ -1875,7 +1884,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
                     const v3 k1 = -rayD;
                     BsdfSample bs;
                     SKH_SP(1) // hit reconstruction, material, textures, bsdf randoms
-                    bsdf_sample<HAIR>(mat, sh.normal, sh.geom_normal, stT, k1, xi0, xi1, xi2, xi3, inside, bs);
+                    bsdf_sample<HAIR>(mat, sh.normal, sh.geom_normal, stT, k1, xi0, xi1, xi2, xi3, inside, bs, HAIR ? sc.hairConst + (mid < sc.numMaterials ? mid : 0u) : nullptr);
                     SKH_SP(2) // bsdf_sample
                     if (bs.event_type == EV_ABSORB)
                     {
@@ -1959,7 +1968,7 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
                                 {
                                     BsdfEval ev;
                                     SKH_SP(3) // light sampling
-                                    bsdf_evaluate<HAIR>(mat, sh.normal, sh.geom_normal, stT, k1, toLight, inside, ev);
+                                    bsdf_evaluate<HAIR>(mat, sh.normal, sh.geom_normal, stT, k1, toLight, inside, ev, HAIR ? sc.hairConst + (mid < sc.numMaterials ? mid : 0u) : nullptr);
                                     SKH_SP(4) // bsdf_evaluate
                                     if (isnan3(ev.bsdf_diffuse) || isnan3(ev.bsdf_glossy))
                                     {

@@ -91,7 +91,7 @@ struct skh_context
     uint32_t nVerts = 0, nIndices = 0, nPoints = 0, nInstances = 0, nLights = 0, nMaterials = 0;
     std::vector<skh_instance> instances;
 
-    DevBuf dVerts, dIndices, dMeshes, dPoints, dRadii, dInstances, dLights, dMaterials;
+    DevBuf dVerts, dIndices, dMeshes, dPoints, dRadii, dInstances, dLights, dMaterials, dHairConst;
     DevBuf dShadeTris, dShadeInst; // shading side: de-indexed triangle records, instance records that carry their mesh's base
     DevBuf dCurveSegBase, dSegStartAll;
     // accel
@@ -1103,7 +1103,7 @@ void skh_destroy(skh_context* c)
         (void)hipStreamSynchronize(c->stream3);
     if (c->comm)
         (void)skh_comm_destroy(c);
-    for (DevBuf* b : { &c->dShadeTris, &c->dShadeInst, &c->dVerts, &c->dIndices, &c->dMeshes, &c->dPoints, &c->dRadii, &c->dInstances, &c->dLights, &c->dMaterials,
+    for (DevBuf* b : { &c->dShadeTris, &c->dShadeInst, &c->dVerts, &c->dIndices, &c->dMeshes, &c->dPoints, &c->dRadii, &c->dInstances, &c->dLights, &c->dMaterials, &c->dHairConst,
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
                        &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dSegInst, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
@@ -1272,7 +1272,16 @@ skh_status skh_set_materials(skh_context* c, const skh_material* materials, uint
     c->hasHairMaterial = false;
     for (uint32_t k = 0; k < n; ++k)
         c->hasHairMaterial = c->hasHairMaterial || materials[k].type == SKH_MAT_HAIR;
-    return dev_upload(c, c->dMaterials, materials, sizeof(skh_material) * (size_t)n);
+    skh_status s = dev_upload(c, c->dMaterials, materials, sizeof(skh_material) * (size_t)n);
+    if (s != SKH_OK)
+        return s;
+    // the material-only terms of the hair BSDF, computed once per material ON THE DEVICE by the code the per-call path ran (skh_device.h hair_const)
+    if ((s = dev_alloc(c, c->dHairConst, sizeof(HairConst) * (size_t)std::max(1u, n))) != SKH_OK)
+        return s;
+    if (n)
+        k_hair_consts<<<(n + 63) / 64, 64, 0, c->stream>>>(c->dMaterials.as<Material>(), n, c->dHairConst.as<HairConst>());
+    SKH_TRY(c, hipStreamSynchronize(c->stream));
+    return SKH_OK;
 }
 
 static skh_status build_shading_tables(skh_context* c)
@@ -2294,6 +2303,7 @@ static DevScene make_dev_scene(const skh_context* c)
     sc.lights = c->dLights.as<Light>();
     sc.numLights = c->nLights;
     sc.materials = c->dMaterials.as<Material>();
+    sc.hairConst = c->dHairConst.as<HairConst>();
     sc.numMaterials = c->nMaterials;
     sc.texels = c->dTexels.as<uint32_t>();
     sc.texDesc = c->dTexDesc.as<uint4>();
@@ -3400,10 +3410,11 @@ __global__ void k_bsdf_probe(const skh_bsdf_query* __restrict__ q, uint32_t n, c
     const v3 N = mk3(in.normal[0], in.normal[1], in.normal[2]), Ng = mk3(in.geom_normal[0], in.geom_normal[1], in.geom_normal[2]);
     const v3 T = mk3(in.tangent_u[0], in.tangent_u[1], in.tangent_u[2]);
     const v3 k1 = mk3(in.k1[0], in.k1[1], in.k1[2]), k2 = mk3(in.k2[0], in.k2[1], in.k2[2]);
+    const HairConst hc = hair_const(m); // (what k_hair_consts tabulates per material for k_shade)
     BsdfSample bs;
-    bsdf_sample<true>(m, N, Ng, T, k1, in.xi[0], in.xi[1], in.xi[2], in.xi[3], in.inside != 0u, bs);
+    bsdf_sample<true>(m, N, Ng, T, k1, in.xi[0], in.xi[1], in.xi[2], in.xi[3], in.inside != 0u, bs, &hc);
     BsdfEval ev;
-    bsdf_evaluate<true>(m, N, Ng, T, k1, k2, in.inside != 0u, ev);
+    bsdf_evaluate<true>(m, N, Ng, T, k1, k2, in.inside != 0u, ev, &hc);
     skh_bsdf_result r;
     r.k2[0] = bs.k2.x, r.k2[1] = bs.k2.y, r.k2[2] = bs.k2.z;
     r.bsdf_over_pdf[0] = bs.bsdf_over_pdf.x, r.bsdf_over_pdf[1] = bs.bsdf_over_pdf.y, r.bsdf_over_pdf[2] = bs.bsdf_over_pdf.z;
