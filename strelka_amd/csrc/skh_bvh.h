@@ -733,7 +733,7 @@ __global__ void k_collapse(const CollapseItem* __restrict__ qin, uint32_t nIn, c
                            const int* __restrict__ childR, const int* __restrict__ nodeSize, const float4* __restrict__ nodeLo,
                            const float4* __restrict__ nodeHi, int n, int leafMax, void* __restrict__ outNodes,
                            uint32_t* __restrict__ allocCounter, CollapseItem* __restrict__ qout, uint32_t* __restrict__ nOut,
-                           uint32_t* __restrict__ leafOrder)
+                           uint32_t* __restrict__ leafOrder, float pairRatio /* > 0: a two-primitive subtree whose box has more than pairRatio x the summed areas of its two primitives' boxes MAY be opened into two one-primitive leaves when the node has a free slot (round 6, option split_pairs) */)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nIn)
@@ -750,12 +750,17 @@ __global__ void k_collapse(const CollapseItem* __restrict__ qin, uint32_t nIn, c
         const float ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z;
         return ex * ey + ey * ez + ez * ex;
     };
+    // a LOOSE PAIR: two primitives (both children are primitives) under a box much larger than their own boxes -- a ray that enters it mostly misses both
+    auto loosePair = [&](int c) {
+        return pairRatio > 0.0f && c < n - 1 && nodeSize[c] == 2 && leafMax >= 2 && childL[c] >= n - 1 && childR[c] >= n - 1 &&
+               area(c) > pairRatio * (area(childL[c]) + area(childR[c]));
+    };
     while (cnt < W)
     {
         int best = -1;
         float bestA = -1.0f;
         for (int k = 0; k < cnt; ++k)
-            if (openable(slot[k]))
+            if (openable(slot[k]) || loosePair(slot[k]))
             {
                 const float a = area(slot[k]);
                 if (a > bestA)

@@ -59,7 +59,9 @@ enum KernelClass
     KC_COUNT
 };
 
-#define SKH_RI_MAX_LEVELS 1024 // tree levels one reinsertion round may have to refit (a deeper tree fails the build)
+#ifndef SKH_RI_MAX_LEVELS
+#define SKH_RI_MAX_LEVELS 1024 // per-level counters of the reinsertion pass's refit: a ring (a deeper tree wraps around it; tests build a variant with 3)
+#endif
 #define SKH_MAX_LAUNCH_ROUNDS 140 // MAX_BOUNCES (128) + slack
 
 struct TimedSpan
@@ -178,6 +180,7 @@ struct skh_context
     uint32_t curveLeaf = 1; // sub-segments per curve leaf (option curve_leaf; hair stand-in after the intersector's early exit, Mray/s: 1: 1456, 2: 1392, 3: 1309, 4: 1240;
                             // the cooperative block takes two candidates per lane and block)
     uint32_t numMergedCurveInst = 0; // (build result) curve instances that share the merged world-space tree
+    uint32_t splitPairs = 0; // (option split_pairs, tenths) triangle trees: a two-triangle subtree whose box exceeds this x the summed areas of its triangles' boxes may be opened into two one-triangle leaves (0 = off)
     uint32_t curveMerge = 1; // (option curve_merge) curve instances under identity transforms share ONE world-space tree in the world-only curve kernel
     uint32_t curveSegNode = 0; // (option curve_segnode) 1: the curve tree is built over whole segments and ends in SEGMENT NODES (skh_bvh.h k_segnode_emit): a segment is a
                                // candidate at most once per ray; 0: parameter sub-ranges as primitives (curve_split), rounds 3-5
@@ -591,15 +594,22 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
                             he = hipMemsetAsync(lv, 0, sizeof(uint32_t) * SKH_RI_MAX_LEVELS, st);
                         uint32_t* lists[2] = { refitList.as<uint32_t>(), refitList.as<uint32_t>() + n };
                         k_ri_pending<<<(n + B - 1) / B, B, 0, st>>>(childL.as<int>(), childR.as<int>(), stamp.as<uint32_t>(), r + 1u, (int)n, rflags.as<uint32_t>(), lists[0], lv);
+                        // (the per-level counters are a RING: a binary tree deeper than SKH_RI_MAX_LEVELS -- nested "onion" geometry, chains the moves themselves
+                        // grow -- wraps around it, each reused counter zeroed before its level runs, instead of failing the whole build for an optional
+                        // pass: ADVICE r5.  A tree has at most n levels.)
                         bool levelsDone = false;
-                        for (uint32_t k = 0; he == hipSuccess && k + 1 < SKH_RI_MAX_LEVELS; ++k)
+                        for (uint32_t k = 0; he == hipSuccess && k < n; ++k)
                         {
-                            k_ri_refit_level<<<256, B, 0, st>>>(lists[k & 1], lv + k, lists[(k + 1) & 1], lv + k + 1, parent.as<int>(), childL.as<int>(), childR.as<int>(),
+                            const uint32_t ci = k % SKH_RI_MAX_LEVELS, cn = (k + 1u) % SKH_RI_MAX_LEVELS;
+                            if (k + 1u >= SKH_RI_MAX_LEVELS)
+                                he = hipMemsetAsync(lv + cn, 0, sizeof(uint32_t), st);
+                            k_ri_refit_level<<<256, B, 0, st>>>(lists[k & 1], lv + ci, lists[(k + 1) & 1], lv + cn, parent.as<int>(), childL.as<int>(), childR.as<int>(),
                                                                 rflags.as<uint32_t>(), nodeLo.as<float4>(), nodeHi.as<float4>(), nodeSize.as<int>(), (int)n);
                             if ((k & 15u) == 15u)
                             {
                                 uint32_t next = 0;
-                                he = hipMemcpyAsync(&next, lv + k + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+                                if (he == hipSuccess)
+                                    he = hipMemcpyAsync(&next, lv + cn, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
                                 if (he == hipSuccess)
                                     he = hipStreamSynchronize(st);
                                 if (next == 0)
@@ -614,7 +624,7 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
                             cleanupR();
                             cleanup2();
                             cleanup();
-                            c->err = "lbvh_build: the binary tree is deeper than SKH_RI_MAX_LEVELS (degenerate geometry?)";
+                            c->err = "lbvh_build: the reinsertion pass's refit did not finish within n levels (a cycle in the tree?)";
                             return SKH_FAIL;
                         }
                     }
@@ -690,7 +700,7 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
         {
             k_collapse<<<(cnt + B - 1) / B, B, 0, st>>>(q[cur].as<CollapseItem>(), cnt, childL.as<int>(), childR.as<int>(), nodeSize.as<int>(),
                                                            nodeLo.as<float4>(), nodeHi.as<float4>(), (int)n, leafMax, out.nodes.p, ctr.as<uint32_t>(),
-                                                           q[cur ^ 1].as<CollapseItem>(), ctr.as<uint32_t>() + 1, leafOrder.as<uint32_t>());
+                                                           q[cur ^ 1].as<CollapseItem>(), ctr.as<uint32_t>() + 1, leafOrder.as<uint32_t>(), search == 0 ? c->splitPairs * 0.1f : 0.0f);
             he = hipMemcpyAsync(hctr, ctr.p, sizeof(hctr), hipMemcpyDeviceToHost, st);
             if (he == hipSuccess)
                 he = hipStreamSynchronize(st);
@@ -1612,10 +1622,17 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
             cleanup();
             return SKH_FAIL;
         }
+        // What a visit of the group's root could find must lie inside: encode_node4's margin -- the LARGEST coordinate magnitude over all three axes
+        // times 2^-20, the same on every axis (a flat light on the plane x = 0 still gets it: ADVICE r5) -- plus two quantisation cells of the
+        // root node per axis (child planes are rounded outward to the node's power-of-two grid, cell < 2 extent / 255).  A larger box only sends
+        // a few more rays to the proxies' tree.
+        float mAll = 0.0f;
+        for (int k = 0; k < 3; ++k)
+            mAll = std::max(mAll, std::max(std::fabs(gb[6 + k]), std::fabs(gb[9 + k])));
         for (int k = 0; k < 3; ++k)
         {
-            // (the margin encode_node4 puts around a node's box: what a visit of the group's root could find lies inside)
-            const float m = nGroup1 ? std::max(std::fabs(gb[6 + k]), std::fabs(gb[9 + k])) * 0x1p-20f + 1e-30f : 0.0f;
+            const float ext = (gb[9 + k] + mAll * 0x1p-20f) - (gb[6 + k] - mAll * 0x1p-20f);
+            const float m = nGroup1 ? mAll * 0x1p-20f + 1e-30f + 2.0f * (2.0f * ext / 255.0f) : 0.0f;
             c->lightBox.lo[k] = nGroup1 ? gb[6 + k] - m : -INFINITY;
             c->lightBox.hi[k] = nGroup1 ? gb[9 + k] + m : INFINITY;
         }
@@ -3669,6 +3686,13 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 1 || value > 4)
             return SKH_INVALID_ARGUMENT;
         c->curveLeaf = (uint32_t)value;
+        c->accelBuilt = false;
+    }
+    else if (n == "split_pairs")
+    {
+        if (value < 0 || value > 1000)
+            return SKH_INVALID_ARGUMENT;
+        c->splitPairs = (uint32_t)value;
         c->accelBuilt = false;
     }
     else if (n == "curve_merge")

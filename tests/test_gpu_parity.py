@@ -232,6 +232,60 @@ def test_render_every_light_type_matches_oracle(gpu, rect_method):
         assert (hit == k).sum() > 3, k
 
 
+def test_rays_grazing_the_edges_of_flat_lights_on_coordinate_planes(gpu):
+    """the box around the baked light proxies -- a radiance ray that misses it skips their tree -- must contain whatever a visit of
+    that tree's root could find.  Flat lights lying IN the planes x = 0 and y = 2 (a box of zero extent on one axis: the per-axis margin the
+    advisor flagged was 1e-30 there), rays aimed at points on their edges and corners and a hair's breadth (1e-7 ... 1e-3) inside and outside,
+    from both sides and at grazing angles: the closest-hit records (light proxies included: mask 255) equal the oracle's brute-force loop."""
+    import math
+    from tests import orklib
+
+    rs = np.random.RandomState(17)
+    sc = S.Scene()
+    mat = sc.addMaterial(S.MAT_DIFFUSE, (0.5, 0.5, 0.5))
+    pos = np.array([[-3, -1, -3], [3, -1, -3], [3, -1, 3], [-3, -1, 3]], np.float32)
+    mesh = sc.createMesh(S.make_vertices(pos, np.tile([[0, 1, 0]], (4, 1))), np.array([0, 1, 2, 0, 2, 3], np.uint32))
+    sc.createInstance(S.INSTANCE_MESH, mesh, mat, np.eye(4))
+    # rect light in the plane x = 0 (its local z = the world's x), one in the plane y = 2
+    sc.createLight({"type": 0, "xform": S.rotate((0, 1, 0), math.pi / 2), "useXform": True, "width": 1.0, "height": 1.0, "color": (1, 1, 1), "intensity": 5.0})
+    sc.createLight({"type": 0, "xform": S.translate((0.5, 2.0, 0.25)) @ S.rotate((1, 0, 0), math.pi / 2), "useXform": True, "width": 0.6, "height": 0.4, "color": (1, 1, 1), "intensity": 5.0})
+    cam = S.Camera(fov=50.0)
+    cam.lookAt((3.0, 1.0, 3.0), (0.0, 0.5, 0.0))
+    sc.addCamera(cam)
+    arr = sc.arrays()
+    targets = []
+    for L in arr["lights"]:
+        P = L["points"][:, :3].astype(np.float64)
+        c = P.mean(0)
+        for k in range(4):
+            a, b = P[k], P[(k + 1) % 4]
+            for s_ in np.linspace(0.0, 1.0, 9):
+                e = a + (b - a) * s_
+                out = (e - c) / np.linalg.norm(e - c)
+                for eps in (0.0, 1e-7, -1e-7, 1e-5, -1e-5, 1e-3, -1e-3):
+                    targets.append(e + out * eps)
+    targets = np.array(targets)
+    rays = np.zeros(len(targets) * 6, S.RAY)
+    k = 0
+    for tgt in targets:
+        for _ in range(6):
+            org = rs.uniform(-3, 3, 3)
+            if _ >= 4:  # grazing: nearly inside the light's plane
+                org = tgt + np.array([rs.uniform(-1e-3, 1e-3), rs.uniform(0.5, 2.0) * rs.choice([-1, 1]), rs.uniform(0.5, 2.0)]) if abs(tgt[0]) < 1e-2 else \
+                    tgt + np.array([rs.uniform(0.5, 2.0), rs.uniform(-1e-3, 1e-3), rs.uniform(0.5, 2.0) * rs.choice([-1, 1])])
+            d = tgt - org
+            rays["origin"][k], rays["dir"][k], rays["tmax"][k] = org, d / np.linalg.norm(d), 1e16
+            k += 1
+    o = orklib.new_context()
+    o.set_scene(arr)
+    gpu.set_scene(arr)
+    want = o.trace(rays, 0, brute=True)
+    light_inst = np.nonzero(arr["instances"]["type"] == S.INSTANCE_LIGHT)[0]
+    assert np.isin(want["instance_id"], light_inst).mean() > 0.2  # the proxies ARE hit by a good share of these rays
+    assert_hits_equal(gpu.trace(rays, 0), want)
+    assert gpu.baked(len(arr["instances"]))[0][light_inst].all()  # ... through the baked proxies' own tree, behind the box test
+
+
 def test_sphere_and_disk_lights_alone(gpu):
     """only types 1 and 2 in the light list: every NEE sample is a sphere sample or a (pdf 0) disk pick"""
     sc = scenes.light_zoo(with_rect=False)
@@ -798,7 +852,8 @@ def test_stack_spill_path_is_exact(tmp_path):
 
     from strelka_amd import build
 
-    lib = build.build_variant(str(tmp_path / "libstrelka_hip_smallstack.so"), ["SKH_STACK_LDS=12"])
+    # (+ a 3-entry ring of per-level counters in the reinsertion pass's refit -- every tree here is deeper --: the wrap-around path of lbvh_build)
+    lib = build.build_variant(str(tmp_path / "libstrelka_hip_smallstack.so"), ["SKH_STACK_LDS=12", "SKH_RI_MAX_LEVELS=3"])
     code = r'''
 import os, sys
 sys.path.insert(0, os.environ["SKH_ROOT"])
