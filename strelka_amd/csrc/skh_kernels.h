@@ -352,7 +352,6 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
     // docs/LOG.md, round 5); one stack entry pays for the 1 KB (19 x 256 + 512 (s_runs) + 1024 = 5 granules, as before).
     constexpr bool BESTLDS = CURVES && !ANY_HIT && SKH_BEST_LDS;
     constexpr int NLDS = (TRICOOP || BESTLDS) ? SKH_STACK_LDS - 1 : SKH_STACK_LDS;
-    static_assert(!(WORLD && CURVES) || SKH_WORLD_CURVES + 4 <= NLDS, "the curve trees' markers and the light root are written to the LDS stack unchecked at refill (ADVICE r5): they must leave room for the walk");
     __shared__ int s_stack[NLDS * SKH_TRACE_BLOCK];
     __shared__ uint32_t s_best[BESTLDS ? 4 * SKH_TRACE_BLOCK : 1];
     __shared__ unsigned char s_tab[TRICOOP ? 128 : 1]; // [0..63] owner lanes by rank, [64..127] helper lanes by rank
@@ -628,13 +627,14 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                     curType = 0;
                     sp = 0;
                     // (the marker popped FIRST -- the last one pushed -- may take the identity short cut: (o, d) still hold the world ray then)
+                    // (through SKH_PUSH / SKH_POP: bounds-checked like every other stack access -- ADVICE r5; at most SKH_WORLD_CURVES + 1 entries, once per ray)
                     for (uint32_t k = 0; k < sc.numWorldCurves; ++k)
-                        lds[(sp++) * SKH_TRACE_BLOCK] = (int)(SKH_REF_CURVEROOT | k | ((k + 1u == sc.numWorldCurves && sc.worldCurveIdentLast) ? SKH_REF_CURVEROOT_IDENT : 0u));
+                        SKH_PUSH((int)(SKH_REF_CURVEROOT | k | ((k + 1u == sc.numWorldCurves && sc.worldCurveIdentLast) ? SKH_REF_CURVEROOT_IDENT : 0u)))
                     if (wr0 != SKH_REF_INVALID && wr1 != SKH_REF_INVALID)
-                        lds[(sp++) * SKH_TRACE_BLOCK] = wr1;
+                        SKH_PUSH(wr1)
                     cur = wr0 != SKH_REF_INVALID ? wr0 : wr1;
                     if (cur == SKH_REF_INVALID)
-                        cur = lds[(--sp) * SKH_TRACE_BLOCK]; // (no triangles at all: the first marker; numWorldCurves >= 1 in this build)
+                        SKH_POP(cur) // (no triangles at all: the first marker; numWorldCurves >= 1 in this build)
                 }
                 else if (wr0 != SKH_REF_INVALID || wr1 != SKH_REF_INVALID)
                 {

@@ -449,11 +449,13 @@ def test_curve_intersector_finds_the_first_entry_into_the_swept_volume(ork):
 
 
 def test_world_curves_rule_decides_the_light_proxies():
-    """Round 5's "world curves": when a scene holds at most 16 curve instances with segments and no mesh or light instance is left unbaked, the
-    curve sets need no top level -- the product walks their trees from the world-only kernel, each instance's transform applied to the ray as
-    at a TLAS leaf -- and the light proxies follow the meshes into world space.  The rule is an integer rule both sides evaluate; here the
-    checker's side: one curve instance, under any transform -> lights baked; a 17th curve instance, or bake mode 1 (the shared light quad
-    stays behind) -> not.  The curves' own hit records never depend on it: closest hits equal the unbaked context's."""
+    """"World curves" (round 5; the table holds two trees since round 6, and curve instances under bit-exact identity transforms share ONE of them):
+    when the scene's curve instances need at most two trees and no mesh or light instance is left unbaked, the curve sets need no top level --
+    the product walks their trees from the world-only kernel, each instance's transform applied to the ray as at a TLAS leaf -- and the light
+    proxies follow the meshes into world space.  The rule is an integer rule both sides evaluate; here the checker's side: one curve instance,
+    under any transform -> lights baked; 16 or 17 copies under the identity (one merged tree) -> baked; the merged tree + one moved instance, or
+    two moved instances (two trees) -> baked; three instances under transforms of their own, or bake mode 1 (the shared light quad stays
+    behind) -> not.  The curves' own hit records never depend on it: closest hits equal the unbaked context's."""
     from tests.test_gpu_parity import camera_rays
 
     sc = scenes.hair_standin(seed=5, n_strands=4000, n_cp=7)
@@ -472,7 +474,7 @@ def test_world_curves_rule_decides_the_light_proxies():
     o_id, b = baked_lights(arr)
     assert b == [1, 1]
     rays = np.concatenate([camera_rays(sc, 48, 48, 20000, 3), scenes.random_rays(20000, 4, -1.5, 1.5)])
-    for change, want in (("rotate", [1, 1]), ("mode1", [0, 0]), ("many", [0, 0]), ("sixteen", [1, 1])):
+    for change, want in (("rotate", [1, 1]), ("mode1", [0, 0]), ("many", [1, 1]), ("sixteen", [1, 1]), ("merged+1", [1, 1]), ("2 moved", [1, 1]), ("3 moved", [0, 0])):
         a2 = dict(arr)
         i2 = inst.copy()
         mode = 4
@@ -482,8 +484,16 @@ def test_world_curves_rule_decides_the_light_proxies():
             i2["transform"][curves[0]] = (S.translate((0.1, -0.2, 0.05)) @ m @ S.rotate((0, 1, 0), 0.3) @ S.scale((1.0, 0.7, 1.3)))[:3].astype(np.float32).reshape(12)
         elif change == "mode1":
             mode = 1
-        else:
+        elif change in ("many", "sixteen"):
             i2 = np.concatenate([i2, np.repeat(i2[curves[:1]], 16 if change == "many" else 15)])
+        else:
+            extra = np.repeat(i2[curves[:1]], 3 if change == "merged+1" else (1 if change == "2 moved" else 2))
+            moved = {"merged+1": [0], "2 moved": [0], "3 moved": [0, 1]}[change]
+            for j in moved:
+                extra["transform"][j] = S.translate((0.01 * (j + 1), 0.0, 0.0))[:3].astype(np.float32).reshape(12)
+            if change != "merged+1":  # ... and the original instance moves too
+                i2["transform"][curves[0]] = S.translate((0.0, 0.02, 0.0))[:3].astype(np.float32).reshape(12)
+            i2 = np.concatenate([i2, extra])
         a2["instances"] = i2
         o2, b2 = baked_lights(a2, mode)
         assert b2 == want, change
