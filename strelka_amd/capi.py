@@ -26,11 +26,11 @@ SYMBOLS = ["skh_create", "skh_destroy", "skh_last_error", "skh_abi_version", "sk
            "skh_render_subframe", "skh_render_subframes", "skh_tonemap", "skh_read_accum", "skh_read_aov",
            "skh_buffer_alloc", "skh_buffer_free", "skh_buffer_download", "skh_copy_accum", "skh_copy_accum_tiles", "skh_scatter_tiles", "skh_trace", "skh_trace_device",
            "skh_set_option", "skh_get_stats", "skh_reset_stats", "skh_synchronize", "skh_get_stream", "skh_bsdf_probe", "skh_get_device_info", "skh_comm_unique_id", "skh_comm_init",
-           "skh_comm_destroy", "skh_gather_tiles", "skh_host_register", "skh_host_unregister", "skh_get_baked", "skh_comm_info", "skh_probe_memory", "skh_unit_probe", "skh_copy_aov", "skh_get_build_info"]
+           "skh_comm_destroy", "skh_gather_tiles", "skh_host_register", "skh_host_unregister", "skh_get_baked", "skh_comm_info", "skh_probe_memory", "skh_unit_probe", "skh_copy_aov", "skh_get_build_info", "skh_refit_accel"]
 
 BUILD_INFO = np.dtype([("triangles", np.uint32), ("nodes", np.uint32), ("reinsert_rounds", np.uint32), ("reinsert_moves", np.uint32),
-                       ("reinsert_min_size", np.uint32), ("reserved", np.uint32), ("cost_before", np.float64), ("cost_after", np.float64),
-                       ("ms_reinsert", np.float64), ("ms_build", np.float64)])
+                       ("reinsert_min_size", np.uint32), ("refit", np.uint32), ("cost_before", np.float64), ("cost_after", np.float64),
+                       ("ms_reinsert", np.float64), ("ms_build", np.float64), ("ms_refit", np.float64)])
 DEVICE_INFO = np.dtype([("compute_units", np.uint32), ("simds_per_cu", np.uint32), ("clock_khz", np.uint32), ("memory_clock_khz", np.uint32),
                         ("memory_bus_bits", np.uint32), ("wavefront_size", np.uint32), ("total_memory_bytes", np.uint64), ("name", "S64")])
 
@@ -72,6 +72,7 @@ def load():
     for n in ("skh_set_instances", "skh_set_lights", "skh_set_textures", "skh_set_materials"):
         getattr(lib, n).argtypes = [vp, vp, u32]
     lib.skh_build_accel.argtypes = [vp, u32]
+    lib.skh_refit_accel.argtypes = [vp]
     lib.skh_resize.argtypes = [vp, u32, u32]
     lib.skh_set_tiles.argtypes = [vp, u32, vp, u32]
     lib.skh_render_subframe.argtypes = [vp, vp, vp]
@@ -314,6 +315,15 @@ class Context:
         d = np.zeros((), DEVICE_INFO)
         self._ck(self.lib.skh_get_device_info(self.h, _p(d)), "skh_get_device_info")
         return {k: (d[k].item().decode() if k == "name" else int(d[k])) for k in DEVICE_INFO.names}
+
+    def set_geometry(self, scene):
+        """skh_set_geometry alone (a vertex edit: follow it with refit_accel)"""
+        v, idx, m = scene["vertices"], scene["indices"], scene["meshes"]
+        self._ck(self.lib.skh_set_geometry(self.h, _p(v), len(v), _p(idx), len(idx), _p(m), len(m)), "skh_set_geometry")
+
+    def refit_accel(self):
+        """skh_refit_accel: keep the hierarchy's topology, recompute leaf records and boxes from the current vertices (falls back to a build)"""
+        self._ck(self.lib.skh_refit_accel(self.h), "skh_refit_accel")
 
     def build_info(self):
         """what the last skh_build_accel did to the triangle hierarchy (reinsertion rounds / moves, cost before and after)"""

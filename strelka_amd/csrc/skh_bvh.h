@@ -839,6 +839,79 @@ __global__ void k_collapse(const CollapseItem* __restrict__ qin, uint32_t nIn, c
     encode_node4(nd, nlo, nhi, clo, chi, refs, cnt);
     static_cast<Node4*>(outNodes)[it.out] = nd;
 }
+// ---- refit (round 6): the 4-wide tree's boxes recomputed from the current leaf records, topology kept -------------------------------------
+// The collapse hands out node slots level by level (one launch per level, internal children take the next free slots), so the nodes of level
+// L occupy one contiguous range and every child node lies in a LATER range: a refit is one launch per level, deepest first, with no atomics and
+// no fences.  A leaf's box = the union of its triangles' boxes from the leaf records the traversal reads (inflated as at build time); an
+// internal child's = the exact box its own refit stored in nodeBox; the node is re-encoded (origin, power-of-two cells, outward-rounded child
+// planes, slots by area) exactly as the collapse encodes it.  Hit records do not depend on the hierarchy: a refitted tree returns what a
+// rebuilt one returns (tests/test_gpu_parity.py::test_refit_after_a_vertex_edit_equals_a_rebuild), only the nodes visited per ray differ.
+SKH_DI void ref_box(int ref, const float4* __restrict__ tris, const float4* __restrict__ nodeBox, float4& lo, float4& hi)
+{
+    if (ref >= 0)
+    {
+        lo = nodeBox[2 * (size_t)ref], hi = nodeBox[2 * (size_t)ref + 1];
+        return;
+    }
+    const uint32_t e = (uint32_t)~ref, first = e >> 3, count = (e & 7u) + 1u;
+    lo = make_float4(INFINITY, INFINITY, INFINITY, 0.0f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+    for (uint32_t k = 0; k < count; ++k)
+    {
+        float4 tl = make_float4(INFINITY, INFINITY, INFINITY, 0.0f), th = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+        {
+            const float4 p = tris[3 * (size_t)(first + k) + v];
+            tl = make_float4(fminf(tl.x, p.x), fminf(tl.y, p.y), fminf(tl.z, p.z), 0.0f);
+            th = make_float4(fmaxf(th.x, p.x), fmaxf(th.y, p.y), fmaxf(th.z, p.z), 0.0f);
+        }
+        inflate_box(tl, th); // (per primitive, as k_refit does for the binary tree's leaves)
+        lo = make_float4(fminf(lo.x, tl.x), fminf(lo.y, tl.y), fminf(lo.z, tl.z), 0.0f);
+        hi = make_float4(fmaxf(hi.x, th.x), fmaxf(hi.y, th.y), fmaxf(hi.z, th.z), 0.0f);
+    }
+}
+__global__ void __launch_bounds__(256) k_node4_refit_level(Node4* __restrict__ nodes, float4* __restrict__ nodeBox /* 2 per node: exact lo, hi */, uint32_t first, uint32_t count,
+                                                           const float4* __restrict__ tris)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count)
+        return;
+    const uint32_t i = first + j;
+    const Node4 old = nodes[i];
+    float clo[4][3], chi[4][3], nlo[3] = { INFINITY, INFINITY, INFINITY }, nhi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    int refs[4];
+    int cnt = 0;
+    for (int s = 0; s < 4; ++s)
+    {
+        const int ref = old.child[s];
+        if (ref == SKH_REF_INVALID)
+            continue;
+        float4 lo, hi;
+        ref_box(ref, tris, nodeBox, lo, hi);
+        clo[cnt][0] = lo.x, clo[cnt][1] = lo.y, clo[cnt][2] = lo.z;
+        chi[cnt][0] = hi.x, chi[cnt][1] = hi.y, chi[cnt][2] = hi.z;
+        for (int a = 0; a < 3; ++a)
+            nlo[a] = fminf(nlo[a], clo[cnt][a]), nhi[a] = fmaxf(nhi[a], chi[cnt][a]);
+        refs[cnt++] = ref;
+    }
+    Node4 nd;
+    encode_node4(nd, nlo, nhi, clo, chi, refs, cnt);
+    nodes[i] = nd;
+    nodeBox[2 * (size_t)i] = make_float4(nlo[0], nlo[1], nlo[2], 0.0f);
+    nodeBox[2 * (size_t)i + 1] = make_float4(nhi[0], nhi[1], nhi[2], 0.0f);
+}
+// boxes of a few references (the groups' roots: a root may be a leaf) -> 6 floats each
+__global__ void k_ref_boxes(const int* __restrict__ refs, uint32_t n, const float4* __restrict__ tris, const float4* __restrict__ nodeBox, float* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.0f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+    if (refs[i] != SKH_REF_INVALID)
+        ref_box(refs[i], tris, nodeBox, lo, hi);
+    out[6 * i] = lo.x, out[6 * i + 1] = lo.y, out[6 * i + 2] = lo.z, out[6 * i + 3] = hi.x, out[6 * i + 4] = hi.y, out[6 * i + 5] = hi.z;
+}
+
 __global__ void k_sizes_from_ranges(const int* __restrict__ rangeF, const int* __restrict__ rangeL, int n, int* __restrict__ nodeSize)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -133,6 +133,16 @@ struct skh_context
     DevBuf dTriNodes, dTris, dSegNodes, dSegs, dSegPrim, dTlasNodes, dTlasInst, dDevInst, dTravInst;
     int tlasRoot = SKH_REF_INVALID;
     bool accelBuilt = false;
+    // skh_refit_accel: what the last build leaves behind for it -- the triangle tree's leaf order and primitive tables (k_gather_tris' inputs), the
+    // nodes' levels -- and what must not have changed since (the signature of the mesh table + index buffer, the vertex count)
+    bool refitReady = false;
+    DevBuf dTriOrder, dTriMeshK, dTriLocalK, dWInstK, dWFirstK, dTriNodeBox;
+    std::vector<uint32_t> triLevelStart;
+    uint32_t nMeshTrisBuilt = 0, nWInstBuilt = 0, triNumNodes = 0, lastBuildFlags = 0, nMeshGroupsBuilt = 0, nGroup1Built = 0;
+    uint64_t geomSig = 0, builtGeomSig = 0;
+    uint32_t builtNVerts = 0;
+    double msRefit = 0.0;
+    uint32_t refits = 0;
     uint32_t nTris = 0, nSegs = 0;
 
     // frame
@@ -334,6 +344,7 @@ struct LbvhOut
     DevBuf nodes, sortedVals, groupRoot, groupBounds;
     std::vector<int> hostGroupRoot;
     uint32_t numNodes = 0;
+    std::vector<uint32_t> levelStart; // the collapse's node slots per level: level L = [levelStart[L], levelStart[L + 1]) -- every child node lies in a later level (skh_refit_accel)
     uint32_t numSlots = 0; // entries of sortedVals: n, or more when the leaves were laid out by 128-byte line (0xffffffff = padding slot)
     // the reinsertion pass (skh_bvh.h k_ri_*), when it ran: rounds done, moves applied, sum of the internal nodes' box areas before / after, time
     uint32_t riRounds = 0, riMoves = 0, riMinSize = 0;
@@ -696,6 +707,8 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
             he = hipMemcpyAsync(out.groupRoot.p, out.hostGroupRoot.data(), sizeof(int) * nGroups, hipMemcpyHostToDevice, st);
         k_iota<<<G1, B, 0, st>>>(leafOrder.as<uint32_t>(), n);
         int cur = 0;
+        out.levelStart.assign(1, 0u);
+        out.levelStart.push_back(cnt); // (level 0 = the groups' roots)
         while (he == hipSuccess && cnt > 0)
         {
             k_collapse<<<(cnt + B - 1) / B, B, 0, st>>>(q[cur].as<CollapseItem>(), cnt, childL.as<int>(), childR.as<int>(), nodeSize.as<int>(),
@@ -705,6 +718,8 @@ static skh_status lbvh_build(skh_context* c, uint32_t n, uint32_t nGroups, const
             if (he == hipSuccess)
                 he = hipStreamSynchronize(st);
             cnt = hctr[1];
+            if (cnt)
+                out.levelStart.push_back(hctr[0]); // (the next level's nodes took the slots up to here)
             const uint32_t zero = 0;
             if (he == hipSuccess)
                 he = hipMemcpyAsync(ctr.as<uint32_t>() + 1, &zero, sizeof(uint32_t), hipMemcpyHostToDevice, st);
@@ -1115,7 +1130,7 @@ void skh_destroy(skh_context* c)
         (void)skh_comm_destroy(c);
     for (DevBuf* b : { &c->dShadeTris, &c->dShadeInst, &c->dVerts, &c->dIndices, &c->dMeshes, &c->dPoints, &c->dRadii, &c->dInstances, &c->dLights, &c->dMaterials, &c->dHairConst,
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
-                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dSegInst, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
+                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dSegInst, &c->dTriOrder, &c->dTriMeshK, &c->dTriLocalK, &c->dWInstK, &c->dWFirstK, &c->dTriNodeBox, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
                        &c->dCounts, &c->dOvf, &c->dOvf2, &c->dStats, &c->dScratchImage, &c->dPathB })
         dev_free(*b);
@@ -1173,6 +1188,17 @@ skh_status skh_set_geometry(skh_context* c, const skh_vertex* verts, uint32_t n_
     c->nVerts = n_verts;
     c->nIndices = n_indices;
     c->accelBuilt = false;
+    {
+        // signature of the TOPOLOGY (mesh table + index buffer, FNV-1a over their words): skh_refit_accel keeps the hierarchy only while it is the built one
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](const uint32_t* w, size_t nw) {
+            for (size_t k = 0; k < nw; ++k)
+                h = (h ^ w[k]) * 1099511628211ull;
+        };
+        mix(reinterpret_cast<const uint32_t*>(meshes), sizeof(skh_mesh) / 4 * (size_t)n_meshes);
+        mix(indices, n_indices);
+        c->geomSig = h ^ ((uint64_t)n_verts << 32);
+    }
     skh_status s;
     if ((s = dev_upload(c, c->dVerts, verts, sizeof(skh_vertex) * (size_t)n_verts)) != SKH_OK)
         return s;
@@ -1211,7 +1237,7 @@ skh_status skh_set_curves(skh_context* c, const float* points_xyz, uint32_t n_po
     c->curves.assign(curves, curves + n_curves);
     c->curveVertexCounts.assign(vertex_counts, vertex_counts + n_vertex_counts);
     c->nPoints = n_points;
-    c->accelBuilt = false;
+    c->accelBuilt = false, c->refitReady = false;
     skh_status s;
     if ((s = dev_upload(c, c->dPoints, points_xyz, sizeof(float) * 3 * (size_t)n_points)) != SKH_OK)
         return s;
@@ -1224,6 +1250,9 @@ skh_status skh_set_instances(skh_context* c, const skh_instance* instances, uint
         return SKH_INVALID_ARGUMENT;
     spec_drop(c);
     (void)hipSetDevice(c->device);
+    // (the same table again -- a caller that re-sends the whole scene with edited vertices -- keeps a refit possible)
+    if (!(n == c->nInstances && n == c->instances.size() && (n == 0 || memcmp(c->instances.data(), instances, sizeof(skh_instance) * (size_t)n) == 0)))
+        c->refitReady = false;
     c->instances.assign(instances, instances + n);
     c->nInstances = n;
     c->accelBuilt = false;
@@ -1336,6 +1365,25 @@ static skh_status build_shading_tables(skh_context* c)
     if (inst.empty())
         inst.resize(1);
     return dev_upload(c, c->dShadeInst, inst.data(), sizeof(skh_instance) * inst.size());
+}
+
+// the box around the baked light proxies' group from its bounds {lo xyz, hi xyz} (a radiance ray that misses it skips the proxies' tree)
+static void set_light_box(skh_context* c, bool any, const float* b6)
+{
+    // What a visit of the group's root could find must lie inside: encode_node4's margin -- the LARGEST coordinate magnitude over all three axes
+    // times 2^-20, the same on every axis (a flat light on the plane x = 0 still gets it: ADVICE r5) -- plus two quantisation cells of the
+    // root node per axis (child planes are rounded outward to the node's power-of-two grid, cell < 2 extent / 255).  A larger box only sends
+    // a few more rays to the proxies' tree.
+    float mAll = 0.0f;
+    for (int k = 0; k < 3; ++k)
+        mAll = std::max(mAll, std::max(std::fabs(b6[k]), std::fabs(b6[3 + k])));
+    for (int k = 0; k < 3; ++k)
+    {
+        const float ext = (b6[3 + k] + mAll * 0x1p-20f) - (b6[k] - mAll * 0x1p-20f);
+        const float m = any ? mAll * 0x1p-20f + 1e-30f + 2.0f * (2.0f * ext / 255.0f) : 0.0f;
+        c->lightBox.lo[k] = any ? b6[k] - m : -INFINITY;
+        c->lightBox.hi[k] = any ? b6[3 + k] + m : INFINITY;
+    }
 }
 
 skh_status skh_build_accel(skh_context* c, uint32_t flags)
@@ -1607,6 +1655,16 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
                                                               c->dTris.as<float4>());
     dev_free(c->dTriNodes);
     c->dTriNodes = triOut.nodes;
+    // what skh_refit_accel needs of this build: k_gather_tris' tables and the tree's levels (the old ones go out with this call's temporaries)
+    std::swap(c->dTriOrder, triOut.sortedVals);
+    std::swap(c->dTriMeshK, dTriMesh);
+    std::swap(c->dTriLocalK, dTriLocal);
+    std::swap(c->dWInstK, dWInst);
+    std::swap(c->dWFirstK, dWFirst);
+    c->triLevelStart = triOut.levelStart;
+    c->nMeshTrisBuilt = nMeshTris, c->nWInstBuilt = (uint32_t)wInst.size(), c->triNumNodes = triOut.numNodes, c->lastBuildFlags = flags, c->nGroup1Built = nGroup1;
+    c->builtGeomSig = c->geomSig, c->builtNVerts = c->nVerts;
+    c->refitReady = usePloc || true; // (either builder ends in the same collapse)
     c->worldRoot = nGroup0 ? triOut.hostGroupRoot[nMeshes] : SKH_REF_INVALID;
     c->lightRoot = nGroup1 ? triOut.hostGroupRoot[nMeshes + 1u] : SKH_REF_INVALID;
     float worldBounds[6] = { INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY };
@@ -1622,20 +1680,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
             cleanup();
             return SKH_FAIL;
         }
-        // What a visit of the group's root could find must lie inside: encode_node4's margin -- the LARGEST coordinate magnitude over all three axes
-        // times 2^-20, the same on every axis (a flat light on the plane x = 0 still gets it: ADVICE r5) -- plus two quantisation cells of the
-        // root node per axis (child planes are rounded outward to the node's power-of-two grid, cell < 2 extent / 255).  A larger box only sends
-        // a few more rays to the proxies' tree.
-        float mAll = 0.0f;
-        for (int k = 0; k < 3; ++k)
-            mAll = std::max(mAll, std::max(std::fabs(gb[6 + k]), std::fabs(gb[9 + k])));
-        for (int k = 0; k < 3; ++k)
-        {
-            const float ext = (gb[9 + k] + mAll * 0x1p-20f) - (gb[6 + k] - mAll * 0x1p-20f);
-            const float m = nGroup1 ? mAll * 0x1p-20f + 1e-30f + 2.0f * (2.0f * ext / 255.0f) : 0.0f;
-            c->lightBox.lo[k] = nGroup1 ? gb[6 + k] - m : -INFINITY;
-            c->lightBox.hi[k] = nGroup1 ? gb[9 + k] + m : INFINITY;
-        }
+        set_light_box(c, nGroup1 != 0u, gb + 6);
         for (uint32_t g = 0; g < 2; ++g)
             if (g == 0 ? nGroup0 : nGroup1)
                 for (int k = 0; k < 3; ++k)
@@ -2094,6 +2139,76 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     c->msBuild = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SKH_OK;
 #undef BA
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// skh_refit_accel: after a VERTEX edit (skh_set_geometry with the same mesh table and index buffer) -- the triangle hierarchy keeps its topology, its
+// leaf records are gathered again from the new vertices and its boxes are recomputed bottom-up, one launch per level (skh_bvh.h k_node4_refit_level).
+// north_star's "SAH refit".  Offered for what a real bake is: every mesh instance baked to world space (no top level: the world-only kernels); anything
+// else -- a top level, edited instances / curves / options, another topology -- falls back to the full rebuild, and the build info says which happened.
+// ---------------------------------------------------------------------------------------------------------------
+skh_status skh_refit_accel(skh_context* c)
+{
+    if (!c)
+        return SKH_INVALID_ARGUMENT;
+    spec_drop(c);
+    (void)hipSetDevice(c->device);
+    const bool can = c->refitReady && c->geomSig == c->builtGeomSig && c->nVerts == c->builtNVerts && c->tlasRoot == SKH_REF_INVALID && c->triNumNodes > 0 &&
+                     c->triLevelStart.size() >= 2;
+    c->buildInfo.refit = 0;
+    if (!can)
+        return skh_build_accel(c, c->lastBuildFlags);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipStream_t st = c->stream;
+    const uint32_t B = 256;
+    skh_status s = build_shading_tables(c); // (normals, tangents, uvs may have changed with the positions)
+    if (s != SKH_OK)
+        return s;
+    if (c->nTriSlots)
+        k_gather_tris<<<(c->nTriSlots + B - 1) / B, B, 0, st>>>(c->dVerts.as<uint8_t>(), c->dIndices.as<uint32_t>(), c->dMeshes.as<uint4>(), c->dTriMeshK.as<uint32_t>(),
+                                                                 c->dTriLocalK.as<uint32_t>(), c->dTriOrder.as<uint32_t>(), c->nTriSlots, c->nMeshTrisBuilt, c->dInstances.as<uint8_t>(),
+                                                                 c->dShadeInst.as<uint8_t>(), c->dWInstK.as<uint32_t>(), c->dWFirstK.as<uint32_t>(), c->nWInstBuilt, c->directRecords,
+                                                                 c->dTris.as<float4>());
+    if ((s = dev_alloc(c, c->dTriNodeBox, sizeof(float4) * 2 * (size_t)c->triNumNodes)) != SKH_OK)
+        return s;
+    for (size_t L = c->triLevelStart.size() - 1; L-- > 0;)
+    {
+        const uint32_t first = c->triLevelStart[L], count = c->triLevelStart[L + 1] - first;
+        if (count)
+            k_node4_refit_level<<<(count + B - 1) / B, B, 0, st>>>(c->dTriNodes.as<Node4>(), c->dTriNodeBox.as<float4>(), first, count, c->dTris.as<float4>());
+    }
+    // the two baked groups' bounds: the box around the light proxies (radiance rays that miss it skip their tree), the scene box
+    DevBuf dRefs, dOut;
+    const int refs[2] = { c->worldRoot, c->lightRoot };
+    float gb[12];
+    if ((s = dev_upload(c, dRefs, refs, sizeof(refs))) != SKH_OK || (s = dev_alloc(c, dOut, sizeof(gb))) != SKH_OK)
+    {
+        dev_free(dRefs), dev_free(dOut);
+        return s;
+    }
+    k_ref_boxes<<<1, 64, 0, st>>>(dRefs.as<int>(), 2u, c->dTris.as<float4>(), c->dTriNodeBox.as<float4>(), dOut.as<float>());
+    hipError_t e = hipMemcpyAsync(gb, dOut.p, sizeof(gb), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    dev_free(dRefs), dev_free(dOut);
+    if (e != hipSuccess || (e = hipGetLastError()) != hipSuccess)
+    {
+        c->err = std::string("skh_refit_accel: ") + hipGetErrorString(e);
+        c->accelBuilt = false, c->refitReady = false;
+        return SKH_FAIL;
+    }
+    set_light_box(c, c->lightRoot != SKH_REF_INVALID && c->nGroup1Built != 0u, gb + 6);
+    for (int k = 0; k < 3; ++k)
+    {
+        c->sceneLo[k] = std::min(c->worldRoot != SKH_REF_INVALID ? gb[k] : INFINITY, c->lightRoot != SKH_REF_INVALID ? gb[6 + k] : INFINITY);
+        c->sceneHi[k] = std::max(c->worldRoot != SKH_REF_INVALID ? gb[3 + k] : -INFINITY, c->lightRoot != SKH_REF_INVALID ? gb[9 + k] : -INFINITY);
+    }
+    c->accelBuilt = true;
+    c->buildInfo.refit = 1;
+    c->msRefit = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c->buildInfo.ms_refit = c->msRefit;
+    c->refits++;
+    return SKH_OK;
 }
 
 skh_status skh_get_baked(skh_context* c, uint8_t* flags, uint32_t n_instances, uint32_t* out_baked_instances, uint32_t* out_baked_triangles)
@@ -3636,21 +3751,21 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value != 0 && value != 1)
             return SKH_INVALID_ARGUMENT;
         c->compactHits = (uint32_t)value;
-        c->accelBuilt = false; // (skh_build_accel decides with it which word a baked triangle's hit carries)
+        c->accelBuilt = false, c->refitReady = false; // (skh_build_accel decides with it which word a baked triangle's hit carries)
     }
     else if (n == "direct_records")
     {
         if (value < -1 || value > 1)
             return SKH_INVALID_ARGUMENT;
         c->directRecordsOpt = (int32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "merge_light_proxies")
     {
         if (value != 0 && value != 1)
             return SKH_INVALID_ARGUMENT;
         c->mergeLightProxies = (uint32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "fetch_chunk")
     {
@@ -3679,42 +3794,42 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
     else if (n == "tight_instance_boxes")
     {
         c->tightInstanceBoxes = value != 0;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "curve_leaf")
     {
         if (value < 1 || value > 4)
             return SKH_INVALID_ARGUMENT;
         c->curveLeaf = (uint32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "split_pairs")
     {
         if (value < 0 || value > 1000)
             return SKH_INVALID_ARGUMENT;
         c->splitPairs = (uint32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "curve_merge")
     {
         if (value < 0 || value > 1)
             return SKH_INVALID_ARGUMENT;
         c->curveMerge = (uint32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "curve_segnode" || n == "curve_strand_major")
     {
         if (value < 0 || value > 1 || (value == 1 && !SKH_SEGNODE)) // (the kernels of this library were compiled without segment-node support: skh_kernels.h SKH_SEGNODE)
             return SKH_INVALID_ARGUMENT;
         (n == "curve_segnode" ? c->curveSegNode : c->curveStrandMajor) = (uint32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "curve_split")
     {
         if (value < 1 || value > 8)
             return SKH_INVALID_ARGUMENT;
         c->curveSplit = (uint32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "speculate")
     {
@@ -3727,14 +3842,14 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 0 || value > 2)
             return SKH_INVALID_ARGUMENT;
         c->tlasBuild = (uint32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "tlas_open")
     {
         if (value < 0 || value > 64)
             return SKH_INVALID_ARGUMENT;
         c->tlasOpen = (uint32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "node_break_closest" || n == "node_break_shadow")
     {
@@ -3757,7 +3872,7 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 0 || value > 4)
             return SKH_INVALID_ARGUMENT;
         c->bakeWorld = (uint32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "world_kernel")
         c->worldKernel = value != 0;
@@ -3766,14 +3881,14 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 0 || value > 100)
             return SKH_INVALID_ARGUMENT; // (leaf references address 2^27 baked triangles)
         c->bakeBudgetMTris = (uint32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "bake_small_tris")
     {
         if (value < 0 || value > (1 << 20))
             return SKH_INVALID_ARGUMENT;
         c->bakeSmallTris = (uint32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "speculate_async")
     {
@@ -3787,21 +3902,21 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < 4 || value > 21)
             return SKH_INVALID_ARGUMENT;
         c->mortonBits = (uint32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "leaf_lines")
     {
         if (value < 0 || value > 1)
             return SKH_INVALID_ARGUMENT;
         c->leafLines = (uint32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "leaf_max_tris")
     {
         if (value < 1 || value > 8)
             return SKH_INVALID_ARGUMENT;
         c->leafMaxTris = (uint32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "small_waves_closest" || n == "small_waves_shadow")
     {
@@ -3812,21 +3927,21 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
     else if (n == "build_quality")
     {
         c->buildQuality = value != 0;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "reinsert_rounds" || n == "reinsert_curve_rounds" || n == "reinsert_min_size")
     {
         if (value < 0 || value > (n == "reinsert_min_size" ? (1 << 24) : 64))
             return SKH_INVALID_ARGUMENT;
         (n == "reinsert_rounds" ? c->reinsertRounds : (n == "reinsert_curve_rounds" ? c->reinsertCurveRounds : c->reinsertMinSize)) = (uint32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "ploc_top")
     {
         if (value < 0)
             return SKH_INVALID_ARGUMENT;
         c->plocTop = (uint32_t)value;
-        c->accelBuilt = false;
+        c->accelBuilt = false, c->refitReady = false;
     }
     else if (n == "waves_per_cu" || n == "waves_per_cu_shadow" || n == "waves_per_cu_world" || n == "waves_per_cu_shadow_world")
     {

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert sorted(capi.SYMBOLS) == syms  # the Python binding covers the whole ABI
     # the library reports the version of the header it was built from
     header = open(os.path.join(ROOT, "include", "strelka_hip.h")).read()
-    assert lib.skh_abi_version() == int(re.search(r"#define SKH_ABI_VERSION (\d+)", header).group(1)) == 4
+    assert lib.skh_abi_version() == int(re.search(r"#define SKH_ABI_VERSION (\d+)", header).group(1)) == 5
 
 
 def test_record_sizes_match_the_reference_layouts(ork):

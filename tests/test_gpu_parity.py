@@ -843,6 +843,89 @@ def test_hit_records_are_hierarchy_independent_inside_the_stated_envelope(bake):
     print("envelope: %d of %d rays at 1e5 thinnest extents differ between a GPU hierarchy and brute force (bake_world %d)" % (differing, len(outside), bake))
 
 
+def test_refit_after_a_vertex_edit_equals_a_rebuild():
+    """skh_refit_accel (round 6; north_star's "SAH refit"): after a vertex edit the triangle hierarchy keeps its topology, its leaf records are gathered again
+    and its boxes recomputed bottom-up, one launch per level.  Hit records do not depend on the hierarchy, so the refitted tree must return what the
+    oracle returns for the EDITED scene -- after a small wobble, after a deformation that moves every vertex by up to half the scene (the tree is then a bad one:
+    still exact), and in a render.  skh_build_info says a refit happened; what a refit cannot keep (a top level: bake_world 0; another index buffer; edited
+    instances) falls back to the full build, also exact."""
+    from strelka_amd import capi
+    from tests import orklib
+
+    sc = small_kitchen()
+    arr = dict(sc.arrays())
+    rays = np.concatenate([camera_rays(sc, 64, 64, 20000, 3), scenes.random_rays(20000, 4, -3.5, 3.5)])
+    rs = np.random.RandomState(8)
+
+    def edited(a, amount):
+        v = a["vertices"].copy()
+        p = v["pos"].astype(np.float64)
+        p += amount * np.stack([np.sin(3.1 * p[:, 1] + 0.3), np.cos(2.3 * p[:, 2]), np.sin(1.7 * p[:, 0] + 1.1)], 1)
+        v["pos"] = p.astype(np.float32)
+        b = dict(a)
+        b["vertices"] = v
+        return b
+
+    def oracle_hits(a, mode):
+        o = orklib.new_context()
+        o.set_scene(a)
+        return o.trace(rays, mode)
+
+    ctx = capi.Context(0)
+    ctx.set_scene(arr)
+    assert ctx.build_info()["refit"] == 0
+    assert_hits_equal(ctx.trace(rays, 0), oracle_hits(arr, 0))
+    for amount in (0.01, 0.2, 1.5):
+        a2 = edited(arr, amount)
+        ctx.set_geometry(a2)
+        ctx.refit_accel()
+        bi = ctx.build_info()
+        assert bi["refit"] == 1 and bi["ms_refit"] > 0
+        assert_hits_equal(ctx.trace(rays, 0), oracle_hits(a2, 0))
+        r2 = rays.copy()
+        r2["tmax"] = 3.0
+        o = orklib.new_context()
+        o.set_scene(a2)
+        assert np.array_equal(ctx.trace(r2, 1)["t"], o.trace(r2, 1)["t"])
+    # a render through the refitted tree (shading tables are rebuilt with it)
+    a2 = edited(arr, 0.2)
+    ctx.set_geometry(a2)
+    ctx.refit_accel()
+    o = orklib.new_context()
+    o.set_scene(a2)
+    o.resize(96, 64)
+    ctx.resize(96, 64)
+    for i in range(3):
+        p = S.frame_params(sc.getCamera(), 96, 64, subframe_index=i, spp_total=3, max_depth=4)
+        o.render_subframe(p)
+        ctx.render_subframe(p)
+    _image_equal(ctx.read_accum(), o.read_accum())
+    # another index buffer (two triangles of mesh 0 swapped): not a refit
+    a3 = dict(a2)
+    idx = a3["indices"].copy()
+    m0 = a3["meshes"][0]
+    o0 = int(m0["index_offset"])
+    idx[o0:o0 + 3], idx[o0 + 3:o0 + 6] = a3["indices"][o0 + 3:o0 + 6].copy(), a3["indices"][o0:o0 + 3].copy()
+    a3["indices"] = idx
+    ctx.set_geometry(a3)
+    ctx.refit_accel()
+    assert ctx.build_info()["refit"] == 0
+    assert_hits_equal(ctx.trace(rays, 0), oracle_hits(a3, 0))
+    ctx.close()
+    # a scene that keeps its top level (nothing baked): refit_accel is a rebuild
+    ctx = capi.Context(0)
+    ctx.set_option("bake_world", 0)
+    ctx.set_scene(arr)
+    ctx.set_geometry(edited(arr, 0.05))
+    ctx.refit_accel()
+    assert ctx.build_info()["refit"] == 0
+    o = orklib.new_context()
+    o.set_bake(0)
+    o.set_scene(edited(arr, 0.05))
+    assert_hits_equal(ctx.trace(rays, 0), o.trace(rays, 0))
+    ctx.close()
+
+
 def test_stack_spill_path_is_exact(tmp_path):
     """A build of the same kernels with a 12-entry LDS stack sends the deeper entries through the per-thread global
     overflow area all the time; hit records must still be bit-identical to the oracle (the default 24-entry build
