@@ -14,7 +14,9 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     if kind == 0:
         sc = scenes.kitchen_standin(seed=seed, n_meshes=10 + seed % 7, n_instances=40 + 13 * (seed % 5), tri_lo=50, tri_hi=3000)
     elif kind == 1:
-        sc = scenes.hair_standin(seed=seed, n_strands=400 + 50 * (seed % 9), n_cp=6 + seed % 5)
+        # (round 6: the same strands as 1..5 curve prims, some of them under translations -- merged world-space tree, markers, two-level fallback)
+        npr = 1 + (seed // 4) % 5
+        sc = scenes.hair_standin(seed=seed, n_strands=400 + 50 * (seed % 9), n_cp=6 + seed % 5, n_prims=npr, prim_offset=0.01 if (seed // 20) % 2 else 0.0, n_moved=(seed // 40) % (npr + 1))
     elif kind == 2:
         sc = thick_curves(seed=seed, n_strands=30 + seed % 40, n_cp=5 + seed % 6)
     else:
@@ -136,7 +138,18 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     ctx.set_option("direct_records", (-1, 0, 1)[(seed // 2) % 3])  # which word a baked triangle's hit carries (raw queries always report the mesh-local primitive)
     if (seed // 4) % 3 == 2:
         ctx.set_option("build_quality", 0)  # the Karras radix tree instead of PLOC must give the same records
-    ctx.set_scene(arr); got = ctx.trace(rays, 0)
+    ctx.set_option("curve_merge", (seed // 8) % 2)  # identity-transform curve instances in one world-space tree, or a tree each
+    ctx.set_option("split_pairs", (0, 7, 15)[(seed // 6) % 3])  # loose two-triangle leaves opened at the collapse
+    ctx.set_scene(arr)
+    if (seed // 5) % 4 == 1 and len(arr["vertices"]):
+        # a vertex edit followed by skh_refit_accel (or the rebuild it falls back to): the oracle gets the edited scene
+        v = arr["vertices"].copy(); p = v["pos"].astype(np.float64)
+        p += rs.choice([0.003, 0.05, 0.5]) * np.stack([np.sin(3.1 * p[:, 1] + 0.3), np.cos(2.3 * p[:, 2]), np.sin(1.7 * p[:, 0] + 1.1)], 1)
+        v["pos"] = p.astype(np.float32)
+        arr = dict(arr); arr["vertices"] = v
+        ctx.set_geometry(arr); ctx.refit_accel()
+        o = orklib.new_context(); o.set_bake(bk); o.set_scene(arr); want = o.trace(rays, 0)
+    got = ctx.trace(rays, 0)
     sh = rays.copy(); sh["tmax"] = rs.uniform(0.5, 5.0)
     ws, gs = o.trace(sh, 1)["t"], ctx.trace(sh, 1)["t"]
     ctx.close()
