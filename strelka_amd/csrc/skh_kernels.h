@@ -439,6 +439,20 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
             dst = SKH_REF_INVALID;                                   \
     }
 
+// cheap conservative rejection of a curve leaf's sub-segments: (distance between the ray's line and the segment's bounding cylinder
+// axis)^2 = ((A - o) . n)^2 / |n|^2, n = d x axis; a long thin diagonal hair fills a tiny part of its box.  Sets bit k of PEND for sub-segment k that passes.
+#define SKH_CYLINDER_TESTS(FIRST, COUNT, PEND)                                                                                   \
+    for (uint32_t k_ = 0; k_ < (COUNT); ++k_)                                                                                    \
+    {                                                                                                                            \
+        const float4 b0 = sc.segBound[2 * (size_t)((FIRST) + k_)], b1 = sc.segBound[2 * (size_t)((FIRST) + k_) + 1];             \
+        const v3 w = mk3(b0.x - o.x, b0.y - o.y, b0.z - o.z);                                                                    \
+        const v3 nn = cross(d, mk3(b1.x, b1.y, b1.z));                                                                           \
+        const float n2 = dot(nn, nn), wn = dot(w, nn);                                                                           \
+        const float Rm = b0.w + (fabsf(w.x) + fabsf(w.y) + fabsf(w.z)) * 4e-6f; /* cancellation in w . n */                      \
+        if (n2 > 1e-12f * dot(d, d) && wn * wn > Rm * Rm * n2 * 1.0001f)                                                         \
+            continue;                                                                                                            \
+        (PEND) |= 1u << k_;                                                                                                      \
+    }
 #define SKH_TAKE_MARKER()                                                                                         \
     {                                                                                                             \
         const uint32_t k = (uint32_t)cur & 0xffffu;                                                               \
@@ -1018,6 +1032,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                 // the whole wave leaves the node loop
                 if (cur == SKH_REF_INVALID && sp > 0)
                     SKH_POP(cur);
+                // (Round 6 measured the curve leaf's cylinder tests INSIDE this loop -- a lane whose walk arrives at a curve leaf tests it here and, rejected 70 % of
+                // the time, pops and goes on descending instead of waiting for the wave to leave the loop: exact, and 21 % slower (hair 2 067 -> 1 631 Mray/s,
+                // closest-hit 70.7 -> 89.3 ms, any-hit 46.2 -> 63.5): two more loads and ~45 instructions in every iteration of every wave cost more than the
+                // waiting they remove, as the curve trees' markers did in round 5.  The while-while structure stays.)
                 // few lanes still descending while the rest wait at their leaves: let the leaves go first
                 if ((uint32_t)__popcll(__ballot(cur >= 0 && cur != SKH_REF_INVALID)) < breakBelow)
                     break;
@@ -1232,19 +1250,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                 }
                 else if (CURVES && curType == 2)
                 {
-                    for (uint32_t k = 0; k < count; ++k)
-                    {
-                        // cheap conservative rejection: (distance between the ray's line and the segment's bounding cylinder
-                        // axis)^2 = ((A - o) . n)^2 / |n|^2, n = d x axis; a long thin diagonal hair fills a tiny part of its box
-                        const float4 b0 = sc.segBound[2 * (size_t)(first + k)], b1 = sc.segBound[2 * (size_t)(first + k) + 1];
-                        const v3 w = mk3(b0.x - o.x, b0.y - o.y, b0.z - o.z);
-                        const v3 nn = cross(d, mk3(b1.x, b1.y, b1.z));
-                        const float n2 = dot(nn, nn), wn = dot(w, nn);
-                        const float Rm = b0.w + (fabsf(w.x) + fabsf(w.y) + fabsf(w.z)) * 4e-6f; // cancellation in w . n
-                        if (n2 > 1e-12f * dot(d, d) && wn * wn > Rm * Rm * n2 * 1.0001f)
-                            continue;
-                        pend |= 1u << k;
-                    }
+                    SKH_CYLINDER_TESTS(first, count, pend)
                     if (pend != 0u)
                         entered = true; // parks in front of the full intersector (see above); `cur` keeps the leaf
                 }
@@ -1353,6 +1359,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
 #undef SKH_POP
 #undef SKH_OVF_AT
 #undef SKH_TAKE_MARKER
+#undef SKH_CYLINDER_TESTS
     if (COUNT)
     {
         const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.prims), c2 = wave_sum(tc.segs), d2 = wave_sum(tc.insts);
