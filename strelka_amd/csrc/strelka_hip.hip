@@ -129,6 +129,7 @@ struct skh_context
     // so that a Mray/s figure from skh_get_stats only counts rays whose sub-frame was delivered
     uint64_t discardedRadiance = 0, discardedShadow = 0;
     uint32_t discardedSubframes = 0;
+    uint32_t speculateGrow = 2; // option speculate_grow: how fast the look-ahead grows while the caller keeps continuing a frame (x2 per pass: 2, 4, 8; 8 = straight to the cap at the second call)
     uint32_t speculateMax = 8; // option "speculate": most sub-frames traced ahead in one pass (0 / 1 = off).  8: a pass stays below ~25 ms at 1080p
     DevBuf dTriNodes, dTris, dSegNodes, dSegs, dSegPrim, dTlasNodes, dTlasInst, dDevInst, dTravInst;
     int tlasRoot = SKH_REF_INVALID;
@@ -2757,7 +2758,7 @@ static skh_status spec_launch_next(skh_context* c)
     if (nextStart >= sp.params.spp_total)
         return SKH_OK;
     const uint32_t cap = std::min(c->speculateMax, c->batchCapacity);
-    const uint32_t n = std::min(std::min(std::max(2u, sp.count * 2u), cap), sp.params.spp_total - nextStart);
+    const uint32_t n = std::min(std::min(std::max(2u, sp.count * c->speculateGrow), cap), sp.params.spp_total - nextStart);
     const uint32_t other = sp.buf ^ 1u;
     if (other == 1u)
     {
@@ -2832,7 +2833,7 @@ skh_status skh_render_subframe(skh_context* c, const skh_frame_params* params, v
     sp.streak = continues ? sp.streak + 1 : 0;
     uint32_t ahead = 1;
     if (continues && params->spp_total > params->subframe_index)
-        ahead = std::min(std::min(std::max(2u, sp.lastBatch * 2u), std::min(c->speculateMax, c->batchCapacity)), params->spp_total - params->subframe_index);
+        ahead = std::min(std::min(std::max(2u, sp.lastBatch * c->speculateGrow), std::min(c->speculateMax, c->batchCapacity)), params->spp_total - params->subframe_index);
     spec_drop(c, true);
     if ((s = ensure_ready(c)) != SKH_OK)
         return s;
@@ -3889,6 +3890,12 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
             return SKH_INVALID_ARGUMENT;
         c->bakeSmallTris = (uint32_t)value;
         c->accelBuilt = false, c->refitReady = false;
+    }
+    else if (n == "speculate_grow")
+    {
+        if (value < 2 || value > 64)
+            return SKH_INVALID_ARGUMENT;
+        c->speculateGrow = (uint32_t)value;
     }
     else if (n == "speculate_async")
     {
