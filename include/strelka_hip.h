@@ -259,7 +259,8 @@ skh_status skh_set_materials(skh_context* ctx, const skh_material* materials, ui
 
 /* ---- createAccelerationStructure (OptixRender.cpp:388-496): per-mesh / per-curve BLAS + one TLAS ---- */
 skh_status skh_build_accel(skh_context* ctx, uint32_t flags);
-/* After a VERTEX edit -- skh_set_geometry with the mesh table and index buffer of the last build, any vertex data -- keep the triangle hierarchy's topology and
+/* After a VERTEX edit -- skh_set_geometry with the mesh table and index buffer of the last build, any vertex data; skh_set_curves with the curve sets and vertex
+ * counts of the last build, any control points and radii (an animated groom) -- keep the hierarchies' topology and
  * recompute its leaf records and boxes bottom-up (north_star's "SAH refit"; the reference has no equivalent: it builds once, on frame 0, OptixRender.cpp:876).
  * Refits when every mesh instance is baked to world space (no top level: what a bake without mesh sharing gives) and nothing but the vertices changed since
  * the build; otherwise it IS skh_build_accel(flags of the last build).  skh_build_info.refit says which happened.  Hit records do not depend on the hierarchy,

@@ -321,6 +321,11 @@ class Context:
         v, idx, m = scene["vertices"], scene["indices"], scene["meshes"]
         self._ck(self.lib.skh_set_geometry(self.h, _p(v), len(v), _p(idx), len(idx), _p(m), len(m)), "skh_set_geometry")
 
+    def set_curves(self, scene):
+        """skh_set_curves alone (edited control points / radii: follow it with refit_accel)"""
+        self._ck(self.lib.skh_set_curves(self.h, _p(scene["curve_points"]), len(scene["curve_points"]), _p(scene["curve_radii"]), len(scene["curve_radii"]),
+                                         _p(scene["curve_vertex_counts"]), len(scene["curve_vertex_counts"]), _p(scene["curves"]), len(scene["curves"])), "skh_set_curves")
+
     def refit_accel(self):
         """skh_refit_accel: keep the hierarchy's topology, recompute leaf records and boxes from the current vertices (falls back to a build)"""
         self._ck(self.lib.skh_refit_accel(self.h), "skh_refit_accel")

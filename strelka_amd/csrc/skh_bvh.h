@@ -900,6 +900,64 @@ __global__ void __launch_bounds__(256) k_node4_refit_level(Node4* __restrict__ n
     nodeBox[2 * (size_t)i] = make_float4(nlo[0], nlo[1], nlo[2], 0.0f);
     nodeBox[2 * (size_t)i + 1] = make_float4(nhi[0], nhi[1], nhi[2], 0.0f);
 }
+// the same for a CURVE tree: a leaf's box = the union of its sub-segments' boxes, recomputed as k_seg_boxes computes them -- the Bezier hull of the
+// (padded) parameter sub-range of the segment's current control points, grown by the radius margin -- from the leaf records k_gather_segs wrote
+SKH_DI void curve_ref_box(int ref, const float4* __restrict__ segs, const uint32_t* __restrict__ segPrim, uint32_t K, const float4* __restrict__ nodeBox, float4& lo, float4& hi)
+{
+    if (ref >= 0)
+    {
+        lo = nodeBox[2 * (size_t)ref], hi = nodeBox[2 * (size_t)ref + 1];
+        return;
+    }
+    const uint32_t e = (uint32_t)~ref, first = e >> 3, count = (e & 7u) + 1u;
+    lo = make_float4(INFINITY, INFINITY, INFINITY, 0.0f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+    for (uint32_t k = 0; k < count; ++k)
+    {
+        float4 q[4];
+        float rmax = 0.0f, cmax = 0.0f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+        {
+            q[v] = segs[4 * (size_t)(first + k) + v];
+            rmax = fmaxf(rmax, fabsf(q[v].w));
+            cmax = fmaxf(cmax, fmaxf(fabsf(q[v].x), fmaxf(fabsf(q[v].y), fabsf(q[v].z))));
+        }
+        v3 l, h;
+        subseg_box(q, K > 1u ? segPrim[first + k] >> 28 : 0u, K, rmax, cmax, l, h);
+        lo = make_float4(fminf(lo.x, l.x), fminf(lo.y, l.y), fminf(lo.z, l.z), 0.0f);
+        hi = make_float4(fmaxf(hi.x, h.x), fmaxf(hi.y, h.y), fmaxf(hi.z, h.z), 0.0f);
+    }
+}
+__global__ void __launch_bounds__(256) k_node4_refit_level_curves(Node4* __restrict__ nodes, float4* __restrict__ nodeBox, uint32_t first, uint32_t count,
+                                                                  const float4* __restrict__ segs, const uint32_t* __restrict__ segPrim, uint32_t K)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count)
+        return;
+    const uint32_t i = first + j;
+    const Node4 old = nodes[i];
+    float clo[4][3], chi[4][3], nlo[3] = { INFINITY, INFINITY, INFINITY }, nhi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    int refs[4];
+    int cnt = 0;
+    for (int s = 0; s < 4; ++s)
+    {
+        const int ref = old.child[s];
+        if (ref == SKH_REF_INVALID)
+            continue;
+        float4 lo, hi;
+        curve_ref_box(ref, segs, segPrim, K, nodeBox, lo, hi);
+        clo[cnt][0] = lo.x, clo[cnt][1] = lo.y, clo[cnt][2] = lo.z;
+        chi[cnt][0] = hi.x, chi[cnt][1] = hi.y, chi[cnt][2] = hi.z;
+        for (int a = 0; a < 3; ++a)
+            nlo[a] = fminf(nlo[a], clo[cnt][a]), nhi[a] = fmaxf(nhi[a], chi[cnt][a]);
+        refs[cnt++] = ref;
+    }
+    Node4 nd;
+    encode_node4(nd, nlo, nhi, clo, chi, refs, cnt);
+    nodes[i] = nd;
+    nodeBox[2 * (size_t)i] = make_float4(nlo[0], nlo[1], nlo[2], 0.0f);
+    nodeBox[2 * (size_t)i + 1] = make_float4(nhi[0], nhi[1], nhi[2], 0.0f);
+}
 // boxes of a few references (the groups' roots: a root may be a leaf) -> 6 floats each
 __global__ void k_ref_boxes(const int* __restrict__ refs, uint32_t n, const float4* __restrict__ tris, const float4* __restrict__ nodeBox, float* __restrict__ out)
 {

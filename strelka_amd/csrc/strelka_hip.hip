@@ -144,6 +144,12 @@ struct skh_context
     uint32_t builtNVerts = 0;
     double msRefit = 0.0;
     uint32_t refits = 0;
+    // ... and of the curve build: k_gather_segs' tables, the curve tree's levels, the signature of the curve sets' topology (control points and radii may change)
+    DevBuf dSegOrder, dSegBuildStartK, dSegLocalK, dSegInstOfK, dSegNodeBox;
+    std::vector<uint32_t> segLevelStart;
+    uint32_t nSubBuilt = 0, segNumNodes = 0;
+    uint64_t curveSig = 0, builtCurveSig = 0;
+    bool curvePointsEdited = false, curveRefitReady = false;
     uint32_t nTris = 0, nSegs = 0;
 
     // frame
@@ -1131,7 +1137,7 @@ void skh_destroy(skh_context* c)
         (void)skh_comm_destroy(c);
     for (DevBuf* b : { &c->dShadeTris, &c->dShadeInst, &c->dVerts, &c->dIndices, &c->dMeshes, &c->dPoints, &c->dRadii, &c->dInstances, &c->dLights, &c->dMaterials, &c->dHairConst,
                        &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
-                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dSegInst, &c->dTriOrder, &c->dTriMeshK, &c->dTriLocalK, &c->dWInstK, &c->dWFirstK, &c->dTriNodeBox, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
+                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dSegInst, &c->dTriOrder, &c->dTriMeshK, &c->dTriLocalK, &c->dWInstK, &c->dWFirstK, &c->dTriNodeBox, &c->dSegOrder, &c->dSegBuildStartK, &c->dSegLocalK, &c->dSegInstOfK, &c->dSegNodeBox, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
                        &c->dCounts, &c->dOvf, &c->dOvf2, &c->dStats, &c->dScratchImage, &c->dPathB })
         dev_free(*b);
@@ -1238,7 +1244,19 @@ skh_status skh_set_curves(skh_context* c, const float* points_xyz, uint32_t n_po
     c->curves.assign(curves, curves + n_curves);
     c->curveVertexCounts.assign(vertex_counts, vertex_counts + n_vertex_counts);
     c->nPoints = n_points;
-    c->accelBuilt = false, c->refitReady = false;
+    c->accelBuilt = false;
+    {
+        // signature of the curve sets' TOPOLOGY (set table + vertex counts + array sizes): control points and radii may change under skh_refit_accel
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](const uint32_t* w, size_t nw) {
+            for (size_t k = 0; k < nw; ++k)
+                h = (h ^ w[k]) * 1099511628211ull;
+        };
+        mix(reinterpret_cast<const uint32_t*>(curves), sizeof(skh_curve) / 4 * (size_t)n_curves);
+        mix(vertex_counts, n_vertex_counts);
+        c->curveSig = h ^ ((uint64_t)n_points << 32);
+        c->curvePointsEdited = true;
+    }
     skh_status s;
     if ((s = dev_upload(c, c->dPoints, points_xyz, sizeof(float) * 3 * (size_t)n_points)) != SKH_OK)
         return s;
@@ -1833,6 +1851,15 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     dev_free(c->dSegNodes);
     c->dSegNodes = segOut.nodes;
     c->hierNodes += segOut.numNodes;
+    // what skh_refit_accel needs of the curve build (segment nodes carry boxes of their own kind: no refit for that experimental build)
+    std::swap(c->dSegOrder, segOut.sortedVals);
+    std::swap(c->dSegBuildStartK, dSegBuildStart);
+    std::swap(c->dSegLocalK, dSegLocal);
+    std::swap(c->dSegInstOfK, dSegInstOf);
+    c->segLevelStart = segOut.levelStart;
+    c->nSubBuilt = nSub, c->segNumNodes = segOut.numNodes;
+    c->builtCurveSig = c->curveSig, c->curvePointsEdited = false;
+    c->curveRefitReady = !segNode;
     // world curves: walked from the world-only kernel (option world_kernel; without it they keep their TLAS leaves: same hit records).  Decided BEFORE the
     // validity flags go to the device: both TLAS builders then agree on which instances have a leaf.
     std::vector<int> curveSetRoot(nCurves, SKH_REF_INVALID); // root of curve set s's own tree (group 1 + s)
@@ -2154,8 +2181,10 @@ skh_status skh_refit_accel(skh_context* c)
         return SKH_INVALID_ARGUMENT;
     spec_drop(c);
     (void)hipSetDevice(c->device);
-    const bool can = c->refitReady && c->geomSig == c->builtGeomSig && c->nVerts == c->builtNVerts && c->tlasRoot == SKH_REF_INVALID && c->triNumNodes > 0 &&
-                     c->triLevelStart.size() >= 2;
+    // (curves: control points and radii may have changed -- skh_set_curves with the built sets' table and vertex counts --; their tree is refitted the same way)
+    const bool curvesOk = c->curves.empty() ? c->nSubBuilt == 0 : (c->curveRefitReady && c->curveSig == c->builtCurveSig);
+    const bool can = c->refitReady && c->geomSig == c->builtGeomSig && c->nVerts == c->builtNVerts && c->tlasRoot == SKH_REF_INVALID && curvesOk &&
+                     (c->triNumNodes > 0 || c->segNumNodes > 0);
     c->buildInfo.refit = 0;
     if (!can)
         return skh_build_accel(c, c->lastBuildFlags);
@@ -2170,13 +2199,30 @@ skh_status skh_refit_accel(skh_context* c)
                                                                  c->dTriLocalK.as<uint32_t>(), c->dTriOrder.as<uint32_t>(), c->nTriSlots, c->nMeshTrisBuilt, c->dInstances.as<uint8_t>(),
                                                                  c->dShadeInst.as<uint8_t>(), c->dWInstK.as<uint32_t>(), c->dWFirstK.as<uint32_t>(), c->nWInstBuilt, c->directRecords,
                                                                  c->dTris.as<float4>());
-    if ((s = dev_alloc(c, c->dTriNodeBox, sizeof(float4) * 2 * (size_t)c->triNumNodes)) != SKH_OK)
+    if ((s = dev_alloc(c, c->dTriNodeBox, sizeof(float4) * 2 * (size_t)std::max(1u, c->triNumNodes))) != SKH_OK)
         return s;
-    for (size_t L = c->triLevelStart.size() - 1; L-- > 0;)
+    for (size_t L = c->triLevelStart.size() > 1 ? c->triLevelStart.size() - 1 : 0; L-- > 0;)
     {
         const uint32_t first = c->triLevelStart[L], count = c->triLevelStart[L + 1] - first;
         if (count)
             k_node4_refit_level<<<(count + B - 1) / B, B, 0, st>>>(c->dTriNodes.as<Node4>(), c->dTriNodeBox.as<float4>(), first, count, c->dTris.as<float4>());
+    }
+    if (c->curvePointsEdited && c->nSubBuilt)
+    {
+        // the curve tree: leaf records (control points, bounding cylinders) gathered again from the new points, boxes level by level
+        k_gather_segs<<<(c->nSubBuilt + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), c->dSegBuildStartK.as<uint32_t>(), c->dSegLocalK.as<uint32_t>(),
+                                                               c->dSegInstOfK.as<uint32_t>(), c->dSegOrder.as<uint32_t>(), c->nSubBuilt, c->curveSplitBuilt, c->dSegs.as<float4>(),
+                                                               c->dSegPrim.as<uint32_t>(), c->dSegBound.as<float4>(), c->dSegInst.as<uint32_t>(), 0u);
+        if ((s = dev_alloc(c, c->dSegNodeBox, sizeof(float4) * 2 * (size_t)std::max(1u, c->segNumNodes))) != SKH_OK)
+            return s;
+        for (size_t L = c->segLevelStart.size() > 1 ? c->segLevelStart.size() - 1 : 0; L-- > 0;)
+        {
+            const uint32_t first = c->segLevelStart[L], count = c->segLevelStart[L + 1] - first;
+            if (count)
+                k_node4_refit_level_curves<<<(count + B - 1) / B, B, 0, st>>>(c->dSegNodes.as<Node4>(), c->dSegNodeBox.as<float4>(), first, count, c->dSegs.as<float4>(),
+                                                                            c->dSegPrim.as<uint32_t>(), c->curveSplitBuilt);
+        }
+        c->curvePointsEdited = false;
     }
     // the two baked groups' bounds: the box around the light proxies (radiance rays that miss it skip their tree), the scene box
     DevBuf dRefs, dOut;
@@ -2187,7 +2233,7 @@ skh_status skh_refit_accel(skh_context* c)
         dev_free(dRefs), dev_free(dOut);
         return s;
     }
-    k_ref_boxes<<<1, 64, 0, st>>>(dRefs.as<int>(), 2u, c->dTris.as<float4>(), c->dTriNodeBox.as<float4>(), dOut.as<float>());
+    k_ref_boxes<<<1, 64, 0, st>>>(dRefs.as<int>(), 2u, c->dTris.as<float4>(), c->dTriNodeBox.as<float4>(), dOut.as<float>()); // (INVALID roots give empty boxes)
     hipError_t e = hipMemcpyAsync(gb, dOut.p, sizeof(gb), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess)
         e = hipStreamSynchronize(st);

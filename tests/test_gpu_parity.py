@@ -926,6 +926,58 @@ def test_refit_after_a_vertex_edit_equals_a_rebuild():
     ctx.close()
 
 
+@pytest.mark.parametrize("n_prims", [1, 4])
+def test_refit_of_an_animated_groom_equals_a_rebuild(n_prims):
+    """skh_refit_accel for curves: the control points and radii of a groom change (the strands sway and thicken), the curve sets and their vertex counts do not -- the
+    curve tree keeps its topology, its leaf records (control points, bounding cylinders) are gathered again and its boxes recomputed level by level.  One prim and the
+    merged tree of four identity prims; hit records (closest + any-hit) and a render equal to the oracle's for the EDITED scene; another vertex-count table falls back to
+    the build."""
+    from strelka_amd import capi
+    from tests import orklib
+
+    sc = scenes.hair_standin(seed=5, n_strands=1500, n_cp=8, n_prims=n_prims)
+    arr = dict(sc.arrays())
+    rays = np.concatenate([camera_rays(sc, 64, 64, 30000, 11), scenes.random_rays(10000, 12, -2.0, 2.0)])
+    ctx = capi.Context(0)
+    ctx.set_scene(arr)
+    for amount in (0.004, 0.08):
+        a2 = dict(arr)
+        p = arr["curve_points"].astype(np.float64)
+        p += amount * np.stack([np.sin(5.0 * p[:, 1] + 0.4), 0.3 * np.cos(4.0 * p[:, 0]), np.sin(3.0 * p[:, 2] + 1.0)], 1) * np.linalg.norm(p, axis=1, keepdims=True)
+        a2["curve_points"] = p.astype(np.float32)
+        a2["curve_radii"] = (arr["curve_radii"] * np.float32(1.0 + 10.0 * amount)).astype(np.float32)
+        ctx.set_curves(a2)
+        ctx.refit_accel()
+        assert ctx.build_info()["refit"] == 1
+        o = orklib.new_context()
+        o.set_scene(a2)
+        want = o.trace(rays, 0)
+        assert np.isin(want["instance_id"], np.nonzero(arr["instances"]["type"] == S.INSTANCE_CURVE)[0]).mean() > 0.01
+        assert_hits_equal(ctx.trace(rays, 0), want)
+        r2 = rays.copy()
+        r2["tmax"] = 4.0
+        assert np.array_equal(ctx.trace(r2, 1)["t"], o.trace(r2, 1)["t"])
+    o.resize(96, 64)
+    ctx.resize(96, 64)
+    for i in range(3):
+        pp = S.frame_params(sc.getCamera(), 96, 64, subframe_index=i, spp_total=3, max_depth=3)
+        o.render_subframe(pp)
+        ctx.render_subframe(pp)
+    _image_equal(ctx.read_accum(), o.read_accum())
+    # two strands swap their vertex counts (same totals): another topology -> a rebuild
+    a3 = dict(a2)
+    vc = a3["curve_vertex_counts"].copy()
+    vc[0], vc[1] = vc[0] - 1, vc[1] + 1
+    a3["curve_vertex_counts"] = vc
+    ctx.set_curves(a3)
+    ctx.refit_accel()
+    assert ctx.build_info()["refit"] == 0
+    o = orklib.new_context()
+    o.set_scene(a3)
+    assert_hits_equal(ctx.trace(rays, 0), o.trace(rays, 0))
+    ctx.close()
+
+
 def test_stack_spill_path_is_exact(tmp_path):
     """A build of the same kernels with a 12-entry LDS stack sends the deeper entries through the per-thread global
     overflow area all the time; hit records must still be bit-identical to the oracle (the default 24-entry build

@@ -149,6 +149,13 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         arr = dict(arr); arr["vertices"] = v
         ctx.set_geometry(arr); ctx.refit_accel()
         o = orklib.new_context(); o.set_bake(bk); o.set_scene(arr); want = o.trace(rays, 0)
+    if (seed // 7) % 3 == 1 and len(arr.get("curves", [])):
+        # an animated groom: control points and radii change, the curve sets do not -> skh_refit_accel refits the curve tree too
+        p = arr["curve_points"].astype(np.float64)
+        p += rs.choice([0.002, 0.03]) * np.stack([np.sin(5.0 * p[:, 1] + 0.4), 0.3 * np.cos(4.0 * p[:, 0]), np.sin(3.0 * p[:, 2] + 1.0)], 1)
+        arr = dict(arr); arr["curve_points"] = p.astype(np.float32); arr["curve_radii"] = (arr["curve_radii"] * np.float32(rs.uniform(0.7, 1.5))).astype(np.float32)
+        ctx.set_curves(arr); ctx.refit_accel()
+        o = orklib.new_context(); o.set_bake(bk); o.set_scene(arr); want = o.trace(rays, 0)
     got = ctx.trace(rays, 0)
     sh = rays.copy(); sh["tmax"] = rs.uniform(0.5, 5.0)
     ws, gs = o.trace(sh, 1)["t"], ctx.trace(sh, 1)["t"]
