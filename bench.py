@@ -178,12 +178,18 @@ def live_pmc(argv, spp, keep_dir=None):
         seconds.append(round(time.time() - t0, 1))
         open(os.path.join(root, "pass%d.log" % k), "w").write(r.stdout[-4000:] + r.stderr[-4000:])
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        optional = group == ("GRBM_GUI_ACTIVE",)  # the clock pass is context: without it the VALU roof is priced at the device's maximum clock and says so
         if r.returncode != 0 or not lines:
+            if optional:
+                sys.stderr.write("[bench] live counters: the clock pass failed (exit code %d): VALU issue priced at the maximum clock\n" % r.returncode)
+                continue
             return fail("pass %d: exit code %d" % (k, r.returncode))
         line = json.loads(lines[-1])
         for name, prefix in KERNELS.items():
             got = _pmc_per_launch(outdir, prefix)
             if not all(g in got for g in group):
+                if optional:
+                    continue
                 return fail("pass %d: no %s counters for %s" % (k, "/".join(group), name))
             counters[name].update(got)
             units[name] = line["roofline"]["kernels"][name]["units_per_launch"]

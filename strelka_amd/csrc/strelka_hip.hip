@@ -1683,7 +1683,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     c->triLevelStart = triOut.levelStart;
     c->nMeshTrisBuilt = nMeshTris, c->nWInstBuilt = (uint32_t)wInst.size(), c->triNumNodes = triOut.numNodes, c->lastBuildFlags = flags, c->nGroup1Built = nGroup1;
     c->builtGeomSig = c->geomSig, c->builtNVerts = c->nVerts;
-    c->refitReady = usePloc || true; // (either builder ends in the same collapse)
+    c->refitReady = true; // (either builder ends in the same collapse)
     c->worldRoot = nGroup0 ? triOut.hostGroupRoot[nMeshes] : SKH_REF_INVALID;
     c->lightRoot = nGroup1 ? triOut.hostGroupRoot[nMeshes + 1u] : SKH_REF_INVALID;
     float worldBounds[6] = { INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY };
