@@ -1318,15 +1318,13 @@ SKH_DI void hair_tilt(const HairTerms& t, const HairGeom& g, int p, float& sinTh
     }
     cosThetaOp = fabsf(cosThetaOp);
 }
-SKH_DI void hair_eval_local(const HairTerms& t, const v3& wo, const v3& wi, v3& f_cos, float& pdf)
+// (the _g forms take the outgoing direction's geometry and the attenuations ready-made: one hit of a hair material evaluates the BSDF twice for the same k1 --
+// the sampled direction and the light sample's -- and k_shade's hair path shares them: hair_sample_and_evaluate)
+SKH_DI void hair_eval_local_g(const HairTerms& t, const HairGeom& g, const v3 ap[4], const float apPdf[4], const v3& wi, v3& f_cos, float& pdf)
 {
-    const HairGeom g = hair_geom(t, wo);
     const float sinThetaI = clampf(wi.x, -1.0f, 1.0f);
     const float cosThetaI = safe_sqrtf_(1.0f - sqrf_(sinThetaI));
     const float phi = skm::atan2f_(wi.z, wi.y) - g.phiO;
-    v3 ap[4];
-    float apPdf[4];
-    hair_Ap(t, g.cosThetaO, g.T, ap, apPdf);
     f_cos = mk3(0.0f);
     pdf = 0.0f;
 #pragma unroll
@@ -1342,12 +1340,16 @@ SKH_DI void hair_eval_local(const HairTerms& t, const v3& wo, const v3& wi, v3& 
     f_cos = f_cos + ap[3] * mr;
     pdf += apPdf[3] * mr;
 }
-SKH_DI v3 hair_sample_local(const HairTerms& t, const v3& wo, float u0, float u1, float u2, float u3)
+SKH_DI void hair_eval_local(const HairTerms& t, const v3& wo, const v3& wi, v3& f_cos, float& pdf)
 {
     const HairGeom g = hair_geom(t, wo);
     v3 ap[4];
     float apPdf[4];
     hair_Ap(t, g.cosThetaO, g.T, ap, apPdf);
+    hair_eval_local_g(t, g, ap, apPdf, wi, f_cos, pdf);
+}
+SKH_DI v3 hair_sample_local_g(const HairTerms& t, const HairGeom& g, const float apPdf[4], float u0, float u1, float u2, float u3)
+{
     int p = 0;
     float u = u2;
     for (; p < 3; ++p)
@@ -1369,6 +1371,14 @@ SKH_DI v3 hair_sample_local(const HairTerms& t, const v3& wo, float u0, float u1
     const float dphi = p < 3 ? hair_Phi(p, g.gammaO, g.gammaT) + hair_sample_trimmed_logistic(u3, *t.c, -SKH_PI, SKH_PI) : 2.0f * SKH_PI * u3;
     const float phiI = g.phiO + dphi;
     return mk3(sinThetaI, cosThetaI * skm::cosf_(phiI), cosThetaI * skm::sinf_(phiI));
+}
+SKH_DI v3 hair_sample_local(const HairTerms& t, const v3& wo, float u0, float u1, float u2, float u3)
+{
+    const HairGeom g = hair_geom(t, wo);
+    v3 ap[4];
+    float apPdf[4];
+    hair_Ap(t, g.cosThetaO, g.T, ap, apPdf);
+    return hair_sample_local_g(t, g, apPdf, u0, u1, u2, u3);
 }
 SKH_DI bool hair_frame(const v3& normal, const v3& tangent_u, v3& X, v3& Y, v3& Z)
 {
@@ -1537,6 +1547,85 @@ SKH_DI void bsdf_sample(const Material& m, const v3& stN, const v3& stNg, const 
         return;
     }
 }
+// One hit of a HAIR material in k_shade's hair build: mdlcode_sample (what bsdf_sample<true> returns for m.type == 3) and, when the light sample's direction k2e is
+// worth evaluating, mdlcode_evaluate for it (what bsdf_evaluate<true> returns) -- the two calls of rounds 2-5 with the fibre frame, the outgoing direction's
+// geometry (atan2, two asin, three exp) and the attenuations A_p computed ONCE: the same operations on the same operands, so the same bits.
+SKH_DI void hair_sample_and_evaluate(const Material& m, const v3& stN, const v3& stNg, const v3& stT, const v3& k1, float xi0, float xi1, float xi2, float xi3,
+                                     const HairConst* hc, BsdfSample& out, bool wantEval, const v3& k2e, BsdfEval& ev)
+{
+    v3 N = stN, Ng = stNg;
+    if (dot(Ng, k1) < 0.0f)
+    {
+        N = -N;
+        Ng = -Ng;
+    }
+    out.k2 = mk3(0.0f);
+    out.bsdf_over_pdf = mk3(0.0f);
+    out.pdf = 0.0f;
+    out.event_type = EV_ABSORB;
+    ev.bsdf_diffuse = mk3(0.0f);
+    ev.bsdf_glossy = mk3(0.0f);
+    ev.pdf = 0.0f;
+    v3 X, Y, Z;
+    if (!hair_frame(stN, stT, X, Y, Z))
+        return;
+    const HairTerms t = hair_terms(m, *hc);
+    const v3 ho = mk3(dot(k1, X), dot(k1, Y), dot(k1, Z));
+    const HairGeom g = hair_geom(t, ho);
+    v3 ap[4];
+    float apPdf[4];
+    hair_Ap(t, g.cosThetaO, g.T, ap, apPdf);
+    if (wantEval)
+    {
+        const v3 hi = mk3(dot(k2e, X), dot(k2e, Y), dot(k2e, Z));
+        v3 fh;
+        float ph;
+        hair_eval_local_g(t, g, ap, apPdf, hi, fh, ph);
+        const float cosN = dot(k2e, N);
+        const float pd = cosN > 0.0f ? cosN / SKH_PI : 0.0f;
+        ev.bsdf_glossy = fh * (1.0f - t.diffuse_w);
+        ev.bsdf_diffuse = t.tint * (t.diffuse_w * pd);
+        ev.pdf = t.diffuse_w * pd + (1.0f - t.diffuse_w) * ph;
+    }
+    float u2 = xi2;
+    if (u2 < t.diffuse_w)
+    {
+        v3 b1, b2;
+        onb_from_z(N, b1, b2);
+        float cosT;
+        const v3 w = cosine_hemisphere(xi0, xi1, cosT);
+        const v3 k2 = normalize(w.x * b1 + w.y * b2 + w.z * N);
+        if (cosT <= 0.0f)
+            return;
+        const v3 hi = mk3(dot(k2, X), dot(k2, Y), dot(k2, Z));
+        v3 fh;
+        float ph;
+        hair_eval_local_g(t, g, ap, apPdf, hi, fh, ph);
+        const float pd = cosT / SKH_PI;
+        const float pdf = t.diffuse_w * pd + (1.0f - t.diffuse_w) * ph;
+        out.k2 = k2;
+        out.pdf = pdf;
+        out.bsdf_over_pdf = (t.tint * (t.diffuse_w * pd) + fh * (1.0f - t.diffuse_w)) / pdf;
+        out.event_type = EV_DIFFUSE | EV_REFLECTION;
+        return;
+    }
+    u2 = (u2 - t.diffuse_w) / (1.0f - t.diffuse_w);
+    const v3 hi = hair_sample_local_g(t, g, apPdf, xi0, xi1, u2, xi3);
+    v3 fh;
+    float ph;
+    hair_eval_local_g(t, g, ap, apPdf, hi, fh, ph);
+    const v3 k2 = normalize(hi.x * X + hi.y * Y + hi.z * Z);
+    const float cosN = dot(k2, N);
+    const float pd = cosN > 0.0f ? cosN / SKH_PI : 0.0f;
+    const float pdf = t.diffuse_w * pd + (1.0f - t.diffuse_w) * ph;
+    if (!(pdf > 0.0f) || !(ph > 0.0f))
+        return;
+    out.k2 = k2;
+    out.pdf = pdf;
+    out.bsdf_over_pdf = (t.tint * (t.diffuse_w * pd) + fh * (1.0f - t.diffuse_w)) / pdf;
+    out.event_type = EV_GLOSSY | EV_REFLECTION;
+}
+
 // mdlcode_evaluate equivalent
 template <bool HAIR>
 SKH_DI void bsdf_evaluate(const Material& m, const v3& stN, const v3& stNg, const v3& stT, const v3& k1, const v3& k2, bool inside, BsdfEval& out,

@@ -1891,7 +1891,72 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
                     const v3 k1 = -rayD;
                     BsdfSample bs;
                     SKH_SP(1) // hit reconstruction, material, textures, bsdf randoms
-                    bsdf_sample<HAIR>(mat, sh.normal, sh.geom_normal, stT, k1, xi0, xi1, xi2, xi3, inside, bs, HAIR ? sc.hairConst + (mid < sc.numMaterials ? mid : 0u) : nullptr);
+                    // estimateDirectLighting + sampleLight: closest_hit.cu:260-324 -- as a block of its own: a hit of a HAIR material (hair build) samples the light FIRST, so that
+                    // the BSDF's two evaluations for this k1 -- the sampled direction's and the light sample's -- share the fibre geometry (hair_sample_and_evaluate); every
+                    // other hit samples it where the reference does, behind the BSDF sample's event type.  The values do not depend on the order.
+                    v3 toLight = mk3(0.0f);
+                    float lightPdf = 0.0f;
+                    v3 lrad = mk3(0.0f);
+                    bool wantShadow = false;
+                    float distToLight = 0.0f;
+                    auto sampleLight = [&]() {
+                        if (sc.numLights > 0)
+                        {
+                            const float u = sampler_random_lut(smp, DIM_LIGHT_ID, s_sobol);
+                            const uint32_t lightId = (uint32_t)((float)sc.numLights * u);
+                            const float lightSelectionPdf = 1.0f / (float)sc.numLights;
+                            // the whole 112-byte record in one round trip (by reference its fields were fetched in three dependent
+                            // steps: type, then the branch's points, then colour / normal)
+                            const Light light = sc.lights[lightId];
+                            asm volatile("" ::"v"(light.points[0].x), "v"(light.points[1].x), "v"(light.points[2].x), "v"(light.points[3].x),
+                                         "v"(light.color.x), "v"(light.normal.x), "v"(light.type));
+                            const float ux = sampler_random_lut(smp, DIM_LIGHT_X, s_sobol), uy = sampler_random_lut(smp, DIM_LIGHT_Y, s_sobol);
+                            LightSample d;
+                            d.pointOnLight = mk3(0.0f);
+                            d.pdf = 0.0f;
+                            d.normal = mk3(0.0f);
+                            d.area = 0.0f;
+                            d.L = mk3(0.0f);
+                            d.distToLight = 0.0f;
+                            switch (light.type)
+                            {
+                            case 0:
+                                d = fp.rectMethod == 0 ? sample_rect_light_uniform(light, ux, uy, sh.position) :
+                                                         sample_rect_light(light, ux, uy, sh.position);
+                                break;
+                            case 2:
+                                d = sample_sphere_light(light, ux, uy, sh.position);
+                                break;
+                            case 3:
+                                d = sample_distant_light(light, ux, uy);
+                                break;
+                            default:
+                                break;
+                            }
+                            toLight = d.L;
+                            const v3 Li = mk3(light.color);
+                            if (dot(sh.normal, d.L) > 0.0f && -dot(d.L, d.normal) > 0.0f && all3(Li))
+                            {
+                                wantShadow = true;
+                                distToLight = d.distToLight;
+                                lightPdf = d.pdf;
+                                lrad = 1.0f * Li * saturatef(dot(sh.normal, d.L)); // visibility applied by k_trace<shadow>
+                            }
+                            lightPdf *= lightSelectionPdf;
+                        }
+                    };
+                    const bool hairHit = HAIR && mat.type == 3u;
+                    BsdfEval evHair;
+                    bool evHairDone = false;
+                    if (hairHit)
+                    {
+                        sampleLight();
+                        // (the evaluation is wanted exactly where the flow below would ask for it, should the sampled event not be an absorption)
+                        evHairDone = !(isnan3(lrad) || isnan(lightPdf)) && (((dot(toLight, sh.normal) > 0.0f) != inside) && lightPdf != 0.0f);
+                        hair_sample_and_evaluate(mat, sh.normal, sh.geom_normal, stT, k1, xi0, xi1, xi2, xi3, sc.hairConst + (mid < sc.numMaterials ? mid : 0u), bs, evHairDone, toLight, evHair);
+                    }
+                    else
+                        bsdf_sample<HAIR>(mat, sh.normal, sh.geom_normal, stT, k1, xi0, xi1, xi2, xi3, inside, bs, HAIR ? sc.hairConst + (mid < sc.numMaterials ? mid : 0u) : nullptr);
                     SKH_SP(2) // bsdf_sample
                     if (bs.event_type == EV_ABSORB)
                     {
@@ -1912,56 +1977,8 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
                         bool errorOut = false;
                         if (bs.event_type & (EV_DIFFUSE | EV_GLOSSY))
                         {
-                            // estimateDirectLighting + sampleLight: closest_hit.cu:260-324
-                            v3 toLight = mk3(0.0f);
-                            float lightPdf = 0.0f;
-                            v3 lrad = mk3(0.0f);
-                            bool wantShadow = false;
-                            float distToLight = 0.0f;
-                            if (sc.numLights > 0)
-                            {
-                                const float u = sampler_random_lut(smp, DIM_LIGHT_ID, s_sobol);
-                                const uint32_t lightId = (uint32_t)((float)sc.numLights * u);
-                                const float lightSelectionPdf = 1.0f / (float)sc.numLights;
-                                // the whole 112-byte record in one round trip (by reference its fields were fetched in three dependent
-                                // steps: type, then the branch's points, then colour / normal)
-                                const Light light = sc.lights[lightId];
-                                asm volatile("" ::"v"(light.points[0].x), "v"(light.points[1].x), "v"(light.points[2].x), "v"(light.points[3].x),
-                                             "v"(light.color.x), "v"(light.normal.x), "v"(light.type));
-                                const float ux = sampler_random_lut(smp, DIM_LIGHT_X, s_sobol), uy = sampler_random_lut(smp, DIM_LIGHT_Y, s_sobol);
-                                LightSample d;
-                                d.pointOnLight = mk3(0.0f);
-                                d.pdf = 0.0f;
-                                d.normal = mk3(0.0f);
-                                d.area = 0.0f;
-                                d.L = mk3(0.0f);
-                                d.distToLight = 0.0f;
-                                switch (light.type)
-                                {
-                                case 0:
-                                    d = fp.rectMethod == 0 ? sample_rect_light_uniform(light, ux, uy, sh.position) :
-                                                             sample_rect_light(light, ux, uy, sh.position);
-                                    break;
-                                case 2:
-                                    d = sample_sphere_light(light, ux, uy, sh.position);
-                                    break;
-                                case 3:
-                                    d = sample_distant_light(light, ux, uy);
-                                    break;
-                                default:
-                                    break;
-                                }
-                                toLight = d.L;
-                                const v3 Li = mk3(light.color);
-                                if (dot(sh.normal, d.L) > 0.0f && -dot(d.L, d.normal) > 0.0f && all3(Li))
-                                {
-                                    wantShadow = true;
-                                    distToLight = d.distToLight;
-                                    lightPdf = d.pdf;
-                                    lrad = 1.0f * Li * saturatef(dot(sh.normal, d.L)); // visibility applied by k_trace<shadow>
-                                }
-                                lightPdf *= lightSelectionPdf;
-                            }
+                            if (!hairHit)
+                                sampleLight();
                             if (isnan3(lrad) || isnan(lightPdf))
                             {
                                 radiance = mk3(10000.0f, 0.0f, 0.0f), radianceDirty = true;
@@ -1975,7 +1992,10 @@ __global__ void __launch_bounds__(SKH_SHADE_BLOCK) SKH_SHADE_ATTR(HAIR)
                                 {
                                     BsdfEval ev;
                                     SKH_SP(3) // light sampling
-                                    bsdf_evaluate<HAIR>(mat, sh.normal, sh.geom_normal, stT, k1, toLight, inside, ev, HAIR ? sc.hairConst + (mid < sc.numMaterials ? mid : 0u) : nullptr);
+                                    if (hairHit)
+                                        ev = evHair; // (evaluated beside the sample: evHairDone holds exactly when this branch is reached)
+                                    else
+                                        bsdf_evaluate<HAIR>(mat, sh.normal, sh.geom_normal, stT, k1, toLight, inside, ev, HAIR ? sc.hairConst + (mid < sc.numMaterials ? mid : 0u) : nullptr);
                                     SKH_SP(4) // bsdf_evaluate
                                     if (isnan3(ev.bsdf_diffuse) || isnan3(ev.bsdf_glossy))
                                     {
