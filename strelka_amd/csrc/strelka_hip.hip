@@ -180,7 +180,7 @@ struct skh_context
     skh_build_info buildInfo = {};
     uint32_t plocTop = 0; // triangle build: clusters left at which PLOC switches to the wide neighbour search (option ploc_top; 0 = never)
     uint32_t wavesPerCUWorld = 32; // the world-only closest-hit build: 64 VGPRs, 8 per SIMD (SKH_WORLD_CLOSEST_MIN_WAVES)
-    uint32_t smallWavesClosest = 16, smallWavesShadow = 16; // overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24
+    uint32_t smallWavesClosest = 0, smallWavesShadow = 0; // (0 = automatic: 20 / 12 for triangle scenes, 16 / 16 with curves -- there the any-hit launch is the heavier one: hair 1-spp calls 687 against 664 Mray/s) overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24; round 6: the closest-hit launch is the one on the critical path -- 20/12: 1-spp 1080p calls 3.49 -> 3.39 ms, drop-in +1 % (18/14 3.41, 22/10 3.48, 24/8 3.67: then the any-hit launch is the long one)
     uint32_t gridOverride = 0; // set by render_one around its launches
     uint32_t fetchMinClosest = 32 /* 24 until round 5: on the reinserted trees 32 is 0.4 ... 0.9 % ahead on all three kitchens, gpurun_out/r6c */, fetchMinShadow = 48; // idle lanes before a wave pulls new rays from the queue (round 3, world-space hierarchy: any-hit 32 -> 48: 39.7 -> 36.2 ms, 56: 37.5, 64: 51; closest 12..40 within 1 %)
     uint32_t curveFetchMinClosest = 16, curveFetchMinShadow = 16 /* 24 until the result writes got cheaper (round 5, late): hair any-hit 47.5-47.8 -> 46.5-47.0 ms with 12 ... 20, gpurun_out/r7v */, curveNodeBreakClosest = 20, curveNodeBreakShadow = 20; // the same four for the curve build (6 waves/SIMD): hair 482 vs 465 Mray/s
@@ -2537,7 +2537,10 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
     // (the world-only triangle builds run 8 waves per SIMD)
     const uint32_t fullGrid = (ANY && !c->nSegs) ? (uint32_t)c->numCUs * (worldOnly ? c->wavesPerCUShadowWorld : c->wavesPerCUShadow)
                                                  : (worldOnly ? (uint32_t)c->numCUs * c->wavesPerCUWorld : c->traceBlocks);
-    const uint32_t blocks = c->gridOverride ? std::min(c->gridOverride, fullGrid) : fullGrid;
+    // (overlapped small passes: small_waves_* are shares of a 32-wave CU; a build that fits fewer waves -- the curve builds: 24 -- takes the same share of what it fits,
+    // so that the two concurrent launches still fit side by side: hair 1-spp calls 651 -> ~680 Mray/s against an unscaled 20 / 12)
+    const uint32_t scaledOverride = (uint32_t)((uint64_t)c->gridOverride * fullGrid / (32u * (uint32_t)c->numCUs));
+    const uint32_t blocks = c->gridOverride ? std::max((uint32_t)c->numCUs, std::min(scaledOverride, fullGrid)) : fullGrid;
     // A hierarchy that fits the L2 many times over (Cornell: 30 triangles) makes rays so cheap that the launch is bound by the eight queue cursors'
     // atomics (~88 M per second and address): such scenes reserve 128 positions per atomic (Cornell 13.5 -> 14.8 Gray/s).  Larger scenes lose by it
     // (neighbouring rays are then traced at different times by one wave instead of together by neighbouring waves: kitchen -1 %, hair -2 %;
@@ -2673,7 +2676,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
         {
             {
                 SpanGuard g(c, KC_TRACE_CLOSEST);
-                c->gridOverride = (useOverlap && smallPass) ? c->smallWavesClosest * (uint32_t)c->numCUs : 0u;
+                c->gridOverride = (useOverlap && smallPass) ? (c->smallWavesClosest ? c->smallWavesClosest : (c->nSegs ? 16u : 20u)) * (uint32_t)c->numCUs : 0u;
                 if (c->countTraversal)
                     launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, hq, ps, nullptr);
                 else
@@ -2705,7 +2708,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                 }
                 {
                     SpanGuard g(c, KC_TRACE_SHADOW, sst);
-                    c->gridOverride = (useOverlap && smallPass) ? c->smallWavesShadow * (uint32_t)c->numCUs : 0u;
+                    c->gridOverride = (useOverlap && smallPass) ? (c->smallWavesShadow ? c->smallWavesShadow : (c->nSegs ? 16u : 12u)) * (uint32_t)c->numCUs : 0u;
                     if (c->countTraversal)
                         launch_trace<true, true>(c, sc, shq, counts + (2 * b + 1) * QW, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, nohq, ps, c->dContrib.as<float4>(), sst);
                     else
