@@ -356,6 +356,7 @@ SCENE_RECIPES = {
     "hair_2_moved": (lambda scenes: scenes.hair_standin(n_prims=2, prim_offset=1e-3), "hair stand-in as 2 curve prims under translations: %d scalp triangles, %d instances of %d meshes + 100 k strands"),
     "hair_4_moved": (lambda scenes: scenes.hair_standin(n_prims=4, prim_offset=1e-3), "hair stand-in as 4 curve prims under translations: %d scalp triangles, %d instances of %d meshes + 100 k strands"),
     "hair_8_moved": (lambda scenes: scenes.hair_standin(n_prims=8, prim_offset=1e-3), "hair stand-in as 8 curve prims under translations: %d scalp triangles, %d instances of %d meshes + 100 k strands"),
+    "hair_17_xform": (lambda scenes: scenes.hair_standin(n_prims=17, prim_offset=0.25, shared_xform=True), "hair stand-in as 17 curve prims under ONE rotation + translation: %d scalp triangles, %d instances of %d meshes + 100 k strands"),
     "hair_17_moved": (lambda scenes: scenes.hair_standin(n_prims=17, prim_offset=1e-3), "hair stand-in as 17 curve prims under translations: %d scalp triangles, %d instances of %d meshes + 100 k strands"),
     "cornell": (lambda scenes: scenes.cornell_box(), "cornell box (C2): %d triangles, %d instances of %d meshes"),
 }
@@ -529,7 +530,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--tile", type=int, default=32)
-    ap.add_argument("--scene", default="kitchen", help="kitchen | kitchen_unshared | kitchen_arch | cornell | hair | hair_8 | hair_16 | hair_17 | hair_17_moved | path to a .skscene dump or a .gltf file")
+    ap.add_argument("--scene", default="kitchen", help="kitchen | kitchen_unshared | kitchen_arch | cornell | hair | hair_8 | hair_16 | hair_17 | hair_17_xform | hair_17_moved | path to a .skscene dump or a .gltf file")
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to skh_set_option")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -728,7 +729,7 @@ def main():
         # the same groom split into several curve prims: Mray/s and what each ray costs
         extra["hair_multi"] = {name: {k: v for k, v in other_workload_leg(name, W, H, args.spp, 3, local_rank).items()
                                       if k in ("workload", "value", "unit", "ms_per_step", "kernel_ms_per_frame", "per_ray", "per_shadow_ray", "bvh_build_ms")}
-                               for name in ("hair_8", "hair_16", "hair_17", "hair_17_moved")}
+                               for name in ("hair_8", "hair_16", "hair_17", "hair_17_xform", "hair_17_moved")}
     if rank == 0:
         K = max(1, args.steps)
         # ---- rooflines of the three hot kernels.  Per kernel, from this run's counters and hipEvent times:

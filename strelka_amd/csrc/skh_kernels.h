@@ -49,6 +49,7 @@ struct DevScene
     int worldCurveRoot[SKH_WORLD_CURVES];
     uint32_t worldCurveInst[SKH_WORLD_CURVES]; // ... and instance ids
     uint32_t worldCurveIdentLast; // 1: the LAST entry's instance sits under a bit-exact identity transform (the host puts such an instance last)
+    uint32_t worldCurveMerged; // bit k: entry k is a MERGED group of curve instances under one transform -- worldCurveInst[k] lends the transform, a hit takes its instance from segInst
     uint32_t numInstances;
     const DevInstance* inst; // per instance (shading side: w2o)
     const DevInstance* tinst; // per TLAS leaf: (instance, BLAS subtree) after opening; pad = instance id
@@ -61,7 +62,7 @@ struct DevScene
     const float4* segs; // 4 x float4 per segment, leaf order
     const uint32_t* segPrim; // leaf order -> segment index inside its curve set
     const float4* segBound; // 2 x float4 per leaf record: bounding cylinder {A, R}, {unit axis, 0}
-    const uint32_t* segInst; // leaf order -> the instance a MERGED segment belongs to (curve instances under identity transforms share one world-space tree: curInst == ~0 there)
+    const uint32_t* segInst; // leaf order -> the instance a MERGED segment belongs to (curve instances under one transform share one tree: curInst == ~0 there)
     uint32_t curveSplit; // parameter sub-ranges per segment (sub-range in segPrim >> 28)
     // shading side
     const HostInstance* instances; // shading copy: for mesh instances `light` holds the mesh's first record in shadeTris
@@ -456,7 +457,8 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
 #define SKH_TAKE_MARKER()                                                                                         \
     {                                                                                                             \
         const uint32_t k = (uint32_t)cur & 0xffffu;                                                               \
-        curInst = sc.worldCurveInst[k];                                                                           \
+        const uint32_t xinst = sc.worldCurveInst[k]; /* whose transform the entry is entered through */          \
+        curInst = ((sc.worldCurveMerged >> k) & 1u) ? 0xffffffffu : xinst; /* ~0: the segment record names the instance */ \
         if ((uint32_t)cur & SKH_REF_CURVEROOT_IDENT)                                                              \
         {                                                                                                         \
             /* a bit-exact identity transform (the common bake): the world ray is still in (o, d); it goes through the identity as it would */ \
@@ -467,7 +469,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
         }                                                                                                         \
         else                                                                                                      \
         {                                                                                                         \
-            const float4* ip = reinterpret_cast<const float4*>(sc.inst + curInst);                                \
+            const float4* ip = reinterpret_cast<const float4*>(sc.inst + xinst);                                  \
             const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2];                                                      \
             const v3 wo = mk3(rq.plane(0)[ridx], rq.plane(1)[ridx], rq.plane(2)[ridx]);                           \
             const v3 wd = mk3(rq.plane(3)[ridx], rq.plane(4)[ridx], rq.plane(5)[ridx]);                           \

@@ -163,6 +163,7 @@ struct skh_context
     uint32_t numWorldCurves = 0; // curve instances under identity transforms that the world-only kernel walks itself (skh_build_accel)
     int worldCurveRoot[SKH_WORLD_CURVES];
     uint32_t worldCurveInst[SKH_WORLD_CURVES];
+    uint32_t worldCurveMerged = 0; // bit k: table entry k is a merged transform group (its hits take their instance from the segment record)
     uint32_t worldCurveIdentLast = 0;
     uint32_t hierNodes = 0;  // 4-wide nodes of the triangle and curve trees (skh_build_accel): decides the automatic fetch_chunk
     int32_t fetchChunk = -1; // option fetch_chunk: queue positions a trace wave reserves per atomic; 0 = one atomic per refill; -1 = automatic
@@ -1451,7 +1452,8 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     // RAY_MASK_SHADOW, closest_hit.cu:191) -- the ray mask stays a property of the group, not of the triangle
     std::vector<uint32_t> wInst, wFirst;
     bool worldCurves = false;
-    std::vector<uint32_t> worldCurveInst, mergedCurveInst; // instances with a table entry of their own / merged into the one world-space curve tree
+    std::vector<uint32_t> worldCurveInst; // curve instances with a table entry (and their set's tree) of their own
+    std::vector<std::vector<uint32_t>> mergedGroups; // ... and the groups of equal transforms whose segments share one tree each
     uint32_t nBakedG[2] = { 0, 0 };
     {
         uint64_t uniqueTris = 0;
@@ -1531,24 +1533,31 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         for (uint32_t i = 0; i < nInst; ++i)
             if (c->instances[i].type == SKH_INSTANCE_LIGHT && eligible(i) && !pick[i])
                 lightsAllPicked = false;
-        // (round 6) Curve instances under a BIT-EXACT IDENTITY transform -- a groom handed over as several HdBasisCurves rprims -- do not take a
-        // table entry each: their segments are MERGED into one world-space curve tree (group 0 of the curve build, the segment records name
-        // their instance), which takes ONE entry.  Walking 8 / 16 per-prim trees one after the other cost the hair stand-in 33 % / 50 % of its
-        // rate (each ray visits every tree's root and whatever overlaps: 40 / 53 instead of 28 nodes per radiance ray), docs/LOG.md.
-        std::vector<uint32_t> identInst, otherInst;
+        // (round 6) Curve instances under the SAME transform, bit for bit -- a groom handed over as several HdBasisCurves rprims, under the identity or
+        // under the one Xform the whole character sits under -- do not take a table entry each: the segments of such a group are MERGED into one
+        // curve tree in the group's object space (the first groups of the curve build; the segment records name their instance), which takes ONE
+        // entry and is entered through the group's one transform.  Walking 8 / 16 per-prim trees one after the other cost the hair stand-in 33 % /
+        // 50 % of its rate (each ray visits every tree's root and whatever overlaps: 40 / 53 instead of 28 nodes per radiance ray), docs/LOG.md.
+        std::vector<std::vector<uint32_t>> xformGroups; // curve instances by transform, in order of first appearance
+        for (uint32_t i : curveInst)
         {
-            static const float kIdent[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
-            for (uint32_t i : curveInst)
-                (memcmp(c->instances[i].transform, kIdent, sizeof(kIdent)) == 0 ? identInst : otherInst).push_back(i);
+            size_t g = 0;
+            for (; g < xformGroups.size(); ++g)
+                if (memcmp(c->instances[xformGroups[g][0]].transform, c->instances[i].transform, sizeof(float) * 12) == 0)
+                    break;
+            if (g == xformGroups.size())
+                xformGroups.emplace_back();
+            xformGroups[g].push_back(i);
         }
-        worldCurves = !meshStays && !curveInst.empty() && otherInst.size() + (identInst.empty() ? 0u : 1u) <= SKH_WORLD_CURVES && lightsAllPicked;
+        worldCurves = !meshStays && !curveInst.empty() && xformGroups.size() <= SKH_WORLD_CURVES && lightsAllPicked;
         if (worldCurves)
         {
-            // option curve_merge = 0 (A/B, tests): identity instances keep a tree and a table entry each while the table can hold them all
+            // option curve_merge = 0 (A/B, tests): every instance keeps a tree and a table entry of its own while the table can hold them all
             const bool merge = c->curveMerge || curveInst.size() > SKH_WORLD_CURVES;
-            worldCurveInst = merge ? otherInst : curveInst;
             if (merge)
-                mergedCurveInst = identInst;
+                mergedGroups = xformGroups;
+            else
+                worldCurveInst = curveInst;
         }
         const bool tlasStays = meshStays || (!curveInst.empty() && !worldCurves);
         for (uint32_t i = 0; i < nInst; ++i)
@@ -1744,45 +1753,47 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         }
     const bool worldCurveKernel = worldCurves && c->worldKernel && !othersInTlas;
     if (!worldCurveKernel)
-        mergedCurveInst.clear(); // (every curve instance keeps its TLAS leaf and its set's own tree)
-    // The curve build's primitives, group after group: group 0 = the segments of the MERGED instances (identity transforms: object space is world
-    // space; the record names the instance), group 1 + s = curve set s (skipped when every instance of the set was merged).
+        mergedGroups.clear(); // (every curve instance keeps its TLAS leaf and its set's own tree)
+    // The curve build's primitives, group after group: groups [0, SKH_WORLD_CURVES) = the segments of the MERGED transform groups (object space of the
+    // group's transform; the record names the instance), group SKH_WORLD_CURVES + s = curve set s (skipped when every instance of the set was merged).
     std::vector<uint32_t> segStart, segCurve, segLocal, segInstOf;
-    std::vector<uint32_t> curveGroupCount(nCurves + 1u, 0u);
+    std::vector<uint32_t> curveGroupCount(nCurves + SKH_WORLD_CURVES, 0u);
     {
-        std::vector<uint8_t> setNeeded(nCurves, mergedCurveInst.empty() ? 1 : 0);
-        if (!mergedCurveInst.empty())
+        std::vector<uint8_t> setNeeded(nCurves, mergedGroups.empty() ? 1 : 0);
+        if (!mergedGroups.empty())
         {
             std::vector<uint8_t> isMerged(std::max(1u, nInst), 0);
-            for (uint32_t i : mergedCurveInst)
-                isMerged[i] = 1;
+            for (const auto& grp : mergedGroups)
+                for (uint32_t i : grp)
+                    isMerged[i] = 1;
             for (uint32_t i = 0; i < nInst; ++i)
                 if (c->instances[i].type == SKH_INSTANCE_CURVE && !isMerged[i] && c->instances[i].geom_id < nCurves)
                     setNeeded[c->instances[i].geom_id] = 1;
         }
-        for (uint32_t i : mergedCurveInst)
-        {
-            const uint32_t ci = c->instances[i].geom_id;
-            for (uint32_t l = 0; l < curveSegCount[ci]; ++l)
+        for (size_t g = 0; g < mergedGroups.size(); ++g)
+            for (uint32_t i : mergedGroups[g])
             {
-                segStart.push_back(setSegStart[curveSegBase[ci] + l]);
-                segCurve.push_back(0u);
-                segLocal.push_back(l);
-                segInstOf.push_back(i);
+                const uint32_t ci = c->instances[i].geom_id;
+                for (uint32_t l = 0; l < curveSegCount[ci]; ++l)
+                {
+                    segStart.push_back(setSegStart[curveSegBase[ci] + l]);
+                    segCurve.push_back((uint32_t)g);
+                    segLocal.push_back(l);
+                    segInstOf.push_back(i);
+                }
+                curveGroupCount[g] += curveSegCount[ci];
             }
-            curveGroupCount[0] += curveSegCount[ci];
-        }
         for (uint32_t ci = 0; ci < nCurves; ++ci)
             if (setNeeded[ci])
             {
                 for (uint32_t l = 0; l < curveSegCount[ci]; ++l)
                 {
                     segStart.push_back(setSegStart[curveSegBase[ci] + l]);
-                    segCurve.push_back(1u + ci);
+                    segCurve.push_back(SKH_WORLD_CURVES + ci);
                     segLocal.push_back(l);
                     segInstOf.push_back(0xffffffffu);
                 }
-                curveGroupCount[1u + ci] = curveSegCount[ci];
+                curveGroupCount[SKH_WORLD_CURVES + ci] = curveSegCount[ci];
             }
     }
     const uint32_t nSegs = (uint32_t)segStart.size();
@@ -1802,7 +1813,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         return SKH_INVALID_ARGUMENT;
     }
     const uint32_t nSub = nSegs * K;
-    const uint32_t nCurveGroups = nCurves + 1u; // [0] the merged world-space curves, [1 + s] curve set s
+    const uint32_t nCurveGroups = nCurves + SKH_WORLD_CURVES; // [0, SKH_WORLD_CURVES) the merged transform groups, [SKH_WORLD_CURVES + s] curve set s
     std::vector<uint32_t> curveSubCount(nCurveGroups);
     for (uint32_t g = 0; g < nCurveGroups; ++g)
         curveSubCount[g] = curveGroupCount[g] * K;
@@ -1862,23 +1873,23 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     c->curveRefitReady = !segNode;
     // world curves: walked from the world-only kernel (option world_kernel; without it they keep their TLAS leaves: same hit records).  Decided BEFORE the
     // validity flags go to the device: both TLAS builders then agree on which instances have a leaf.
-    std::vector<int> curveSetRoot(nCurves, SKH_REF_INVALID); // root of curve set s's own tree (group 1 + s)
+    std::vector<int> curveSetRoot(nCurves, SKH_REF_INVALID); // root of curve set s's own tree (group SKH_WORLD_CURVES + s)
     for (uint32_t ci = 0; ci < nCurves; ++ci)
-        curveSetRoot[ci] = segOut.hostGroupRoot[1u + ci];
+        curveSetRoot[ci] = segOut.hostGroupRoot[SKH_WORLD_CURVES + ci];
     c->numWorldCurves = 0;
     c->worldCurveIdentLast = 0;
+    c->worldCurveMerged = 0;
+    c->numMergedCurveInst = 0;
     if (worldCurveKernel)
     {
-        // (an instance under a bit-exact identity transform goes LAST in the table = first off every ray's stack: the kernel skips its matrix fetch.  With
-        // merged curves that entry is the merged tree's; without -- curve_merge 0 -- one identity instance is moved there)
+        // (an entry under a bit-exact identity transform goes LAST in the table = first off every ray's stack: the kernel skips its matrix fetch)
         static const float kIdentity[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
-        if (mergedCurveInst.empty())
-            for (size_t k = 0; k + 1 < worldCurveInst.size(); ++k)
-                if (memcmp(c->instances[worldCurveInst[k]].transform, kIdentity, sizeof(kIdentity)) == 0)
-                {
-                    std::swap(worldCurveInst[k], worldCurveInst.back());
-                    break;
-                }
+        for (size_t k = 0; k + 1 < worldCurveInst.size(); ++k)
+            if (memcmp(c->instances[worldCurveInst[k]].transform, kIdentity, sizeof(kIdentity)) == 0)
+            {
+                std::swap(worldCurveInst[k], worldCurveInst.back());
+                break;
+            }
         for (uint32_t i : worldCurveInst)
         {
             const int root = c->instances[i].geom_id < nCurves ? curveSetRoot[c->instances[i].geom_id] : SKH_REF_INVALID;
@@ -1889,16 +1900,26 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
             c->worldCurveIdentLast = memcmp(c->instances[i].transform, kIdentity, sizeof(kIdentity)) == 0 ? 1u : 0u; // (of the last one entered)
             valid[i] = 0; // no TLAS leaf
         }
-        if (!mergedCurveInst.empty() && segOut.hostGroupRoot[0] != SKH_REF_INVALID)
+        std::vector<size_t> order; // merged groups: the identity group last
+        for (size_t g = 0; g < mergedGroups.size(); ++g)
+            if (memcmp(c->instances[mergedGroups[g][0]].transform, kIdentity, sizeof(kIdentity)) != 0)
+                order.push_back(g);
+        for (size_t g = 0; g < mergedGroups.size(); ++g)
+            if (memcmp(c->instances[mergedGroups[g][0]].transform, kIdentity, sizeof(kIdentity)) == 0)
+                order.push_back(g);
+        for (size_t g : order)
         {
-            c->worldCurveRoot[c->numWorldCurves] = segOut.hostGroupRoot[0];
-            c->worldCurveInst[c->numWorldCurves++] = 0xffffffffu; // = "the segment record names the instance" (DevScene::segInst)
-            c->worldCurveIdentLast = 1u;
-            for (uint32_t i : mergedCurveInst)
+            for (uint32_t i : mergedGroups[g])
                 valid[i] = 0;
+            if (segOut.hostGroupRoot[g] == SKH_REF_INVALID)
+                continue;
+            c->worldCurveMerged |= 1u << c->numWorldCurves; // = "the segment record names the instance" (DevScene::segInst); the entry's instance lends its transform
+            c->worldCurveRoot[c->numWorldCurves] = segOut.hostGroupRoot[g];
+            c->worldCurveInst[c->numWorldCurves++] = mergedGroups[g][0];
+            c->worldCurveIdentLast = memcmp(c->instances[mergedGroups[g][0]].transform, kIdentity, sizeof(kIdentity)) == 0 ? 1u : 0u;
+            c->numMergedCurveInst += (uint32_t)mergedGroups[g].size();
         }
     }
-    c->numMergedCurveInst = worldCurveKernel ? (uint32_t)mergedCurveInst.size() : 0u;
     // ---- instances -> TLAS (baked instances were marked invalid above: they get a record for shading, no leaf) ----
     BA(dev_upload(c, dW2o, w2o.data(), sizeof(float) * w2o.size()));
     BA(dev_upload(c, dValid, valid.data(), valid.size()));
@@ -1906,7 +1927,7 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
     if (nInst)
         k_instance_boxes<<<(nInst + B - 1) / B, B, 0, st>>>(c->dInstances.as<HostInstance>(), dW2o.as<float>(), dValid.as<uint8_t>(),
                                                            triOut.groupBounds.as<float>(), triOut.groupRoot.as<int>(),
-                                                           segOut.groupBounds.as<float>() + 6, segOut.groupRoot.as<int>() + 1 /* curve set s = group 1 + s */, nMeshes, nCurves,
+                                                           segOut.groupBounds.as<float>() + 6 * SKH_WORLD_CURVES, segOut.groupRoot.as<int>() + SKH_WORLD_CURVES /* curve set s = group SKH_WORLD_CURVES + s */, nMeshes, nCurves,
                                                            nInst, c->dDevInst.as<DevInstance>(), dBoxLo.as<float4>(),
                                                            dBoxHi.as<float4>(), dGrp.as<uint32_t>());
     if (nInst > 0 && c->tightInstanceBoxes)
@@ -2455,6 +2476,7 @@ static DevScene make_dev_scene(const skh_context* c)
     sc.tlasRoot = c->tlasRoot;
     sc.numWorldCurves = c->numWorldCurves;
     sc.worldCurveIdentLast = c->worldCurveIdentLast;
+    sc.worldCurveMerged = c->worldCurveMerged;
     for (uint32_t k = 0; k < SKH_WORLD_CURVES; ++k)
         sc.worldCurveRoot[k] = k < c->numWorldCurves ? c->worldCurveRoot[k] : SKH_REF_INVALID, sc.worldCurveInst[k] = k < c->numWorldCurves ? c->worldCurveInst[k] : 0u;
     sc.numInstances = c->nInstances;

@@ -405,14 +405,15 @@ def kitchen_architectural(seed=4321, n_objects=1500, target_tris=1.6e6):
     return sc
 
 
-def hair_standin(seed=77, n_strands=100000, n_cp=16, n_prims=1, prim_offset=0.0, n_moved=None):
+def hair_standin(seed=77, n_strands=100000, n_cp=16, n_prims=1, prim_offset=0.0, n_moved=None, shared_xform=False):
     """C5 "hair stand-in" (SURVEY 8d): strands rooted on a unit sphere, length U[0.3,0.6], gravity-bent, root radius
     4e-4 -> tip 1e-4, +2 phantom points per strand (BasisCurves.cpp:189-232); one ~5 k-triangle scalp mesh; 2 rect
     lights; hair BSDF.
     n_prims > 1: the SAME strands handed over as n_prims curve sets, one instance each (a groom authored as several HdBasisCurves
     rprims: RenderPass.cpp:281 makes one oka::Curve + one instance per rprim) -- cut by azimuth around the head, so that a prim is a
     region of the scalp; prim_offset != 0 gives prim k (all of them, or the first n_moved) the translation (k + 1) * prim_offset along x
-    instead of the identity (the strands are moved back by the same amount first, in float64, so the picture stays what it was to ~1e-7)."""
+    instead of the identity (the strands are moved back by the same amount first, in float64, so the picture stays what it was to ~1e-7);
+    shared_xform: the moved prims all sit under ONE transform -- a rotation about y + the translation: the groom of a character under an Xform."""
     rs = np.random.RandomState(seed)
     sc = S.Scene()
     sc.addMaterial(S.MAT_DIFFUSE, (0.6, 0.5, 0.45))
@@ -448,8 +449,16 @@ def hair_standin(seed=77, n_strands=100000, n_cp=16, n_prims=1, prim_offset=0.0,
         order = np.argsort(ph, kind="stable")
         for k, chunk in enumerate(np.array_split(order, n_prims)):
             moved = prim_offset != 0.0 and (n_moved is None or k < n_moved)
-            off = np.array([(k + 1) * prim_offset if moved else 0.0, 0.0, 0.0])
             counts = np.full(len(chunk), n_cp + 2, np.uint32)
+            if moved and shared_xform:
+                M = S.translate((prim_offset, 0.5 * prim_offset, 0.0)) @ S.rotate((0, 1, 0), 0.3)
+                Mi = np.linalg.inv(M)
+                p = pts[chunk].reshape(-1, 3)
+                p = p @ Mi[:3, :3].T + Mi[:3, 3]
+                cid = sc.createCurve(counts, p, rad[chunk].reshape(-1))
+                sc.createInstance(S.INSTANCE_CURVE, cid, hair, M)
+                continue
+            off = np.array([(k + 1) * prim_offset if moved else 0.0, 0.0, 0.0])
             cid = sc.createCurve(counts, (pts[chunk] - off).reshape(-1, 3), rad[chunk].reshape(-1))
             sc.createInstance(S.INSTANCE_CURVE, cid, hair, S.translate(tuple(off)) if moved else np.eye(4))
     for pos, rot in [((2.5, 2.5, 2.5), (-45, 45, 0)), ((-3.0, 1.5, 1.0), (-20, -70, 0))]:

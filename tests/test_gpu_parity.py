@@ -533,18 +533,21 @@ print("SEGNODE-OK")
     assert out.returncode == 0 and "SEGNODE-OK" in out.stdout, out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("n_prims,n_moved,merge", [(5, 1, 1), (5, 1, 0), (2, 0, 0), (2, 2, 1), (3, 2, 1), (8, 0, 1), (20, 0, 1), (20, 3, 1), (20, 18, 1), (1, 0, 1)])
+@pytest.mark.parametrize("n_prims,n_moved,merge", [(5, 1, 1), (5, 1, 0), (2, 0, 0), (2, 2, 1), (3, 2, 1), (8, 0, 1), (20, 0, 1), (20, 3, 1), (20, 18, 1), (1, 0, 1),
+                                                   (8, -8, 1), (8, -3, 1), (8, -3, 0), (2, -2, 1)])
 def test_groom_split_into_several_curve_prims_is_exact(n_prims, n_moved, merge):
     """Round 6: curve instances under bit-exact identity transforms are MERGED into one world-space curve tree of the world-only curve kernel (its
     segment records name their instance); the others keep a tree and a table entry each (<= 2 entries, the merged tree counting once -- the
     integer rule the checker shares, it decides which light proxies are baked); more than that falls back to the two-level kernel.  The same
     strands as 1 / 2 / 3 / 5 / 8 / 20 prims, some under translations, with and without merging (curve_merge): merged + one marker, two identity markers,
-    two moved markers, the two-level fallback (3 entries; 20 prims with 3 / 18 moved), 8 and 20 merged prims, one prim -- hit records (closest + any-hit)
-    and a render equal to the oracle's."""
+    two moved markers, the two-level fallback (3 entries; 20 prims with 3 / 18 moved), 8 and 20 merged prims, one prim; and groups under a SHARED non-identity
+    transform (a rotation + translation): all 8 prims under it (one merged tree entered through the transform), 3 of 8 (two merged groups), the same unmerged -> merged
+    anyway (8 instances do not fit two entries), 2 prims both under it -- hit records (closest + any-hit) and a render equal to the oracle's."""
     from strelka_amd import capi
     from tests import orklib
 
-    sc = scenes.hair_standin(seed=5, n_strands=1500, n_cp=8, n_prims=n_prims, prim_offset=0.01 if n_moved else 0.0, n_moved=n_moved)
+    # (n_moved < 0: that many prims under ONE shared transform -- a rotation + translation --: a second merged group beside the identity one, or the only one)
+    sc = scenes.hair_standin(seed=5, n_strands=1500, n_cp=8, n_prims=n_prims, prim_offset=0.01 if n_moved else 0.0, n_moved=abs(n_moved), shared_xform=n_moved < 0)
     arr = sc.arrays()
     assert (arr["instances"]["type"] == S.INSTANCE_CURVE).sum() == n_prims
     o = orklib.new_context()

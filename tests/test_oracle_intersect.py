@@ -454,7 +454,7 @@ def test_world_curves_rule_decides_the_light_proxies():
     the product walks their trees from the world-only kernel, each instance's transform applied to the ray as at a TLAS leaf -- and the light
     proxies follow the meshes into world space.  The rule is an integer rule both sides evaluate; here the checker's side: one curve instance,
     under any transform -> lights baked; 16 or 17 copies under the identity (one merged tree) -> baked; the merged tree + one moved instance, or
-    two moved instances (two trees) -> baked; three instances under transforms of their own, or bake mode 1 (the shared light quad stays
+    two moved instances (two trees) -> baked; five instances under ONE non-identity transform (one merged tree) -> baked; three instances under transforms of their own, or bake mode 1 (the shared light quad stays
     behind) -> not.  The curves' own hit records never depend on it: closest hits equal the unbaked context's."""
     from tests.test_gpu_parity import camera_rays
 
@@ -474,7 +474,7 @@ def test_world_curves_rule_decides_the_light_proxies():
     o_id, b = baked_lights(arr)
     assert b == [1, 1]
     rays = np.concatenate([camera_rays(sc, 48, 48, 20000, 3), scenes.random_rays(20000, 4, -1.5, 1.5)])
-    for change, want in (("rotate", [1, 1]), ("mode1", [0, 0]), ("many", [1, 1]), ("sixteen", [1, 1]), ("merged+1", [1, 1]), ("2 moved", [1, 1]), ("3 moved", [0, 0])):
+    for change, want in (("rotate", [1, 1]), ("mode1", [0, 0]), ("many", [1, 1]), ("sixteen", [1, 1]), ("merged+1", [1, 1]), ("2 moved", [1, 1]), ("3 moved", [0, 0]), ("5 under one transform", [1, 1])):
         a2 = dict(arr)
         i2 = inst.copy()
         mode = 4
@@ -484,6 +484,10 @@ def test_world_curves_rule_decides_the_light_proxies():
             i2["transform"][curves[0]] = (S.translate((0.1, -0.2, 0.05)) @ m @ S.rotate((0, 1, 0), 0.3) @ S.scale((1.0, 0.7, 1.3)))[:3].astype(np.float32).reshape(12)
         elif change == "mode1":
             mode = 1
+        elif change == "5 under one transform":
+            M = (S.translate((0.1, 0.0, -0.05)) @ S.rotate((0, 1, 0), 0.4))[:3].astype(np.float32).reshape(12)
+            i2 = np.concatenate([i2, np.repeat(i2[curves[:1]], 4)])
+            i2["transform"][i2["type"] == S.INSTANCE_CURVE] = M
         elif change in ("many", "sixteen"):
             i2 = np.concatenate([i2, np.repeat(i2[curves[:1]], 16 if change == "many" else 15)])
         else:

@@ -16,7 +16,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     elif kind == 1:
         # (round 6: the same strands as 1..5 curve prims, some of them under translations -- merged world-space tree, markers, two-level fallback)
         npr = 1 + (seed // 4) % 5
-        sc = scenes.hair_standin(seed=seed, n_strands=400 + 50 * (seed % 9), n_cp=6 + seed % 5, n_prims=npr, prim_offset=0.01 if (seed // 20) % 2 else 0.0, n_moved=(seed // 40) % (npr + 1))
+        sc = scenes.hair_standin(seed=seed, n_strands=400 + 50 * (seed % 9), n_cp=6 + seed % 5, n_prims=npr, prim_offset=0.01 if (seed // 20) % 2 else 0.0, n_moved=(seed // 40) % (npr + 1), shared_xform=bool((seed // 80) % 2))
     elif kind == 2:
         sc = thick_curves(seed=seed, n_strands=30 + seed % 40, n_cp=5 + seed % 6)
     else:

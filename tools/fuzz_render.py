@@ -28,7 +28,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         sc = scenes.kitchen_standin(seed=seed, n_meshes=8 + seed % 7, n_instances=30 + 11 * (seed % 5), tri_lo=50, tri_hi=2000)
     elif kind == 1:
         npr = 1 + (seed // 7) % 4  # (round 6: 1..4 curve prims, some moved)
-        sc = scenes.hair_standin(seed=seed, n_strands=300 + 40 * (seed % 9), n_cp=6 + seed % 5, n_prims=npr, prim_offset=0.01 if (seed // 28) % 2 else 0.0, n_moved=(seed // 56) % (npr + 1))
+        sc = scenes.hair_standin(seed=seed, n_strands=300 + 40 * (seed % 9), n_cp=6 + seed % 5, n_prims=npr, prim_offset=0.01 if (seed // 28) % 2 else 0.0, n_moved=(seed // 56) % (npr + 1), shared_xform=bool((seed // 112) % 2))
     elif kind == 2:
         sc = thick_curves(seed=seed, n_strands=20 + seed % 30, n_cp=5 + seed % 6)
         sc.createLight({"type": 0, "useXform": False, "position": (0.0, 3.0, 1.0), "orientation": (-70.0, 0.0, 0.0), "width": 2.0, "height": 2.0,
