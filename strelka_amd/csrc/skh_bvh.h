@@ -282,6 +282,9 @@ __global__ void k_seg_boxes(const float* __restrict__ points, const float* __res
 // sub-range rule of the Newton block (a sub-range leaf keeps a hit only if u is its own) is gone.  Boxes stay conservative, intersect_curve_segment
 // decides: same hit records.  A reference with SKH_REF_SEGNODE set indexes the node array like any other (low 28 bits).
 #define SKH_REF_SEGNODE 0x10000000
+#ifndef SKH_SEG_STRIDE
+#define SKH_SEG_STRIDE 8 // float4 per curve leaf record: 4 control points, 2 of bounding cylinder, 1 of ids, 1 spare (skh_kernels.h DevScene::segs)
+#endif
 #define SKH_SEGNODE_K 4u
 // box of a whole segment for the tree above the segment nodes = the union of its sub-range boxes (so a segment node's children lie inside what its parent stores for it)
 __global__ void k_seg_union_boxes(const float* __restrict__ points, const float* __restrict__ radii, const uint32_t* __restrict__ segStart,
@@ -902,7 +905,7 @@ __global__ void __launch_bounds__(256) k_node4_refit_level(Node4* __restrict__ n
 }
 // the same for a CURVE tree: a leaf's box = the union of its sub-segments' boxes, recomputed as k_seg_boxes computes them -- the Bezier hull of the
 // (padded) parameter sub-range of the segment's current control points, grown by the radius margin -- from the leaf records k_gather_segs wrote
-SKH_DI void curve_ref_box(int ref, const float4* __restrict__ segs, const uint32_t* __restrict__ segPrim, uint32_t K, const float4* __restrict__ nodeBox, float4& lo, float4& hi)
+SKH_DI void curve_ref_box(int ref, const float4* __restrict__ segs, uint32_t K, const float4* __restrict__ nodeBox, float4& lo, float4& hi)
 {
     if (ref >= 0)
     {
@@ -918,18 +921,18 @@ SKH_DI void curve_ref_box(int ref, const float4* __restrict__ segs, const uint32
 #pragma unroll
         for (int v = 0; v < 4; ++v)
         {
-            q[v] = segs[4 * (size_t)(first + k) + v];
+            q[v] = segs[SKH_SEG_STRIDE * (size_t)(first + k) + v];
             rmax = fmaxf(rmax, fabsf(q[v].w));
             cmax = fmaxf(cmax, fmaxf(fabsf(q[v].x), fmaxf(fabsf(q[v].y), fabsf(q[v].z))));
         }
         v3 l, h;
-        subseg_box(q, K > 1u ? segPrim[first + k] >> 28 : 0u, K, rmax, cmax, l, h);
+        subseg_box(q, K > 1u ? __float_as_uint(segs[SKH_SEG_STRIDE * (size_t)(first + k) + 6].x) >> 28 : 0u, K, rmax, cmax, l, h);
         lo = make_float4(fminf(lo.x, l.x), fminf(lo.y, l.y), fminf(lo.z, l.z), 0.0f);
         hi = make_float4(fmaxf(hi.x, h.x), fmaxf(hi.y, h.y), fmaxf(hi.z, h.z), 0.0f);
     }
 }
 __global__ void __launch_bounds__(256) k_node4_refit_level_curves(Node4* __restrict__ nodes, float4* __restrict__ nodeBox, uint32_t first, uint32_t count,
-                                                                  const float4* __restrict__ segs, const uint32_t* __restrict__ segPrim, uint32_t K)
+                                                                  const float4* __restrict__ segs, uint32_t K)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count)
@@ -945,7 +948,7 @@ __global__ void __launch_bounds__(256) k_node4_refit_level_curves(Node4* __restr
         if (ref == SKH_REF_INVALID)
             continue;
         float4 lo, hi;
-        curve_ref_box(ref, segs, segPrim, K, nodeBox, lo, hi);
+        curve_ref_box(ref, segs, K, nodeBox, lo, hi);
         clo[cnt][0] = lo.x, clo[cnt][1] = lo.y, clo[cnt][2] = lo.z;
         chi[cnt][0] = hi.x, chi[cnt][1] = hi.y, chi[cnt][2] = hi.z;
         for (int a = 0; a < 3; ++a)
@@ -1681,17 +1684,16 @@ __global__ void k_gather_tris(const uint8_t* __restrict__ verts, const uint32_t*
     out[3 * (size_t)j + 2] = r[2];
 }
 
-// gather curve segments into leaf order: 64 B records (4 x {xyz, radius}) + the segment's primitive index
-// leaf order -> leaf records.  out: the segment's four control points (duplicated per sub-range: one 64-byte fetch per test);
-// outPrim: segment index inside its curve set | sub-range << 28; outBound: conservative bounding cylinder of the (padded)
-// sub-range for the cheap rejection test in front of the iterative intersector: {A.xyz, R}, {unit axis.xyz, 0}.  The curve
+// gather curve segments into leaf order: ONE 128-byte record per sub-segment (SKH_SEG_STRIDE float4) --
+// [0..3] the segment's four control points {xyz, radius} (duplicated per sub-range: one record per test); [4] [5] a conservative bounding cylinder of the (padded)
+// sub-range for the cheap rejection test in front of the iterative intersector: {A.xyz, R}, {unit axis.xyz, 0}; [6] {segment index inside its curve set | sub-range << 28,
+// the instance of a merged segment or ~0, 0, 0}.  The curve
 // part is inside the hull of its Bezier points, so every accepted hit point lies within  max_i dist(c_i, L) + 2 r_max  of the
 // line L through the part's end points (r_max for the unsplit segment, see k_seg_boxes); a degenerate chord gives axis = 0,
 // which switches the test off.
 __global__ void k_gather_segs(const float* __restrict__ points, const float* __restrict__ radii,
                               const uint32_t* __restrict__ segStart, const uint32_t* __restrict__ segLocal, const uint32_t* __restrict__ segInstOf /* per build primitive: the instance of a merged segment, ~0 otherwise */,
-                              const uint32_t* __restrict__ sortedVals, uint32_t n /*segments x K*/, uint32_t K, float4* __restrict__ out,
-                              uint32_t* __restrict__ outPrim, float4* __restrict__ outBound, uint32_t* __restrict__ outInst, uint32_t strandMajor /* (segment-node build, K = 1) records at the segment's own index: consecutive segments of a strand adjacent in memory */)
+                              const uint32_t* __restrict__ sortedVals, uint32_t n /*segments x K*/, uint32_t K, float4* __restrict__ out, uint32_t strandMajor /* (segment-node build, K = 1) records at the segment's own index: consecutive segments of a strand adjacent in memory */)
 {
     const uint32_t jj = blockIdx.x * blockDim.x + threadIdx.x;
     if (jj >= n)
@@ -1707,12 +1709,12 @@ __global__ void k_gather_segs(const float* __restrict__ points, const float* __r
     {
         const float* p = points + 3 * (size_t)(s + k);
         q[k] = make_float4(p[0], p[1], p[2], radii[s + k]);
-        out[4 * (size_t)j + k] = q[k];
+        out[SKH_SEG_STRIDE * (size_t)j + k] = q[k];
         rmax = fmaxf(rmax, fabsf(q[k].w));
         cmax = fmaxf(cmax, fmaxf(fabsf(p[0]), fmaxf(fabsf(p[1]), fabsf(p[2]))));
     }
-    outPrim[j] = segLocal[seg] | (sub << 28);
-    outInst[j] = segInstOf[seg];
+    out[SKH_SEG_STRIDE * (size_t)j + 6] = make_float4(__uint_as_float(segLocal[seg] | (sub << 28)), __uint_as_float(segInstOf[seg]), 0.0f, 0.0f);
+    out[SKH_SEG_STRIDE * (size_t)j + 7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float u0, u1;
     subseg_range(sub, K, u0, u1);
     subcurve_bezier(q, u0, u1, c);
@@ -1735,8 +1737,8 @@ __global__ void k_gather_segs(const float* __restrict__ points, const float* __r
     else
         ux = uy = uz = 0.0f;
     const float R = (dmax + (K > 1u ? 2.0f : 1.0f) * rmax) * 1.001f + cmax * 4e-6f + 1e-30f;
-    outBound[2 * (size_t)j] = make_float4(ax, ay, az, R);
-    outBound[2 * (size_t)j + 1] = make_float4(ux, uy, uz, 0.0f);
+    out[SKH_SEG_STRIDE * (size_t)j + 4] = make_float4(ax, ay, az, R);
+    out[SKH_SEG_STRIDE * (size_t)j + 5] = make_float4(ux, uy, uz, 0.0f);
 }
 
 } // namespace skh

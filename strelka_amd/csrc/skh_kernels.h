@@ -38,6 +38,7 @@ struct HostInstance // == skh_instance (64 B), as uploaded
 // 16; measured in round 6 against the two-level kernel on the hair stand-in cut into N prims under translations (gpurun_out/r6j): N = 2 -4 %, 4 -11 %, 8 -20 % --
 // every ray visits every tree, nothing culls an instance the ray misses.  Two entries keep "the merged groom + one moved prim" and "one prim under a transform".
 #define SKH_WORLD_CURVES 2
+#define SKH_SEG_STRIDE 8 // float4 per curve leaf record (DevScene::segs)
 #define SKH_REF_CURVEROOT 0x40000000 // stack entry (world-only kernel with curves): (ref & 0xffff) indexes DevScene::worldCurveRoot / worldCurveInst
 #define SKH_REF_CURVEROOT_IDENT 0x20000000 // ... of an instance under a bit-exact identity transform, which is only valid as the FIRST curve tree of a ray (o, d still the world ray)
 struct DevScene
@@ -49,7 +50,7 @@ struct DevScene
     int worldCurveRoot[SKH_WORLD_CURVES];
     uint32_t worldCurveInst[SKH_WORLD_CURVES]; // ... and instance ids
     uint32_t worldCurveIdentLast; // 1: the LAST entry's instance sits under a bit-exact identity transform (the host puts such an instance last)
-    uint32_t worldCurveMerged; // bit k: entry k is a MERGED group of curve instances under one transform -- worldCurveInst[k] lends the transform, a hit takes its instance from segInst
+    uint32_t worldCurveMerged; // bit k: entry k is a MERGED group of curve instances under one transform -- worldCurveInst[k] lends the transform, a hit takes its instance from the segment's leaf record
     uint32_t numInstances;
     const DevInstance* inst; // per instance (shading side: w2o)
     const DevInstance* tinst; // per TLAS leaf: (instance, BLAS subtree) after opening; pad = instance id
@@ -59,11 +60,12 @@ struct DevScene
                    // ray walks first, in world space, with no instance entry; SKH_REF_INVALID = nothing baked
     int lightRoot; // the same for baked light proxies: radiance rays only (shadow rays do not see lights)
     const Node4* segNodes;
-    const float4* segs; // 4 x float4 per segment, leaf order
-    const uint32_t* segPrim; // leaf order -> segment index inside its curve set
-    const float4* segBound; // 2 x float4 per leaf record: bounding cylinder {A, R}, {unit axis, 0}
-    const uint32_t* segInst; // leaf order -> the instance a MERGED segment belongs to (curve instances under one transform share one tree: curInst == ~0 there)
-    uint32_t curveSplit; // parameter sub-ranges per segment (sub-range in segPrim >> 28)
+    // ONE 128-byte record per curve sub-segment, leaf order (round 6: control points, bounding cylinder and ids were three arrays -- a leaf visit fetched the cylinder's
+    // line, a candidate then the control points' line and, accepted, the ids': the any-hit launches of the hair stand-in miss the L2 on 24.5 lines per ray, 0.69 of the
+    // random-line rate).  float4 [0..3] the segment's four control points {xyz, radius} (duplicated per sub-range: one record per test), [4] [5] the conservative bounding
+    // cylinder of the (padded) sub-range {A, R} {unit axis, 0}, [6] {segment index inside its curve set | sub-range << 28, instance of a MERGED segment or ~0, -, -}, [7] -
+    const float4* segs;
+    uint32_t curveSplit; // parameter sub-ranges per segment (sub-range in word [6].x >> 28 of the leaf record)
     // shading side
     const HostInstance* instances; // shading copy: for mesh instances `light` holds the mesh's first record in shadeTris
     const float4* shadeTris; // de-indexed shading records, 96 B per triangle (k_gather_shade_tris), meshes back to back
@@ -445,7 +447,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
 #define SKH_CYLINDER_TESTS(FIRST, COUNT, PEND)                                                                                   \
     for (uint32_t k_ = 0; k_ < (COUNT); ++k_)                                                                                    \
     {                                                                                                                            \
-        const float4 b0 = sc.segBound[2 * (size_t)((FIRST) + k_)], b1 = sc.segBound[2 * (size_t)((FIRST) + k_) + 1];             \
+        const float4 b0 = sc.segs[SKH_SEG_STRIDE * (size_t)((FIRST) + k_) + 4], b1 = sc.segs[SKH_SEG_STRIDE * (size_t)((FIRST) + k_) + 5]; \
         const v3 w = mk3(b0.x - o.x, b0.y - o.y, b0.z - o.z);                                                                    \
         const v3 nn = cross(d, mk3(b1.x, b1.y, b1.z));                                                                           \
         const float n2 = dot(nn, nn), wn = dot(w, nn);                                                                           \
@@ -755,7 +757,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                     SKH_LP(uint32_t runSteps = 0;)
                     if (work)
                     {
-                        const float4* cp = sc.segs + 4 * (size_t)(ofirst + slot);
+                        const float4* cp = sc.segs + SKH_SEG_STRIDE * (size_t)(ofirst + slot);
                         const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
                         const float dlen = sqrtf(dot(od, od));
                         const float inv_dlen = 1.0f / dlen;
@@ -863,10 +865,11 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                             const float t = first ? t0 : t1, u = first ? u0 : u1;
                             if ((f0 || f1) && (best.found || t < best.t)) // (open at tmax: best.t is the ray's tmax until a hit is found)
                             {
-                                const uint32_t spw = sc.segPrim[myFirst + k];
+                                const float4 idw = sc.segs[SKH_SEG_STRIDE * (size_t)(myFirst + k) + 6]; // {primitive | sub-range << 28, instance of a merged segment, -, -}
+                                const uint32_t spw = __float_as_uint(idw.x);
                                 const uint32_t prim = spw & 0x0fffffffu;
-                                // (the merged world-space tree -- curve instances under identity transforms -- names the instance per segment)
-                                const uint32_t hinst = (WORLD && curInst == 0xffffffffu) ? sc.segInst[myFirst + k] : curInst;
+                                // (a merged tree -- curve instances under one transform -- names the instance per segment)
+                                const uint32_t hinst = (WORLD && curInst == 0xffffffffu) ? __float_as_uint(idw.y) : curInst;
                                 // a sub-range leaf keeps the hit only if u is its own (the leaf that owns u reports the same bits)
                                 if (min((uint32_t)(u * (float)sc.curveSplit), sc.curveSplit - 1u) == (spw >> 28) &&
                                     (!best.found || t < best.t || hinst < SKH_BEST_INST() || (hinst == SKH_BEST_INST() && prim < SKH_BEST_PRIM())))

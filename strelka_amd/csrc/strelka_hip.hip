@@ -97,7 +97,7 @@ struct skh_context
     DevBuf dShadeTris, dShadeInst; // shading side: de-indexed triangle records, instance records that carry their mesh's base
     DevBuf dCurveSegBase, dSegStartAll;
     // accel
-    DevBuf dTexels, dTexDesc, dSegBound, dSegInst, dScatterXY, dRaygenBase;
+    DevBuf dTexels, dTexDesc, dScatterXY, dRaygenBase;
     uint32_t raygenBlocksPerSub = 0, raygenValidPerSub = 0;
     uint32_t nTextures = 0;
     bool hasHairMaterial = false; // selects the k_shade build that carries df::chiang_hair_bsdf
@@ -131,7 +131,7 @@ struct skh_context
     uint32_t discardedSubframes = 0;
     uint32_t speculateGrow = 2; // option speculate_grow: how fast the look-ahead grows while the caller keeps continuing a frame (x2 per pass: 2, 4, 8; 8 = straight to the cap at the second call)
     uint32_t speculateMax = 8; // option "speculate": most sub-frames traced ahead in one pass (0 / 1 = off).  8: a pass stays below ~25 ms at 1080p
-    DevBuf dTriNodes, dTris, dSegNodes, dSegs, dSegPrim, dTlasNodes, dTlasInst, dDevInst, dTravInst;
+    DevBuf dTriNodes, dTris, dSegNodes, dSegs, dTlasNodes, dTlasInst, dDevInst, dTravInst;
     int tlasRoot = SKH_REF_INVALID;
     bool accelBuilt = false;
     // skh_refit_accel: what the last build leaves behind for it -- the triangle tree's leaf order and primitive tables (k_gather_tris' inputs), the
@@ -1137,8 +1137,8 @@ void skh_destroy(skh_context* c)
     if (c->comm)
         (void)skh_comm_destroy(c);
     for (DevBuf* b : { &c->dShadeTris, &c->dShadeInst, &c->dVerts, &c->dIndices, &c->dMeshes, &c->dPoints, &c->dRadii, &c->dInstances, &c->dLights, &c->dMaterials, &c->dHairConst,
-                       &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs, &c->dSegPrim,
-                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dSegBound, &c->dSegInst, &c->dTriOrder, &c->dTriMeshK, &c->dTriLocalK, &c->dWInstK, &c->dWFirstK, &c->dTriNodeBox, &c->dSegOrder, &c->dSegBuildStartK, &c->dSegLocalK, &c->dSegInstOfK, &c->dSegNodeBox, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
+                       &c->dCurveSegBase, &c->dSegStartAll, &c->dTriNodes, &c->dTris, &c->dSegNodes, &c->dSegs,
+                       &c->dTlasNodes, &c->dTlasInst, &c->dDevInst, &c->dTravInst, &c->dTexels, &c->dTexDesc, &c->dTriOrder, &c->dTriMeshK, &c->dTriLocalK, &c->dWInstK, &c->dWFirstK, &c->dTriNodeBox, &c->dSegOrder, &c->dSegBuildStartK, &c->dSegLocalK, &c->dSegInstOfK, &c->dSegNodeBox, &c->dScatterXY, &c->dRaygenBase, &c->dTileXY, &c->dAccum, &c->dDiffuse, &c->dSpecular, &c->dDiffCnt,
                        &c->dSpecCnt, &c->dSums, &c->dPath, &c->dRayQ[0], &c->dRayQ[1], &c->dHits, &c->dShadowQ, &c->dContrib,
                        &c->dCounts, &c->dOvf, &c->dOvf2, &c->dStats, &c->dScratchImage, &c->dPathB })
         dev_free(*b);
@@ -1850,14 +1850,11 @@ skh_status skh_build_accel(skh_context* c, uint32_t flags)
         segOut.nodes = grown;
         segOut.numNodes += nSegs;
     }
-    BA(dev_alloc(c, c->dSegs, sizeof(float4) * 4 * (size_t)std::max(1u, nSub)));
-    BA(dev_alloc(c, c->dSegPrim, sizeof(uint32_t) * (size_t)std::max(1u, nSub)));
-    BA(dev_alloc(c, c->dSegBound, sizeof(float4) * 2 * (size_t)std::max(1u, nSub)));
-    BA(dev_alloc(c, c->dSegInst, sizeof(uint32_t) * (size_t)std::max(1u, nSub)));
+    BA(dev_alloc(c, c->dSegs, sizeof(float4) * SKH_SEG_STRIDE * (size_t)std::max(1u, nSub)));
     if (nSub)
         k_gather_segs<<<(nSub + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), dSegBuildStart.as<uint32_t>(),
                                                         dSegLocal.as<uint32_t>(), dSegInstOf.as<uint32_t>(), segOut.sortedVals.as<uint32_t>(), nSub, K,
-                                                        c->dSegs.as<float4>(), c->dSegPrim.as<uint32_t>(), c->dSegBound.as<float4>(), c->dSegInst.as<uint32_t>(), strandMajor);
+                                                        c->dSegs.as<float4>(), strandMajor);
     c->curveSplitBuilt = K;
     dev_free(c->dSegNodes);
     c->dSegNodes = segOut.nodes;
@@ -2232,16 +2229,14 @@ skh_status skh_refit_accel(skh_context* c)
     {
         // the curve tree: leaf records (control points, bounding cylinders) gathered again from the new points, boxes level by level
         k_gather_segs<<<(c->nSubBuilt + B - 1) / B, B, 0, st>>>(c->dPoints.as<float>(), c->dRadii.as<float>(), c->dSegBuildStartK.as<uint32_t>(), c->dSegLocalK.as<uint32_t>(),
-                                                               c->dSegInstOfK.as<uint32_t>(), c->dSegOrder.as<uint32_t>(), c->nSubBuilt, c->curveSplitBuilt, c->dSegs.as<float4>(),
-                                                               c->dSegPrim.as<uint32_t>(), c->dSegBound.as<float4>(), c->dSegInst.as<uint32_t>(), 0u);
+                                                               c->dSegInstOfK.as<uint32_t>(), c->dSegOrder.as<uint32_t>(), c->nSubBuilt, c->curveSplitBuilt, c->dSegs.as<float4>(), 0u);
         if ((s = dev_alloc(c, c->dSegNodeBox, sizeof(float4) * 2 * (size_t)std::max(1u, c->segNumNodes))) != SKH_OK)
             return s;
         for (size_t L = c->segLevelStart.size() > 1 ? c->segLevelStart.size() - 1 : 0; L-- > 0;)
         {
             const uint32_t first = c->segLevelStart[L], count = c->segLevelStart[L + 1] - first;
             if (count)
-                k_node4_refit_level_curves<<<(count + B - 1) / B, B, 0, st>>>(c->dSegNodes.as<Node4>(), c->dSegNodeBox.as<float4>(), first, count, c->dSegs.as<float4>(),
-                                                                            c->dSegPrim.as<uint32_t>(), c->curveSplitBuilt);
+                k_node4_refit_level_curves<<<(count + B - 1) / B, B, 0, st>>>(c->dSegNodes.as<Node4>(), c->dSegNodeBox.as<float4>(), first, count, c->dSegs.as<float4>(), c->curveSplitBuilt);
         }
         c->curvePointsEdited = false;
     }
@@ -2486,9 +2481,6 @@ static DevScene make_dev_scene(const skh_context* c)
     sc.tris = c->dTris.as<float4>();
     sc.segNodes = c->dSegNodes.as<Node4>();
     sc.segs = c->dSegs.as<float4>();
-    sc.segPrim = c->dSegPrim.as<uint32_t>();
-    sc.segBound = c->dSegBound.as<float4>();
-    sc.segInst = c->dSegInst.as<uint32_t>();
     sc.curveSplit = c->curveSplitBuilt;
     sc.worldRoot = c->worldRoot;
     sc.lightRoot = c->lightRoot;
