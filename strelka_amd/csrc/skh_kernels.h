@@ -229,6 +229,12 @@ struct StatsDev
     unsigned long long runHist[2][42], blockHist[2][42]; // Newton steps per run / of the longest run of a block (curve builds)
     unsigned long long cyc[2][10]; // summed over waves: [0] refill [1] node loop [2] leaf [3] pop [4] result write [5] whole kernel [6] cycles [7] 100 MHz ticks [8] the curve block
 #endif
+#ifdef SKH_TAIL_PROFILE
+    // launch tails (a build of its own: a few atomics per WAVE, nothing in the loops), in 16-microsecond bins from the launch's first wave (launchT0: reset by the
+    // host before every trace launch; 100 MHz ticks): when the waves found the queue dry, when they left, how long after their dry point, how many lanes they had
+    // alive then, and the ray-ticks they spent after it (a ray alive for one tick)
+    unsigned long long launchT0[2], dryHist[2][64], exitHist[2][64], afterDryHist[2][64], dryLive[2][65], rayTicksAfterDry[2], waveTicksAfterDry[2];
+#endif
 };
 
 // number of set bits of `mask` in the lanes below this one: v_mbcnt_lo / v_mbcnt_hi on the ballot's two scalar halves -- two instructions and
@@ -387,6 +393,13 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
 #else
 #define SKH_LP(...)
 #endif
+#ifdef SKH_TAIL_PROFILE
+    if (threadIdx.x == 0)
+        atomicMin(&stats->launchT0[ANY_HIT ? 1 : 0], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    bool dryNoted = false;
+    unsigned long long dryLast = 0, dryAt = 0, rayTicks = 0;
+    uint32_t dryLiveLanes = 0;
+#endif
 
     // per-lane traversal state
     bool hasRay = false, pending = false;
@@ -490,6 +503,17 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
         const unsigned long long needMask = __ballot(!hasRay);
         const uint32_t want = (uint32_t)__popcll(needMask);
         SKH_LP(wv[3]++; unsigned long long cyA = __builtin_readcyclecounter();)
+#ifdef SKH_TAIL_PROFILE
+        if (exhausted)
+        {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (!dryNoted)
+                dryNoted = true, dryAt = now, dryLiveLanes = 64u - want;
+            else
+                rayTicks += (unsigned long long)(64u - want) * (now - dryLast); // (the lanes alive now were alive since the last look at least)
+            dryLast = now;
+        }
+#endif
         if (want >= fetchMin || want == 64u)
         {
             // results of the lanes that finished since the last refill: written together, once per refill
@@ -1365,6 +1389,19 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
 #undef SKH_OVF_AT
 #undef SKH_TAKE_MARKER
 #undef SKH_CYLINDER_TESTS
+#ifdef SKH_TAIL_PROFILE
+    if (lane == 0 && dryNoted)
+    {
+        const int A = ANY_HIT ? 1 : 0;
+        const unsigned long long t0 = *(volatile unsigned long long*)&stats->launchT0[A], now = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&stats->dryHist[A][min(63ull, (dryAt - t0) / 1600ull)], 1ull);
+        atomicAdd(&stats->exitHist[A][min(63ull, (now - t0) / 1600ull)], 1ull);
+        atomicAdd(&stats->afterDryHist[A][min(63ull, (now - dryAt) / 1600ull)], 1ull);
+        atomicAdd(&stats->dryLive[A][dryLiveLanes], 1ull);
+        atomicAdd(&stats->rayTicksAfterDry[A], rayTicks);
+        atomicAdd(&stats->waveTicksAfterDry[A], now - dryAt);
+    }
+#endif
     if (COUNT)
     {
         const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.prims), c2 = wave_sum(tc.segs), d2 = wave_sum(tc.insts);

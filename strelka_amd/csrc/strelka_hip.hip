@@ -2560,6 +2560,9 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
     // (neighbouring rays are then traced at different times by one wave instead of together by neighbouring waves: kitchen -1 %, hair -2 %;
     // docs/LOG.md, round 5); only the world-only triangle builds carry the code.
     const uint32_t chunk = c->fetchChunk >= 0 ? (uint32_t)c->fetchChunk : (c->hierNodes <= 16384u ? 128u : 0u);
+#ifdef SKH_TAIL_PROFILE
+    (void)hipMemsetAsync(&sd->launchT0[ANY ? 1 : 0], 0xff, sizeof(unsigned long long), st);
+#endif
     if (worldOnly)
         // every instance is baked: the world-only build of the kernel (no instance entry, no object-space copy of the ray)
         k_trace<ANY, COUNT, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, ovf, sd, c->lightBox, chunk);
@@ -4128,6 +4131,27 @@ skh_status skh_get_stats(skh_context* c, skh_stats* out)
         fprintf(stderr, "[lane-cycles] %s: refill %.3g curve-block %.3g node %.3g leaf %.3g pop %.3g write %.3g total %.3g | shader clock while the waves ran: %.1f MHz (wave-seconds %.4g)\n", k ? "shadow" : "closest", (double)sd.cyc[k][0], (double)sd.cyc[k][8],
                 (double)sd.cyc[k][1], (double)sd.cyc[k][2], (double)sd.cyc[k][3], (double)sd.cyc[k][4], (double)sd.cyc[k][5],
                 sd.cyc[k][7] ? (double)sd.cyc[k][6] / (double)sd.cyc[k][7] * 100.0 : 0.0, (double)sd.cyc[k][7] / 1e8);
+#endif
+#ifdef SKH_TAIL_PROFILE
+    for (int k = 0; k < 2; ++k)
+    {
+        unsigned long long waves = 0;
+        double liveSum = 0;
+        for (int j = 0; j < 64; ++j)
+            waves += sd.exitHist[k][j];
+        for (int j = 0; j < 65; ++j)
+            liveSum += (double)j * (double)sd.dryLive[k][j];
+        if (!waves)
+            continue;
+        fprintf(stderr, "[launch-tail] %s: %llu waves; lanes alive at a wave's dry point: mean %.1f; after it a wave stays %.1f us and spends %.1f ray-us (= %.1f lanes alive on average)\n", k ? "shadow" : "closest",
+                waves, liveSum / (double)waves, (double)sd.waveTicksAfterDry[k] / 100.0 / (double)waves, (double)sd.rayTicksAfterDry[k] / 100.0 / (double)waves,
+                sd.waveTicksAfterDry[k] ? (double)sd.rayTicksAfterDry[k] / (double)sd.waveTicksAfterDry[k] : 0.0);
+        fprintf(stderr, "[launch-tail]   16-us bins: from the launch's first wave -- waves finding the queue dry %%, waves leaving %% | from a wave's own dry point -- waves leaving %%\n");
+        for (int j = 0; j < 64; ++j)
+            if (sd.dryHist[k][j] || sd.exitHist[k][j] || sd.afterDryHist[k][j])
+                fprintf(stderr, "[launch-tail]   %4d us: dry %5.1f%%  exit %5.1f%% | exit after dry %5.1f%%\n", 16 * j, 100.0 * (double)sd.dryHist[k][j] / (double)waves, 100.0 * (double)sd.exitHist[k][j] / (double)waves,
+                        100.0 * (double)sd.afterDryHist[k][j] / (double)waves);
+    }
 #endif
     out->ms_trace_closest = c->msClass[KC_TRACE_CLOSEST];
     out->ms_trace_shadow = c->msClass[KC_TRACE_SHADOW];

@@ -27,7 +27,7 @@ def params_at(k):
     e = target + np.array([r[0] * math.cos(a) + r[2] * math.sin(a), r[1], -r[0] * math.sin(a) + r[2] * math.cos(a)])
     cam.lookAt(tuple(e), tuple(target))
     return np.array(S.frame_params(cam, W, H, subframe_index=0, samples_this_launch=1, spp_total=64, max_depth=depth), copy=True)
-P = [params_at(k) for k in range(3 * calls)]
+P = [params_at(k) for k in range(3 * calls + 16)]
 for with_map in (True, False):
     for rep in range(2):
         ctx.reset_stats(); torch.cuda.synchronize(); t0 = time.perf_counter()
