@@ -340,7 +340,7 @@ struct LightBox
 #ifndef SKH_ANYHIT_FLAT_PUSH
 #define SKH_ANYHIT_FLAT_PUSH 1 // the any-hit node loop pushes its hit children without a branch per child (A/B: -DSKH_ANYHIT_FLAT_PUSH=0)
 #endif
-template <bool ANY_HIT, bool COUNT, bool CURVES, bool WORLD = false>
+template <bool ANY_HIT, bool COUNT, bool CURVES, bool WORLD = false, bool SPLIT = false>
 __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? SKH_WORLD_CURVE_ANYHIT_MIN_WAVES : SKH_WORLD_CURVE_MIN_WAVES) : SKH_CURVE_MIN_WAVES) : (WORLD ? (ANY_HIT ? SKH_WORLD_ANYHIT_MIN_WAVES : SKH_WORLD_CLOSEST_MIN_WAVES) : (ANY_HIT ? SKH_ANYHIT_MIN_WAVES : SKH_TRACE_MIN_WAVES))) SKH_TRACE_ATTR
     k_trace(DevScene sc, RayQ rq, const uint32_t* __restrict__ countPtr, uint32_t* __restrict__ fetch /*8 counters, zeroed*/,
             uint32_t fetchArg /* refill threshold | curve-test threshold << 8 | node-break threshold << 16 | leaf-kind threshold << 24 */, 
@@ -360,10 +360,18 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
     // and once per ray for the result -- in LDS instead of four registers (they are the builds that spill, and their scratch traffic goes to HBM:
     // docs/LOG.md, round 5); one stack entry pays for the 1 KB (19 x 256 + 512 (s_runs) + 1024 = 5 granules, as before).
     constexpr bool BESTLDS = CURVES && !ANY_HIT && SKH_BEST_LDS;
-    constexpr int NLDS = (TRICOOP || BESTLDS) ? SKH_STACK_LDS - 1 : SKH_STACK_LDS;
+    // SPLIT (round 6, the world-only triangle builds, small passes): once the queue is dry the idle lanes of a wave take stack entries of the lanes that still
+    // have a ray -- a long ray's subtrees are walked side by side instead of one after the other: docs/LOG.md "launch tails".  The fragments of one ray (a
+    // FAMILY, named by the lane that held the ray when the wave went dry) merge their results in LDS by the rule of the sequential walk -- nearer, or equally near
+    // with the smaller (instance, primitive) key: the record does not depend on who found what -- and the last one to finish writes it.  Seven 256-byte
+    // tables (pruning bound, t, instance, primitive, u, v, live fragments) come out of the stack's LDS entries.
+    static_assert(!SPLIT || (WORLD && !CURVES), "SPLIT: the world-only triangle builds");
+    constexpr int NLDS0 = (TRICOOP || BESTLDS) ? SKH_STACK_LDS - 1 : SKH_STACK_LDS;
+    constexpr int NLDS = (SPLIT && NLDS0 >= 11) ? NLDS0 - 7 : NLDS0; // (the tests' tiny-stack variants keep what little they have)
     __shared__ int s_stack[NLDS * SKH_TRACE_BLOCK];
+    __shared__ uint32_t s_fam[SPLIT ? 7 * SKH_TRACE_BLOCK : 1];
     __shared__ uint32_t s_best[BESTLDS ? 4 * SKH_TRACE_BLOCK : 1];
-    __shared__ unsigned char s_tab[TRICOOP ? 128 : 1]; // [0..63] owner lanes by rank, [64..127] helper lanes by rank
+    __shared__ unsigned char s_tab[(TRICOOP || SPLIT) ? 128 : 1]; // [0..63] owner lanes by rank, [64..127] helper lanes by rank (SPLIT: [0..63] giving lanes by rank)
     const uint32_t fetchMin = fetchArg & 0xffu, curveMin = (fetchArg >> 8) & 0xffu, nodeBreak = (fetchArg >> 16) & 0xffu, leafMin = fetchArg >> 24;
     const uint32_t lane = threadIdx.x;
     uint32_t n = 0; // (countPtr: SKH_SHARDS queue-length words, SKH_COUNT_STRIDE apart)
@@ -377,6 +385,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
     uint32_t tries = 0;
     bool exhausted = false;
     uint32_t resBase = 0, resLeft = 0; // the wave's reservation in the ray queue (fetchChunk): wave-uniform
+    uint32_t fam = threadIdx.x; // (SPLIT) the family this lane's ray fragment belongs to
+    bool tailOn = false; // (SPLIT) the wave has found the queue dry: family records are live
+#define SKH_FAM(k, l) s_fam[(k) * SKH_TRACE_BLOCK + (l)] /* 0 bound (bits of a non-negative t) 1 t 2 instance 3 primitive 4 u 5 v 6 fragments alive */
     int* lds = s_stack + lane;
     // (the overflow area is addressed from ovfBase where it is used -- rare paths -- instead of through a per-lane 64-bit pointer held across the loops)
 #define SKH_OVF_AT(e) ovfBase[(size_t)(e) * ovfStride + (skh_opaque(blockIdx.x * SKH_TRACE_BLOCK) + threadIdx.x)]
@@ -514,9 +525,9 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
             dryLast = now;
         }
 #endif
-        if (want >= fetchMin || want == 64u)
+        if (want >= fetchMin || want == 64u || (SPLIT && exhausted))
         {
-            // results of the lanes that finished since the last refill: written together, once per refill
+            // results of the lanes that finished since the last refill: written together, once per refill (SPLIT, queue dry: at once -- the lane is wanted as a helper)
             if (pending)
             {
                 pending = false;
@@ -712,6 +723,116 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
                 best.found = false;
                 pend = 0;
                 hasRay = true;
+            }
+        }
+        if constexpr (SPLIT)
+        {
+            if (exhausted)
+            {
+                // ---------------- the queue is dry: idle lanes take stack entries of the lanes that still have a ray ----------------
+                if (!tailOn)
+                {
+                    tailOn = true; // every ray the wave holds becomes a family of one; its record starts as the lane's best hit so far
+                    if (hasRay)
+                    {
+                        fam = lane;
+                        SKH_FAM(0, lane) = __float_as_uint(best.t);
+                        SKH_FAM(1, lane) = __float_as_uint(best.t);
+                        SKH_FAM(2, lane) = best.found ? (ANY_HIT ? 0u : best.inst) : 0xffffffffu; // (all ones: nothing found yet)
+                        SKH_FAM(3, lane) = best.prim, SKH_FAM(4, lane) = __float_as_uint(best.u), SKH_FAM(5, lane) = __float_as_uint(best.v);
+                        SKH_FAM(6, lane) = 1u;
+                    }
+                }
+                else if (!ANY_HIT && hasRay && best.found)
+                    atomicMin(&SKH_FAM(0, fam), __float_as_uint(best.t)); // (t >= 0: its bits order as it does) what this fragment has found prunes the others
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                bool famDone = false;
+                if (hasRay)
+                {
+                    if (ANY_HIT)
+                    {
+                        // another fragment has found an occluder (merged at its termination): this one has nothing left to look for
+                        if (SKH_FAM(2, fam) != 0xffffffffu)
+                        {
+                            famDone = true;
+                            best.found = true;
+                            cur = SKH_REF_INVALID;
+                            sp = 0;
+                        }
+                    }
+                    else
+                    {
+                        // The family's bound below this lane's: nothing beyond it can win.  The lane forgets its own (farther) hit and keeps the interval CLOSED at
+                        // the bound -- an equally near hit with a smaller key still has to be found; the merge decides --: "not found, tmax = the next float up".
+                        const uint32_t tb = SKH_FAM(0, fam);
+                        if (__uint_as_float(tb) < best.t)
+                        {
+                            best.t = __uint_as_float(tb + 1u);
+                            best.found = false;
+                            best.inst = best.prim = 0xffffffffu;
+                            best.u = best.v = 0.0f;
+                        }
+                    }
+                }
+                // Every idle lane gets an entry while the givers have any: idle lane r takes entry r / nG (counted from the top) of giver r % nG, straight out of the
+                // giver's stack column (LDS, or the overflow area); a giver knows from the two counts how many of its entries went.
+                const bool giver = hasRay && sp > 0 && !famDone;
+                const unsigned long long idleM = __ballot(!hasRay), giveM = __ballot(giver);
+                const uint32_t nI = (uint32_t)__popcll(idleM), nG = (uint32_t)__popcll(giveM);
+                if (nI != 0u && nG != 0u)
+                {
+                    const uint32_t rI = rank_below(idleM), rG = rank_below(giveM);
+                    if (giver)
+                        s_tab[rG] = (unsigned char)lane;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const bool idle = !hasRay;
+                    const int depth = idle ? (int)(rI / nG) : 0;
+                    const int src = idle ? (int)s_tab[rI % nG] : (int)lane;
+                    const int psp = __shfl(sp, src);
+                    const bool takes = idle && depth < psp && depth < NLDS + SKH_STACK_OVF;
+                    int pgive = SKH_REF_INVALID;
+                    if (takes)
+                    {
+                        const int e = min(psp, NLDS + SKH_STACK_OVF) - 1 - depth;
+                        pgive = e < NLDS ? s_stack[e * SKH_TRACE_BLOCK + src] : ovfBase[(size_t)(e - NLDS) * ovfStride + (blockIdx.x * SKH_TRACE_BLOCK + (uint32_t)src)];
+                    }
+                    if (giver)
+                    {
+                        const uint32_t offered = nI > rG ? (nI - rG + nG - 1u) / nG : 0u; // idle lanes r with r % nG == rG
+                        const uint32_t gone = min(min((uint32_t)sp, (uint32_t)(NLDS + SKH_STACK_OVF)), offered);
+                        if (gone != 0u)
+                        {
+                            atomicAdd(&SKH_FAM(6, fam), gone);
+                            sp = min(sp, NLDS + SKH_STACK_OVF) - (int)gone;
+                        }
+                    }
+                    // (every lane takes part in the exchange: a disabled source lane would read as zero)
+                    const float pox = __shfl(o.x, src), poy = __shfl(o.y, src), poz = __shfl(o.z, src);
+                    const float pix = __shfl(inv.x, src), piy = __shfl(inv.y, src), piz = __shfl(inv.z, src);
+                    const int pperm = __shfl(sh.perm, src);
+                    const float psx = __shfl(sh.Sx, src), psy = __shfl(sh.Sy, src), psz = __shfl(sh.Sz, src);
+                    const float ptmin = __shfl(tmin, src), pbt = __shfl(best.t, src), pbu = __shfl(best.u, src), pbv = __shfl(best.v, src);
+                    const uint32_t pbi = (uint32_t)__shfl((int)best.inst, src), pbp = (uint32_t)__shfl((int)best.prim, src);
+                    const bool pbf = __shfl((int)best.found, src) != 0;
+                    const uint32_t pridx = (uint32_t)__shfl((int)ridx, src), pfam = (uint32_t)__shfl((int)fam, src);
+                    if (takes)
+                    {
+                        o = mk3(pox, poy, poz);
+                        inv = mk3(pix, piy, piz);
+                        sh.perm = pperm, sh.Sx = psx, sh.Sy = psy, sh.Sz = psz;
+                        tmin = ptmin;
+                        best.t = pbt, best.u = pbu, best.v = pbv, best.inst = pbi, best.prim = pbp, best.found = pbf;
+                        ridx = pridx;
+                        fam = pfam;
+                        cur = pgive;
+                        sp = 0;
+                        hasRay = true;
+                    }
+                }
             }
         }
         if (!__any(hasRay))
@@ -1363,6 +1484,54 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
         if (!CURVES)
             wv[2] += __any((itT >> 16) != 0) ? 1u : 0u;
 #endif
+        if constexpr (SPLIT)
+        {
+            if (tailOn)
+            {
+                // fragments that end here merge into their family's record, one lane at a time (several may belong to one family); the family's last
+                // fragment takes the merged record: it is the ray's result, written by the block at the top of the loop
+                unsigned long long tm = __ballot(terminated);
+                bool last = false;
+                while (tm != 0ull)
+                {
+                    const int l = __ffsll((long long)tm) - 1;
+                    tm &= tm - 1ull;
+                    if ((int)lane == l)
+                    {
+                        const float ft = __uint_as_float(SKH_FAM(1, fam));
+                        const uint32_t fi = SKH_FAM(2, fam), fp = SKH_FAM(3, fam);
+                        const bool recFound = fi != 0xffffffffu;
+                        const bool take = ANY_HIT ? (best.found && !recFound)
+                                                  : (best.found && (!recFound || best.t < ft || (best.t == ft && (best.inst < fi || (best.inst == fi && best.prim < fp)))));
+                        if (take)
+                        {
+                            SKH_FAM(1, fam) = __float_as_uint(best.t), SKH_FAM(2, fam) = ANY_HIT ? 0u : best.inst, SKH_FAM(3, fam) = best.prim;
+                            SKH_FAM(4, fam) = __float_as_uint(best.u), SKH_FAM(5, fam) = __float_as_uint(best.v);
+                            if (!ANY_HIT)
+                                SKH_FAM(0, fam) = min(SKH_FAM(0, fam), __float_as_uint(best.t));
+                        }
+                        const uint32_t left = SKH_FAM(6, fam) - 1u;
+                        SKH_FAM(6, fam) = left;
+                        if (left == 0u)
+                        {
+                            last = true;
+                            best.found = SKH_FAM(2, fam) != 0xffffffffu;
+                            best.t = __uint_as_float(SKH_FAM(1, fam)), best.inst = SKH_FAM(2, fam), best.prim = SKH_FAM(3, fam);
+                            best.u = __uint_as_float(SKH_FAM(4, fam)), best.v = __uint_as_float(SKH_FAM(5, fam));
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                if (terminated)
+                {
+                    hasRay = false;
+                    pending = last;
+                    terminated = false;
+                }
+            }
+        }
         if (terminated)
         {
             hasRay = false;
@@ -1389,6 +1558,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
 #undef SKH_OVF_AT
 #undef SKH_TAKE_MARKER
 #undef SKH_CYLINDER_TESTS
+#undef SKH_FAM
 #ifdef SKH_TAIL_PROFILE
     if (lane == 0 && dryNoted)
     {

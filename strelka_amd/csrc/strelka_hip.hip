@@ -183,6 +183,10 @@ struct skh_context
     uint32_t wavesPerCUWorld = 32; // the world-only closest-hit build: 64 VGPRs, 8 per SIMD (SKH_WORLD_CLOSEST_MIN_WAVES)
     uint32_t smallWavesClosest = 0, smallWavesShadow = 0; // (0 = automatic: 20 / 12 for triangle scenes, 16 / 16 with curves -- there the any-hit launch is the heavier one: hair 1-spp calls 687 against 664 Mray/s) overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24; round 6: the closest-hit launch is the one on the critical path -- 20/12: 1-spp 1080p calls 3.49 -> 3.39 ms, drop-in +1 % (18/14 3.41, 22/10 3.48, 24/8 3.67: then the any-hit launch is the long one)
     uint32_t gridOverride = 0; // set by render_one around its launches
+    int tailSplit = -1; // option tail_split: 1 = the world-only triangle kernels' SPLIT build (idle lanes of a dry wave take stack entries of its last rays) for every launch,
+                        // -1 = for passes of 2^17 ... 2^23 paths (a 1-spp 1080p call: 3.37-3.39 -> 3.22-3.25 ms; the build's main phase is 4 % slower -- seven LDS stack
+                        // entries go to the family tables --, so large passes lose: 64 sub-frames 17.83 -> 18.48 ms per closest-hit launch), 0 = never
+    bool splitNow = false; // set by render_one around its launches
     uint32_t fetchMinClosest = 32 /* 24 until round 5: on the reinserted trees 32 is 0.4 ... 0.9 % ahead on all three kitchens, gpurun_out/r6c */, fetchMinShadow = 48; // idle lanes before a wave pulls new rays from the queue (round 3, world-space hierarchy: any-hit 32 -> 48: 39.7 -> 36.2 ms, 56: 37.5, 64: 51; closest 12..40 within 1 %)
     uint32_t curveFetchMinClosest = 16, curveFetchMinShadow = 16 /* 24 until the result writes got cheaper (round 5, late): hair any-hit 47.5-47.8 -> 46.5-47.0 ms with 12 ... 20, gpurun_out/r7v */, curveNodeBreakClosest = 20, curveNodeBreakShadow = 20; // the same four for the curve build (6 waves/SIMD): hair 482 vs 465 Mray/s
     uint32_t nodeBreakClosest = 32, nodeBreakShadow = 28; // (closest: 24 -> 32 in round 3 for the world-only kernel: kitchen 86.6 -> 85.9 ms, unshared 74.7 -> 73.6, three runs each;
@@ -2563,7 +2567,9 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
 #ifdef SKH_TAIL_PROFILE
     (void)hipMemsetAsync(&sd->launchT0[ANY ? 1 : 0], 0xff, sizeof(unsigned long long), st);
 #endif
-    if (worldOnly)
+    if (worldOnly && (c->tailSplit == 1 || c->splitNow))
+        k_trace<ANY, COUNT, false, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, ovf, sd, c->lightBox, chunk);
+    else if (worldOnly)
         // every instance is baked: the world-only build of the kernel (no instance entry, no object-space copy of the ray)
         k_trace<ANY, COUNT, false, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, ovf, sd, c->lightBox, chunk);
     else if (worldCurves)
@@ -2681,6 +2687,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     const bool smallPass = NP <= (1u << 23) || c->overlap == 2;
     const bool useOverlap = (c->overlap == 2 || (c->overlap == 1 && NP <= (1u << 25))) && fp.debug != 1;
     const uint32_t rounds = fp.maxDepth;
+    c->splitNow = c->tailSplit < 0 && smallPass && NP >= (1u << 17);
     for (uint32_t s = 0; trace && s < fp.samplesThisLaunch; ++s)
     {
         SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (QW * 2 * SKH_MAX_LAUNCH_ROUNDS + 16 * SKH_FETCH_STRIDE * (rounds + 1)), st));
@@ -2747,6 +2754,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                 k_collect<<<gridSlots, 256, 0, st>>>(fp, tiles, s, ps, c->dSums.as<float>());
         }
     }
+    c->splitNow = false;
     hipStream_t fs = finStream ? finStream : st;
     if (finalize && batch > 1)
     {
@@ -3990,6 +3998,12 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
             return SKH_INVALID_ARGUMENT;
         c->leafMaxTris = (uint32_t)value;
         c->accelBuilt = false, c->refitReady = false;
+    }
+    else if (n == "tail_split")
+    {
+        if (value < -1 || value > 1)
+            return SKH_INVALID_ARGUMENT;
+        c->tailSplit = (int)value;
     }
     else if (n == "small_waves_closest" || n == "small_waves_shadow")
     {
