@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.environ.get("SKH_LIB") or os.path.join(HERE, "libstrelka_hip.so")  # SKH_LIB: A/B builds of the same HIP source
 SRC = os.path.join(HERE, "csrc", "strelka_hip.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("skh_device.h", "skh_bvh.h", "skh_kernels.h", "skh_libm.h")] + [
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("skh_device.h", "skh_bvh.h", "skh_kernels.h", "skh_trace_body.inc", "skh_libm.h")] + [
     os.path.join(ROOT, "include", "strelka_hip.h"), os.path.abspath(__file__)]  # (this file: the flags)
 # -fno-slp-vectorize: the SLP pass pairs scalar float ops into v_pk_* and pays for it in v_mov packing and registers (k_shade
 #   128 -> 112 VGPRs, k_trace 80 + 4 spilled -> 77; kitchen +3 %, hair +13 %); max-ilp scheduling: another +0.5 %.  Neither changes

@@ -169,6 +169,7 @@ struct FrameP // skh_frame_params + launch geometry
 #ifndef SKH_STACK_OVF
 #define SKH_STACK_OVF 104
 #endif
+#define SKH_TAIL_EXTRA 8 // slots every overflow column has beyond SKH_STACK_OVF: where the SPLIT builds' tail phase keeps the stack entries whose LDS its family tables take
 #define SKH_TRACE_BLOCK 64
 
 // Reciprocal ray direction for the SLAB tests only: v_rcp_f32 (1 ulp) instead of the ten-instruction IEEE division.  Box
@@ -367,9 +368,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
     // tables (pruning bound, t, instance, primitive, u, v, live fragments) come out of the stack's LDS entries.
     static_assert(!SPLIT || (WORLD && !CURVES), "SPLIT: the world-only triangle builds");
     constexpr int NLDS0 = (TRICOOP || BESTLDS) ? SKH_STACK_LDS - 1 : SKH_STACK_LDS;
-    constexpr int NLDS = (SPLIT && NLDS0 >= 11) ? NLDS0 - 7 : NLDS0; // (the tests' tiny-stack variants keep what little they have)
-    __shared__ int s_stack[NLDS * SKH_TRACE_BLOCK];
-    __shared__ uint32_t s_fam[SPLIT ? 7 * SKH_TRACE_BLOCK : 1];
+    constexpr int NLDST = (SPLIT && NLDS0 >= 11) ? NLDS0 - 7 : NLDS0; // LDS stack entries of the tail phase (the tests' tiny-stack variants keep what little they have: their tables get LDS of their own)
+    __shared__ int s_stack[NLDS0 * SKH_TRACE_BLOCK];
+    __shared__ uint32_t s_famx[(SPLIT && NLDST == NLDS0) ? 7 * SKH_TRACE_BLOCK : 1];
+    uint32_t* const s_fam = NLDST < NLDS0 ? reinterpret_cast<uint32_t*>(s_stack + NLDST * SKH_TRACE_BLOCK) : s_famx;
     __shared__ uint32_t s_best[BESTLDS ? 4 * SKH_TRACE_BLOCK : 1];
     __shared__ unsigned char s_tab[(TRICOOP || SPLIT) ? 128 : 1]; // [0..63] owner lanes by rank, [64..127] helper lanes by rank (SPLIT: [0..63] giving lanes by rank)
     const uint32_t fetchMin = fetchArg & 0xffu, curveMin = (fetchArg >> 8) & 0xffu, nodeBreak = (fetchArg >> 16) & 0xffu, leafMin = fetchArg >> 24;
@@ -386,10 +388,11 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
     bool exhausted = false;
     uint32_t resBase = 0, resLeft = 0; // the wave's reservation in the ray queue (fetchChunk): wave-uniform
     uint32_t fam = threadIdx.x; // (SPLIT) the family this lane's ray fragment belongs to
-    bool tailOn = false; // (SPLIT) the wave has found the queue dry: family records are live
 #define SKH_FAM(k, l) s_fam[(k) * SKH_TRACE_BLOCK + (l)] /* 0 bound (bits of a non-negative t) 1 t 2 instance 3 primitive 4 u 5 v 6 fragments alive */
     int* lds = s_stack + lane;
     // (the overflow area is addressed from ovfBase where it is used -- rare paths -- instead of through a per-lane 64-bit pointer held across the loops)
+// (stack entry e of a lane: LDS below NLDSP; from NLDS0 on the overflow column's slot e - NLDS0; the tail phase's entries NLDSP .. NLDS0 - 1 -- LDS in the main phase -- SKH_STACK_OVF + e - NLDSP)
+#define SKH_OVF_SLOT(e) ((SKH_TAIL_PHASE && (e) < NLDS0) ? SKH_STACK_OVF + ((e) - NLDSP) : (e) - NLDS0)
 #define SKH_OVF_AT(e) ovfBase[(size_t)(e) * ovfStride + (skh_opaque(blockIdx.x * SKH_TRACE_BLOCK) + threadIdx.x)]
     const uint32_t ovfStride = gridDim.x * SKH_TRACE_BLOCK;
     const uint32_t rayMask = CURVES ? (ANY_HIT ? 3u : 255u) : (ANY_HIT ? 1u : 253u);
@@ -447,10 +450,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
 #define SKH_HIDDEN_LIGHT(C) (ANY_HIT && __float_as_uint((C).w) != 0u)
 #define SKH_PUSH(v)                                                  \
     {                                                                \
-        if (sp < NLDS)                                               \
+        if (sp < NLDSP)                                              \
             lds[sp * SKH_TRACE_BLOCK] = (v);                         \
-        else if (sp < NLDS + SKH_STACK_OVF)                          \
-            SKH_OVF_AT(sp - NLDS) = (v);                             \
+        else if (sp < NLDS0 + SKH_STACK_OVF)                         \
+            SKH_OVF_AT(SKH_OVF_SLOT(sp)) = (v);                      \
         else                                                         \
             *sc.overflowFlag = 1u; /* the entry is dropped: the call that launched this kernel returns SKH_FAIL, never silent */ \
         ++sp;                                                        \
@@ -458,10 +461,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
 #define SKH_POP(dst)                                                 \
     {                                                                \
         --sp;                                                        \
-        if (sp < NLDS)                                               \
+        if (sp < NLDSP)                                              \
             dst = lds[sp * SKH_TRACE_BLOCK];                         \
-        else if (sp < NLDS + SKH_STACK_OVF)                          \
-            dst = SKH_OVF_AT(sp - NLDS);                             \
+        else if (sp < NLDS0 + SKH_STACK_OVF)                         \
+            dst = SKH_OVF_AT(SKH_OVF_SLOT(sp));                      \
         else                                                         \
             dst = SKH_REF_INVALID;                                   \
     }
@@ -508,1054 +511,56 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
         cur = sc.worldCurveRoot[k];                                                                               \
     }
 
-    for (;;)
+    // The main phase: every build.  (SPLIT: left as soon as the wave finds the queue dry.)
     {
-        // ---------------- refill idle lanes from the queue ----------------
-        const unsigned long long needMask = __ballot(!hasRay);
-        const uint32_t want = (uint32_t)__popcll(needMask);
-        SKH_LP(wv[3]++; unsigned long long cyA = __builtin_readcyclecounter();)
-#ifdef SKH_TAIL_PROFILE
-        if (exhausted)
+        constexpr int NLDSP = NLDS0;
+#define SKH_TAIL_PHASE 0
+        for (;;)
         {
-            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            if (!dryNoted)
-                dryNoted = true, dryAt = now, dryLiveLanes = 64u - want;
-            else
-                rayTicks += (unsigned long long)(64u - want) * (now - dryLast); // (the lanes alive now were alive since the last look at least)
-            dryLast = now;
+#include "skh_trace_body.inc"
         }
-#endif
-        if (want >= fetchMin || want == 64u || (SPLIT && exhausted))
-        {
-            // results of the lanes that finished since the last refill: written together, once per refill (SPLIT, queue dry: at once -- the lane is wanted as a helper)
-            if (pending)
-            {
-                pending = false;
-                const uint32_t i = ridx;
-                if (ANY_HIT)
-                {
-                    if (hq.base) // raw query mode (skh_trace): 1 = occluded, -1 = not
-                        hq.base[i] = best.found ? 1.0f : -1.0f;
-                    else if (!best.found)
-                    {
-                        // (one scattered 16-byte load: the light sample's contribution and the path it goes to, as k_shade wrote them)
-                        const float4 cw = contrib[i];
-                        float4* rad = ps.rad() + __float_as_uint(cw.w);
-                        float4 r = *rad;
-                        r.x += cw.x;
-                        r.y += cw.y;
-                        r.z += cw.z;
-                        *rad = r;
-                    }
-                }
-                else
-                {
-                    float4* hr = hq.rec(i);
-                    if (BESTLDS && hq.primBits != 0u)
-                    {
-                        const bool f = best.found;
-                        *hq.rec16(i) = make_float4(f ? best.t : -1.0f, f ? __uint_as_float(s_best[2 * SKH_TRACE_BLOCK + lane]) : 0.0f, f ? __uint_as_float(s_best[3 * SKH_TRACE_BLOCK + lane]) : 0.0f,
-                                                   __uint_as_float(f ? (s_best[lane] << hq.primBits) | (s_best[SKH_TRACE_BLOCK + lane] & ((1u << hq.primBits) - 1u)) : 0xffffffffu));
-                    }
-                    else if (BESTLDS)
-                    {
-                        // (a miss reports what a fresh record holds: u = v = 0, instance = primitive = ~0)
-                        const bool f = best.found;
-                        hr[0] = make_float4(f ? best.t : -1.0f, f ? __uint_as_float(s_best[2 * SKH_TRACE_BLOCK + lane]) : 0.0f,
-                                            f ? __uint_as_float(s_best[3 * SKH_TRACE_BLOCK + lane]) : 0.0f, 0.0f);
-                        hr[1] = make_float4(__uint_as_float(f ? s_best[lane] : 0xffffffffu), __uint_as_float(f ? s_best[SKH_TRACE_BLOCK + lane] : 0xffffffffu), 0.0f, 0.0f);
-                    }
-                    else if (hq.primBits != 0u)
-                        *hq.rec16(i) = make_float4(best.found ? best.t : -1.0f, best.u, best.v,
-                                                   __uint_as_float(best.found ? (best.inst << hq.primBits) | (best.prim & ((1u << hq.primBits) - 1u)) : 0xffffffffu));
-                    else
-                    {
-                        hr[0] = make_float4(best.found ? best.t : -1.0f, best.u, best.v, 0.0f);
-                        hr[1] = make_float4(__uint_as_float(best.inst), __uint_as_float(best.prim), 0.0f, 0.0f);
-                    }
-                }
-            }
-        }
-        if (!exhausted && (want >= fetchMin || want == 64u))
-        {
-            SKH_LP(wv[4]++; wv[5] += want;)
-            uint32_t base = 0, count = 0, base2 = 0, count1 = 0;
-            if constexpr (WORLD && !CURVES)
-            {
-                // The wave takes `want` positions from its shard's cursor -- or, for hierarchies small enough that the launch would be bound by the cursors'
-                // atomics (fetchChunk: Cornell), reserves a chunk per atomic and serves its next refills from the reservation; a refill that finds the
-                // reservation short takes what is left and the start of the next chunk.  (Which wave traces which ray does not show in any result.)
-                const uint32_t chunk = fetchChunk;
-                count1 = min(want, resLeft); // (0 without chunks)
-                base = resBase, count = count1;
-                resBase += count1, resLeft -= count1;
-                if (count1 < want)
-                {
-                    const uint32_t ask = chunk ? chunk : want;
-                    const int leader = __ffsll((long long)needMask) - 1;
-                    while (tries < 8u)
-                    {
-                        const uint32_t g = (group + tries) & 7u;
-                        uint32_t b = 0;
-                        if ((int)lane == leader)
-                            b = atomicAdd(&fetch[g * SKH_FETCH_STRIDE], ask);
-                        b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader); // (a scalar: the reservation lives in SGPRs)
-                        const uint32_t lo = g * perGroup;
-                        const uint32_t hi = lo + min(countPtr[g * SKH_COUNT_STRIDE], perGroup);
-                        if (lo < hi && b < hi - lo)
-                        {
-                            const uint32_t got = min(ask, hi - (lo + b));
-                            if (got < ask)
-                                ++tries; // this range is now empty
-                            const uint32_t count2 = min(want - count1, got);
-                            base2 = lo + b;
-                            if (chunk)
-                                resBase = base2 + count2, resLeft = got - count2;
-                            count = count1 + count2;
-                            break;
-                        }
-                        ++tries;
-                    }
-                    if (tries >= 8u && count == 0)
-                        exhausted = true;
-                }
-            }
-            else
-            {
-                const int leader = __ffsll((long long)needMask) - 1;
-                while (tries < 8u)
-                {
-                    const uint32_t g = (group + tries) & 7u;
-                    uint32_t b = 0;
-                    if ((int)lane == leader)
-                        b = atomicAdd(&fetch[g * SKH_FETCH_STRIDE], want);
-                    b = __shfl(b, leader);
-                    const uint32_t lo = g * perGroup;
-                    const uint32_t hi = lo + min(countPtr[g * SKH_COUNT_STRIDE], perGroup);
-                    if (lo < hi && b < hi - lo)
-                    {
-                        base = lo + b;
-                        count = min(want, hi - base);
-                        if (count < want)
-                            ++tries; // this range is now empty
-                        break;
-                    }
-                    ++tries;
-                }
-                if (tries >= 8u && count == 0)
-                    exhausted = true;
-            }
-            const uint32_t rank = rank_below(needMask);
-            if (!hasRay && rank < count)
-            {
-                ridx = (WORLD && !CURVES) ? (rank < count1 ? base + rank : base2 + (rank - count1)) : base + rank;
-                ow = mk3(rq.plane(0)[ridx], rq.plane(1)[ridx], rq.plane(2)[ridx]);
-                dw = mk3(rq.plane(3)[ridx], rq.plane(4)[ridx], rq.plane(5)[ridx]);
-                tmin = rq.plane(6)[ridx];
-                o = ow;
-                d = dw;
-                inv = rcp3(d);
-                if (ANY_HIT && !WORLD)
-                    invw = inv;
-                const int wr0 = sc.worldRoot; // (kernel arguments: scalar branches)
-                int wr1 = ANY_HIT ? SKH_REF_INVALID : sc.lightRoot;
-                if (!ANY_HIT && wr1 != SKH_REF_INVALID)
-                {
-                    // The baked light proxies' tree is every radiance ray's LAST stop (one node visit per ray at least: 4 % of the kitchen's): a ray that
-                    // misses the box around ALL of them (lightBox: the group's bounds plus the node encoder's margin; the node test's own slab
-                    // arithmetic and slack, so whatever a visit of the root could find lies inside) does not go there at all.
-                    const float lnx = ((inv.x >= 0.0f ? lightBox.lo[0] : lightBox.hi[0]) - o.x) * inv.x, lfx = ((inv.x >= 0.0f ? lightBox.hi[0] : lightBox.lo[0]) - o.x) * inv.x;
-                    const float lny = ((inv.y >= 0.0f ? lightBox.lo[1] : lightBox.hi[1]) - o.y) * inv.y, lfy = ((inv.y >= 0.0f ? lightBox.hi[1] : lightBox.lo[1]) - o.y) * inv.y;
-                    const float lnz = ((inv.z >= 0.0f ? lightBox.lo[2] : lightBox.hi[2]) - o.z) * inv.z, lfz = ((inv.z >= 0.0f ? lightBox.hi[2] : lightBox.lo[2]) - o.z) * inv.z;
-                    const float ltn = fmaxf(fmaxf(lnx, lny), fmaxf(lnz, tmin)), ltf = fminf(fminf(lfx, lfy), fminf(lfz, rq.plane(7)[ridx] /* the ray's tmax */));
-                    if (!(ltn <= ltf * SKH_SLAB_SLACK))
-                        wr1 = SKH_REF_INVALID;
-                }
-                if (WORLD && CURVES)
-                {
-                    // stack, bottom to top: the curve trees' markers, the light proxies' root; current node: the world-space triangles' root
-                    if (!CURVES) // (the curve builds are short of registers and meet few triangles: they recompute the shear at every triangle leaf)
-                        sh = make_shear(dw);
-                    curInst = 0xffffffffu;
-                    curType = 0;
-                    sp = 0;
-                    // (the marker popped FIRST -- the last one pushed -- may take the identity short cut: (o, d) still hold the world ray then)
-                    // (through SKH_PUSH / SKH_POP: bounds-checked like every other stack access -- ADVICE r5; at most SKH_WORLD_CURVES + 1 entries, once per ray)
-                    for (uint32_t k = 0; k < sc.numWorldCurves; ++k)
-                        SKH_PUSH((int)(SKH_REF_CURVEROOT | k | ((k + 1u == sc.numWorldCurves && sc.worldCurveIdentLast) ? SKH_REF_CURVEROOT_IDENT : 0u)))
-                    if (wr0 != SKH_REF_INVALID && wr1 != SKH_REF_INVALID)
-                        SKH_PUSH(wr1)
-                    cur = wr0 != SKH_REF_INVALID ? wr0 : wr1;
-                    if (cur == SKH_REF_INVALID)
-                        SKH_POP(cur) // (no triangles at all: the first marker; numWorldCurves >= 1 in this build)
-                }
-                else if (wr0 != SKH_REF_INVALID || wr1 != SKH_REF_INVALID)
-                {
-                    // baked instances first: the ray starts INSIDE their world-space groups (identity entry: o = ow, d = dw), the top
-                    // level waits under a sentinel on the stack
-                    if (!CURVES) // (the curve builds are short of registers and meet few triangles: they recompute the shear at every triangle leaf)
-                        sh = make_shear(dw);
-                    nodes = sc.triNodes;
-                    inBlas = true;
-                    curInst = 0xffffffffu; // = "the instance id is in the triangle record"
-                    curType = 0;
-                    sp = 0;
-                    if (!WORLD && sc.tlasRoot != SKH_REF_INVALID)
-                    {
-                        lds[0] = sc.tlasRoot;
-                        lds[SKH_TRACE_BLOCK] = SKH_REF_SENTINEL;
-                        sp = 2;
-                    }
-                    if (wr0 != SKH_REF_INVALID && wr1 != SKH_REF_INVALID)
-                        lds[(sp++) * SKH_TRACE_BLOCK] = wr1;
-                    cur = wr0 != SKH_REF_INVALID ? wr0 : wr1;
-                }
-                else
-                {
-                    nodes = sc.tlasNodes;
-                    inBlas = false;
-                    sp = 0;
-                    cur = sc.tlasRoot;
-                }
-                best.t = rq.plane(7)[ridx];
-                best.inst = best.prim = 0xffffffffu;
-                best.u = best.v = 0.0f;
-                best.found = false;
-                pend = 0;
-                hasRay = true;
-            }
-        }
-        if constexpr (SPLIT)
-        {
-            if (exhausted)
-            {
-                // ---------------- the queue is dry: idle lanes take stack entries of the lanes that still have a ray ----------------
-                if (!tailOn)
-                {
-                    tailOn = true; // every ray the wave holds becomes a family of one; its record starts as the lane's best hit so far
-                    if (hasRay)
-                    {
-                        fam = lane;
-                        SKH_FAM(0, lane) = __float_as_uint(best.t);
-                        SKH_FAM(1, lane) = __float_as_uint(best.t);
-                        SKH_FAM(2, lane) = best.found ? (ANY_HIT ? 0u : best.inst) : 0xffffffffu; // (all ones: nothing found yet)
-                        SKH_FAM(3, lane) = best.prim, SKH_FAM(4, lane) = __float_as_uint(best.u), SKH_FAM(5, lane) = __float_as_uint(best.v);
-                        SKH_FAM(6, lane) = 1u;
-                    }
-                }
-                else if (!ANY_HIT && hasRay && best.found)
-                    atomicMin(&SKH_FAM(0, fam), __float_as_uint(best.t)); // (t >= 0: its bits order as it does) what this fragment has found prunes the others
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                bool famDone = false;
-                if (hasRay)
-                {
-                    if (ANY_HIT)
-                    {
-                        // another fragment has found an occluder (merged at its termination): this one has nothing left to look for
-                        if (SKH_FAM(2, fam) != 0xffffffffu)
-                        {
-                            famDone = true;
-                            best.found = true;
-                            cur = SKH_REF_INVALID;
-                            sp = 0;
-                        }
-                    }
-                    else
-                    {
-                        // The family's bound below this lane's: nothing beyond it can win.  The lane forgets its own (farther) hit and keeps the interval CLOSED at
-                        // the bound -- an equally near hit with a smaller key still has to be found; the merge decides --: "not found, tmax = the next float up".
-                        const uint32_t tb = SKH_FAM(0, fam);
-                        if (__uint_as_float(tb) < best.t)
-                        {
-                            best.t = __uint_as_float(tb + 1u);
-                            best.found = false;
-                            best.inst = best.prim = 0xffffffffu;
-                            best.u = best.v = 0.0f;
-                        }
-                    }
-                }
-                // Every idle lane gets an entry while the givers have any: idle lane r takes entry r / nG (counted from the top) of giver r % nG, straight out of the
-                // giver's stack column (LDS, or the overflow area); a giver knows from the two counts how many of its entries went.
-                const bool giver = hasRay && sp > 0 && !famDone;
-                const unsigned long long idleM = __ballot(!hasRay), giveM = __ballot(giver);
-                const uint32_t nI = (uint32_t)__popcll(idleM), nG = (uint32_t)__popcll(giveM);
-                if (nI != 0u && nG != 0u)
-                {
-                    const uint32_t rI = rank_below(idleM), rG = rank_below(giveM);
-                    if (giver)
-                        s_tab[rG] = (unsigned char)lane;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const bool idle = !hasRay;
-                    const int depth = idle ? (int)(rI / nG) : 0;
-                    const int src = idle ? (int)s_tab[rI % nG] : (int)lane;
-                    const int psp = __shfl(sp, src);
-                    const bool takes = idle && depth < psp && depth < NLDS + SKH_STACK_OVF;
-                    int pgive = SKH_REF_INVALID;
-                    if (takes)
-                    {
-                        const int e = min(psp, NLDS + SKH_STACK_OVF) - 1 - depth;
-                        pgive = e < NLDS ? s_stack[e * SKH_TRACE_BLOCK + src] : ovfBase[(size_t)(e - NLDS) * ovfStride + (blockIdx.x * SKH_TRACE_BLOCK + (uint32_t)src)];
-                    }
-                    if (giver)
-                    {
-                        const uint32_t offered = nI > rG ? (nI - rG + nG - 1u) / nG : 0u; // idle lanes r with r % nG == rG
-                        const uint32_t gone = min(min((uint32_t)sp, (uint32_t)(NLDS + SKH_STACK_OVF)), offered);
-                        if (gone != 0u)
-                        {
-                            atomicAdd(&SKH_FAM(6, fam), gone);
-                            sp = min(sp, NLDS + SKH_STACK_OVF) - (int)gone;
-                        }
-                    }
-                    // (every lane takes part in the exchange: a disabled source lane would read as zero)
-                    const float pox = __shfl(o.x, src), poy = __shfl(o.y, src), poz = __shfl(o.z, src);
-                    const float pix = __shfl(inv.x, src), piy = __shfl(inv.y, src), piz = __shfl(inv.z, src);
-                    const int pperm = __shfl(sh.perm, src);
-                    const float psx = __shfl(sh.Sx, src), psy = __shfl(sh.Sy, src), psz = __shfl(sh.Sz, src);
-                    const float ptmin = __shfl(tmin, src), pbt = __shfl(best.t, src), pbu = __shfl(best.u, src), pbv = __shfl(best.v, src);
-                    const uint32_t pbi = (uint32_t)__shfl((int)best.inst, src), pbp = (uint32_t)__shfl((int)best.prim, src);
-                    const bool pbf = __shfl((int)best.found, src) != 0;
-                    const uint32_t pridx = (uint32_t)__shfl((int)ridx, src), pfam = (uint32_t)__shfl((int)fam, src);
-                    if (takes)
-                    {
-                        o = mk3(pox, poy, poz);
-                        inv = mk3(pix, piy, piz);
-                        sh.perm = pperm, sh.Sx = psx, sh.Sy = psy, sh.Sz = psz;
-                        tmin = ptmin;
-                        best.t = pbt, best.u = pbu, best.v = pbv, best.inst = pbi, best.prim = pbp, best.found = pbf;
-                        ridx = pridx;
-                        fam = pfam;
-                        cur = pgive;
-                        sp = 0;
-                        hasRay = true;
-                    }
-                }
-            }
-        }
-        if (!__any(hasRay))
-        {
-            if (exhausted)
-                break;
-            continue;
-        }
-        SKH_LP({ const unsigned long long t = __builtin_readcyclecounter(); cy[0] += t - cyA; cyA = t; })
-        if constexpr (CURVES)
-        {
-            // ---- the iterative curve intersector, wave-cooperative ----
-            // A lane whose leaf produced candidates (segments that passed the cylinder test) parks; each candidate needs two independent
-            // Newton runs (one from either end of the segment, up to 40 steps of ~70 instructions).  Run by their owners, the wave waited
-            // for 48 parked lanes before it started them (a block costs the same for 3 lanes as for 64) and then ran two to four runs per
-            // lane back to back: on average half of the wave sat parked (hair stand-in: 13 of 64 lanes per VALU instruction).  Here the
-            // runs of all parked lanes are dealt out one per lane -- to EVERY lane, idle and descending ones included --, so ~25 parked
-            // lanes already fill the wave and a block lasts one run.  A run sees the owner's ray (pulled with ds_bpermute) and returns
-            // (t, u) or nothing; the owner applies the interval's upper end, takes the nearer root of a candidate (the first run's on a
-            // tie) and merges candidates in slot order -- the same decisions in the same order as intersect_curve_segment, same bits.
-            __shared__ uint16_t s_runs[256]; // run -> owner lane | slot << 6 | end << 9
-            // (a block takes at most two candidates per lane -- a curve leaf holds at most two sub-segments; anything beyond waits for the next block)
-            const uint32_t take = hasRay ? ((pend & (0u - pend)) | ((pend & (pend - 1u)) & (0u - (pend & (pend - 1u))))) : 0u;
-            const uint32_t myCand = (uint32_t)__popc(take);
-            uint32_t incl = 2u * myCand; // inclusive prefix sum of the run counts
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1)
-            {
-                const uint32_t v = __shfl_up(incl, off);
-                incl += lane >= (uint32_t)off ? v : 0u;
-            }
-            const uint32_t nRuns = (uint32_t)__shfl(incl, 63);
-            const uint32_t nWalking = (uint32_t)__popcll(__ballot(hasRay && pend == 0u));
-            if (nRuns != 0u && (nRuns >= curveMin || nWalking == 0u))
-            {
-                SKH_LP(wv[9]++; wv[2] += nRuns;) // (profile build: curve blocks, Newton runs dealt)
-                const uint32_t P = incl - 2u * myCand;
-                {
-                    uint32_t bits = take, j = P; // (<= 64 lanes x 2 candidates x 2 ends = 256 runs)
-                    while (bits != 0u)
-                    {
-                        const uint32_t k = (uint32_t)__ffs((int)bits) - 1u;
-                        bits &= bits - 1u;
-                        s_runs[j] = (uint16_t)(lane | (k << 6));
-                        s_runs[j + 1u] = (uint16_t)(lane | (k << 6) | (1u << 9));
-                        j += 2u;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t myFirst = ((uint32_t)~cur) >> 3; // (a parked lane keeps its leaf in `cur`)
-                uint32_t bitsLeft = take, doneCand = 0;
-                for (uint32_t base = 0; base < nRuns; base += 64u)
-                {
-                    const uint32_t r = base + lane;
-                    const bool work = r < nRuns;
-                    const uint32_t desc = work ? (uint32_t)s_runs[r & 255u] : 0u;
-                    const int owner = (int)(desc & 63u);
-                    const uint32_t slot = (desc >> 6) & 7u, ep = desc >> 9;
-                    // the owner's (object-space) ray and leaf
-                    const v3 oo = mk3(__shfl(o.x, owner), __shfl(o.y, owner), __shfl(o.z, owner));
-                    const v3 od = mk3(__shfl(d.x, owner), __shfl(d.y, owner), __shfl(d.z, owner));
-                    const float otmin = __shfl(tmin, owner);
-                    const uint32_t ofirst = (uint32_t)__shfl((int)myFirst, owner);
-                    float resT = 0.0f, resU = -1.0f;
-                    SKH_LP(uint32_t runSteps = 0;)
-                    if (work)
-                    {
-                        const float4* cp = sc.segs + SKH_SEG_STRIDE * (size_t)(ofirst + slot);
-                        const float4 c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
-                        const float dlen = sqrtf(dot(od, od));
-                        const float inv_dlen = 1.0f / dlen;
-                        const v3 dn = od * inv_dlen;
-                        v3 bx, by;
-                        onb_from_z(dn, bx, by);
-                        CubicPoly poly;
-                        {
-                            v4 qc[4];
-                            const v3 p0 = mk3(c0.x, c0.y, c0.z) - oo, p1 = mk3(c1.x, c1.y, c1.z) - oo, p2 = mk3(c2.x, c2.y, c2.z) - oo, p3 = mk3(c3.x, c3.y, c3.z) - oo;
-                            qc[0] = mk4(dot(p0, bx), dot(p0, by), dot(p0, dn), c0.w);
-                            qc[1] = mk4(dot(p1, bx), dot(p1, by), dot(p1, dn), c1.w);
-                            qc[2] = mk4(dot(p2, bx), dot(p2, by), dot(p2, dn), c2.w);
-                            qc[3] = mk4(dot(p3, bx), dot(p3, by), dot(p3, dn), c3.w);
-                            cubic_from_bspline(poly, qc);
-                        }
-                        const v4 e0 = cubic_position(poly, 0.0f);
-                        const v4 e1 = cubic_position(poly, 1.0f);
-                        const float tstart = (e1.z - e0.z) > 0.0f ? 0.0f : 1.0f;
-                        float tpar = ep == 0u ? tstart : 1.0f - tstart;
-                        float told = 0.0f, dt1 = 0.0f, dt2 = 0.0f;
-                        for (int it = 0; it < 40; ++it)
-                        {
-                            SKH_LP(runSteps = (uint32_t)it + 1u;)
-                            // one step of the ray / tangent-cone iteration (intersect_curve_segment, loop body)
-                            const v4 c4 = cubic_position(poly, tpar);
-                            const v4 d4 = ((3.0f * poly.p[0] * tpar) + 2.0f * poly.p[1]) * tpar + poly.p[2];
-                            const v3 cc0 = mk3(c4), cd = mk3(d4);
-                            const float rr = c4.w, dr = d4.w;
-                            const float r2 = rr * rr;
-                            const float drr = rr * dr;
-                            float ddd = cd.x * cd.x + cd.y * cd.y;
-                            const float dp = cc0.x * cc0.x + cc0.y * cc0.y;
-                            const float cdd = cc0.x * cd.x + cc0.y * cd.y;
-                            const float cxd = cc0.x * cd.y - cc0.y * cd.x;
-                            const float cc = ddd;
-                            const float bb = cd.z * (drr - cdd);
-                            const float cdz2 = cd.z * cd.z;
-                            ddd += cdz2;
-                            const float aa = ((2.0f * drr * cdd + cxd * cxd) - ddd * r2) + dp * cdz2;
-                            const float det = bb * bb - aa * cc;
-                            const float ss = (bb - (det > 0.0f ? sqrtf(det) : 0.0f)) / cc;
-                            float dt = (ss * cd.z - cdd) / ddd;
-                            const bool phantom = !(det > 0.0f);
-                            if (!phantom && fabsf(dt) < 5e-5f)
-                            {
-                                const float sw = (ss + cc0.z) * inv_dlen;
-                                if (sw > otmin && tpar >= 0.0f && tpar <= 1.0f) // (the upper end of the interval is the owner's to apply)
-                                {
-                                    resT = sw;
-                                    resU = tpar;
-                                }
-                                break;
-                            }
-                            if (phantom && fabsf(dt) < 5e-5f)
-                                break; // converged onto a point the ray does not touch: a miss (intersect_curve_segment's rule)
-                            dt = fminf(dt, 0.5f);
-                            dt = fmaxf(dt, -0.5f);
-                            dt1 = dt2;
-                            dt2 = dt;
-                            if (dt1 * dt2 < 0.0f)
-                            {
-                                float tnext;
-                                if ((it & 3) == 0)
-                                    tnext = 0.5f * (told + tpar);
-                                else
-                                    tnext = (dt2 * told - dt1 * tpar) / (dt2 - dt1);
-                                told = tpar;
-                                tpar = tnext;
-                            }
-                            else
-                            {
-                                told = tpar;
-                                tpar += dt;
-                            }
-#ifdef SKH_ITER_STATS
-                            if (COUNT)
-                                tc.insts++; // (one-off measurement: Newton steps, reported as "instances")
-#endif
-                            if (!(tpar >= 0.0f && tpar <= 1.0f))
-                                break;
-                        }
-                    }
-                    SKH_LP(if (work) atomicAdd(&stats->runHist[ANY_HIT ? 1 : 0][min(runSteps, 41u)], 1ull); { const uint32_t mx = wave_max(runSteps); if (lane == 0) atomicAdd(&stats->blockHist[ANY_HIT ? 1 : 0][min(mx, 41u)], 1ull); })
-                    // owners collect the runs of this round: candidate c of a lane = runs P + 2c (its first end) and P + 2c + 1
-                    const uint32_t maxCand = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max(myCand));
-                    for (uint32_t c = 0; c < maxCand; ++c)
-                    {
-                        const uint32_t rr0 = P + 2u * c;
-                        const bool mine = c < myCand && c == doneCand && rr0 >= base && rr0 < base + 64u;
-                        const int src = (int)((rr0 - base) & 63u);
-                        const float t0 = __shfl(resT, src), u0 = __shfl(resU, src);
-                        const float t1 = __shfl(resT, (src + 1) & 63), u1 = __shfl(resU, (src + 1) & 63);
-                        if (mine)
-                        {
-                            const uint32_t k = (uint32_t)__ffs((int)bitsLeft) - 1u;
-                            bitsLeft &= bitsLeft - 1u;
-                            ++doneCand;
-                            if (COUNT)
-                                tc.segs++;
-                            // intersect_curve_segment's acceptance: a root counts if it is within (tmin, tmax], tmax = best.t now; the nearer
-                            // root wins, the first run's on a tie
-                            const bool f0 = u0 >= 0.0f && t0 <= best.t, f1 = u1 >= 0.0f && t1 <= best.t;
-                            const bool first = f0 && !(f1 && t1 < t0);
-                            const float t = first ? t0 : t1, u = first ? u0 : u1;
-                            if ((f0 || f1) && (best.found || t < best.t)) // (open at tmax: best.t is the ray's tmax until a hit is found)
-                            {
-                                const float4 idw = sc.segs[SKH_SEG_STRIDE * (size_t)(myFirst + k) + 6]; // {primitive | sub-range << 28, instance of a merged segment, -, -}
-                                const uint32_t spw = __float_as_uint(idw.x);
-                                const uint32_t prim = spw & 0x0fffffffu;
-                                // (a merged tree -- curve instances under one transform -- names the instance per segment)
-                                const uint32_t hinst = (WORLD && curInst == 0xffffffffu) ? __float_as_uint(idw.y) : curInst;
-                                // a sub-range leaf keeps the hit only if u is its own (the leaf that owns u reports the same bits)
-                                if (min((uint32_t)(u * (float)sc.curveSplit), sc.curveSplit - 1u) == (spw >> 28) &&
-                                    (!best.found || t < best.t || hinst < SKH_BEST_INST() || (hinst == SKH_BEST_INST() && prim < SKH_BEST_PRIM())))
-                                {
-                                    best.t = t;
-                                    SKH_BEST_SET(hinst, prim, u, 0.0f)
-                                    best.found = true;
-                                }
-                            }
-                        }
-                    }
-                }
-                if (myCand != 0u)
-                {
-                    pend &= ~take;
-                    if (pend == 0u)
-                        cur = SKH_REF_INVALID; // leaf done: the lane pops its next entry below
-                }
-                // the reciprocal direction is not needed inside the block: recomputed here (same operation on the same d: same bits) instead of
-                // being held -- or spilled -- across the Newton runs
-                inv = rcp3(d);
-                __builtin_amdgcn_wave_barrier(); // (s_runs is rewritten by the next block)
-            }
-        }
-        bool terminated = false;
-        SKH_LP(uint32_t itN = 0, itT = 0; { const unsigned long long t = __builtin_readcyclecounter(); cy[6] += t - cyA; cyA = t; })
-        // (lanes parked in front of the curve intersector do not count: they are not waiting for the node loop to end)
-        const uint32_t breakBelow = ((uint32_t)__popcll(__ballot(hasRay && !(CURVES && pend != 0u))) * nodeBreak) >> 6;
-        if (hasRay || TRICOOP) // (TRICOOP: every lane comes along to the triangle pass; the node loop and the pop stay with the lanes that have a ray)
-        {
-            // ---- descend through internal nodes ----
-            // (a curve tree's marker under a general transform ends the node loop -- its nine loads must not sit in every iteration of every wave:
-            // hair 1 937 -> 1 637 Mray/s --; the identity short cut is taken right here, so that a lane whose triangle walk ends on a missed box
-            // goes on into the curve tree without a pass of its own: closest-hit 76.8 -> 71.5 ms)
-            while ((!TRICOOP || hasRay) && cur >= 0 && cur != SKH_REF_INVALID &&
-                   !(WORLD && CURVES && ((uint32_t)cur & SKH_REF_CURVEROOT) != 0u && (ANY_HIT || ((uint32_t)cur & SKH_REF_CURVEROOT_IDENT) == 0u)))
-            {
-                // (the any-hit build takes every marker outside the loop: measured 49.9 against 53.8 ms; the closest-hit build the other way round)
-                if constexpr (WORLD && CURVES && !ANY_HIT)
-                {
-                    if ((uint32_t)cur & SKH_REF_CURVEROOT_IDENT)
-                    {
-                        SKH_TAKE_MARKER()
-                        if (cur < 0 || cur == SKH_REF_INVALID)
-                            break; // (a tree of one leaf)
-                    }
-                }
-                SKH_LP(itN++; rayNodes++;)
-                // one 64-byte fetch = four quantised child boxes
-                // (curve builds: a reference with SKH_REF_SEGNODE set is a segment node -- same array, same layout: the low 28 bits index it)
-                const float4* np = reinterpret_cast<const float4*>((WORLD ? (CURVES && curType == 2 ? sc.segNodes : sc.triNodes) : nodes) + ((CURVES && SKH_SEGNODE) ? (cur & 0x0fffffff) : cur));
-                const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-                if (COUNT)
-                    tc.nodes++;
-                SKH_LP(if (!inBlas) tc.segs++;) // (profile build: TLAS share of the node visits, reported as "segs")
-                // per axis: plane t = q * (cell * inv) + (o_node - o_ray) * inv (cell sizes come as floats); near/far bytes picked by the sign of inv
-                const float ax = w1.w * inv.x, bx = (w0.x - o.x) * inv.x;
-                const float ay = w2.w * inv.y, by = (w0.y - o.y) * inv.y;
-                const float az = w0.w * inv.z, bz = (w0.z - o.z) * inv.z;
-                const bool px = inv.x >= 0.0f, py = inv.y >= 0.0f, pz = inv.z >= 0.0f;
-                const uint32_t nxw = __float_as_uint(px ? w1.x : w2.x), fxw = __float_as_uint(px ? w2.x : w1.x);
-                const uint32_t nyw = __float_as_uint(py ? w1.y : w2.y), fyw = __float_as_uint(py ? w2.y : w1.y);
-                const uint32_t nzw = __float_as_uint(pz ? w1.z : w2.z), fzw = __float_as_uint(pz ? w2.z : w1.z);
-                float tn[4];
-                int rf[4];
-                rf[0] = __float_as_int(w3.x), rf[1] = __float_as_int(w3.y), rf[2] = __float_as_int(w3.z), rf[3] = __float_as_int(w3.w);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                {
-                    const float nx = fmaf((float)((nxw >> (8 * k)) & 0xffu), ax, bx), fx = fmaf((float)((fxw >> (8 * k)) & 0xffu), ax, bx);
-                    const float ny = fmaf((float)((nyw >> (8 * k)) & 0xffu), ay, by), fy = fmaf((float)((fyw >> (8 * k)) & 0xffu), ay, by);
-                    const float nz = fmaf((float)((nzw >> (8 * k)) & 0xffu), az, bz), fz = fmaf((float)((fzw >> (8 * k)) & 0xffu), az, bz);
-                    const float tnear = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
-                    const float tfar = fminf(fminf(fx, fy), fminf(fz, best.t));
-                    // (an empty slot is stored as the inverted box 255 > 0 on every axis and fails this test by itself; should rounding
-                    // ever let one through, its SKH_REF_INVALID is pushed and skipped when popped)
-                    const bool hit = tnear <= tfar * SKH_SLAB_SLACK;
-                    tn[k] = hit ? tnear : INFINITY;
-                }
-                if (CURVES && SKH_SEGNODE && ((uint32_t)cur & SKH_REF_SEGNODE) != 0u)
-                {
-                    // a SEGMENT NODE (skh_bvh.h k_segnode_emit): its four boxes are one segment's parameter sub-ranges and its four references all name the
-                    // segment's leaf.  Meeting any of them makes the segment ONE candidate (the lane leaves the loop with the leaf in `cur`: cylinder test, then
-                    // the cooperative block); nothing is pushed.
-                    tn[0] = fminf(fminf(tn[0], tn[1]), fminf(tn[2], tn[3]));
-                    tn[1] = tn[2] = tn[3] = INFINITY;
-                }
-                // sort the four candidates by entry distance (5-comparator network), nearest first
-#define SKH_CSWAP(a, b)                      \
-    {                                        \
-        const bool sw = tn[b] < tn[a];       \
-        const float ta = sw ? tn[b] : tn[a]; \
-        const float tb = sw ? tn[a] : tn[b]; \
-        const int ra = sw ? rf[b] : rf[a];   \
-        const int rb = sw ? rf[a] : rf[b];   \
-        tn[a] = ta, tn[b] = tb;              \
-        rf[a] = ra, rf[b] = rb;              \
+#undef SKH_TAIL_PHASE
     }
-                if (!ANY_HIT)
-                {
-                    SKH_CSWAP(0, 1)
-                    SKH_CSWAP(2, 3)
-                    SKH_CSWAP(0, 2)
-                    SKH_CSWAP(1, 3)
-                    SKH_CSWAP(1, 2)
-                    if (sp + 3 <= NLDS)
-                    {
-                        // the c hit children among rf[1..3] go to slots sp .. sp+c-1 (farthest first); the writes are
-                        // unconditional (what lands above the new top is never read): no branch per push
-                        const int c = (tn[1] < INFINITY ? 1 : 0) + (tn[2] < INFINITY ? 1 : 0) + (tn[3] < INFINITY ? 1 : 0);
-                        int* p = lds + sp * SKH_TRACE_BLOCK;
-                        p[0] = c == 3 ? rf[3] : (c == 2 ? rf[2] : rf[1]);
-                        p[SKH_TRACE_BLOCK] = c == 3 ? rf[2] : rf[1];
-                        p[2 * SKH_TRACE_BLOCK] = rf[1];
-                        sp += c;
-                    }
-                    else
-                    {
-                        if (tn[3] < INFINITY)
-                            SKH_PUSH(rf[3]);
-                        if (tn[2] < INFINITY)
-                            SKH_PUSH(rf[2]);
-                        if (tn[1] < INFINITY)
-                            SKH_PUSH(rf[1]);
-                    }
-                    cur = tn[0] < INFINITY ? rf[0] : SKH_REF_INVALID;
-                }
-                else
-                {
-                    // occlusion query: any order finds an occluder; skip the ordering network.  The hit children in slot order: the last one becomes
-                    // `cur`, the ones before it are pushed in that order.
-                    if (SKH_ANYHIT_FLAT_PUSH && sp + 3 <= NLDS)
-                    {
-                        // (round 6) without a branch per child: the store is unconditional -- what lands above the new top is never read -- and the
-                        // top only moves for a real push: the compiler's version of the loop below was 22 branches and 74 scalar instructions in a
-                        // 257-instruction iteration
-                        int nc = tn[0] < INFINITY ? rf[0] : SKH_REF_INVALID;
-                        int top = sp;
-#pragma unroll
-                        for (int k = 1; k < 4; ++k)
-                        {
-                            const bool h = tn[k] < INFINITY;
-                            lds[top * SKH_TRACE_BLOCK] = nc;
-                            top += (h && nc != SKH_REF_INVALID) ? 1 : 0;
-                            nc = h ? rf[k] : nc;
-                        }
-                        sp = top;
-                        cur = nc;
-                    }
-                    else
-                    {
-                        cur = SKH_REF_INVALID;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (tn[k] < INFINITY)
-                            {
-                                if (cur != SKH_REF_INVALID)
-                                    SKH_PUSH(cur);
-                                cur = rf[k];
-                            }
-                    }
-                }
-#undef SKH_CSWAP
-                // a lane whose node had no hit child takes its next stack entry right here instead of idling until
-                // the whole wave leaves the node loop
-                if (cur == SKH_REF_INVALID && sp > 0)
-                    SKH_POP(cur);
-                // (Round 6 measured the curve leaf's cylinder tests INSIDE this loop -- a lane whose walk arrives at a curve leaf tests it here and, rejected 70 % of
-                // the time, pops and goes on descending instead of waiting for the wave to leave the loop: exact, and 21 % slower (hair 2 067 -> 1 631 Mray/s,
-                // closest-hit 70.7 -> 89.3 ms, any-hit 46.2 -> 63.5): two more loads and ~45 instructions in every iteration of every wave cost more than the
-                // waiting they remove, as the curve trees' markers did in round 5.  The while-while structure stays.)
-                // few lanes still descending while the rest wait at their leaves: let the leaves go first
-                if ((uint32_t)__popcll(__ballot(cur >= 0 && cur != SKH_REF_INVALID)) < breakBelow)
-                    break;
-            }
-            bool tookMarker = false;
-            if constexpr (WORLD && CURVES)
-            {
-                if (hasRay && cur >= 0 && cur != SKH_REF_INVALID && (cur & SKH_REF_CURVEROOT))
-                {
-                    // the next curve tree (the triangles and the trees before it are done): the WORLD ray -- read back from the queue: once per
-                    // ray and curve instance, cheaper than six registers held through the whole traversal -- goes through the instance's
-                    // transform exactly as it would at a TLAS leaf (same record, same operations: same object-space ray, same hit records).
-                    // Outside the node loop: inside it the nine loads cost every iteration of every wave (hair 1 937 -> 1 637 Mray/s)
-                    SKH_TAKE_MARKER();
-                    tookMarker = true; // (like an instance entry: the lane keeps `cur` and descends in the next pass)
-                }
-            }
-            if (!WORLD && cur == SKH_REF_SENTINEL)
-            {
-                o = ow;
-                d = dw;
-                inv = ANY_HIT ? invw : rcp3(dw);
-                nodes = sc.tlasNodes;
-                inBlas = false;
-                cur = SKH_REF_INVALID;
-            }
-            // ---- leaf ----
-            SKH_LP({ const unsigned long long t = __builtin_readcyclecounter(); cy[1] += t - cyA; cyA = t; })
-            bool entered = tookMarker;
-            // Two kinds of leaf work (instance entry, primitive tests) are two branches of the same wave.  When one of them has
-            // only a few takers it is postponed: those lanes keep their leaf and meet the next pass's takers (leafMin = 0/1: off)
-            bool isLeaf = (!TRICOOP || hasRay) && cur < 0 && cur != SKH_REF_SENTINEL && !tookMarker;
-            if (CURVES)
-            {
-                // The iterative curve intersector costs ~1000 instructions; run for the one or two lanes that happen to need it, it
-                // owns the wave (measured on the hair stand-in: 89 % of the kernel time at ~3 active lanes).  Lanes whose segment
-                // passed the cheap cylinder test PARK in front of it (`pend`) and the block runs once `curveMin` lanes wait, or
-                // when no other lane of the wave can make progress.
-                if (pend != 0u)
-                {
-                    isLeaf = false;
-                    entered = true; // parked: waits for the cooperative block at the top of the loop (no pop)
-                }
-            }
-            if (!WORLD && leafMin > 1u)
-            {
-                const uint32_t nI = (uint32_t)__popcll(__ballot(isLeaf && !inBlas)), nT = (uint32_t)__popcll(__ballot(isLeaf && inBlas));
-                const bool runI = nI >= nT || nI >= leafMin, runT = nT > nI || nT >= leafMin;
-                if (isLeaf && !(inBlas ? runT : runI))
-                {
-                    isLeaf = false;
-                    entered = true; // (keeps `cur`: no pop)
-                }
-            }
-            // (Round 6 measured the same postponement for the few TRIANGLE leaves of the world-only curve builds -- the hair stand-in's scalp: the triangle
-            // branch runs in 94 % of the outer iterations for 7.9 / 2.6 of 64 lanes -- and it loses: lanes waiting at a leaf are rays not traced;
-            // hair 2 055 Mray/s without, 2 017 / 1 894 / 1 649 / 1 327 with a threshold of 8 / 16 / 24 / 32 lanes: docs/LOG.md.)
-            uint32_t kStart = 0; // (TRICOOP) triangles of this lane's leaf the shared pass has dealt with
-            if constexpr (TRICOOP)
-            {
-                // ---- the shared triangle pass ----
-                // Lanes at a leaf test its first triangle; lanes that are NOT at a leaf (descending ones taken out of the node loop, lanes without a
-                // ray) test the SECOND triangle of the two-triangle leaves, one each, in the same instructions: a helper parks its own o / shear /
-                // tmin / best.t in the free part of its LDS stack column, pulls the owner's with ds_bpermute, and restores.  The owner merges its own
-                // result first, then the helper's, by the rule of the sequential loop -- a candidate is accepted if it is nearer than the best hit
-                // so far, or equally near with the smaller (instance, primitive) key -- the helper's test only saw a STALE, i.e. larger, tmax, so it
-                // reports every candidate the sequential loop could have accepted: same records, bit for bit.
-                uint32_t cfirst = 0, ccount = 0;
-                if (isLeaf)
-                {
-                    const uint32_t e = (uint32_t)~cur;
-                    cfirst = e >> 3, ccount = (e & 7u) + 1u;
-                }
-                const bool has2 = ccount >= 2u;
-                const int freeFrom = hasRay ? sp : 0;
-                const bool canHelp = !isLeaf && (ANY_HIT || freeFrom + 9 <= NLDS);
-                const unsigned long long mB = __ballot(has2), mI = __ballot(canHelp);
-                const uint32_t nH = min((uint32_t)__popcll(mB), (uint32_t)__popcll(mI));
-                bool helped = false, helper = false;
-                int partner = (int)lane;
-                if (nH != 0u)
-                {
-                    const uint32_t rankB = rank_below(mB), rankI = rank_below(mI);
-                    helped = has2 && rankB < nH;
-                    helper = canHelp && rankI < nH;
-                    if (helped)
-                        s_tab[rankB] = (unsigned char)lane;
-                    if (helper)
-                        s_tab[64u + rankI] = (unsigned char)lane;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    partner = helped ? (int)s_tab[64u + rankB] : (helper ? (int)s_tab[rankI] : (int)lane);
-                }
-                // Where the helper keeps the owner's ray: the any-hit build has registers to spare (63 + 9 <= 72: a copy, nothing to park); the
-                // closest-hit build sits at its 72-VGPR limit, so there a helper OVERWRITES its own o / shear / tmin / best.t after parking them
-                // in the free part of its LDS stack column, and restores them after the test.
-                constexpr bool COOP_REGS = ANY_HIT;
-                int* park = lds + freeFrom * SKH_TRACE_BLOCK;
-                if (!COOP_REGS && helper)
-                {
-                    park[0] = __float_as_int(o.x), park[SKH_TRACE_BLOCK] = __float_as_int(o.y), park[2 * SKH_TRACE_BLOCK] = __float_as_int(o.z);
-                    park[3 * SKH_TRACE_BLOCK] = sh.perm, park[4 * SKH_TRACE_BLOCK] = __float_as_int(sh.Sx), park[5 * SKH_TRACE_BLOCK] = __float_as_int(sh.Sy);
-                    park[6 * SKH_TRACE_BLOCK] = __float_as_int(sh.Sz), park[7 * SKH_TRACE_BLOCK] = __float_as_int(tmin), park[8 * SKH_TRACE_BLOCK] = __float_as_int(best.t);
-                }
-                uint32_t triIdx = cfirst;
-                v3 to = o;
-                RayShear tsh = sh;
-                float ttmin = tmin, ttmax = best.t;
-                if (nH != 0u)
-                {
-                    // (every lane takes part in the exchange: a disabled source lane would read as zero)
-                    const float pox = __shfl(o.x, partner), poy = __shfl(o.y, partner), poz = __shfl(o.z, partner);
-                    const int pperm = __shfl(sh.perm, partner);
-                    const float psx = __shfl(sh.Sx, partner), psy = __shfl(sh.Sy, partner), psz = __shfl(sh.Sz, partner);
-                    const float ptmin = __shfl(tmin, partner), pbt = __shfl(best.t, partner);
-                    const uint32_t pfirst = (uint32_t)__shfl((int)cfirst, partner);
-                    if (helper)
-                    {
-                        if (COOP_REGS)
-                        {
-                            to = mk3(pox, poy, poz);
-                            tsh.perm = pperm, tsh.Sx = psx, tsh.Sy = psy, tsh.Sz = psz;
-                            ttmin = ptmin, ttmax = pbt;
-                        }
-                        else
-                        {
-                            o = mk3(pox, poy, poz);
-                            sh.perm = pperm, sh.Sx = psx, sh.Sy = psy, sh.Sz = psz;
-                            tmin = ptmin;
-                            best.t = pbt;
-                        }
-                        triIdx = pfirst + 1u;
-                    }
-                }
-                bool ih = false;
-                float ht = 0.0f, hu = 0.0f, hv = 0.0f;
-                uint32_t hprim = 0, hinst = 0;
-                if (isLeaf || helper)
-                {
-                    const float4* tp = sc.tris + 3 * (size_t)triIdx;
-                    const float4 a = tp[0], b = tp[1], c = tp[2];
-                    if (COUNT)
-                        tc.prims++;
-                    if (COOP_REGS)
-                        ih = intersect_triangle(to, tsh, ttmin, ttmax, mk3(a), mk3(b), mk3(c), ht, hu, hv);
-                    else
-                        ih = intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), ht, hu, hv);
-                    hprim = __float_as_uint(a.w), hinst = __float_as_uint(b.w);
-                    // (a baked light proxy in the world-space group -- merge_light_proxies --: any-hit queries do not see lights; k_gather_tris marks its triangles in the record's last word)
-                    if (ANY_HIT && __float_as_uint(c.w) != 0u)
-                        ih = false;
-                }
-                if (!COOP_REGS && helper)
-                {
-                    o = mk3(__int_as_float(park[0]), __int_as_float(park[SKH_TRACE_BLOCK]), __int_as_float(park[2 * SKH_TRACE_BLOCK]));
-                    sh.perm = park[3 * SKH_TRACE_BLOCK], sh.Sx = __int_as_float(park[4 * SKH_TRACE_BLOCK]), sh.Sy = __int_as_float(park[5 * SKH_TRACE_BLOCK]);
-                    sh.Sz = __int_as_float(park[6 * SKH_TRACE_BLOCK]), tmin = __int_as_float(park[7 * SKH_TRACE_BLOCK]), best.t = __int_as_float(park[8 * SKH_TRACE_BLOCK]);
-                }
-#define SKH_MERGE_HIT(H, T, U, V, PRIM, INST)                                                                                         \
-    if ((H) && (best.found ? ((T) < best.t || ((T) == best.t && ((INST) < best.inst || ((INST) == best.inst && (PRIM) < best.prim)))) \
-                           : (T) < best.t)) /* (open at tmax: best.t is the ray's tmax until a hit is found) */                       \
-    {                                                                                                                                 \
-        best.t = (T), best.inst = (INST), best.prim = (PRIM), best.u = (U), best.v = (V), best.found = true;                          \
-    }
-                if (isLeaf)
-                    SKH_MERGE_HIT(ih, ht, hu, hv, hprim, hinst)
-                kStart = 1u;
-                if (nH != 0u)
-                {
-                    const bool rh = __shfl((int)ih, partner) != 0;
-                    const float rt = __shfl(ht, partner), ru = __shfl(hu, partner), rv = __shfl(hv, partner);
-                    const uint32_t rprim = (uint32_t)__shfl((int)hprim, partner), rinst = (uint32_t)__shfl((int)hinst, partner);
-                    if (helped)
-                    {
-                        SKH_MERGE_HIT(rh, rt, ru, rv, rprim, rinst)
-                        kStart = 2u;
-                    }
-                }
-#undef SKH_MERGE_HIT
-            }
-            if (isLeaf)
-            {
-                const uint32_t enc = (uint32_t)~cur;
-                const uint32_t first = enc >> 3, count = (enc & 7u) + 1u;
-                if (!WORLD && !inBlas)
-                {
-                    // TLAS leaves hold exactly one instance
-                    // the whole 64-byte record in one round trip (loading the transform only after the mask test made it two)
-                    const float4* ip = reinterpret_cast<const float4*>(sc.tinst + first); // `first` = TLAS leaf number
-                    const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2], i3 = ip[3];
-                    asm volatile("" ::"v"(i0.x), "v"(i1.x), "v"(i2.x)); // (keeps the three loads above the branch: the compiler sinks them into it)
-                    if (__float_as_uint(i3.y) & rayMask)
-                    {
-                        if (COUNT)
-                            tc.insts++;
-                        SKH_LP(rayInsts++;)
-                        const float m[12] = { i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w };
-                        o = xform_point_rel(m, ow);
-                        d = xform_vector(m, dw);
-                        inv = rcp3(d);
-                        if (!CURVES)
-                            sh = make_shear(d);
-                        curInst = __float_as_uint(i3.w); // the instance this leaf belongs to
-                        curType = __float_as_uint(i3.z);
-                        nodes = (CURVES && curType == 2) ? sc.segNodes : sc.triNodes;
-                        inBlas = true;
-                        SKH_PUSH(SKH_REF_SENTINEL);
-                        cur = __float_as_int(i3.x);
-                        entered = true;
-                    }
-                }
-                else if (CURVES && curType == 2)
-                {
-                    SKH_CYLINDER_TESTS(first, count, pend)
-                    if (pend != 0u)
-                        entered = true; // parks in front of the full intersector (see above); `cur` keeps the leaf
-                }
-                else
-                {
-                    if (CURVES)
-                        sh = make_shear(d); // (same function of the same direction: same bits as the value the other builds keep)
-                    for (uint32_t k = (TRICOOP ? kStart : 0u); k < count; ++k)
-                    {
-                        const float4* tp = sc.tris + 3 * (size_t)(first + k);
-                        const float4 a = tp[0], b = tp[1], c = tp[2];
-                        if (COUNT)
-                            tc.prims++;
-                        SKH_LP(itT++; rayTris++;)
-                        float t, u, v;
-#ifdef SKH_LANE_PROFILE
-                        uint32_t pf = 0;
-                        const bool ih = intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), t, u, v, &pf);
-                        wv[6] += __any(pf & 1u) ? 1u : 0u; // triangle passes in which some lane took the fp64 edge-function fallback
-                        wv[7] += __any(pf & 4u) ? 1u : 0u; // ... in which some lane got as far as the division
-                        wv[8] += __any(pf & 2u) ? 1u : 0u; // ... passed the sign test
-                        if (ih && (best.found || t < best.t) && !SKH_HIDDEN_LIGHT(c))
-#else
-                        if (intersect_triangle(o, sh, tmin, best.t, mk3(a), mk3(b), mk3(c), t, u, v) && (best.found || t < best.t) && !SKH_HIDDEN_LIGHT(c))
-#endif
-                        {
-                            const uint32_t prim = __float_as_uint(a.w);
-                            const uint32_t hinst = (WORLD || curInst == 0xffffffffu) ? __float_as_uint(b.w) : curInst; // (baked group: the record names its instance)
-                            if (!best.found || t < best.t || hinst < SKH_BEST_INST() || (hinst == SKH_BEST_INST() && prim < SKH_BEST_PRIM()))
-                            {
-                                best.t = t;
-                                SKH_BEST_SET(hinst, prim, u, v)
-                                best.found = true;
-                            }
-                        }
-                    }
-                    // (curve builds: the reciprocal direction is not needed by the triangle test -- recomputed here, same operation on the same d: same bits,
-                    // instead of being held, or spilled, across it: the two-level curve builds 19 -> 17 / 27 -> 21 spilled dwords; the world-only builds keep their 3 / 17)
-                    if (CURVES)
-                        inv = rcp3(d);
-                }
-            }
-            SKH_LP(if (entered) itT |= 0x10000u; { const unsigned long long t = __builtin_readcyclecounter(); cy[2] += t - cyA; cyA = t; })
-            // ---- pop ----
-            if (ANY_HIT && (!TRICOOP || hasRay) && best.found)
-                terminated = true;
-            else if ((!TRICOOP || hasRay) && !entered && !(cur >= 0 && cur != SKH_REF_INVALID)) // (a lane taken out of the node loop early keeps its node)
-            {
-                for (;;)
-                {
-                    if (sp == 0)
-                    {
-                        terminated = true;
-                        break;
-                    }
-                    SKH_POP(cur);
-                    if (WORLD && CURVES && cur >= 0 && cur != SKH_REF_INVALID && (cur & SKH_REF_CURVEROOT))
-                        SKH_TAKE_MARKER() // (popped right behind a leaf: the lane descends into the curve tree in the next pass, no pass of its own)
-                    if (!WORLD && cur == SKH_REF_SENTINEL)
-                    {
-                        o = ow;
-                        d = dw;
-                        inv = ANY_HIT ? invw : rcp3(dw);
-                        nodes = sc.tlasNodes;
-                        inBlas = false;
-                        continue;
-                    }
-                    break;
-                }
-            }
+    if constexpr (SPLIT)
+    {
+        // The tail phase (SPLIT builds): the same pass without the refill; the family tables take the place of the upper LDS stack entries, which move to
+        // SKH_TAIL_EXTRA more slots at the end of the lane's overflow column (a lane rarely has that many).
+        constexpr int NLDSP = NLDST;
+        if (NLDST < NLDS0)
+        {
+            for (int e = NLDST; e < NLDS0; ++e)
+                if (hasRay && e < sp)
+                    SKH_OVF_AT(SKH_STACK_OVF + e - NLDST) = lds[e * SKH_TRACE_BLOCK];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-#ifdef SKH_LANE_PROFILE
+        // every ray the wave holds becomes a family of one; its record starts as the lane's best hit so far
         if (hasRay)
         {
-            const unsigned long long t = __builtin_readcyclecounter();
-            cy[3] += t - cyA;
+            fam = lane;
+            SKH_FAM(0, lane) = __float_as_uint(best.t);
+            SKH_FAM(1, lane) = __float_as_uint(best.t);
+            SKH_FAM(2, lane) = best.found ? (ANY_HIT ? 0u : best.inst) : 0xffffffffu; // (all ones: nothing found yet)
+            if constexpr (!ANY_HIT) // (an occlusion query's record is one word: found or not)
+                SKH_FAM(3, lane) = best.prim, SKH_FAM(4, lane) = __float_as_uint(best.u), SKH_FAM(5, lane) = __float_as_uint(best.v);
+            SKH_FAM(6, lane) = 1u;
         }
-        cyA = __builtin_readcyclecounter();
-        wv[0] += wave_max(itN);
-        wv[1] += wave_max(itT & 0xffffu);
-        if (!CURVES)
-            wv[2] += __any((itT >> 16) != 0) ? 1u : 0u;
-#endif
-        if constexpr (SPLIT)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#define SKH_TAIL_PHASE 1
+        for (;;)
         {
-            if (tailOn)
-            {
-                // fragments that end here merge into their family's record, one lane at a time (several may belong to one family); the family's last
-                // fragment takes the merged record: it is the ray's result, written by the block at the top of the loop
-                unsigned long long tm = __ballot(terminated);
-                bool last = false;
-                while (tm != 0ull)
-                {
-                    const int l = __ffsll((long long)tm) - 1;
-                    tm &= tm - 1ull;
-                    if ((int)lane == l)
-                    {
-                        const float ft = __uint_as_float(SKH_FAM(1, fam));
-                        const uint32_t fi = SKH_FAM(2, fam), fp = SKH_FAM(3, fam);
-                        const bool recFound = fi != 0xffffffffu;
-                        const bool take = ANY_HIT ? (best.found && !recFound)
-                                                  : (best.found && (!recFound || best.t < ft || (best.t == ft && (best.inst < fi || (best.inst == fi && best.prim < fp)))));
-                        if (take)
-                        {
-                            SKH_FAM(1, fam) = __float_as_uint(best.t), SKH_FAM(2, fam) = ANY_HIT ? 0u : best.inst, SKH_FAM(3, fam) = best.prim;
-                            SKH_FAM(4, fam) = __float_as_uint(best.u), SKH_FAM(5, fam) = __float_as_uint(best.v);
-                            if (!ANY_HIT)
-                                SKH_FAM(0, fam) = min(SKH_FAM(0, fam), __float_as_uint(best.t));
-                        }
-                        const uint32_t left = SKH_FAM(6, fam) - 1u;
-                        SKH_FAM(6, fam) = left;
-                        if (left == 0u)
-                        {
-                            last = true;
-                            best.found = SKH_FAM(2, fam) != 0xffffffffu;
-                            best.t = __uint_as_float(SKH_FAM(1, fam)), best.inst = SKH_FAM(2, fam), best.prim = SKH_FAM(3, fam);
-                            best.u = __uint_as_float(SKH_FAM(4, fam)), best.v = __uint_as_float(SKH_FAM(5, fam));
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                }
-                if (terminated)
-                {
-                    hasRay = false;
-                    pending = last;
-                    terminated = false;
-                }
-            }
+#include "skh_trace_body.inc"
         }
-        if (terminated)
-        {
-            hasRay = false;
-            pending = true; // the result stays in registers until the next refill: one write block per refill, not per termination
-#ifdef SKH_LANE_PROFILE
-            if (rayNodes > 700u)
-            {
-                const uint32_t k = atomicAdd(&stats->slowCount, 1u);
-                if (k < 16u)
-                {
-                    float* r = stats->slow[k];
-                    r[0] = (float)rayNodes, r[1] = (float)rayTris, r[2] = (float)rayInsts, r[3] = ANY_HIT ? 1.0f : 0.0f;
-                    r[4] = ow.x, r[5] = ow.y, r[6] = ow.z, r[7] = dw.x, r[8] = dw.y, r[9] = dw.z, r[10] = tmin, r[11] = (ridx & 0x80000000u) ? 0.0f : rq.plane(7)[ridx];
-                }
-            }
-            rayNodes = rayTris = rayInsts = 0;
-#endif
-        }
-        SKH_LP(cy[4] += __builtin_readcyclecounter() - cyA;)
+#undef SKH_TAIL_PHASE
     }
 #undef SKH_PUSH
 #undef SKH_HIDDEN_LIGHT
 #undef SKH_POP
 #undef SKH_OVF_AT
+#undef SKH_OVF_SLOT
 #undef SKH_TAKE_MARKER
 #undef SKH_CYLINDER_TESTS
 #undef SKH_FAM

@@ -183,9 +183,9 @@ struct skh_context
     uint32_t wavesPerCUWorld = 32; // the world-only closest-hit build: 64 VGPRs, 8 per SIMD (SKH_WORLD_CLOSEST_MIN_WAVES)
     uint32_t smallWavesClosest = 0, smallWavesShadow = 0; // (0 = automatic: 20 / 12 for triangle scenes, 16 / 16 with curves -- there the any-hit launch is the heavier one: hair 1-spp calls 687 against 664 Mray/s) overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24; round 6: the closest-hit launch is the one on the critical path -- 20/12: 1-spp 1080p calls 3.49 -> 3.39 ms, drop-in +1 % (18/14 3.41, 22/10 3.48, 24/8 3.67: then the any-hit launch is the long one)
     uint32_t gridOverride = 0; // set by render_one around its launches
-    int tailSplit = -1; // option tail_split: 1 = the world-only triangle kernels' SPLIT build (idle lanes of a dry wave take stack entries of its last rays) for every launch,
-                        // -1 = for passes of 2^17 ... 2^23 paths (a 1-spp 1080p call: 3.37-3.39 -> 3.22-3.25 ms; the build's main phase is 4 % slower -- seven LDS stack
-                        // entries go to the family tables --, so large passes lose: 64 sub-frames 17.83 -> 18.48 ms per closest-hit launch), 0 = never
+    int tailSplit = 1; // option tail_split: 1 (default) = the world-only triangle kernels' SPLIT build for every launch -- once a wave finds the ray queue dry (the tail phase of k_trace: skh_trace_body.inc
+                       // included a second time), its idle lanes take stack entries of the lanes that still hold a ray --, -1 = for passes of 2^17 ... 2^23 paths only, 0 = never.  Per launch
+                       // 285 + 274.5 n -> 225 + 272.9 n us (closest-hit, n sub-frames of 2.07 M paths), 228 + 115.0 n -> 148 + 114.8 n (any-hit): the main phase is the plain build's, instruction for instruction
     bool splitNow = false; // set by render_one around its launches
     uint32_t fetchMinClosest = 32 /* 24 until round 5: on the reinserted trees 32 is 0.4 ... 0.9 % ahead on all three kitchens, gpurun_out/r6c */, fetchMinShadow = 48; // idle lanes before a wave pulls new rays from the queue (round 3, world-space hierarchy: any-hit 32 -> 48: 39.7 -> 36.2 ms, 56: 37.5, 64: 51; closest 12..40 within 1 %)
     uint32_t curveFetchMinClosest = 16, curveFetchMinShadow = 16 /* 24 until the result writes got cheaper (round 5, late): hair any-hit 47.5-47.8 -> 46.5-47.0 ms with 12 ... 20, gpurun_out/r7v */, curveNodeBreakClosest = 20, curveNodeBreakShadow = 20; // the same four for the curve build (6 waves/SIMD): hair 482 vs 465 Mray/s
@@ -2374,8 +2374,8 @@ static skh_status alloc_frame(skh_context* c)
     c->queueConstFilled = false;
     AF(dev_alloc(c, c->dCounts, sizeof(uint32_t) * (SKH_COUNT_STRIDE * SKH_SHARDS * 2 * SKH_MAX_LAUNCH_ROUNDS + 16 * SKH_FETCH_STRIDE * SKH_MAX_LAUNCH_ROUNDS)));
     c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
-    AF(dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * (uint32_t)c->numCUs * std::max(std::max(c->wavesPerCU, c->wavesPerCUWorld), std::max(c->wavesPerCUShadow, c->wavesPerCUShadowWorld)) * SKH_TRACE_BLOCK));
-    AF(dev_alloc(c, c->dOvf2, sizeof(int) * (size_t)SKH_STACK_OVF * (uint32_t)c->numCUs * std::max(std::max(c->wavesPerCU, c->wavesPerCUWorld), std::max(c->wavesPerCUShadow, c->wavesPerCUShadowWorld)) * SKH_TRACE_BLOCK));
+    AF(dev_alloc(c, c->dOvf, sizeof(int) * (size_t)(SKH_STACK_OVF + SKH_TAIL_EXTRA) * (uint32_t)c->numCUs * std::max(std::max(c->wavesPerCU, c->wavesPerCUWorld), std::max(c->wavesPerCUShadow, c->wavesPerCUShadowWorld)) * SKH_TRACE_BLOCK));
+    AF(dev_alloc(c, c->dOvf2, sizeof(int) * (size_t)(SKH_STACK_OVF + SKH_TAIL_EXTRA) * (uint32_t)c->numCUs * std::max(std::max(c->wavesPerCU, c->wavesPerCUWorld), std::max(c->wavesPerCUShadow, c->wavesPerCUShadowWorld)) * SKH_TRACE_BLOCK));
 #undef AF
     SKH_TRY(c, hipMemsetAsync(c->dAccum.p, 0, sizeof(float4) * N1, c->stream));
     SKH_TRY(c, hipMemsetAsync(c->dDiffuse.p, 0, sizeof(float4) * N1, c->stream));
@@ -3525,7 +3525,7 @@ skh_status skh_trace_device(skh_context* c, const void* d_rays, uint32_t n_rays,
     }
     if (!c->traceBlocks)
         c->traceBlocks = (uint32_t)c->numCUs * c->wavesPerCU;
-    if ((s = dev_alloc(c, c->dOvf, sizeof(int) * (size_t)SKH_STACK_OVF * (uint32_t)c->numCUs * std::max(std::max(c->wavesPerCU, c->wavesPerCUWorld), std::max(c->wavesPerCUShadow, c->wavesPerCUShadowWorld)) * SKH_TRACE_BLOCK)) != SKH_OK)
+    if ((s = dev_alloc(c, c->dOvf, sizeof(int) * (size_t)(SKH_STACK_OVF + SKH_TAIL_EXTRA) * (uint32_t)c->numCUs * std::max(std::max(c->wavesPerCU, c->wavesPerCUWorld), std::max(c->wavesPerCUShadow, c->wavesPerCUShadowWorld)) * SKH_TRACE_BLOCK)) != SKH_OK)
     {
         cleanup();
         return s;

@@ -664,10 +664,10 @@ def test_results_do_not_depend_on_the_acceleration_structure_or_scheduling(opts)
 
 
 def test_split_launch_tails_are_exact_at_the_size_they_switch_on(gpu, ork):
-    """Option tail_split (default -1): passes of 2^17 ... 2^23 paths on a scene without a top level run the SPLIT build of the world-only triangle kernels -- once a
+    """Option tail_split (default 1; -1 = passes of 2^17 ... 2^23 paths only): scenes without a top level run the SPLIT build of the world-only triangle kernels -- once a
     wave finds the ray queue dry, its idle lanes take stack entries of the lanes that still hold a ray, and the fragments of a ray merge their hits by the closest-hit
-    rule (nearer, or equally near with the smaller (instance, primitive) key).  A 512 x 288 frame (147 456 paths per pass: the automatic mode is on) must give the
-    image and AOVs of the same frame with the option off, bit for bit, and 300 000 raw queries with the option forced on must equal the oracle's records."""
+    rule (nearer, or equally near with the smaller (instance, primitive) key).  A 512 x 288 frame (147 456 paths per pass: the size-dependent mode is on as well) must give the
+    image and AOVs of the same frame with the option off, bit for bit, and 300 000 raw queries with the option on must equal the oracle's records."""
     from strelka_amd import capi
     from tests import orklib
 
