@@ -514,6 +514,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
     // The main phase: every build.  (SPLIT: left as soon as the wave finds the queue dry.)
     {
         constexpr int NLDSP = NLDS0;
+        constexpr bool TRICOOPP = TRICOOP;
 #define SKH_TAIL_PHASE 0
         for (;;)
         {
@@ -526,6 +527,10 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
         // The tail phase (SPLIT builds): the same pass without the refill; the family tables take the place of the upper LDS stack entries, which move to
         // SKH_TAIL_EXTRA more slots at the end of the lane's overflow column (a lane rarely has that many).
         constexpr int NLDSP = NLDST;
+#ifndef SKH_TAIL_TRICOOP
+#define SKH_TAIL_TRICOOP 1
+#endif
+        constexpr bool TRICOOPP = TRICOOP && SKH_TAIL_TRICOOP;
         if (NLDST < NLDS0)
         {
             for (int e = NLDST; e < NLDS0; ++e)
