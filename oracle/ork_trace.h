@@ -154,7 +154,7 @@ static inline void onb_from_z(const f3& n, f3& b1, f3& b2) // Duff et al. 2017, 
 struct ConeIsect
 {
     f3 c0, cd;
-    float s, dt, dp, dc, sp;
+    float s, dt, dp, dc, sp, dd; // (dd = |cd|^2)
     bool intersect(float r, float dr)
     {
         const float r2 = r * r;
@@ -171,6 +171,7 @@ struct ConeIsect
         const float det = b * b - a * c;
         s = (b - (det > 0.0f ? sqrtf(det) : 0.0f)) / c;
         dt = (s * cd.z - cdd) / ddd;
+        dd = ddd;
         dc = s * s + dp;
         sp = cdd / cd.z;
         dp += sp * sp;
@@ -220,7 +221,14 @@ static inline bool intersect_curve_segment(const f3& o, const f3& d, float tmin,
             if (!phantom && fabsf(rci.dt) < 5e-5f)
             {
                 const float s = (rci.s + rci.c0.z) * inv_dlen;
-                if (s > tmin && s <= tmax && t >= 0.0f && t <= 1.0f && (!found || s < t_out))
+                // A converged point lies ON the tube: its distance from the curve point, less the part along the tangent (dt |c'|), is the radius there.  A ray
+                // (nearly) parallel to the tangent makes the cone's quadratic degenerate -- c = |c'_xy|^2 -> 0, b - sqrt(det) cancels to 0, dt comes out small and
+                // det > 0 by rounding -- and the iteration "converges" at once on a point half a tube length away (round 6, fuzz_render seed 5483: 0.49 from a curve
+                // point of radius 0.096).  Such a root is not a hit; every bound the hierarchies keep (hull + largest radius) relies on that: the radius along the
+                // segment stays inside the hull of the control radii, and an accepted point is within 1.0005 of the cone's radius of the curve point.
+                const float radial2 = rci.dc - (rci.dt * rci.dt) * rci.dd;
+                const float rb = c4.w + d4.w * rci.dt; // the cone's radius at that offset along the tangent (linear: exact for the cone)
+                if (radial2 <= 1.001f * (rb * rb) && s > tmin && s <= tmax && t >= 0.0f && t <= 1.0f && (!found || s < t_out))
                 {
                     t_out = s;
                     u_out = t;

@@ -868,7 +868,14 @@ SKH_DI bool intersect_curve_segment(const v3& o, const v3& d, float tmin, float 
             if (!phantom && fabsf(dt) < 5e-5f)
             {
                 const float sw = (s + c0.z) * inv_dlen;
-                if (sw > tmin && sw <= tmax && t >= 0.0f && t <= 1.0f && (!found || sw < t_out))
+                // A converged point lies ON the tube: its distance from the curve point, less the part along the tangent (dt |c'|), is the radius there.  A ray (nearly)
+                // parallel to the tangent makes the cone's quadratic degenerate -- c = |c'_xy|^2 -> 0, b - sqrt(det) cancels to 0, dt comes out small and det > 0 by
+                // rounding -- and the iteration "converges" at once on a point far off the tube (round 6, fuzz_render seed 5483: 0.49 from a curve point of radius
+                // 0.096; found or not depending on which boxes the ray met).  Such a root is not a hit: every bound the hierarchies keep (hull + largest radius) relies on that -- the radius along the
+                // segment stays inside the hull of the control radii, and an accepted point is within 1.0005 of the cone's radius of the curve point.
+                const float radial2 = (s * s + dp) - (dt * dt) * ddd;
+                const float rb = r + dr * dt; // the cone's radius at that offset along the tangent (linear: exact for the cone)
+                if (radial2 <= 1.001f * (rb * rb) && sw > tmin && sw <= tmax && t >= 0.0f && t <= 1.0f && (!found || sw < t_out))
                 {
                     t_out = sw;
                     u_out = t;

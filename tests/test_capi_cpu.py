@@ -68,7 +68,7 @@ def test_product_never_imports_the_oracle():
     bad = []
     for dirpath, _, files in os.walk(os.path.join(ROOT, "strelka_amd")):
         for f in files:
-            if f.endswith((".py", ".h", ".hip", ".cpp")):
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".inc")):
                 t = open(os.path.join(dirpath, f), errors="ignore").read()
                 if re.search(r"orklib|liboracle|oracle/|ork_[a-z]", t):
                     bad.append(os.path.join(dirpath, f))

@@ -109,6 +109,40 @@ def test_curve_hits_lie_on_the_surface_for_random_rays(ork):
     assert hits > 1500
 
 
+def test_a_ray_along_the_tangent_does_not_hit_a_tube_it_passes_far_from(ork):
+    """Round 6, `tools/fuzz_render.py` seed 5483: the ray is parallel to the curve's tangent at u = 0.5 (|c'_xy|^2 = 3e-12 in ray-centric coordinates), the tangent
+    cone's quadratic degenerates -- b - sqrt(det) cancels to 0 in single precision, det > 0 and |dt| < 5e-5 by rounding --, and the iteration reported a hit at its first
+    bisection point, 0.49 away from a curve point of radius 0.096; the GPU's hierarchy never offered that segment to the intersector (its boxes bound the TUBE), the
+    checker's did.  A converged point must lie on the tube (`intersect_curve_segment`: radial distance <= 1.0005 x the tangent cone's radius there): the segment is a miss now,
+    for this ray and for rays along the tangents of random thick tubes; genuine hits (the tests above) keep their bits."""
+    q = f32(-0.9328025, 0.13670611, 0.85035706, 0.04938295, -0.9328025, 0.13670611, 0.85035706, 0.04938295,
+            -0.8231476, 0.1149258, 0.7187781, 0.14358711, -0.7598083, 0.0917983, 0.5723765, 0.13822867)
+    out = np.zeros(2, np.float32)
+    assert ork.ork_intersect_curve(p(f32(-2.2888184, 0.875, 3.0703347)), p(f32(0.51597244, -0.11002403, -0.6694812)), 0.0, 1e16, p(q), p(out)) == 0
+    # rays along the tangent at a random parameter, passing 2.5 ... 6 radii from the axis: whatever is reported must lie on the tube
+    rs = np.random.RandomState(9)
+    ev = np.zeros(21, np.float32)
+    reported = 0
+    for _ in range(4000):
+        q = np.concatenate([np.cumsum(rs.uniform(-0.2, 0.2, (4, 3)), 0), rs.uniform(0.03, 0.15, (4, 1))], 1).astype(np.float32).ravel()
+        u = float(rs.choice([0.5, 0.25, 0.75, rs.uniform(0, 1)]))
+        ork.ork_curve_eval(p(q), u, p(f32(0, 0, 0)), p(ev))
+        c, tan = ev[:3].astype(np.float64), ev[4:7].astype(np.float64)
+        if np.linalg.norm(tan) < 1e-6:
+            continue
+        tan /= np.linalg.norm(tan)
+        side = np.cross(tan, rs.normal(size=3))
+        side /= np.linalg.norm(side)
+        o = (c + side * float(ev[3]) * rs.uniform(2.5, 6.0) - tan * 3.0).astype(np.float32)
+        d = tan.astype(np.float32)
+        if ork.ork_intersect_curve(p(o), p(d), 0.0, 1e16, p(q), p(out)):
+            reported += 1
+            ork.ork_curve_eval(p(q), float(out[1]), p(f32(0, 0, 0)), p(ev))
+            hp = o.astype(np.float64) + float(out[0]) * d.astype(np.float64)
+            assert abs(np.linalg.norm(hp - ev[:3]) - ev[3]) < 1e-3 + 0.02 * ev[3], (q, o, d, out)
+    assert reported < 4000
+
+
 @pytest.mark.parametrize("maker", ["cornell", "kitchen", "hair"])
 def test_bvh_never_changes_a_result(maker):
     """closest hit and occlusion through the oracle's SAH BVH == brute force over every primitive, bit for bit
