@@ -663,6 +663,41 @@ def test_results_do_not_depend_on_the_acceleration_structure_or_scheduling(opts)
         assert a.tobytes() == b.tobytes()
 
 
+def test_ray_along_a_curve_tangent_meets_what_the_checker_meets(gpu, ork):
+    """Round 6, `tools/fuzz_render.py` seed 5483 (docs/LOG.md): a primary ray of this thick-tube scene runs along a segment's tangent at u = 0.5; the tangent cone's
+    quadratic degenerated and the iteration reported a point half a tube length off the tube -- on the side whose boxes let the ray reach that segment (the checker's),
+    not on the other.  With the on-the-tube rule in the intersector both sides meet the segment behind it: the ray, a fan of 4 096 rays within 1e-4 rad of it, and the
+    frame the fuzzer drew (76 x 54, 2 spp, depth 6)."""
+    from tests import orklib
+
+    seed = 5483
+    sc = thick_curves(seed=seed, n_strands=20 + seed % 30, n_cp=5 + seed % 6)
+    sc.createLight({"type": 0, "useXform": False, "position": (0.0, 3.0, 1.0), "orientation": (-70.0, 0.0, 0.0), "width": 2.0, "height": 2.0,
+                    "color": (1.0, 1.0, 1.0), "intensity": 20.0})
+    arr = sc.arrays()
+    o = orklib.new_context()
+    o.set_scene(arr)
+    gpu.set_scene(arr)
+    rs = np.random.RandomState(1)
+    rays = np.zeros(4097, S.RAY)
+    rays["origin"] = (0.0, 0.5, 4.5)
+    d0 = np.array([0.038607944, -0.08801922, -0.9953704], np.float32)
+    rays["dir"] = d0 + np.concatenate([np.zeros((1, 3)), rs.normal(size=(4096, 3)) * 1e-4]).astype(np.float32)
+    rays["tmax"] = 1e16
+    want, got = o.trace(rays, 0), gpu.trace(rays, 0)
+    assert want["prim_id"][0] == 361 and abs(want["t"][0] - 3.3334234) < 1e-5  # (not segment 306 at t = 3.2255, 0.49 off the tube)
+    assert_hits_equal(got, want)
+    assert_hits_equal(o.trace(rays, 0, brute=True), want)
+    w, h = 76, 54
+    o.resize(w, h)
+    gpu.resize(w, h)
+    for i in range(2):
+        p = S.frame_params(sc.getCamera(), w, h, subframe_index=i, spp_total=2, max_depth=6, rect_light_sampling_method=1)
+        o.render_subframe(p)
+        gpu.render_subframe(p)
+    _image_equal(gpu.read_accum(), o.read_accum())
+
+
 def test_split_launch_tails_are_exact_at_the_size_they_switch_on(gpu, ork):
     """Option tail_split (default 1; -1 = passes of 2^17 ... 2^23 paths only): scenes without a top level run the SPLIT build of the world-only triangle kernels -- once a
     wave finds the ray queue dry, its idle lanes take stack entries of the lanes that still hold a ray, and the fragments of a ray merge their hits by the closest-hit
