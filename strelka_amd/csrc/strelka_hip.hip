@@ -183,6 +183,7 @@ struct skh_context
     uint32_t wavesPerCUWorld = 32; // the world-only closest-hit build: 64 VGPRs, 8 per SIMD (SKH_WORLD_CLOSEST_MIN_WAVES)
     uint32_t smallWavesClosest = 0, smallWavesShadow = 0; // (0 = automatic: 20 / 12 for triangle scenes, 16 / 16 with curves -- there the any-hit launch is the heavier one: hair 1-spp calls 687 against 664 Mray/s) overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24; round 6: the closest-hit launch is the one on the critical path -- 20/12: 1-spp 1080p calls 3.49 -> 3.39 ms, drop-in +1 % (18/14 3.41, 22/10 3.48, 24/8 3.67: then the any-hit launch is the long one)
     uint32_t gridOverride = 0; // set by render_one around its launches
+    uint32_t smallWavesFirst = 0, smallWavesLast = 0; // (small overlapped passes) waves per CU of the FIRST closest-hit launch and of the LAST any-hit launch, which have the machine to themselves; 0 = as the others, except that the last any-hit launch of a triangle scene takes 20 of 32 instead of 12 (1-spp 1080p call 3.13 -> 3.10 ms; 16 / 24 the same, 32: 3.13; the first closest-hit launch at 24 / 28 / 32: 3.12 / 3.13 / 3.15)
     int tailSplit = 1; // option tail_split: 1 (default) = the world-only triangle kernels' SPLIT build for every launch -- once a wave finds the ray queue dry (the tail phase of k_trace: skh_trace_body.inc
                        // included a second time), its idle lanes take stack entries of the lanes that still hold a ray --, -1 = for passes of 2^17 ... 2^23 paths only, 0 = never.  Per launch
                        // 285 + 274.5 n -> 225 + 272.9 n us (closest-hit, n sub-frames of 2.07 M paths), 228 + 115.0 n -> 148 + 114.8 n (any-hit): the main phase is the plain build's, instruction for instruction
@@ -2700,7 +2701,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
         {
             {
                 SpanGuard g(c, KC_TRACE_CLOSEST);
-                c->gridOverride = (useOverlap && smallPass) ? (c->smallWavesClosest ? c->smallWavesClosest : (c->nSegs ? 16u : 20u)) * (uint32_t)c->numCUs : 0u;
+                c->gridOverride = (useOverlap && smallPass) ? ((b == 0 && c->smallWavesFirst) ? c->smallWavesFirst : c->smallWavesClosest ? c->smallWavesClosest : (c->nSegs ? 16u : 20u)) * (uint32_t)c->numCUs : 0u;
                 if (c->countTraversal)
                     launch_trace<false, true>(c, sc, rq[b & 1], counts + 2 * b * QW, fetch + 16 * b * SKH_FETCH_STRIDE, hq, ps, nullptr);
                 else
@@ -2732,7 +2733,7 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
                 }
                 {
                     SpanGuard g(c, KC_TRACE_SHADOW, sst);
-                    c->gridOverride = (useOverlap && smallPass) ? (c->smallWavesShadow ? c->smallWavesShadow : (c->nSegs ? 16u : 12u)) * (uint32_t)c->numCUs : 0u;
+                    c->gridOverride = (useOverlap && smallPass) ? ((b + 1 == rounds && (c->smallWavesLast || (!c->smallWavesShadow && !c->nSegs))) ? (c->smallWavesLast ? c->smallWavesLast : 20u) : c->smallWavesShadow ? c->smallWavesShadow : (c->nSegs ? 16u : 12u)) * (uint32_t)c->numCUs : 0u;
                     if (c->countTraversal)
                         launch_trace<true, true>(c, sc, shq, counts + (2 * b + 1) * QW, fetch + (16 * b + 8) * SKH_FETCH_STRIDE, nohq, ps, c->dContrib.as<float4>(), sst);
                     else
@@ -4004,6 +4005,12 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
         if (value < -1 || value > 1)
             return SKH_INVALID_ARGUMENT;
         c->tailSplit = (int)value;
+    }
+    else if (n == "small_waves_first" || n == "small_waves_last")
+    {
+        if (value < 0 || value > 64)
+            return SKH_INVALID_ARGUMENT;
+        (n == "small_waves_first" ? c->smallWavesFirst : c->smallWavesLast) = (uint32_t)value;
     }
     else if (n == "small_waves_closest" || n == "small_waves_shadow")
     {
