@@ -438,8 +438,9 @@ skh_status skh_unit_probe(skh_context* ctx, uint32_t unit, uint32_t param, const
  *                 copies cost nothing any more.  A camera move waits for the pass in flight, <= `speculate` sub-frames),
  *                 overlap 0|1|2 (any-hit launches on a second stream beside the next closest-hit launch: off | small passes |
  *                 always), small_waves_closest / small_waves_shadow (shares of a 32-wave CU the two overlapped launches of a small pass take, scaled to what their build fits; 0 = automatic: 20 / 12 for triangle scenes -- the closest-hit launch is the one on the critical path --, 16 / 16 with curves; >= 32 = the full grid), small_waves_first / small_waves_last (the same for the pass's FIRST closest-hit and LAST any-hit launch, which run alone; 0 = automatic: as the others, the last any-hit launch of a triangle scene 20),
- *                 tail_split (1 | 0 | -1: the world-only triangle kernels' build whose waves, once the ray queue is dry, hand stack entries of their last rays to their idle lanes -- a long ray's
- *                 subtrees walked side by side, results merged by the closest-hit rule: same records --; 1 = every launch, the default; -1 = passes of 2^17 ... 2^23 paths only; 0 = never)
+ *                 tail_split (1 | 2 | 0 | -1: the world-only triangle kernels' build whose waves, once the ray queue is dry, hand stack entries of their last rays to their idle lanes -- a long ray's
+ *                 subtrees walked side by side, results merged by the closest-hit rule: same records --; 1 = every launch of a scene whose hierarchy has more than 16 384 nodes, the default; 2 = every launch; -1 = passes of
+ *                 2^17 ... 2^23 paths only; 0 = never)
  *   definition    bake_world 4|3|2|1|0 (mesh instances intersected in world space, no instance entry: 1 = instances whose mesh has one
  *                 user -- what HdStrelka's per-instance meshes are --, 2 = also instances of meshes with <= bake_small_tris (64)
  *                 triangles when that empties the top level, 3 = every mesh instance, 4 (default) = 3 while the instanced triangles stay

@@ -184,9 +184,11 @@ struct skh_context
     uint32_t smallWavesClosest = 0, smallWavesShadow = 0; // (0 = automatic: 20 / 12 for triangle scenes, 16 / 16 with curves -- there the any-hit launch is the heavier one: hair 1-spp calls 687 against 664 Mray/s) overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24; round 6: the closest-hit launch is the one on the critical path -- 20/12: 1-spp 1080p calls 3.49 -> 3.39 ms, drop-in +1 % (18/14 3.41, 22/10 3.48, 24/8 3.67: then the any-hit launch is the long one)
     uint32_t gridOverride = 0; // set by render_one around its launches
     uint32_t smallWavesFirst = 0, smallWavesLast = 0; // (small overlapped passes) waves per CU of the FIRST closest-hit launch and of the LAST any-hit launch, which have the machine to themselves; 0 = as the others, except that the last any-hit launch of a triangle scene takes 20 of 32 instead of 12 (1-spp 1080p call 3.13 -> 3.10 ms; 16 / 24 the same, 32: 3.13; the first closest-hit launch at 24 / 28 / 32: 3.12 / 3.13 / 3.15)
-    int tailSplit = 1; // option tail_split: 1 (default) = the world-only triangle kernels' SPLIT build for every launch -- once a wave finds the ray queue dry (the tail phase of k_trace: skh_trace_body.inc
-                       // included a second time), its idle lanes take stack entries of the lanes that still hold a ray --, -1 = for passes of 2^17 ... 2^23 paths only, 0 = never.  Per launch
-                       // 285 + 274.5 n -> 225 + 272.9 n us (closest-hit, n sub-frames of 2.07 M paths), 228 + 115.0 n -> 148 + 114.8 n (any-hit): the main phase is the plain build's, instruction for instruction
+    int tailSplit = 1; // option tail_split: 1 (default) = the world-only triangle kernels' SPLIT build for every launch of a scene whose hierarchy has more than 16 384 nodes -- once a wave finds the ray queue dry (the tail
+                       // phase of k_trace: skh_trace_body.inc included a second time), its idle lanes take stack entries of the lanes that still hold a ray --, 2 = for every launch whatever the hierarchy (tests), -1 = for passes
+                       // of 2^17 ... 2^23 paths only, 0 = never.  Per launch 285 + 274.5 n -> 225 + 272.9 n us (closest-hit, n sub-frames of 2.07 M paths), 228 + 115.0 n -> 148 + 114.8 n (any-hit): the main phase is the plain
+                       // build's, instruction for instruction.  Hierarchies that fit the L2 many times over (Cornell: 30 triangles, rays of two or three steps) have no tails to speak of and lose by the hand-out:
+                       // closest-hit 27.6 -> 28.4 ms with it (the same scenes whose launches are bound by the queue cursors: fetch_chunk)
     bool splitNow = false; // set by render_one around its launches
     uint32_t fetchMinClosest = 32 /* 24 until round 5: on the reinserted trees 32 is 0.4 ... 0.9 % ahead on all three kitchens, gpurun_out/r6c */, fetchMinShadow = 48; // idle lanes before a wave pulls new rays from the queue (round 3, world-space hierarchy: any-hit 32 -> 48: 39.7 -> 36.2 ms, 56: 37.5, 64: 51; closest 12..40 within 1 %)
     uint32_t curveFetchMinClosest = 16, curveFetchMinShadow = 16 /* 24 until the result writes got cheaper (round 5, late): hair any-hit 47.5-47.8 -> 46.5-47.0 ms with 12 ... 20, gpurun_out/r7v */, curveNodeBreakClosest = 20, curveNodeBreakShadow = 20; // the same four for the curve build (6 waves/SIMD): hair 482 vs 465 Mray/s
@@ -2568,7 +2570,7 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
 #ifdef SKH_TAIL_PROFILE
     (void)hipMemsetAsync(&sd->launchT0[ANY ? 1 : 0], 0xff, sizeof(unsigned long long), st);
 #endif
-    if (worldOnly && (c->tailSplit == 1 || c->splitNow))
+    if (worldOnly && (c->tailSplit == 2 || (c->tailSplit == 1 && c->hierNodes > 16384u) || c->splitNow))
         k_trace<ANY, COUNT, false, true, true><<<blocks, SKH_TRACE_BLOCK, 0, st>>>(sc, rq, countPtr, fetch, fm, hq, ps, contrib, ovf, sd, c->lightBox, chunk);
     else if (worldOnly)
         // every instance is baked: the world-only build of the kernel (no instance entry, no object-space copy of the ray)
@@ -4002,7 +4004,7 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
     }
     else if (n == "tail_split")
     {
-        if (value < -1 || value > 1)
+        if (value < -1 || value > 2)
             return SKH_INVALID_ARGUMENT;
         c->tailSplit = (int)value;
     }

@@ -630,7 +630,7 @@ def test_tonemap_kernels_match_oracle(gpu, ork):
                                   {"waves_per_cu_world": 5, "waves_per_cu_shadow_world": 17, "waves_per_cu_shadow": 3},
                                   {"node_break_closest": 0, "node_break_shadow": 48, "leaf_min": 0}, {"leaf_min": 40}, {"tlas_open": 8}, {"tlas_build": 0}, {"tlas_build": 1}, {"curve_split": 1}, {"curve_split": 5, "curve_min": 1}, {"reinsert_rounds": 0, "reinsert_curve_rounds": 0}, {"reinsert_rounds": 3, "reinsert_min_size": 4}, {"reinsert_rounds": 13, "reinsert_curve_rounds": 9, "reinsert_min_size": 1}, {"world_kernel": 0}, {"curve_min": 64}, {"tight_instance_boxes": 0}, {"overlap": 2}, {"overlap": 0}, {"leaf_lines": 1}, {"leaf_lines": 1, "leaf_max_tris": 4},
                                   {"leaf_lines": 1, "leaf_max_tris": 7, "build_quality": 0}, {"morton_bits": 18}, {"morton_bits": 21, "build_quality": 0}, {"morton_bits": 5}, {"ploc_top": 4096}, {"merge_light_proxies": 1}, {"compact_hits": 0}, {"direct_records": 0}, {"direct_records": 0, "compact_hits": 0}, {"fetch_chunk": 0}, {"fetch_chunk": 7, "fetch_min_closest": 64}, {"fetch_chunk": 1000},
-                                  {"tail_split": 1}, {"tail_split": 1, "fetch_min_closest": 1, "fetch_min_shadow": 1, "compact_hits": 0}, {"tail_split": 1, "fetch_chunk": 1000, "waves_per_cu_world": 1, "waves_per_cu_shadow_world": 1}, {"tail_split": 0}])
+                                  {"tail_split": 2}, {"tail_split": 2, "fetch_min_closest": 1, "fetch_min_shadow": 1, "compact_hits": 0}, {"tail_split": 2, "fetch_chunk": 1000, "waves_per_cu_world": 1, "waves_per_cu_shadow_world": 1}, {"tail_split": 0}])
 def test_results_do_not_depend_on_the_acceleration_structure_or_scheduling(opts):
     """Closest hit = min t with (instance, primitive) tie-break and conservative boxes, any-hit = existence: builder
     (PLOC / radix tree), the reinsertion pass (rounds, truncation), the world-only kernels (with and without the curve block) against the two-level
@@ -699,7 +699,7 @@ def test_ray_along_a_curve_tangent_meets_what_the_checker_meets(gpu, ork):
 
 
 def test_split_launch_tails_are_exact_at_the_size_they_switch_on(gpu, ork):
-    """Option tail_split (default 1; -1 = passes of 2^17 ... 2^23 paths only): scenes without a top level run the SPLIT build of the world-only triangle kernels -- once a
+    """Option tail_split (default 1 = hierarchies of more than 16 384 nodes; 2 = always; -1 = passes of 2^17 ... 2^23 paths only): scenes without a top level run the SPLIT build of the world-only triangle kernels -- once a
     wave finds the ray queue dry, its idle lanes take stack entries of the lanes that still hold a ray, and the fragments of a ray merge their hits by the closest-hit
     rule (nearer, or equally near with the smaller (instance, primitive) key).  A 512 x 288 frame (147 456 paths per pass: the size-dependent mode is on as well) must give the
     image and AOVs of the same frame with the option off, bit for bit, and 300 000 raw queries with the option on must equal the oracle's records."""
@@ -710,7 +710,7 @@ def test_split_launch_tails_are_exact_at_the_size_they_switch_on(gpu, ork):
     arr = sc.arrays()
     W, H = 512, 288
     out = []
-    for split in (-1, 0, 1):
+    for split in (-1, 0, 2):
         ctx = capi.Context(0)
         ctx.set_option("tail_split", split)
         ctx.set_scene(arr)
@@ -718,7 +718,7 @@ def test_split_launch_tails_are_exact_at_the_size_they_switch_on(gpu, ork):
         for i in range(2):
             ctx.render_subframe(S.frame_params(sc.getCamera(), W, H, subframe_index=i, spp_total=2, max_depth=4))
         out.append((ctx.read_accum(), ctx.read_aov(0), ctx.read_aov(1)))
-        if split == 1:
+        if split == 2:
             rays = np.concatenate([camera_rays(sc, 512, 512, 250000, 5), scenes.random_rays(50000, 6, -3.0, 3.0)])
             o = orklib.new_context()
             o.set_scene(arr)
@@ -1070,7 +1070,7 @@ from strelka_amd import capi, scenes
 from tests import orklib
 from tests.test_gpu_parity import small_kitchen, small_hair, camera_rays, assert_hits_equal
 ctx = capi.Context(0)
-for split in (0, 1):  # (1: the SPLIT build of the world-only triangle kernels -- 4 LDS entries here; stolen entries come out of the givers' overflow columns)
+for split in (0, 2):  # (2: the SPLIT build of the world-only triangle kernels -- 4 LDS entries here; stolen entries come out of the givers' overflow columns)
     ctx.set_option("tail_split", split)
     for sc in (small_kitchen(), small_hair()):
         arr = sc.arrays()

@@ -140,7 +140,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         ctx.set_option("build_quality", 0)  # the Karras radix tree instead of PLOC must give the same records
     ctx.set_option("curve_merge", (seed // 8) % 2)  # identity-transform curve instances in one world-space tree, or a tree each
     ctx.set_option("split_pairs", (0, 7, 15)[(seed // 6) % 3])  # loose two-triangle leaves opened at the collapse
-    ctx.set_option("tail_split", (seed // 2) % 2)  # the world-only triangle kernels' SPLIT build: idle lanes of a dry wave walk stack entries of its last rays
+    ctx.set_option("tail_split", 2 * ((seed // 2) % 2))  # the world-only triangle kernels' SPLIT build: idle lanes of a dry wave walk stack entries of its last rays
     ctx.set_scene(arr)
     if (seed // 5) % 4 == 1 and len(arr["vertices"]):
         # a vertex edit followed by skh_refit_accel (or the rebuild it falls back to): the oracle gets the edited scene

@@ -56,7 +56,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     ctx.set_option("direct_records", (-1, 0, 1)[seed % 3])  # which word a baked triangle's hit carries: the image does not depend on it
     ctx.set_option("compact_hits", 0 if seed % 5 == 4 else 1)
     ctx.set_option("curve_merge", (seed // 9) % 2)
-    ctx.set_option("tail_split", (seed // 4) % 2)  # the SPLIT build of the world-only triangle kernels for every pass, or never: the image does not depend on it
+    ctx.set_option("tail_split", 2 * ((seed // 4) % 2))  # the SPLIT build of the world-only triangle kernels for every pass, or never: the image does not depend on it
     crc_g = crc()  # ... and as the GPU receives them
     ctx.set_scene(arr)
     ctx.set_tiles(int(rs.choice([8, 16, 32, 64])), None)
