@@ -63,6 +63,30 @@ def test_no_gpu_means_loud_failure_not_fallback(lib):
     assert lib.skh_last_error(None) == b"null context"
 
 
+def test_the_library_is_rebuilt_when_any_file_it_includes_changes():
+    """`strelka_amd/build.py` rebuilds libstrelka_hip.so when a file of `DEPS` is newer than it.  Round 6 moved `k_trace`'s loop body into a new file and a STALE
+    library went to the GPU box with it (19 false occluders in a test of code that was already fixed): every quoted `#include` reachable from the one translation
+    unit, and the C ABI header, must be in `DEPS`."""
+    from strelka_amd import build
+
+    seen, todo = set(), [build.SRC]
+    while todo:
+        f = todo.pop()
+        if f in seen:
+            continue
+        seen.add(f)
+        for m in re.finditer(r'^\s*#\s*include\s+"([^"]+)"', open(f, errors="ignore").read(), re.M):
+            for base in (os.path.dirname(f), os.path.join(ROOT, "include")):
+                cand = os.path.normpath(os.path.join(base, m.group(1)))
+                if os.path.exists(cand):
+                    todo.append(cand)
+                    break
+    deps = {os.path.normpath(d) for d in build.DEPS}
+    missing = sorted(seen - deps)
+    assert not missing, missing
+    assert len(seen) >= 6  # the .hip, four headers, the loop body
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under strelka_amd/ (or the C-ABI sources) may reference it."""
     bad = []
