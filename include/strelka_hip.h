@@ -424,7 +424,7 @@ skh_status skh_unit_probe(skh_context* ctx, uint32_t unit, uint32_t param, const
  * t, u, v of hits on it differ in the last bits from the object-space test (same instance, same primitive; the CPU oracle
  * takes the same setting and the bit-exact contract holds per setting).
  *   measurement   count_traversal 0|1 (counter build of the trace kernels), timing 0|1 (per-kernel hipEvent spans)
- *   scheduling    waves_per_cu (28) / waves_per_cu_shadow (28) (7 waves per SIMD) / waves_per_cu_world, waves_per_cu_shadow_world (32 / 32: the world-only builds run 8), fetch_min_closest / fetch_min_shadow (32 / 48, scenes with curves 16 / 16: idle lanes before a wave refills),
+ *   scheduling    waves_per_cu (28) / waves_per_cu_shadow (28) (7 waves per SIMD) / waves_per_cu_world, waves_per_cu_shadow_world (32 / 32: the world-only builds run 8), fetch_min_closest / fetch_min_shadow (32 / 48, scenes with curves 16 / 16: idle lanes before a wave refills), fetch_min_closest_small (48: the closest-hit threshold of small overlapped passes of triangle scenes, unless fetch_min_closest is set),
  *                 merge_light_proxies (0; 1: baked light proxies share the baked mesh triangles' world-space tree and any-hit queries skip their triangles -- closest-hit -2 ... -4 %, any-hit +8 ... +13 %: measured a net loss; 0: a tree of their own, visited by the radiance rays that meet the box around all of them),
  *                 compact_hits (1: render passes of scenes the world-only kernels trace, whose instance count and primitive range share 32 bits, keep 16-byte hit records {t, u, v, instance | record or segment}; 0: 32-byte records always),
  *                 direct_records (-1 = by the counts: a baked mesh triangle's hit names its shading record, unless only (instance, mesh-local primitive) fits a 16-byte hit record; 0 / 1 forced),

@@ -183,6 +183,8 @@ struct skh_context
     uint32_t wavesPerCUWorld = 32; // the world-only closest-hit build: 64 VGPRs, 8 per SIMD (SKH_WORLD_CLOSEST_MIN_WAVES)
     uint32_t smallWavesClosest = 0, smallWavesShadow = 0; // (0 = automatic: 20 / 12 for triangle scenes, 16 / 16 with curves -- there the any-hit launch is the heavier one: hair 1-spp calls 687 against 664 Mray/s) overlapped (small) passes: waves per CU of each of the two concurrent trace kernels (0 = wavesPerCU); 16/16: +4 % on 1-spp 1080p launches over 24/24; round 6: the closest-hit launch is the one on the critical path -- 20/12: 1-spp 1080p calls 3.49 -> 3.39 ms, drop-in +1 % (18/14 3.41, 22/10 3.48, 24/8 3.67: then the any-hit launch is the long one)
     uint32_t gridOverride = 0; // set by render_one around its launches
+    uint32_t fetchMinClosestSmall = 48; // option fetch_min_closest_small
+    bool fetchMinClosestSet = false;
     uint32_t smallWavesFirst = 0, smallWavesLast = 0; // (small overlapped passes) waves per CU of the FIRST closest-hit launch and of the LAST any-hit launch, which have the machine to themselves; 0 = as the others, except that the last any-hit launch of a triangle scene takes 20 of 32 instead of 12 (1-spp 1080p call 3.13 -> 3.10 ms; 16 / 24 the same, 32: 3.13; the first closest-hit launch at 24 / 28 / 32: 3.12 / 3.13 / 3.15)
     int tailSplit = 1; // option tail_split: 1 (default) = the world-only triangle kernels' SPLIT build for every launch of a scene whose hierarchy has more than 16 384 nodes -- once a wave finds the ray queue dry (the tail
                        // phase of k_trace: skh_trace_body.inc included a second time), its idle lanes take stack entries of the lanes that still hold a ray --, 2 = for every launch whatever the hierarchy (tests), -1 = for passes
@@ -2542,7 +2544,10 @@ static void launch_trace(skh_context* c, const DevScene& sc, RayQ rq, const uint
 {
     // scenes without curve instances run the build of the kernel that has no curve intersector in it (fewer VGPRs)
     const bool curveBuild = c->nSegs != 0;
-    const uint32_t fetchMin = ANY ? (curveBuild ? c->curveFetchMinShadow : c->fetchMinShadow) : (curveBuild ? c->curveFetchMinClosest : c->fetchMinClosest);
+    // (small overlapped passes, triangle scenes: a closest-hit wave asks for rays when 48 instead of 32 of its lanes are idle -- 1-spp 1080p call 3.11 -> 3.01 ms; 40 / 56: 3.04 / 3.04; lower
+    // thresholds lose: 24 / 16 / 8: 3.20 / 3.29 / 3.44; the any-hit threshold stays: 32 / 56 of 64: 3.16 / 3.12 against 3.11 at 48.  An explicit fetch_min_closest applies everywhere.)
+    const uint32_t fetchMinClosest = (c->gridOverride && !curveBuild && !c->fetchMinClosestSet) ? c->fetchMinClosestSmall : (curveBuild ? c->curveFetchMinClosest : c->fetchMinClosest);
+    const uint32_t fetchMin = ANY ? (curveBuild ? c->curveFetchMinShadow : c->fetchMinShadow) : fetchMinClosest;
     const uint32_t nodeBreak = ANY ? (curveBuild ? c->curveNodeBreakShadow : c->nodeBreakShadow) : (curveBuild ? c->curveNodeBreakClosest : c->nodeBreakClosest);
     // (the world-only kernel with the curve block -- curve instances under identity transforms -- wants the triangle kernels' node-loop exits and
     // an earlier curve block: hair stand-in 1 862 -> 1 937 Mray/s with 32 / 28 / 32 against the two-level curve build's 20 / 20 / 48, gpurun_out/r5t)
@@ -3821,8 +3826,16 @@ skh_status skh_set_option(skh_context* c, const char* name, int64_t value)
     {
         if (value < 1 || value > 64)
             return SKH_INVALID_ARGUMENT;
+        if (n == "fetch_min_closest")
+            c->fetchMinClosestSet = true;
         (n == "fetch_min_closest" ? c->fetchMinClosest : c->fetchMinShadow) = (uint32_t)value; // (an explicit value applies to both builds)
         (n == "fetch_min_closest" ? c->curveFetchMinClosest : c->curveFetchMinShadow) = (uint32_t)value;
+    }
+    else if (n == "fetch_min_closest_small")
+    {
+        if (value < 1 || value > 64)
+            return SKH_INVALID_ARGUMENT;
+        c->fetchMinClosestSmall = (uint32_t)value;
     }
     else if (n == "compact_hits")
     {
