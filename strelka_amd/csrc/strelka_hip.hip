@@ -2696,6 +2696,9 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
     const bool useOverlap = (c->overlap == 2 || (c->overlap == 1 && NP <= (1u << 25))) && fp.debug != 1;
     const uint32_t rounds = fp.maxDepth;
     c->splitNow = c->tailSplit < 0 && smallPass && NP >= (1u << 17);
+    // One sub-frame of one sample, accumulated in this call (the reference caller's pattern): its sums ARE the path's radiance and event word -- the batch kernel reads
+    // them where they lie (0.0f + radiance, / 1.0f: the same operations), and the k_collect launch and its 11 planes of sums are not needed.
+    const bool oneSampleDirect = batch == 1 && fp.samplesThisLaunch == 1 && finalize && fp.finalFirst == 0 && fp.finalCount == 1;
     for (uint32_t s = 0; trace && s < fp.samplesThisLaunch; ++s)
     {
         SKH_TRY(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * (QW * 2 * SKH_MAX_LAUNCH_ROUNDS + 16 * SKH_FETCH_STRIDE * (rounds + 1)), st));
@@ -2758,13 +2761,13 @@ static skh_status render_one(skh_context* c, const skh_frame_params* p, uint32_t
         {
             SpanGuard g(c, KC_ACCUM);
             k_add_stats<<<1, 64, 0, st>>>(counts, rounds, c->dStats.as<StatsDev>());
-            if (batch == 1)
+            if (batch == 1 && !oneSampleDirect)
                 k_collect<<<gridSlots, 256, 0, st>>>(fp, tiles, s, ps, c->dSums.as<float>());
         }
     }
     c->splitNow = false;
     hipStream_t fs = finStream ? finStream : st;
-    if (finalize && batch > 1)
+    if (finalize && (batch > 1 || oneSampleDirect))
     {
         SpanGuard g(c, KC_ACCUM, fs);
         k_finalize_batch<<<gridSlots, 256, 0, fs>>>(fp, tiles, ps, c->dAccum.as<float4>(), c->dDiffuse.as<float4>(), c->dSpecular.as<float4>(),
