@@ -369,6 +369,7 @@ __global__ void __launch_bounds__(SKH_TRACE_BLOCK, CURVES ? (WORLD ? (ANY_HIT ? 
     static_assert(!SPLIT || (WORLD && !CURVES), "SPLIT: the world-only triangle builds");
     constexpr int NLDS0 = (TRICOOP || BESTLDS) ? SKH_STACK_LDS - 1 : SKH_STACK_LDS;
     constexpr int NLDST = (SPLIT && NLDS0 >= 11) ? NLDS0 - 7 : NLDS0; // LDS stack entries of the tail phase (the tests' tiny-stack variants keep what little they have: their tables get LDS of their own)
+    static_assert(NLDS0 - NLDST <= SKH_TAIL_EXTRA, "the overflow columns' extra slots hold the LDS entries the tail phase gives up");
     __shared__ int s_stack[NLDS0 * SKH_TRACE_BLOCK];
     __shared__ uint32_t s_famx[(SPLIT && NLDST == NLDS0) ? 7 * SKH_TRACE_BLOCK : 1];
     uint32_t* const s_fam = NLDST < NLDS0 ? reinterpret_cast<uint32_t*>(s_stack + NLDST * SKH_TRACE_BLOCK) : s_famx;
